@@ -1,0 +1,124 @@
+"""Configuration objects for the Depth Pro hot path.
+
+Mirrors the reference's configuration surface:
+
+* ``ViTConfig`` / presets      -- /root/reference/src/model/depth_pro/layers/vit.rs:4-43
+* ``DepthProConfig``           -- /root/reference/src/model/depth_pro/mod.rs:35-66
+* ``InterpolationMethod``      -- /root/reference/src/model/depth_pro/interpolate.rs:11-22
+
+The reference hard-wires ViT-L (burn_dino ``DinoVisionTransformerConfig::vitl``) for both
+of its presets; this engine carries the transformer dimensions explicitly so a small
+test-only preset (``tiny16_128``) can run the *same* code path in seconds on a CPU oracle.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+DINOV2_L16_384 = "dinov2l16_384"
+DINOV2_L16_128 = "dinov2l16_128"
+TINY16_128 = "tiny16_128"  # test-only preset, not in the reference
+
+
+class InterpolationMethod:
+    """reference: depth_pro/interpolate.rs:11-22. ``CUSTOM`` = PyTorch align_corners=False
+    (the reference default); ``BURN`` = Burn ``module::interpolate`` = align_corners=True."""
+
+    CUSTOM = 0
+    BURN = 1
+
+
+class Precision:
+    """Arithmetic type of the MFMA operands (accumulation is always fp32)."""
+
+    BF16 = 0
+    F32 = 1
+
+
+@dataclass(frozen=True)
+class ViTConfig:
+    name: str
+    in_chans: int
+    embed_dim: int
+    depth: int
+    num_heads: int
+    mlp_ratio: int
+    img_size: int
+    patch_size: int
+    encoder_feature_layer_ids: tuple
+    encoder_feature_dims: tuple
+    ln_eps: float = 1e-6  # burn_dino's value is not visible: config field
+
+    def grid_size(self) -> int:
+        return self.img_size // self.patch_size
+
+    @property
+    def num_tokens(self) -> int:
+        return self.grid_size() ** 2 + 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+
+_PRESETS = {
+    # vit.rs:25-32
+    DINOV2_L16_384: ViTConfig(DINOV2_L16_384, 3, 1024, 24, 16, 4, 384, 16,
+                              (5, 11, 17, 23), (256, 512, 1024, 1024)),
+    # vit.rs:33-40
+    DINOV2_L16_128: ViTConfig(DINOV2_L16_128, 3, 1024, 24, 16, 4, 128, 16,
+                              (5, 11, 17, 23), (256, 512, 1024, 1024)),
+    # test-only: same topology, 4 blocks of width 256 (head_dim stays 64)
+    TINY16_128: ViTConfig(TINY16_128, 3, 256, 4, 4, 4, 128, 16,
+                          (1, 2, 3, 3), (64, 128, 256, 256)),
+}
+
+
+def vit_config_from_preset(preset: str) -> ViTConfig:
+    """reference: vit.rs:23-43 (panics on unknown preset -> ValueError here)."""
+    try:
+        return _PRESETS[preset]
+    except KeyError:
+        raise ValueError(f"unsupported ViT preset `{preset}`") from None
+
+
+@dataclass
+class DepthProConfig:
+    """reference: depth_pro/mod.rs:35-66 (same field names and defaults)."""
+
+    patch_encoder_preset: str = DINOV2_L16_384
+    image_encoder_preset: str = DINOV2_L16_384
+    decoder_features: int = 256
+    checkpoint_uri: Optional[str] = None
+    fov_encoder_preset: Optional[str] = DINOV2_L16_384
+    use_fov_head: bool = True
+    interpolation: int = InterpolationMethod.CUSTOM
+    # engine-side additions (not in the reference)
+    precision: int = Precision.BF16
+    max_batch: int = 1
+    ln_eps: float = 1e-6
+
+    @staticmethod
+    def small_test() -> "DepthProConfig":
+        """reference: src/lib.rs:102-112 (128-window preset, decoder 64)."""
+        return DepthProConfig(DINOV2_L16_128, DINOV2_L16_128, 64, None, DINOV2_L16_128)
+
+    @staticmethod
+    def tiny_test() -> "DepthProConfig":
+        return DepthProConfig(TINY16_128, TINY16_128, 64, None, TINY16_128)
+
+    def patch_vit(self) -> ViTConfig:
+        return dataclasses.replace(vit_config_from_preset(self.patch_encoder_preset), ln_eps=self.ln_eps)
+
+    def image_vit(self) -> ViTConfig:
+        return dataclasses.replace(vit_config_from_preset(self.image_encoder_preset), ln_eps=self.ln_eps)
+
+    def fov_vit(self) -> Optional[ViTConfig]:
+        if self.fov_encoder_preset is None:
+            return None
+        return dataclasses.replace(vit_config_from_preset(self.fov_encoder_preset), ln_eps=self.ln_eps)
+
+    def img_size(self) -> int:
+        """reference: encoder.rs:139-140 (img_size = 4 * patch window)."""
+        return self.patch_vit().img_size * 4

@@ -1,0 +1,318 @@
+"""Depth Pro parameter inventory, seeded synthetic initialisation and weight container.
+
+Parameter names are the reference's Burn field paths after the importer's key remap
+(/root/reference/tool/import_depth_pro.rs:344-437):
+
+* ViT (timm names with ``norm*.weight/bias -> gamma/beta``):
+  ``<vit>.patch_embed.proj.{weight,bias}``, ``<vit>.cls_token``, ``<vit>.pos_embed``,
+  ``<vit>.blocks.N.{norm1,norm2}.{gamma,beta}``, ``<vit>.blocks.N.attn.{qkv,proj}.{weight,bias}``,
+  ``<vit>.blocks.N.{ls1,ls2}.gamma``, ``<vit>.blocks.N.mlp.{fc1,fc2}.{weight,bias}``,
+  ``<vit>.norm.{gamma,beta}`` with ``<vit>`` in {encoder.patch_encoder, encoder.image_encoder,
+  fov.encoder}.
+* Linear weights are stored ``[out, in]`` (PyTorch layout); Conv ``[Cout, Cin, kh, kw]``;
+  ConvTranspose ``[Cin, Cout, kh, kw]`` (depth_pro/mod.rs:416-431).
+
+There are no trained weights on disk (reference .gitignore drops ``*.pt``/``*.mpk``), so every
+test/bench uses *synthetic* weights from a counter-based generator that is implemented twice,
+bit-identically: here (numpy) and in ``csrc/md_weights.cpp`` (``md_depth_pro_create``).
+
+Container format: safetensors (8-byte LE header length, JSON header, raw little-endian data),
+dtype F32 / F16 / BF16, keyed by the names above, plus ``__metadata__`` carrying the config.
+"""
+from __future__ import annotations
+
+import json
+import struct
+from typing import Dict, Iterable, List, NamedTuple, Optional, Tuple
+
+import numpy as np
+
+from .config import DepthProConfig, ViTConfig
+
+# --------------------------------------------------------------------------------------------
+# Parameter inventory
+# --------------------------------------------------------------------------------------------
+
+INIT_REFERENCE = 0  # Burn default initialisers: U(+-1/sqrt(fan_in)), LN gamma 1 / beta 0
+INIT_PARITY = 1     # variance-preserving ranges so that depth/fov land away from the clamps
+
+
+class ParamSpec(NamedTuple):
+    name: str
+    shape: Tuple[int, ...]
+    lo: float  # uniform range [lo, hi); lo == hi => constant
+    hi: float
+
+
+def _sym(bound: float) -> Tuple[float, float]:
+    return (-bound, bound)
+
+
+def _vit_specs(prefix: str, v: ViTConfig, scheme: int) -> List[ParamSpec]:
+    D, P, C = v.embed_dim, v.patch_size, v.in_chans
+    hidden = D * v.mlp_ratio
+    out: List[ParamSpec] = []
+    par = scheme == INIT_PARITY
+
+    def lin(name, fan_out, fan_in, bias=True):
+        b = (3.0 / fan_in) ** 0.5 if par else (1.0 / fan_in) ** 0.5
+        out.append(ParamSpec(f"{name}.weight", (fan_out, fan_in), *_sym(b)))
+        if bias:
+            bb = 0.1 if par else (1.0 / fan_in) ** 0.5
+            out.append(ParamSpec(f"{name}.bias", (fan_out,), *_sym(bb)))
+
+    fan = C * P * P
+    b = (3.0 / fan) ** 0.5 if par else (1.0 / fan) ** 0.5
+    out.append(ParamSpec(f"{prefix}.patch_embed.proj.weight", (D, C, P, P), *_sym(b)))
+    out.append(ParamSpec(f"{prefix}.patch_embed.proj.bias", (D,), *_sym(0.1 if par else b)))
+    out.append(ParamSpec(f"{prefix}.cls_token", (1, 1, D), *_sym(0.5 if par else 1e-6)))
+    # N(0, 0.02) in DINOv2; a uniform of the same std keeps the generator transcendental-free
+    s = 0.02 * 3.0 ** 0.5
+    out.append(ParamSpec(f"{prefix}.pos_embed", (1, v.num_tokens, D), *_sym(0.3 if par else s)))
+    for i in range(v.depth):
+        blk = f"{prefix}.blocks.{i}"
+        for n in ("norm1", "norm2"):
+            out.append(ParamSpec(f"{blk}.{n}.gamma", (D,), *((0.5, 1.5) if par else (1.0, 1.0))))
+            out.append(ParamSpec(f"{blk}.{n}.beta", (D,), *(_sym(0.1) if par else (0.0, 0.0))))
+        lin(f"{blk}.attn.qkv", 3 * D, D)
+        lin(f"{blk}.attn.proj", D, D)
+        out.append(ParamSpec(f"{blk}.ls1.gamma", (D,), *((0.05, 0.3) if par else (1.0, 1.0))))
+        lin(f"{blk}.mlp.fc1", hidden, D)
+        lin(f"{blk}.mlp.fc2", D, hidden)
+        out.append(ParamSpec(f"{blk}.ls2.gamma", (D,), *((0.05, 0.3) if par else (1.0, 1.0))))
+    out.append(ParamSpec(f"{prefix}.norm.gamma", (D,), *((0.5, 1.5) if par else (1.0, 1.0))))
+    out.append(ParamSpec(f"{prefix}.norm.beta", (D,), *(_sym(0.1) if par else (0.0, 0.0))))
+    return out
+
+
+def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> List[ParamSpec]:
+    """Every parameter of ``DepthPro::new`` (depth_pro/mod.rs:145-191), in a fixed order.
+
+    Shapes follow encoder.rs:127-184, decoder.rs:152-193, mod.rs:77-103, fov.rs:63-166."""
+    pv, iv, fv = cfg.patch_vit(), cfg.image_vit(), cfg.fov_vit()
+    dims = list(pv.encoder_feature_dims)
+    F = cfg.decoder_features
+    E = pv.embed_dim
+    par = scheme == INIT_PARITY
+    specs: List[ParamSpec] = []
+
+    def conv(name, cout, cin, k, bias, relu_after=False, gain=None):
+        fan = cin * k * k
+        if par:
+            b = ((6.0 if relu_after else 3.0) / fan) ** 0.5
+            if gain is not None:
+                b *= gain
+        else:
+            b = (1.0 / fan) ** 0.5
+        specs.append(ParamSpec(f"{name}.weight", (cout, cin, k, k), *_sym(b)))
+        if bias:
+            specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
+
+    def deconv(name, cin, cout, bias):
+        # Burn's ConvTranspose2d fan_in uses channels[1]*k*k (out channels); only the range matters
+        fan = cin
+        b = (3.0 / fan) ** 0.5 if par else (1.0 / (cout * 4)) ** 0.5
+        specs.append(ParamSpec(f"{name}.weight", (cin, cout, 2, 2), *_sym(b)))
+        if bias:
+            specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
+
+    specs += _vit_specs("encoder.patch_encoder", pv, scheme)
+    specs += _vit_specs("encoder.image_encoder", iv, scheme)
+
+    def pub(name, dim_in, dim_out, layers, dim_int=None):  # ProjectUpsampleBlock, encoder.rs:47-75
+        inter = dim_int if dim_int is not None else dim_out
+        conv(f"{name}.projection", inter, dim_in, 1, False)
+        for l in range(layers):
+            deconv(f"{name}.upsample.{l}", inter if l == 0 else dim_out, dim_out, False)
+
+    pub("encoder.upsample_latent0", E, F, 3, dims[0])
+    pub("encoder.upsample_latent1", E, dims[0], 2)
+    pub("encoder.upsample0", E, dims[1], 1)
+    pub("encoder.upsample1", E, dims[2], 1)
+    pub("encoder.upsample2", E, dims[3], 1)
+    deconv("encoder.upsample_lowres", iv.embed_dim, dims[3], True)
+    conv("encoder.fuse_lowres", dims[3], dims[3] * 2, 1, True)
+
+    ddims = [F] + dims  # mod.rs:162-163
+    if ddims[0] != F:  # decoder.rs:155-165 (never taken: ddims[0] == F by construction)
+        conv("decoder.convs.0.conv", F, ddims[0], 1, False)
+    for l in range(1, len(ddims)):
+        conv(f"decoder.convs.{l}.conv", F, ddims[l], 3, False)
+    for l in range(len(ddims)):
+        for r in ("resnet1", "resnet2"):
+            conv(f"decoder.fusions.{l}.{r}.conv1", F, F, 3, True, relu_after=True)
+            conv(f"decoder.fusions.{l}.{r}.conv2", F, F, 3, True, relu_after=True, gain=0.5)
+        if l != 0:
+            deconv(f"decoder.fusions.{l}.deconv", F, F, False)
+        conv(f"decoder.fusions.{l}.out_conv", F, F, 1, True)
+
+    conv("head.conv0", F // 2, F, 3, True)
+    deconv("head.deconv", F // 2, F // 2, True)
+    conv("head.conv1", 32, F // 2, 3, True, relu_after=True)
+    if par:
+        # positive weights + positive bias keep canonical inverse depth off the 1e-4 clamp
+        specs.append(ParamSpec("head.conv_out.weight", (1, 32, 1, 1), 0.0, 0.08))
+        specs.append(ParamSpec("head.conv_out.bias", (1,), 0.05, 0.05))
+    else:
+        b = (1.0 / 32) ** 0.5
+        specs.append(ParamSpec("head.conv_out.weight", (1, 32, 1, 1), *_sym(b)))
+        specs.append(ParamSpec("head.conv_out.bias", (1,), 0.0, 0.0))  # mod.rs:92-95
+
+    if cfg.use_fov_head:
+        if fv is not None:
+            specs += _vit_specs("fov.encoder", fv, scheme)
+            fan = fv.embed_dim
+            b = (3.0 / fan) ** 0.5 if par else (1.0 / fan) ** 0.5
+            specs.append(ParamSpec("fov.encoder_proj.weight", (F // 2, fan), *_sym(b)))
+            specs.append(ParamSpec("fov.encoder_proj.bias", (F // 2,), *_sym(0.1 if par else b)))
+            conv("fov.downsample_blocks.0.conv", F // 2, F, 3, True, relu_after=True)
+            conv("fov.head_blocks.0.conv", F // 4, F // 2, 3, True, relu_after=True)
+            conv("fov.head_blocks.1.conv", F // 8, F // 4, 3, True, relu_after=True)
+            last = ("fov.head_blocks.2.conv", 1, F // 8, 6)
+        else:
+            conv("fov.head_blocks.0.conv", F // 2, F, 3, True, relu_after=True)
+            conv("fov.head_blocks.1.conv", F // 4, F // 2, 3, True, relu_after=True)
+            conv("fov.head_blocks.2.conv", F // 8, F // 4, 3, True, relu_after=True)
+            last = ("fov.head_blocks.3.conv", 1, F // 8, 6)
+        name, cout, cin, k = last
+        fan = cin * k * k
+        b = (3.0 / fan) ** 0.5 if par else (1.0 / fan) ** 0.5
+        specs.append(ParamSpec(f"{name}.weight", (cout, cin, k, k), *_sym(b)))
+        # parity scheme: field of view around 55 degrees so tan(fov/2) is well conditioned
+        specs.append(ParamSpec(f"{name}.bias", (cout,), *((55.0, 55.0) if par else _sym(b))))
+    return specs
+
+
+# --------------------------------------------------------------------------------------------
+# Counter-based generator (bit-identical twin in csrc/md_weights.cpp)
+# --------------------------------------------------------------------------------------------
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def fnv1a64(name: str) -> int:
+    h = 0xCBF29CE484222325
+    for ch in name.encode("utf-8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def stream_key(name: str, seed: int) -> int:
+    return (fnv1a64(name) ^ ((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+
+
+def uniform_stream(name: str, seed: int, count: int, lo: float, hi: float) -> np.ndarray:
+    """``count`` float32 values in [lo, hi): element i = lo + (hi-lo) * (u24(i)+0.5)/2^24 with
+    u24 the top 24 bits of splitmix64(key + (i+1)*golden). Arithmetic in float64, one cast."""
+    lo32, hi32 = np.float32(lo), np.float32(hi)
+    if lo32 == hi32:
+        return np.full(count, lo32, dtype=np.float32)
+    key = np.uint64(stream_key(name, seed))
+    with np.errstate(over="ignore"):
+        z = key + (np.arange(1, count + 1, dtype=np.uint64) * _GOLDEN)
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    u = ((z >> np.uint64(40)).astype(np.float64) + 0.5) * (1.0 / 16777216.0)
+    w = np.float64(hi32) - np.float64(lo32)
+    prod = w * u
+    return (np.float64(lo32) + prod).astype(np.float32)
+
+
+def generate_depth_pro_weights(cfg: DepthProConfig, seed: int = 0,
+                               scheme: int = INIT_REFERENCE) -> Dict[str, np.ndarray]:
+    """Synthetic weights for ``DepthPro::new`` (random init; depth_pro/mod.rs:145-191)."""
+    out: Dict[str, np.ndarray] = {}
+    for spec in depth_pro_param_specs(cfg, scheme):
+        n = int(np.prod(spec.shape))
+        out[spec.name] = uniform_stream(spec.name, seed, n, spec.lo, spec.hi).reshape(spec.shape)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# Container (safetensors subset)
+# --------------------------------------------------------------------------------------------
+
+_DTYPES = {"F32": np.float32, "F16": np.float16}
+
+
+def _f32_to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return r.astype(np.uint16)
+
+
+def _bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def save_container(path: str, tensors: Dict[str, np.ndarray], metadata: Optional[Dict[str, str]] = None,
+                   dtype: str = "F32") -> None:
+    """Write a safetensors file. ``dtype`` in {F32, F16, BF16} (the reference's .mpk stores f16,
+    depth_pro/mod.rs:206)."""
+    header: Dict[str, object] = {}
+    if metadata:
+        header["__metadata__"] = {str(k): str(v) for k, v in metadata.items()}
+    blobs: List[bytes] = []
+    off = 0
+    for name in sorted(tensors):
+        arr = np.ascontiguousarray(tensors[name], dtype=np.float32)
+        if dtype == "F32":
+            raw = arr.tobytes()
+        elif dtype == "F16":
+            raw = arr.astype(np.float16).tobytes()
+        elif dtype == "BF16":
+            raw = _f32_to_bf16_bits(arr).tobytes()
+        else:
+            raise ValueError(f"unsupported container dtype {dtype}")
+        header[name] = {"dtype": dtype, "shape": list(arr.shape), "data_offsets": [off, off + len(raw)]}
+        blobs.append(raw)
+        off += len(raw)
+    hjson = json.dumps(header, separators=(",", ":")).encode("utf-8")
+    pad = (8 - len(hjson) % 8) % 8
+    hjson += b" " * pad
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hjson)))
+        f.write(hjson)
+        for raw in blobs:
+            f.write(raw)
+
+
+def load_container(path: str) -> Tuple[Dict[str, np.ndarray], Dict[str, str]]:
+    with open(path, "rb") as f:
+        raw = f.read()
+    if len(raw) < 8:
+        raise ValueError("container too short")
+    (hlen,) = struct.unpack("<Q", raw[:8])
+    if 8 + hlen > len(raw):
+        raise ValueError("container header length exceeds file size")
+    header = json.loads(raw[8:8 + hlen].decode("utf-8"))
+    meta = header.pop("__metadata__", {})
+    data = memoryview(raw)[8 + hlen:]
+    out: Dict[str, np.ndarray] = {}
+    for name, info in header.items():
+        b, e = info["data_offsets"]
+        dt = info["dtype"]
+        buf = np.frombuffer(data[b:e], dtype=np.uint8)
+        if dt == "BF16":
+            arr = _bf16_bits_to_f32(buf.view(np.uint16))
+        elif dt in _DTYPES:
+            arr = buf.view(_DTYPES[dt]).astype(np.float32)
+        else:
+            raise ValueError(f"unsupported dtype {dt} for {name}")
+        out[name] = arr.reshape(info["shape"]).copy()
+    return out, meta
+
+
+def config_metadata(cfg: DepthProConfig) -> Dict[str, str]:
+    return {
+        "model": "depth_pro",
+        "patch_encoder_preset": cfg.patch_encoder_preset,
+        "image_encoder_preset": cfg.image_encoder_preset,
+        "fov_encoder_preset": cfg.fov_encoder_preset or "",
+        "decoder_features": str(cfg.decoder_features),
+        "use_fov_head": "1" if cfg.use_fov_head else "0",
+    }
