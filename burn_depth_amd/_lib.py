@@ -1,0 +1,115 @@
+"""ctypes binding of libmi_depth.so (include/mi_depth.h).
+
+The HIP library is the product: if it is missing the import fails loudly -- there is no
+CPU/PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_depth.so")
+
+MD_OK = 0
+MD_ERR_INVALID_ARG, MD_ERR_SHAPE, MD_ERR_IO, MD_ERR_FORMAT, MD_ERR_HIP = -1, -2, -3, -4, -5
+MD_ERR_UNSUPPORTED, MD_ERR_NO_FOV, MD_ERR_OOM, MD_ERR_LEVELS = -6, -7, -8, -9
+MD_MEM_HOST, MD_MEM_DEVICE = 0, 1
+TILE_256x256, TILE_128x128, TILE_256x32, TILE_AUTO = 0, 1, 2, 99
+
+
+class MdError(RuntimeError):
+    """Maps the reference's `Result::Err(String)` / `RecorderError` / panics."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mi_depth error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class MdDepthProCfg(C.Structure):
+    _fields_ = [
+        ("patch_encoder_preset", C.c_char_p),
+        ("image_encoder_preset", C.c_char_p),
+        ("fov_encoder_preset", C.c_char_p),
+        ("decoder_features", C.c_int),
+        ("use_fov_head", C.c_int),
+        ("interpolation", C.c_int),
+        ("precision", C.c_int),
+        ("max_batch", C.c_int),
+        ("ln_eps", C.c_float),
+    ]
+
+
+# every symbol include/mi_depth.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+_I = C.c_int
+SYMBOLS = {
+    "md_last_error": (C.c_char_p, []),
+    "md_version": (C.c_char_p, []),
+    "md_device_open": (_I, [_I, C.POINTER(_P)]),
+    "md_device_close": (_I, [_P]),
+    "md_device_synchronize": (_I, [_P]),
+    "md_depth_pro_cfg_default": (None, [C.POINTER(MdDepthProCfg)]),
+    "md_depth_pro_create": (_I, [_P, C.POINTER(MdDepthProCfg), C.c_uint64, _I, C.POINTER(_P)]),
+    "md_depth_pro_load": (_I, [_P, C.c_char_p, C.POINTER(_P)]),
+    "md_depth_pro_load_with_config": (_I, [_P, C.POINTER(MdDepthProCfg), C.c_char_p, C.POINTER(_P)]),
+    "md_model_set_tensor": (_I, [_P, C.c_char_p, _P, C.c_size_t]),
+    "md_model_get_tensor": (_I, [_P, C.c_char_p, _P, C.c_size_t]),
+    "md_model_param_count": (_I, [_P]),
+    "md_model_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
+    "md_model_commit_weights": (_I, [_P]),
+    "md_model_weight_arena": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "md_model_destroy": (_I, [_P]),
+    "md_depth_pro_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "md_infer_from_rgb": (_I, [_P, _P, C.c_size_t, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "md_model_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "md_model_enable_taps": (_I, [_P, _I]),
+    "md_model_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int64 * 4)]),
+    "md_model_enable_timing": (_I, [_P, _I]),
+    "md_model_read_timing": (_I, [_P, C.POINTER(C.c_char_p), _F, C.POINTER(_I), _I, C.POINTER(_I)]),
+    "md_op_rgb_to_input": (_I, [_P, _P, C.c_size_t, _I, _I, _P, _P]),
+    "md_op_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "md_op_resize_output_size": (_I, [_I, _I, C.c_float, C.c_float, C.POINTER(_I), C.POINTER(_I)]),
+    "md_op_split": (_I, [_P, _P, _I, _I, _I, _I, C.c_float, _P, C.POINTER(_I), _P]),
+    "md_op_merge": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, C.POINTER(_I), C.POINTER(_I), _P]),
+    "md_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, C.c_float, _P, _P]),
+    "md_op_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "md_op_linear_tile": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "md_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "md_op_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "md_op_deconv2x2": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "md_op_conv2d_direct": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "md_op_fov_to_focal": (_I, [C.c_float, _I, _I, _F, _F]),
+    "md_param_inventory": (_I, [C.POINTER(MdDepthProCfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
+    "md_uniform_stream": (_I, [C.c_char_p, C.c_uint64, C.c_size_t, C.c_float, C.c_float, _P]),
+    "md_split_geometry": (_I, [_I, _I, C.c_float, C.POINTER(_I), C.POINTER(_I)]),
+    "md_feature_padding": (_I, [_I, _I, _I]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmi_depth.so (built by `__graft_entry__.build()` / `make -C burn_depth_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "burn_depth_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted from the header
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != MD_OK:
+        msg = load().md_last_error()
+        raise MdError(code, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,227 @@
+// K5: fused multi-head attention for gfx950, bf16 MFMA operands / fp32 softmax and accumulation.
+//
+//   out[q, h*64 + d] = sum_k softmax_k(q.k / 8) * v[k, d]        head_dim = 64 (ViT-L/16, ViT-S/14)
+//
+// Layout contract (produced by the QKV GEMM epilogue, gemm.hip EPI_QKV):
+//   qk  [rows, 2D]  bf16, row = seq*S + token; q at column h*64, k at column D + h*64
+//   vT  [seq][head][64][kpad] bf16: V transposed so that keys are contiguous (the P.V MFMA wants
+//       both operands K-contiguous; the transpose is paid once in the GEMM epilogue).
+//
+// One workgroup = 4 waves = 128 consecutive queries of one (sequence, head); a wave owns 32
+// queries. K and V^T tiles of 64 keys are streamed through a 2-stage LDS ring with
+// global_load_lds (swizzled on the source address like the GEMM), shared by the 4 waves.
+// "Swapped" QK^T: S^T = K.Q^T puts one query per lane (column) and 16 keys per lane in the
+// accumulator registers, so the online-softmax max/sum are in-register reductions plus ONE
+// cross-half exchange, and the exponentiated accumulator registers are -- after a bf16 pack --
+// directly the B operand of the P.V MFMA (no LDS round trip, no cross-lane movement). The key
+// order inside a 32-key sub-tile is permuted (bits 2 and 3 of the key index swapped when K rows
+// are read from LDS) so that registers 8s..8s+7 hold the 8 consecutive keys the V^T fragment
+// of k-step s holds.
+#include "ops.h"
+
+namespace md {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+__device__ __forceinline__ void glds16a(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ int pack_bf16x2(float a, float b) {
+  bf16x2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(int, v);
+}
+
+// grid: (q blocks of 128, heads, sequences); block 256.
+__global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __restrict__ qk,
+                                                             const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
+                                                             int S, int n_tokens, int heads, int D, int kpad) {
+  constexpr int STAGE = 16384;  // K tile 64x128B + V^T tile 64x128B
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < n_tokens;  // wave-uniform
+  const int h = lane >> 5, c = lane & 31;
+  const long two_d = 2L * D;
+  const long seq_row0 = (long)seq * S;
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane (c,h) holds Q[q0+c][16s + 8h + j] ----
+  i32x4_t qf[4];
+  {
+    int q = q0 + c;
+    q = q < n_tokens ? q : n_tokens - 1;
+    const char* qp = (const char*)(qk + (seq_row0 + q) * two_d + head * 64) + h * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const i32x4_t*)(qp + s * 32);
+  }
+
+  // ---- global->LDS sources: 16 row-groups per stage (8 K + 8 V^T), 4 per wave ----
+  const int lrow = lane >> 3, pc = lane & 7;
+  const char* ksrc[2];
+  const char* vsrc[2];
+  int kmaxrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (i * 4 + wave) * 8 + lrow;  // tile row 0..63
+    const int lc = pc ^ ((r >> 1) & 7);
+    ksrc[i] = (const char*)(qk + D + head * 64) + lc * 16;  // + key row * two_d * 2 per tile
+    kmaxrow[i] = r;
+    vsrc[i] = (const char*)(vT + (((long)seq * heads + head) * 64 + r) * kpad) + lc * 16;  // + kv0*2 per tile
+  }
+
+  auto issue = [&](int stage, int t) {
+    char* sb = smem + stage * STAGE;
+    const int kv0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kv0 + kmaxrow[i];
+      key = key < n_tokens ? key : n_tokens - 1;  // clamped rows are masked below
+      glds16a(ksrc[i] + (seq_row0 + key) * two_d * 2, sb + (i * 4 + wave) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16a(vsrc[i] + (long)kv0 * 2, sb + 8192 + (i * 4 + wave) * 1024);
+  };
+
+  // LDS read offsets. K rows are read through the bit-2/bit-3 swap; V^T rows (= d) directly.
+  const int pk = (c & 0x13) | ((c & 4) << 1) | ((c & 8) >> 1);
+  int koff[2], voff[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const int R = sub * 32 + pk;
+    koff[sub] = R * 128 + ((((R >> 1) & 7) ^ h) << 4);  // chunk (2s+h) ^ swz -> xor (s<<5) per k-step
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int R = dt * 32 + c;
+    voff[dt] = 8192 + R * 128 + ((((R >> 1) & 7) ^ h) << 4);  // chunk (sub*4 + 2s' + h) ^ swz
+  }
+
+  f32x16_t o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float cs = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e)
+
+  const int NT = (n_tokens + 63) / 64;
+  issue(0, 0);
+  for (int t = 0; t < NT; ++t) {
+    const int cur = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < NT) issue(cur ^ 1, t + 1);
+    if (!active) continue;
+    const char* sb = smem + cur * STAGE;
+
+    // ---- S^T[sub] = K[sub] . Q^T ----
+    f32x16_t st[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
+        st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                          __builtin_bit_cast(bf16x8_t, qf[s]), st[sub], 0, 0, 0);
+      }
+    }
+    // register r of lane half h holds local key (r&7) + 8h + 16(r>>3) of the sub-tile
+    const int kv0 = t * 64;
+    if (kv0 + 64 > n_tokens) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + sub * 32 + (r & 7) + 8 * h + 16 * (r >> 3);
+          if (key >= n_tokens) st[sub][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax (one query per lane; the two lane halves share a query) ----
+    float mx = st[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+    const float mc = m_new * cs;
+    m_run = m_new;
+    float psum = 0.f;
+    i32x4_t pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(st[sub][r] * cs - mc);
+        psum += p[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[sub][s2][0] = pack_bf16x2(p[8 * s2 + 0], p[8 * s2 + 1]);
+        pf[sub][s2][1] = pack_bf16x2(p[8 * s2 + 2], p[8 * s2 + 3]);
+        pf[sub][s2][2] = pack_bf16x2(p[8 * s2 + 4], p[8 * s2 + 5]);
+        pf[sub][s2][3] = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    // ---- O^T[dt] += V^T[dt] . P^T ----
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const i32x4_t vf = *(const i32x4_t*)(sb + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                          __builtin_bit_cast(bf16x8_t, pf[sub][s2]), o[dt], 0, 0, 0);
+        }
+  }
+
+  if (!active) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv_l = 1.0f / l_tot;
+  const int q = q0 + c;
+  if (q < n_tokens) {
+    bf16_t* orow = out + (seq_row0 + q) * (long)D + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * h;
+        bf16x4_t b = {(__bf16)(o[dt][4 * q4] * inv_l), (__bf16)(o[dt][4 * q4 + 1] * inv_l),
+                      (__bf16)(o[dt][4 * q4 + 2] * inv_l), (__bf16)(o[dt][4 * q4 + 3] * inv_l)};
+        *(bf16x4_t*)(orow + d) = b;
+      }
+  }
+}
+
+int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
+                          int kpad, hipStream_t s) {
+  if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
+  if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
+    MD_FAIL(MD_ERR_INVALID_ARG, "attention: kpad=%d must be a multiple of 64 covering %d keys", kpad, n_tokens);
+  if (nseq <= 0 || nseq > 65535) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
+  dim3 grid((n_tokens + 127) / 128, heads, nseq);
+  hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out,
+                     S, n_tokens, heads, D, kpad);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+}  // namespace md

@@ -1,0 +1,78 @@
+// Parameters of the MFMA GEMM family: C = A[M,K] * W[N,K]^T with grouped weights, three
+// A-operand addressing modes (dense rows / indexed rows / 3x3-conv taps over NHWC) and fused
+// epilogues. One kernel template serves every dense contraction of the Depth Pro path
+// (SURVEY 8a rows a4, a7, a8, a9, a10, a11).
+#pragma once
+
+#include "../md_common.h"
+
+namespace md {
+
+constexpr int kMaxGroups = 4;
+
+enum AMode : int { A_DENSE = 0, A_INDEXED = 1, A_CONV3 = 2 };
+
+enum EpiMode : int {
+  EPI_STORE = 0,        // out = act(acc + bias + res1 + res2); optional out2 = relu(out)
+  EPI_RESID_LS = 1,     // x(f32) += scale[n] * (acc + bias[n])              (ViT residual + LayerScale)
+  EPI_PATCH_EMBED = 2,  // x(f32)[seq*S + 1 + p] = acc + bias + pos[1+p]     (patch embed + pos embed)
+  EPI_QKV = 3,          // q,k -> row-major T; v -> transposed V^T[seq][head][d][key]
+  EPI_PIXSHUF = 4,      // ConvTranspose2d k=s=2 as GEMM: pixel-shuffle scatter (+bias, + relu copy)
+  EPI_HEAD = 5          // depth head tail: relu(conv1) . w_out + b_out, relu  -> f32 [M]
+};
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+struct GemmParams {
+  // ---- problem ----
+  int N = 0, K = 0;  // K in elements of T
+  int ngroups = 1;
+  int g_row0[kMaxGroups] = {0, 0, 0, 0};   // first logical row of each group (output row space)
+  int g_rows[kMaxGroups] = {0, 0, 0, 0};   // rows in each group
+  int g_arow0[kMaxGroups] = {0, 0, 0, 0};  // first PHYSICAL A row of each group (aliasing allowed)
+  int g_tile0[kMaxGroups + 1] = {0, 0, 0, 0, 0};  // prefix sum of m-tiles (filled by the launcher)
+  const void* W[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // [N][ldw] per group
+  long ldw = 0;                 // elements between consecutive W rows (0 = K)
+  // ---- batching (blockIdx.y): batch index by -> (bo, bi) = (by / batch_inner, by % batch_inner);
+  //      A, W (all groups) and out advance by bo*stride[0] + bi*stride[1] elements ----
+  int batch = 1, batch_inner = 1;
+  long a_bs[2] = {0, 0}, w_bs[2] = {0, 0}, o_bs[2] = {0, 0};
+  // ---- A operand ----
+  const void* A = nullptr;
+  long lda = 0;                 // elements between consecutive rows (dense / indexed)
+  const int* a_index = nullptr; // A_INDEXED: logical row m reads physical row a_index[m]
+  int cH = 0, cW = 0, cC = 0;   // A_CONV3: NHWC [B, cH, cW, cC]; M = B*cH*cW; K = 9*cC (tap-major)
+  const void* zero_page = nullptr;  // >= 256 zero bytes (A_CONV3 halo)
+  // ---- epilogue ----
+  int epi = EPI_STORE;
+  int act = ACT_NONE;
+  int out_f32 = 0;              // primary output element type: 0 = T, 1 = float
+  const float* bias[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+  const float* scale[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+  const float* pos[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+  void* out = nullptr;
+  long ldo = 0;
+  void* out2 = nullptr;         // optional relu(out) copy, element type T, same ld
+  const void* res1 = nullptr;   // optional residual inputs, element type T
+  const void* res2 = nullptr;
+  long ldr = 0;
+  // EPI_PATCH_EMBED / EPI_QKV
+  int seq_stride = 0;           // rows per sequence in the token buffers (tokens padded to x4)
+  int seq_patches = 0;          // patches per sequence (EPI_PATCH_EMBED input rows per sequence)
+  int embed = 0;                // D
+  int heads = 0;
+  int kpad = 0;                 // padded key count of V^T rows
+  void* vT = nullptr;
+  // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = 4*psC; out NHWC [B, 2psH, 2psW, ldo] at +ps_coff
+  int psH = 0, psW = 0, psC = 0, ps_coff = 0;
+  // EPI_HEAD
+  const float* head_w = nullptr;  // [32]
+  float head_b = 0.f;
+};
+
+enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_AUTO = 99 };
+
+// Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16) or MD_PREC_F32 (T = float).
+int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream);
+
+}  // namespace md

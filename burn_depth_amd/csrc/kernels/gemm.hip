@@ -1,0 +1,53 @@
+// Host-side validation, tile selection and precision dispatch of the MFMA GEMM family.
+// The kernel template lives in gemm_impl.h and is instantiated per precision in
+// gemm_bf16.hip / gemm_f32.hip (separate translation units so they compile in parallel).
+#include "gemm.h"
+
+namespace md {
+
+int launch_gemm_bf16(GemmParams& p, int amode, int tile, hipStream_t stream);
+int launch_gemm_f32(GemmParams& p, int amode, int tile, hipStream_t stream);
+
+static int pick_tile(const GemmParams& p) {
+  if (p.epi == EPI_HEAD || p.N <= 32) return TILE_256x32;
+  long rows = 0;
+  int t256 = 0, t128 = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    rows += p.g_rows[g];
+    t256 += cdiv(p.g_rows[g], 256);
+    t128 += cdiv(p.g_rows[g], 128);
+  }
+  if (p.N < 256 || rows < 256) return TILE_128x128;
+  // estimated time in units of one 128x128 tile-pass per CU; 256^2 tiles run ~1.25x more
+  // efficiently per flop but leave CUs idle when there are few of them.
+  const long b256 = (long)t256 * cdiv(p.N, 256), b128 = (long)t128 * cdiv(p.N, 128);
+  const double c256 = (double)cdiv(b256, 256) * 4.0 / 1.25;
+  const double c128 = (double)cdiv(b128, 512) * 2.0;
+  return c256 <= c128 ? TILE_256x256 : TILE_128x128;
+}
+
+int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream) {
+  const int ke = prec == MD_PREC_F32 ? 32 : 64;
+  if (p.ngroups < 1 || p.ngroups > kMaxGroups) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: ngroups %d", p.ngroups);
+  if (p.N <= 0 || p.N % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: N=%d must be a positive multiple of 4", p.N);
+  if (p.K <= 0 || p.K % ke != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", p.K, ke);
+  if (amode == A_CONV3) {
+    if (p.cC % ke != 0 || p.K != 9 * p.cC)
+      MD_FAIL(MD_ERR_UNSUPPORTED, "conv3x3: Cin=%d must be a multiple of %d (K=%d)", p.cC, ke, p.K);
+    if (!p.zero_page) MD_FAIL(MD_ERR_INVALID_ARG, "conv3x3: zero page missing");
+  }
+  if (amode == A_INDEXED && !p.a_index) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: index table missing");
+  if (p.batch > 1 && (p.epi != EPI_STORE || p.res1 || p.res2 || p.batch > 65535 || p.batch_inner < 1))
+    MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: batching supports the plain store epilogue only (batch=%d)", p.batch);
+  if (p.epi == EPI_HEAD && p.N != 32) MD_FAIL(MD_ERR_UNSUPPORTED, "head epilogue needs N == 32");
+  for (int g = 0; g < p.ngroups; ++g) {
+    if (p.g_rows[g] <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has %d rows", g, p.g_rows[g]);
+    if (!p.W[g]) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has no weights", g);
+  }
+  if (tile == TILE_AUTO) tile = pick_tile(p);
+  if (p.epi == EPI_HEAD) tile = TILE_256x32;
+  if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);
+  return launch_gemm_bf16(p, amode, tile, stream);
+}
+
+}  // namespace md

@@ -1,0 +1,448 @@
+// MFMA GEMM / implicit-GEMM convolution for gfx950 (CDNA4).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]          (both operands K-contiguous)
+//
+// Design (MI355X-first; see DESIGN.md "K4/K8"):
+//  * 64-lane waves, v_mfma_f32_32x32x16_bf16 (bf16 mode) or v_mfma_f32_32x32x2_f32 (fp32 mode),
+//    fp32 accumulation in both.  The MFMA "A" operand is the WEIGHT tile and the "B" operand the
+//    activation tile, so a lane ends up holding 4 consecutive output columns n of ONE row m:
+//    the epilogue stores 8-byte (bf16) / 16-byte (f32) vectors and per-column vectors (bias,
+//    LayerScale) are loaded as float4.
+//  * LDS tiles are rows of exactly 128 bytes (64 bf16 or 32 f32 of K) -- byte-identical addressing
+//    for both precisions.  Tiles are filled with `global_load_lds_dwordx4` (no VGPR round trip);
+//    the bank-conflict swizzle (16-byte chunk index XOR ((row>>1)&7)) is applied on the per-lane
+//    GLOBAL source address and again on the ds_read_b128 address (the LDS image written by one
+//    wave-instruction must stay lane-linear).
+//  * Two LDS stages; the global->LDS loads of k-tile t+1 are in flight while k-tile t is
+//    multiplied; one barrier per k-tile.
+//  * A-operand modes: dense rows, indexed rows (token->map "merge" gather, encoder.rs:234-319) and
+//    3x3 stride-1 pad-1 convolution taps over an NHWC tensor (out-of-image taps read a zero page).
+//  * Grouped weights: up to 4 row ranges, each with its own W / bias / scale (the three ViT-L
+//    encoders of Depth Pro advance layer by layer in ONE launch).
+//  * XCD-aware block order: logical tile ids are dealt so that each XCD (private L2) works on a
+//    contiguous range of tiles that share the same A row-panel.
+#pragma once
+#include "gemm.h"
+
+namespace md {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+#define MD_SEL_G(arr, g) ((g) == 0 ? (arr)[0] : (g) == 1 ? (arr)[1] : (g) == 2 ? (arr)[2] : (arr)[3])
+
+template <typename T>
+struct Atom;
+
+template <>
+struct Atom<bf16_t> {
+  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                0, 0, 0);
+  }
+};
+
+template <>
+struct Atom<float> {
+  // one 16-byte read = 4 consecutive k per lane-half; 4 MFMAs of K=2 (k = {j, 4+j} per call)
+  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+    f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4_t load4(const T* p);
+template <>
+__device__ __forceinline__ f32x4_t load4<float>(const float* p) {
+  return *(const f32x4_t*)p;
+}
+template <>
+__device__ __forceinline__ f32x4_t load4<bf16_t>(const bf16_t* p) {
+  bf16x4_t b = *(const bf16x4_t*)p;
+  f32x4_t r = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, f32x4_t v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, f32x4_t v) {
+  *(f32x4_t*)p = v;
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4_t v) {
+  bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *(bf16x4_t*)p = b;
+}
+template <typename T>
+__device__ __forceinline__ void store1(T* p, float v);
+template <>
+__device__ __forceinline__ void store1<float>(float* p, float v) {
+  *p = v;
+}
+template <>
+__device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
+  *(__bf16*)p = (__bf16)v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
+  f32x4_t r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue for 4 consecutive columns n..n+3 of row m (all bounds already checked by the caller).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int n, f32x4_t v, long boff) {
+  const float* bias = MD_SEL_G(p.bias, g);
+  switch (p.epi) {
+    case EPI_STORE: {
+      if (bias) v += *(const f32x4_t*)(bias + n);
+      if (p.res1) v += load4<T>((const T*)p.res1 + (long)m * p.ldr + n);
+      if (p.res2) v += load4<T>((const T*)p.res2 + (long)m * p.ldr + n);
+      if (p.act == ACT_RELU) {
+        v = relu4(v);
+      } else if (p.act == ACT_GELU) {
+        v[0] = gelu_erf(v[0]);
+        v[1] = gelu_erf(v[1]);
+        v[2] = gelu_erf(v[2]);
+        v[3] = gelu_erf(v[3]);
+      }
+      if (p.out_f32)
+        store4<float>((float*)p.out + boff + (long)m * p.ldo + n, v);
+      else
+        store4<T>((T*)p.out + boff + (long)m * p.ldo + n, v);
+      if (p.out2) store4<T>((T*)p.out2 + boff + (long)m * p.ldo + n, relu4(v));
+      break;
+    }
+    case EPI_RESID_LS: {
+      const float* sc = MD_SEL_G(p.scale, g);
+      float* x = (float*)p.out + (long)m * p.ldo + n;
+      f32x4_t r = *(const f32x4_t*)x;
+      v += *(const f32x4_t*)(bias + n);
+      f32x4_t s = *(const f32x4_t*)(sc + n);
+      r += s * v;
+      *(f32x4_t*)x = r;
+      break;
+    }
+    case EPI_PATCH_EMBED: {
+      const float* pos = MD_SEL_G(p.pos, g);
+      int t = m / p.seq_patches;
+      int pi = m - t * p.seq_patches;
+      long row = (long)t * p.seq_stride + 1 + pi;
+      v += *(const f32x4_t*)(bias + n);
+      v += *(const f32x4_t*)(pos + (long)(1 + pi) * p.embed + n);
+      *(f32x4_t*)((float*)p.out + row * p.ldo + n) = v;
+      break;
+    }
+    case EPI_QKV: {
+      v += *(const f32x4_t*)(bias + n);
+      const int two_d = 2 * p.embed;
+      if (n < two_d) {
+        store4<T>((T*)p.out + (long)m * two_d + n, v);
+      } else {
+        int c = n - two_d;
+        int hd = c >> 6, d = c & 63;
+        int seq = m / p.seq_stride;
+        int i = m - seq * p.seq_stride;
+        long base = (((long)seq * p.heads + hd) * 64 + d) * p.kpad + i;
+        T* vt = (T*)p.vT;
+        store1<T>(vt + base, v[0]);
+        store1<T>(vt + base + p.kpad, v[1]);
+        store1<T>(vt + base + 2L * p.kpad, v[2]);
+        store1<T>(vt + base + 3L * p.kpad, v[3]);
+      }
+      break;
+    }
+    case EPI_PIXSHUF: {
+      int tap = n / p.psC;
+      int co = n - tap * p.psC;
+      int dy = tap >> 1, dx = tap & 1;
+      int x = m % p.psW;
+      int t = m / p.psW;
+      int y = t % p.psH;
+      int b = t / p.psH;
+      long orow = ((long)b * 2 * p.psH + 2 * y + dy) * (2L * p.psW) + 2 * x + dx;
+      if (bias) v += *(const f32x4_t*)(bias + co);
+      long o = orow * p.ldo + p.ps_coff + co;
+      if (p.out_f32)
+        store4<float>((float*)p.out + o, v);
+      else
+        store4<T>((T*)p.out + o, v);
+      if (p.out2) store4<T>((T*)p.out2 + o, relu4(v));
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN, int AMODE>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int RG_A = BM / 8, RG_W = BN / 8;  // 8-row groups (one glds wave-instruction each)
+  static_assert(RG_A % NW == 0, "A row groups must divide evenly over the waves");
+  constexpr int A_ITERS = RG_A / NW;
+  constexpr int W_ITERS = (RG_W + NW - 1) / NW;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int KE = 128 / ESZ;  // K elements per 128-byte LDS row
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  // ---- XCD-aware, bijective block -> logical tile id (blocks b and b+8 share an XCD) ----
+  const int nwg = gridDim.x;
+  int id;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_n = id % tiles_n;
+  const int tile_mg = id / tiles_n;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroups; ++i)
+    if (i < p.ngroups && tile_mg >= p.g_tile0[i]) g = i;
+  const int g_row0 = MD_SEL_G(p.g_row0, g);
+  const int g_arow0 = MD_SEL_G(p.g_arow0, g);
+  const int m_base = g_row0 + (tile_mg - MD_SEL_G(p.g_tile0, g)) * BM;
+  const int m_end = g_row0 + MD_SEL_G(p.g_rows, g);
+  const int n0 = tile_n * BN;
+  const char* Wg = (const char*)MD_SEL_G(p.W, g);
+  const char* Ab = (const char*)p.A;
+  long out_boff = 0;  // element offset of this batch in the output
+  if (p.batch > 1) {
+    const int by = blockIdx.y;
+    const int bo = by / p.batch_inner, bi = by - bo * p.batch_inner;
+    Ab += (bo * p.a_bs[0] + bi * p.a_bs[1]) * ESZ;
+    Wg += (bo * p.w_bs[0] + bi * p.w_bs[1]) * ESZ;
+    out_boff = bo * p.o_bs[0] + bi * p.o_bs[1];
+  }
+
+  // ---- per-lane global source pointers (swizzle applied on the source side) ----
+  const int lrow = lane >> 3;  // row inside an 8-row group
+  const int pc = lane & 7;     // physical 16-byte chunk inside the 128-byte row
+  const char* srcA[A_ITERS];
+  unsigned maskA[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int lc = pc ^ ((r >> 1) & 7);
+    int m = m_base + r;
+    m = m < m_end ? m : m_end - 1;
+    const long am = (long)g_arow0 + (m - g_row0);  // physical A row
+    if constexpr (AMODE == A_DENSE) {
+      srcA[i] = Ab + am * p.lda * ESZ + lc * 16;
+      maskA[i] = 0;
+    } else if constexpr (AMODE == A_INDEXED) {
+      srcA[i] = Ab + (long)p.a_index[am] * p.lda * ESZ + lc * 16;
+      maskA[i] = 0;
+    } else {
+      const int x = (int)(am % p.cW);
+      const int y = (int)((am / p.cW) % p.cH);
+      unsigned mk = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) mk |= 1u << (ky * 3 + kx);
+        }
+      maskA[i] = mk;
+      srcA[i] = Ab + am * p.cC * ESZ + lc * 16;
+    }
+  }
+  const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
+  const char* srcW[W_ITERS];
+#pragma unroll
+  for (int i = 0; i < W_ITERS; ++i) {
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int lc = pc ^ ((r >> 1) & 7);
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    srcW[i] = Wg + (long)n * ldw * ESZ + lc * 16;
+  }
+  const char* zsrc = (const char*)p.zero_page + pc * 16;
+
+  const int KT = p.K / KE;
+  // conv bookkeeping: k-tile -> (tap, channel block); all wave-uniform
+  const int cblocks = (AMODE == A_CONV3) ? p.cC / KE : 1;
+
+  auto issue = [&](int stage, int kt) {
+    char* sbase = smem + stage * STAGE_BYTES;
+    long a_delta;
+    int tap = 0;
+    if constexpr (AMODE == A_CONV3) {
+      tap = kt / cblocks;
+      const int cb = kt - tap * cblocks;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * ESZ + (long)cb * 128;
+    } else {
+      a_delta = (long)kt * 128;
+    }
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const char* s = srcA[i] + a_delta;
+      if constexpr (AMODE == A_CONV3) {
+        if (!((maskA[i] >> tap) & 1u)) s = zsrc;
+      }
+      glds16(s, sbase + (i * NW + wave) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < W_ITERS; ++i) {
+      const int rgw = i * NW + wave;
+      if (rgw < RG_W) glds16(srcW[i] + (long)kt * 128, sbase + BM * 128 + rgw * 1024);
+    }
+  };
+
+  f32x16_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int h = lane >> 5;
+  const int lane_off = (lane & 31) * 128 + ((((lane >> 1) & 7) ^ h) << 4);
+
+  issue(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) issue(cur ^ 1, kt + 1);
+    const char* As = smem + cur * STAGE_BYTES + wm * WTM * 128;
+    const char* Ws = smem + cur * STAGE_BYTES + BM * 128 + wn * WTN * 128;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = lane_off ^ (s << 5);
+      i32x4_t af[TM], wf[TN];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) af[b] = *(const i32x4_t*)(As + b * 4096 + off);
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[a], af[b], acc[a][b]);
+    }
+  }
+
+  // ---- epilogue: lane holds row m = ..+(lane&31); cols n = ..+8*(r>>2)+4*h+(r&3) ----
+  if (p.epi == EPI_HEAD) {
+    // depth head tail (mod.rs:108-111): relu(conv1+b1) . w_out + b_out, relu. N == 32 == one tile.
+    if constexpr (TN == 1 && WGN == 1) {
+      const float* bias = MD_SEL_G(p.bias, g);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = 8 * (r >> 2) + 4 * h + (r & 3);
+          float v = fmaxf(acc[0][b][r] + bias[n], 0.f);
+          part += v * p.head_w[n];
+        }
+        part += __shfl_xor(part, 32);
+        const int m = m_base + wm * WTM + b * 32 + (lane & 31);
+        if (h == 0 && m < m_end) ((float*)p.out)[m] = fmaxf(part + p.head_b, 0.f);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int m = m_base + wm * WTM + b * 32 + (lane & 31);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int n = n0 + wn * WTN + a * 32 + 8 * q4 + 4 * h;
+        if (m < m_end && n < p.N) {
+          f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
+          epilogue4<T>(p, g, m, n, v, out_boff);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN, int AMODE>
+static int launch_cfg(GemmParams& p, hipStream_t stream) {
+  int tiles_m = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    p.g_tile0[g] = tiles_m;
+    tiles_m += cdiv(p.g_rows[g], BM);
+  }
+  p.g_tile0[p.ngroups] = tiles_m;
+  for (int g = p.ngroups + 1; g <= kMaxGroups; ++g) p.g_tile0[g] = tiles_m;
+  const int tiles_n = cdiv(p.N, BN);
+  const long blocks = (long)tiles_m * tiles_n;
+  if (blocks <= 0) return MD_OK;
+  if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = gemm_kernel<T, BM, BN, WGM, WGN, AMODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(WGM * WGN * 64), smem, stream, p);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+template <typename T, int AMODE>
+static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
+  switch (tile) {
+    case TILE_256x256:
+      return launch_cfg<T, 256, 256, 2, 4, AMODE>(p, stream);
+    case TILE_128x128:
+      return launch_cfg<T, 128, 128, 2, 2, AMODE>(p, stream);
+    case TILE_256x32:
+      return launch_cfg<T, 256, 32, 8, 1, AMODE>(p, stream);
+    default:
+      MD_FAIL(MD_ERR_INVALID_ARG, "gemm: unknown tile config %d", tile);
+  }
+}
+
+
+template <typename T>
+static int launch_gemm_typed(GemmParams& p, int amode, int tile, hipStream_t stream) {
+  switch (amode) {
+    case A_DENSE:
+      return launch_tile<T, A_DENSE>(p, tile, stream);
+    case A_INDEXED:
+      return launch_tile<T, A_INDEXED>(p, tile, stream);
+    case A_CONV3:
+      return launch_tile<T, A_CONV3>(p, tile, stream);
+    default:
+      MD_FAIL(MD_ERR_INVALID_ARG, "gemm: bad amode %d", amode);
+  }
+}
+
+}  // namespace md

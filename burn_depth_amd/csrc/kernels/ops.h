@@ -1,0 +1,84 @@
+// Launchers for the HBM-bound and small kernels of the Depth Pro path (device pointers only).
+#pragma once
+
+#include "../md_common.h"
+
+namespace md {
+
+// a1  rgb_to_input_tensor (src/inference.rs:79-121): u8 HWC -> f32 NCHW, one image.
+int launch_rgb_to_input(const uint8_t* rgb, int w, int h, float* out, hipStream_t s);
+
+// a2  bilinear resize, fp32 NCHW (interpolate.rs:54-121). method: MD_INTERP_*.
+// post: 0 none, 1 = 1/clamp(v,1e-4,1e4) (DepthPro::infer tail, mod.rs:356).
+int launch_resize_bilinear(const float* in, int planes, int H, int W, float* out, int OH, int OW, int method,
+                           int post, hipStream_t s);
+
+// a2+a3 fused: image pyramid (x1 = resize 0.5, x2 = resize 0.25; encoder.rs:326-327), sliding
+// window split (encoder.rs:190-232) and 16x16 patch extraction, written as the A matrix of the
+// patch-embed GEMM: out[(tile*P + py*g + px)][c*ps*ps + ky*ps + kx], T = bf16 or float.
+// Tile order = reference cat order: level0 (j*steps0+i)*B+b, then level1, then level2 (x2).
+struct PyramidGeom {
+  int B, S, win, ps;         // S = 4*win input size, ps = ViT patch size
+  int steps0, stride0;       // level 0 (overlap .25)
+  int steps1, stride1;       // level 1 (overlap .5)
+  int method;                // MD_INTERP_*
+};
+int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s);
+
+// a3 stand-alone split on fp32 NCHW (debug tap / md_op_split).
+int launch_split(const float* x, int B, int C, int S, int win, int stride, int steps, float* out, hipStream_t s);
+// a6 stand-alone merge on fp32 NCHW (encoder.rs:234-282).
+int launch_merge(const float* tiles, int B, int C, int h, int w, int steps, int pad, float* out, int OH, int OW,
+                 hipStream_t s);
+
+// cls token + pos_embed[0] rows and zero padding rows of the fp32 residual stream.
+// x[seq*S + 0] = cls_g + pos_g[0]; x[seq*S + n_tokens ..] = 0, group g by sequence ranges.
+struct SeqGroups {
+  int ngroups;
+  int seq0[4];  // first sequence of each group
+  int nseq[4];
+  const float* a[4];  // per-group pointers (meaning depends on the kernel)
+  const float* b[4];
+};
+int launch_cls_init(float* x, int nseq_total, int S, int n_tokens, int D, const SeqGroups& g, hipStream_t s);
+
+// K3 LayerNorm over D (biased variance), fp32 rows -> T rows (bf16/f32) or fp32 (out_f32).
+// gamma/beta per group (a = gamma, b = beta); NULL gamma = non-affine. Rows grouped by sequence.
+int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
+                     int out_f32, hipStream_t s);
+// fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
+int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s);
+
+// layout converters (debug taps, stand-alone ops)
+int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s);
+int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int coff, float* out, int prec,
+                        hipStream_t s);
+int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s);
+int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s);
+
+// Small direct convolution, NHWC, fp32 accumulate (FOV head, fov.rs:16-49).
+// in: element type by in_prec (MD_PREC_BF16 -> bf16, MD_PREC_F32 -> float); w packed
+// [Cout][kh][kw][Cin] f32; add: optional f32 NHWC tensor added to the INPUT (fov.rs:185).
+int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
+                       const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s);
+
+// fov degrees -> focal length / fovy / ratio (mod.rs:330-346, 370-414). All [B] f32.
+int launch_fov_post(const float* fov_deg, int B, int H, int W, float* focal_px, float* fovy_rad, float* ratio,
+                    hipStream_t s);
+// inv = canonical * ratio[b]; post 1: depth = 1/clamp(inv); post 0: keep inv (then resize).
+int launch_depth_post(const float* canonical, const float* ratio, int B, long hw, float* out, int post, hipStream_t s);
+
+// softmax over rows of fp32 scores (fp32 attention path): row length ld, valid n, scale.
+int launch_softmax_rows(float* s, long rows, int n_valid, int ld, float scale, hipStream_t st);
+
+// test helpers for the stand-alone attention op: fused fp32 qkv [T, N, 3*heads*64] (timm layout) ->
+// engine layout (qk rows padded to SS per sequence, V transposed), and padded rows -> [T, N, D] fp32.
+int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad, void* qk, void* vT, int prec,
+                     hipStream_t s);
+int launch_unpad_rows(const void* in, int T, int N, int SS, int D, float* out, int prec, hipStream_t s);
+
+// fused multi-head attention, bf16 (K5): qk [rows, 2D] (q | k), vT [seq][heads][64][kpad], out [rows, D].
+int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
+                          int kpad, hipStream_t s);
+
+}  // namespace md

@@ -1,0 +1,726 @@
+// HBM-bound and small kernels of the Depth Pro path for gfx950: every thread moves 16 bytes
+// where the layout allows it, blocks are 256 threads (4 waves of 64), grids are capped and
+// grid-strided (MI355X: 256 CUs x 8 blocks).
+#include "ops.h"
+
+namespace md {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+static inline int grid_for(long work_items, int block = 256, int cap = 256 * 8) {
+  long g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1 rgb_to_input_tensor (src/inference.rs:103-111)
+// ------------------------------------------------------------------------------------------------
+__global__ void rgb_to_input_kernel(const uint8_t* __restrict__ rgb, long hw, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float sd[3] = {0.229f, 0.224f, 0.225f};
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = (float)rgb[i * 3 + c] / 255.0f;
+      out[c * hw + i] = (v - mean[c]) / sd[c];
+    }
+  }
+}
+
+int launch_rgb_to_input(const uint8_t* rgb, int w, int h, float* out, hipStream_t s) {
+  long hw = (long)w * h;
+  hipLaunchKernelGGL(rgb_to_input_kernel, dim3(grid_for(hw)), dim3(256), 0, s, rgb, hw, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2 bilinear sampling (interpolate.rs:29-52, 78-89). fp contraction off: bit-exact with the
+// reference's separate f32 multiplies and adds.
+// ------------------------------------------------------------------------------------------------
+struct AxisTap {
+  int i0, i1;
+  float d;
+};
+
+__device__ __forceinline__ AxisTap axis_tap(int o, int in_size, int out_size, int method) {
+#pragma clang fp contract(off)
+  AxisTap t;
+  if (method == MD_INTERP_CUSTOM) {
+    const float scale = (float)in_size / (float)out_size;
+    const float src = ((float)o + 0.5f) * scale - 0.5f;
+    const float f0 = floorf(src);
+    const float f1 = fminf(f0 + 1.0f, (float)(in_size - 1));
+    t.i0 = (int)fmaxf(f0, 0.0f);
+    t.i1 = (int)f1;
+    t.d = src - f0;
+  } else {  // align_corners = true (Burn module::interpolate)
+    float src = 0.f;
+    if (out_size > 1) src = (float)o * ((float)(in_size - 1) / (float)(out_size - 1));
+    const float f0 = floorf(src);
+    int i0 = (int)f0;
+    i0 = i0 < 0 ? 0 : (i0 > in_size - 1 ? in_size - 1 : i0);
+    t.i0 = i0;
+    t.i1 = i0 + 1 > in_size - 1 ? in_size - 1 : i0 + 1;
+    t.d = src - f0;
+  }
+  return t;
+}
+
+__device__ __forceinline__ float bilerp(const float* __restrict__ plane, int iw, const AxisTap& ty, const AxisTap& tx) {
+#pragma clang fp contract(off)
+  const float tl = plane[(long)ty.i0 * iw + tx.i0], tr = plane[(long)ty.i0 * iw + tx.i1];
+  const float bl = plane[(long)ty.i1 * iw + tx.i0], br = plane[(long)ty.i1 * iw + tx.i1];
+  const float top = tl * (1.0f - tx.d) + tr * tx.d;
+  const float bottom = bl * (1.0f - tx.d) + br * tx.d;
+  return top * (1.0f - ty.d) + bottom * ty.d;
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, int planes, int H, int W, float* __restrict__ out,
+                                       int OH, int OW, int method, int post) {
+  const long total = (long)planes * OH * OW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const long t = i / OW;
+    const int oy = (int)(t % OH);
+    const long pl = t / OH;
+    const AxisTap ty = axis_tap(oy, H, OH, method);
+    const AxisTap tx = axis_tap(ox, W, OW, method);
+    float v = bilerp(in + pl * (long)H * W, W, ty, tx);
+    if (post == 1) v = 1.0f / fminf(fmaxf(v, 1e-4f), 1e4f);
+    out[i] = v;
+  }
+}
+
+__global__ void copy_post_kernel(const float* __restrict__ in, long n, float* __restrict__ out, int post) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = in[i];
+    if (post == 1) v = 1.0f / fminf(fmaxf(v, 1e-4f), 1e4f);
+    out[i] = v;
+  }
+}
+
+int launch_resize_bilinear(const float* in, int planes, int H, int W, float* out, int OH, int OW, int method,
+                           int post, hipStream_t s) {
+  if (OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_SHAPE, "output size must be positive");
+  if (H == OH && W == OW) {  // identity (interpolate.rs:61-63)
+    const long n = (long)planes * H * W;
+    if (in != out || post)
+      hipLaunchKernelGGL(copy_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, n, out, post);
+  } else {
+    const long n = (long)planes * OH * OW;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, planes, H, W, out, OH, OW,
+                       method, post);
+  }
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2+a3 fused pyramid + split + patchify -> A matrix of the patch-embed GEMM
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float* v) {
+  *(f32x4_t*)p = (f32x4_t){v[0], v[1], v[2], v[3]};
+  *(f32x4_t*)(p + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
+  bf16x8_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3],
+                (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+  *(bf16x8_t*)p = b;
+}
+
+template <typename T>
+__global__ void pyramid_patchify_kernel(const float* __restrict__ x, PyramidGeom g, T* __restrict__ out) {
+  const int grid = g.win / g.ps;             // patches per tile side
+  const int P = grid * grid;
+  const int K = 3 * g.ps * g.ps;
+  const int K8 = K / 8;
+  const int n0 = g.steps0 * g.steps0 * g.B, n1 = g.steps1 * g.steps1 * g.B;
+  const long total = (long)(n0 + n1 + g.B) * P * K8;
+  const int S = g.S;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % K8) * 8;
+    const long row = e / K8;
+    const int pidx = (int)(row % P);
+    const int tile = (int)(row / P);
+    const int c = col / (g.ps * g.ps);
+    const int ky = (col / g.ps) % g.ps;
+    const int kx = col % g.ps;
+    const int py = pidx / grid, px = pidx % grid;
+    const int ty = py * g.ps + ky, tx = px * g.ps + kx;
+    int level, b, j, i, stride;
+    if (tile < n0) {
+      level = 0; b = tile % g.B; int ji = tile / g.B; j = ji / g.steps0; i = ji % g.steps0; stride = g.stride0;
+    } else if (tile < n0 + n1) {
+      level = 1; int t = tile - n0; b = t % g.B; int ji = t / g.B; j = ji / g.steps1; i = ji % g.steps1; stride = g.stride1;
+    } else {
+      level = 2; b = tile - n0 - n1; j = 0; i = 0; stride = 0;
+    }
+    const int Y = j * stride + ty, X = i * stride + tx;
+    const float* plane = x + ((long)b * 3 + c) * (long)S * S;
+    float v[8];
+    if (level == 0) {
+      const f32x4_t a0 = *(const f32x4_t*)(plane + (long)Y * S + X);
+      const f32x4_t a1 = *(const f32x4_t*)(plane + (long)Y * S + X + 4);
+      v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
+      v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
+    } else {
+      const int SL = level == 1 ? S / 2 : S / 4;  // compute_output_size(S, .5|.25), S % 4 == 0
+      const AxisTap tyy = axis_tap(Y, S, SL, g.method);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const AxisTap txx = axis_tap(X + q, S, SL, g.method);
+        v[q] = bilerp(plane, S, tyy, txx);
+      }
+    }
+    store8<T>(out + row * K + col, v);
+  }
+}
+
+int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s) {
+  if (g.ps % 8 != 0 || g.win % g.ps != 0 || g.S % 4 != 0)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "pyramid: patch %d / window %d / size %d unsupported", g.ps, g.win, g.S);
+  const int grid = g.win / g.ps;
+  const long total = (long)(g.steps0 * g.steps0 * g.B + g.steps1 * g.steps1 * g.B + g.B) * grid * grid *
+                     (3 * g.ps * g.ps / 8);
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(pyramid_patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, g, (float*)patches);
+  else
+    hipLaunchKernelGGL(pyramid_patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, g,
+                       (bf16_t*)patches);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a3 split / a6 merge on fp32 NCHW (stand-alone ops and debug taps)
+// ------------------------------------------------------------------------------------------------
+__global__ void split_kernel(const float* __restrict__ x, int B, int C, int S, int win, int stride, int steps,
+                             float* __restrict__ out) {
+  const long total = (long)steps * steps * B * C * win * win;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tx = (int)(e % win);
+    long t = e / win;
+    const int ty = (int)(t % win);
+    t /= win;
+    const int c = (int)(t % C);
+    t /= C;
+    const int b = (int)(t % B);
+    const int ji = (int)(t / B);
+    const int j = ji / steps, i = ji % steps;
+    out[e] = x[(((long)b * C + c) * S + j * stride + ty) * S + i * stride + tx];
+  }
+}
+
+int launch_split(const float* x, int B, int C, int S, int win, int stride, int steps, float* out, hipStream_t s) {
+  const long total = (long)steps * steps * B * C * win * win;
+  hipLaunchKernelGGL(split_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, B, C, S, win, stride, steps, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+__global__ void merge_kernel(const float* __restrict__ tiles, int B, int C, int h, int w, int steps, int pad,
+                             float* __restrict__ out, int OH, int OW) {
+  const long total = (long)B * C * OH * OW;
+  const int ih = h - 2 * pad, iw = w - 2 * pad;  // interior extent
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(e % OW);
+    long t = e / OW;
+    const int Y = (int)(t % OH);
+    t /= OH;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    int j = 0, i = 0;
+    if (steps > 1) {
+      j = Y < pad ? 0 : (Y - pad) / ih;
+      j = j > steps - 1 ? steps - 1 : j;
+      i = X < pad ? 0 : (X - pad) / iw;
+      i = i > steps - 1 ? steps - 1 : i;
+    }
+    const int ty = Y - j * ih, tx = X - i * iw;
+    const long tile = (long)(j * steps + i) * B + b;
+    out[e] = tiles[((tile * C + c) * h + ty) * w + tx];
+  }
+}
+
+int launch_merge(const float* tiles, int B, int C, int h, int w, int steps, int pad, float* out, int OH, int OW,
+                 hipStream_t s) {
+  const long total = (long)B * C * OH * OW;
+  hipLaunchKernelGGL(merge_kernel, dim3(grid_for(total)), dim3(256), 0, s, tiles, B, C, h, w, steps, pad, out, OH,
+                     OW);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cls token row + zero padding rows of the residual stream
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int group_of_seq(const SeqGroups& g, int seq) {
+  int r = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < g.ngroups && seq >= g.seq0[i]) r = i;
+  return r;
+}
+
+#define MD_SEL4(arr, g) ((g) == 0 ? (arr)[0] : (g) == 1 ? (arr)[1] : (g) == 2 ? (arr)[2] : (arr)[3])
+
+__global__ void cls_init_kernel(float* __restrict__ x, int nseq, int S, int n_tokens, int D, SeqGroups g) {
+  const int extra = 1 + (S - n_tokens);  // cls row + padding rows
+  const long total = (long)nseq * extra * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(e % D);
+    long t = e / D;
+    const int r = (int)(t % extra);
+    const int seq = (int)(t / extra);
+    const int gi = group_of_seq(g, seq);
+    if (r == 0) {
+      const float* cls = MD_SEL4(g.a, gi);
+      const float* pos = MD_SEL4(g.b, gi);
+      x[((long)seq * S) * D + d] = cls[d] + pos[d];
+    } else {
+      x[((long)seq * S + n_tokens + r - 1) * D + d] = 0.f;
+    }
+  }
+}
+
+int launch_cls_init(float* x, int nseq_total, int S, int n_tokens, int D, const SeqGroups& g, hipStream_t s) {
+  const long total = (long)nseq_total * (1 + S - n_tokens) * D;
+  hipLaunchKernelGGL(cls_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, nseq_total, S, n_tokens, D, g);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 LayerNorm: one wave per row, row held in registers (D <= 1024), two-pass statistics in fp32.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <typename TO, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, TO* __restrict__ out, long rows,
+                                                        int D, float eps, int S, SeqGroups g) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long row = wave_id; row < rows; row += nwaves) {
+    const float* xr = x + row * D;
+    f32x4_t v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane * 4 + k * 256;
+      if (i < D) {
+        v[k] = *(const f32x4_t*)(xr + i);
+        sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+      } else {
+        v[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane * 4 + k * 256;
+      if (i < D) {
+        const f32x4_t c = v[k] - mean;
+        sq += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+    const int gi = group_of_seq(g, (int)(row / S));
+    const float* gamma = MD_SEL4(g.a, gi);
+    const float* beta = MD_SEL4(g.b, gi);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane * 4 + k * 256;
+      if (i < D) {
+        f32x4_t y = (v[k] - mean) * rstd;
+        if (gamma) y = y * *(const f32x4_t*)(gamma + i) + *(const f32x4_t*)(beta + i);
+        if constexpr (sizeof(TO) == 4) {
+          *(f32x4_t*)((float*)out + row * D + i) = y;
+        } else {
+          bf16x4_t b = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
+          *(bf16x4_t*)((bf16_t*)out + row * D + i) = b;
+        }
+      }
+    }
+  }
+}
+
+int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
+                     int out_f32, hipStream_t s) {
+  if (D % 4 != 0 || D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+  const int nv = (D + 255) / 256;
+  const int grid = grid_for(rows * 64);
+  const bool f32o = out_f32 || prec == MD_PREC_F32;
+#define MD_LN(NV)                                                                                                   \
+  if (f32o)                                                                                                         \
+    hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3(grid), dim3(256), 0, s, x, (float*)out, rows, D, eps, S, g); \
+  else                                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g);
+  switch (nv) {
+    case 1: MD_LN(1) break;
+    case 2: MD_LN(2) break;
+    case 3: MD_LN(3) break;
+    default: MD_LN(4) break;
+  }
+#undef MD_LN
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-type converters
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void f32_to_rows_kernel(const float* __restrict__ in, long n, T* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if constexpr (sizeof(T) == 4)
+      ((float*)out)[i] = in[i];
+    else
+      *((__bf16*)out + i) = (__bf16)in[i];
+  }
+}
+template <typename T>
+__global__ void rows_to_f32_kernel(const T* __restrict__ in, long n, float* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if constexpr (sizeof(T) == 4)
+      out[i] = ((const float*)in)[i];
+    else
+      out[i] = (float)*((const __bf16*)in + i);
+  }
+}
+
+int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s) {
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(f32_to_rows_kernel<float>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (float*)out);
+  else
+    hipLaunchKernelGGL(f32_to_rows_kernel<bf16_t>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (bf16_t*)out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s) {
+  return launch_f32_to_rows(x, count, out, prec, s);
+}
+int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s) {
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(rows_to_f32_kernel<float>, dim3(grid_for(count)), dim3(256), 0, s, (const float*)in, count, out);
+  else
+    hipLaunchKernelGGL(rows_to_f32_kernel<bf16_t>, dim3(grid_for(count)), dim3(256), 0, s, (const bf16_t*)in, count,
+                       out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, int H, int W, T* __restrict__ out,
+                                    int relu) {
+  const long total = (long)B * C * H * W;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    long t = e / C;
+    const int xw = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float v = in[(((long)b * C + c) * H + y) * W + xw];
+    if (relu) v = fmaxf(v, 0.f);
+    if constexpr (sizeof(T) == 4)
+      ((float*)out)[e] = v;
+    else
+      *((__bf16*)out + e) = (__bf16)v;
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, int B, int C, int H, int W, long ld, int coff,
+                                    float* __restrict__ out) {
+  const long total = (long)B * C * H * W;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int xw = (int)(e % W);
+    long t = e / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const long src = (((long)b * H + y) * W + xw) * ld + coff + c;
+    if constexpr (sizeof(T) == 4)
+      out[e] = ((const float*)in)[src];
+    else
+      out[e] = (float)*((const __bf16*)in + src);
+  }
+}
+
+int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s) {
+  const long total = (long)B * C * H * W;
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W, (float*)out,
+                       relu);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W,
+                       (bf16_t*)out, relu);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int coff, float* out, int prec,
+                        hipStream_t s) {
+  const long total = (long)B * C * H * W;
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, B, C, H, W,
+                       ld, coff, out);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, B, C, H,
+                       W, ld, coff, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small direct convolution (FOV head): one wave per output element, lanes stride over k*k*Cin.
+// ------------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__ in, const float* __restrict__ add,
+                                                          int B, int H, int W, int Cin, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, int Cout, int k, int stride,
+                                                          int pad, int relu, float* __restrict__ out, int OH, int OW) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long total = (long)B * OH * OW * Cout;
+  const int KK = k * k * Cin;
+  for (long e = wave_id; e < total; e += nwaves) {
+    const int co = (int)(e % Cout);
+    long t = e / Cout;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float acc = 0.f;
+    for (int idx = lane; idx < KK; idx += 64) {
+      const int ci = idx % Cin;
+      const int tap = idx / Cin;
+      const int ky = tap / k, kx = tap % k;
+      const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const long src = (((long)b * H + iy) * W + ix) * Cin + ci;
+        float v;
+        if constexpr (sizeof(TI) == 4)
+          v = ((const float*)in)[src];
+        else
+          v = (float)*((const __bf16*)in + src);
+        if (add) v += add[src];
+        acc += v * w[(long)co * KK + idx];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      acc += bias ? bias[co] : 0.f;
+      if (relu) acc = fmaxf(acc, 0.f);
+      out[e] = acc;
+    }
+  }
+}
+
+int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
+                       const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s) {
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+  if (OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_SHAPE, "conv_direct: input %dx%d smaller than kernel %d", H, W, k);
+  const long total = (long)B * OH * OW * Cout;
+  const int grid = grid_for(total * 64);
+  if (in_prec == MD_PREC_F32)
+    hipLaunchKernelGGL(conv_direct_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, add, B, H, W, Cin, w,
+                       bias, Cout, k, stride, pad, relu, out, OH, OW);
+  else
+    hipLaunchKernelGGL(conv_direct_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, add, B, H, W, Cin,
+                       w, bias, Cout, k, stride, pad, relu, out, OH, OW);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12/a13 scalar tail (depth_pro/mod.rs:330-346, 370-414)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void fov_scalar_math(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad,
+                                                float* ratio) {
+#pragma clang fp contract(off)
+  const float fovx_rad = fovx_deg * (float)(3.14159265358979323846 / 180.0);
+  const float denom = tanf(fovx_rad * 0.5f);
+  const float focal = ((float)W * 0.5f) / denom;
+  if (focal_px) *focal_px = focal;
+  if (ratio) *ratio = (float)W / focal;
+  if (fovy_rad) {
+    const float k = (float)0.273;
+    const float pi4 = (float)0.78539816339744830962, pi2 = (float)1.57079632679489661923;
+    const float aspect = (float)((double)H / (double)W);
+    const float t = tanf(fovx_rad * 0.5f) * aspect;
+    const float sgn = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
+    const float ax = fabsf(t);
+    const float use_inv = ax > 1.0f ? 1.f : 0.f;
+    const float inv = 1.0f / ax;
+    const float xr = ax * (1.0f - use_inv) + (use_inv != 0.f ? inv * use_inv : 0.f);
+    const float inner = (1.0f - xr) * k + pi4;
+    const float atan_reduced = xr * inner;
+    const float delta = pi2 - atan_reduced * 2.0f;
+    const float atan_ax = atan_reduced + delta * use_inv;
+    *fovy_rad = atan_ax * sgn * 2.0f;
+  }
+}
+
+__global__ void fov_post_kernel(const float* __restrict__ fov_deg, int B, int H, int W, float* focal_px,
+                                float* fovy_rad, float* ratio) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) fov_scalar_math(fov_deg[b], H, W, focal_px ? focal_px + b : nullptr, fovy_rad ? fovy_rad + b : nullptr,
+                             ratio ? ratio + b : nullptr);
+}
+
+int launch_fov_post(const float* fov_deg, int B, int H, int W, float* focal_px, float* fovy_rad, float* ratio,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(fov_post_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, fov_deg, B, H, W, focal_px, fovy_rad, ratio);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+void fov_scalar_host(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad) {
+  fov_scalar_math(fovx_deg, H, W, focal_px, fovy_rad, nullptr);
+}
+
+__global__ void depth_post_kernel(const float* __restrict__ canonical, const float* __restrict__ ratio, int B, long hw,
+                                  float* __restrict__ out, int post) {
+#pragma clang fp contract(off)
+  const long total = (long)B * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float v = canonical[i] * ratio[i / hw];
+    if (post == 1) v = 1.0f / fminf(fmaxf(v, 1e-4f), 1e4f);
+    out[i] = v;
+  }
+}
+
+int launch_depth_post(const float* canonical, const float* ratio, int B, long hw, float* out, int post, hipStream_t s) {
+  hipLaunchKernelGGL(depth_post_kernel, dim3(grid_for((long)B * hw)), dim3(256), 0, s, canonical, ratio, B, hw, out,
+                     post);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax on fp32 scores (fp32 attention path): one wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, long rows, int n_valid, int ld,
+                                                           float scale) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long row = wave_id; row < rows; row += nwaves) {
+    float* r = s + row * ld;
+    float mx = -INFINITY;
+    for (int i = lane; i < n_valid; i += 64) mx = fmaxf(mx, r[i] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < n_valid; i += 64) {
+      const float e = expf(r[i] * scale - mx);
+      r[i] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < ld; i += 64) r[i] = i < n_valid ? r[i] * inv : 0.f;
+  }
+}
+
+int launch_softmax_rows(float* s, long rows, int n_valid, int ld, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows * 64)), dim3(256), 0, st, s, rows, n_valid, ld, scale);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone attention op helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void qkv_split_kernel(const float* __restrict__ qkv, int Tn, int N, int heads, int SS, int kpad,
+                                 T* __restrict__ qk, T* __restrict__ vT) {
+  const int D = heads * 64;
+  const long total = (long)Tn * N * 3 * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % (3 * D));
+    const long t = e / (3 * D);
+    const int i = (int)(t % N);
+    const int seq = (int)(t / N);
+    const float v = qkv[e];
+    long dst;
+    T* base;
+    if (c < 2 * D) {
+      base = qk;
+      dst = ((long)seq * SS + i) * 2 * D + c;
+    } else {
+      const int cc = c - 2 * D;
+      base = vT;
+      dst = (((long)seq * heads + (cc >> 6)) * 64 + (cc & 63)) * kpad + i;
+    }
+    if constexpr (sizeof(T) == 4)
+      ((float*)base)[dst] = v;
+    else
+      *((__bf16*)base + dst) = (__bf16)v;
+  }
+}
+
+int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad, void* qk, void* vT, int prec,
+                     hipStream_t s) {
+  const long total = (long)T * N * 3 * heads * 64;
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, qkv, T, N, heads, SS, kpad,
+                       (float*)qk, (float*)vT);
+  else
+    hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, qkv, T, N, heads, SS, kpad,
+                       (bf16_t*)qk, (bf16_t*)vT);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+template <typename T>
+__global__ void unpad_rows_kernel(const T* __restrict__ in, int Tn, int N, int SS, int D, float* __restrict__ out) {
+  const long total = (long)Tn * N * D;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(e % D);
+    const long t = e / D;
+    const int i = (int)(t % N);
+    const int seq = (int)(t / N);
+    const long src = ((long)seq * SS + i) * D + d;
+    if constexpr (sizeof(T) == 4)
+      out[e] = ((const float*)in)[src];
+    else
+      out[e] = (float)*((const __bf16*)in + src);
+  }
+}
+
+int launch_unpad_rows(const void* in, int T, int N, int SS, int D, float* out, int prec, hipStream_t s) {
+  const long total = (long)T * N * D;
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(unpad_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, T, N, SS, D,
+                       out);
+  else
+    hipLaunchKernelGGL(unpad_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, T, N, SS,
+                       D, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+}  // namespace md

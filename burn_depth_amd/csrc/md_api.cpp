@@ -1,0 +1,520 @@
+// extern "C" surface of libmi_depth.so (include/mi_depth.h).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "md_engine.h"
+
+using namespace md;
+
+namespace {
+struct DevBuf {  // scoped device allocation for the stand-alone test operators
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (hipMalloc(&p, bytes + 4096) != hipSuccess) {
+      set_error("hipMalloc(%zu) failed", bytes);
+      return MD_ERR_OOM;
+    }
+    return hipMemset(p, 0, bytes + 4096) == hipSuccess ? MD_OK : MD_ERR_HIP;
+  }
+};
+hipStream_t pick_stream(md_device_t dev, void* stream) { return stream ? (hipStream_t)stream : dev->stream; }
+int ke_of(int prec) { return prec == MD_PREC_F32 ? 32 : 64; }
+size_t esz_of(int prec) { return prec == MD_PREC_F32 ? 4 : 2; }
+}  // namespace
+
+extern "C" {
+
+const char* md_last_error(void) { return get_error(); }
+const char* md_version(void) { return "mi_depth 0.1 (gfx950)"; }
+
+int md_device_open(int hip_ordinal, md_device_t* out) {
+  if (!out) MD_FAIL(MD_ERR_INVALID_ARG, "out is null");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) MD_FAIL(MD_ERR_HIP, "no HIP device available");
+  if (hip_ordinal < 0 || hip_ordinal >= n) MD_FAIL(MD_ERR_INVALID_ARG, "device ordinal %d out of range [0,%d)", hip_ordinal, n);
+  MD_HIP(hipSetDevice(hip_ordinal));
+  md_device_s* d = new md_device_s();
+  d->ordinal = hip_ordinal;
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete d;
+    MD_FAIL(MD_ERR_HIP, "hipStreamCreate failed");
+  }
+  *out = d;
+  return MD_OK;
+}
+
+int md_device_close(md_device_t dev) {
+  if (!dev) return MD_OK;
+  (void)hipSetDevice(dev->ordinal);
+  if (dev->stream) (void)hipStreamDestroy(dev->stream);
+  delete dev;
+  return MD_OK;
+}
+
+int md_device_synchronize(md_device_t dev) {
+  if (!dev) MD_FAIL(MD_ERR_INVALID_ARG, "device is null");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  MD_HIP(hipDeviceSynchronize());
+  return MD_OK;
+}
+
+void md_depth_pro_cfg_default(md_depth_pro_cfg* cfg) {
+  if (!cfg) return;
+  cfg->patch_encoder_preset = "dinov2l16_384";
+  cfg->image_encoder_preset = "dinov2l16_384";
+  cfg->fov_encoder_preset = "dinov2l16_384";
+  cfg->decoder_features = 256;
+  cfg->use_fov_head = 1;
+  cfg->interpolation = MD_INTERP_CUSTOM;
+  cfg->precision = MD_PREC_BF16;
+  cfg->max_batch = 1;
+  cfg->ln_eps = 1e-6f;
+}
+
+int md_depth_pro_create(md_device_t dev, const md_depth_pro_cfg* cfg, uint64_t seed, int init_scheme, md_model_t* out) {
+  if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/out is null");
+  ModelCfg mc;
+  MD_TRY(parse_cfg(cfg, &mc));
+  md_model_t m = nullptr;
+  MD_TRY(model_create(dev, mc, &m));
+  int s = model_init_seeded(m, seed, init_scheme);
+  if (s != MD_OK) {
+    model_destroy(m);
+    return s;
+  }
+  *out = m;
+  return MD_OK;
+}
+
+int md_depth_pro_load_with_config(md_device_t dev, const md_depth_pro_cfg* cfg, const char* path, md_model_t* out) {
+  if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/out is null");
+  ModelCfg mc;
+  MD_TRY(parse_cfg(cfg, &mc));
+  // fail on I/O problems before touching the GPU (RecorderError path, mod.rs:193-208)
+  {
+    Container probe;
+    MD_TRY(read_container(path, &probe));
+  }
+  md_model_t m = nullptr;
+  MD_TRY(model_create(dev, mc, &m));
+  int s = model_load_container(m, path);
+  if (s != MD_OK) {
+    model_destroy(m);
+    return s;
+  }
+  *out = m;
+  return MD_OK;
+}
+
+int md_depth_pro_load(md_device_t dev, const char* path, md_model_t* out) {
+  md_depth_pro_cfg c;
+  md_depth_pro_cfg_default(&c);
+  return md_depth_pro_load_with_config(dev, &c, path, out);
+}
+
+int md_model_param_count(md_model_t m) { return m ? (int)m->params.size() : 0; }
+
+int md_model_param_info(md_model_t m, int index, const char** name, size_t* count) {
+  if (!m || index < 0 || index >= (int)m->params.size()) MD_FAIL(MD_ERR_INVALID_ARG, "parameter index %d out of range", index);
+  if (name) *name = m->params[index].name.c_str();
+  if (count) *count = m->params[index].count();
+  return MD_OK;
+}
+
+int md_model_set_tensor(md_model_t m, const char* name, const float* host_data, size_t count) {
+  if (!m || !name || !host_data) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  auto it = m->pindex.find(name);
+  if (it == m->pindex.end()) MD_FAIL(MD_ERR_INVALID_ARG, "unknown parameter `%s`", name);
+  if (m->params[it->second].count() != count)
+    MD_FAIL(MD_ERR_SHAPE, "parameter `%s` has %zu elements, got %zu", name, m->params[it->second].count(), count);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  MD_HIP(hipMemcpy(m->w32[it->second], host_data, count * 4, hipMemcpyHostToDevice));
+  m->committed = false;
+  return MD_OK;
+}
+
+int md_model_get_tensor(md_model_t m, const char* name, float* host_data, size_t count) {
+  if (!m || !name || !host_data) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  auto it = m->pindex.find(name);
+  if (it == m->pindex.end()) MD_FAIL(MD_ERR_INVALID_ARG, "unknown parameter `%s`", name);
+  if (m->params[it->second].count() != count)
+    MD_FAIL(MD_ERR_SHAPE, "parameter `%s` has %zu elements, got %zu", name, m->params[it->second].count(), count);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  MD_HIP(hipMemcpy(host_data, m->w32[it->second], count * 4, hipMemcpyDeviceToHost));
+  return MD_OK;
+}
+
+int md_model_commit_weights(md_model_t m) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  return model_commit(m);
+}
+
+int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes) {
+  if (!m || !device_ptr || !bytes) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  *device_ptr = m->w32_base;
+  *bytes = m->w32_bytes;
+  m->committed = false;  // the caller is about to overwrite it (broadcast); commit afterwards
+  return MD_OK;
+}
+
+int md_model_destroy(md_model_t m) { return model_destroy(m); }
+
+int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
+                       float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream) {
+  if (!nchw) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");
+  return model_infer(m, nchw, B, H, W, in_kind, depth, focallength_px, fovx_deg, fovy_rad, out_kind, (hipStream_t)stream,
+                     nullptr, 0);
+}
+
+int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, int h, int in_kind, float* depth,
+                      float* focallength_px, float* fovy_rad, int out_kind, void* stream) {
+  if (!rgb) MD_FAIL(MD_ERR_INVALID_ARG, "rgb pointer is null");
+  if (w <= 0 || h <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid image size %dx%d", w, h);
+  // inference.rs:85-95: length check comes first and is an Err, not a panic
+  const size_t expected = (size_t)w * (size_t)h * 3;
+  if (rgb_len != expected) MD_FAIL(MD_ERR_SHAPE, "expected %zu RGB bytes for %dx%d, got %zu", expected, w, h, rgb_len);
+  return model_infer(m, nullptr, 1, h, w, in_kind, depth, focallength_px, nullptr, fovy_rad, out_kind, (hipStream_t)stream,
+                     rgb, rgb_len);
+}
+
+int md_model_query(md_model_t m, const char* key, int64_t* out) {
+  if (!m || !key || !out) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  const std::string k = key;
+  if (k == "img_size") *out = m->S;
+  else if (k == "patch_window") *out = m->win;
+  else if (k == "interpolation") *out = m->cfg.interpolation;
+  else if (k == "precision") *out = m->prec;
+  else if (k == "max_batch") *out = m->cfg.max_batch;
+  else if (k == "num_params") {
+    int64_t n = 0;
+    for (auto& p : m->params) n += (int64_t)p.count();
+    *out = n;
+  } else if (k == "workspace_bytes") *out = (int64_t)m->ws.cap;
+  else if (k == "weight_bytes") *out = (int64_t)(m->w32_bytes + m->wpk_bytes);
+  else if (k == "tiles_per_image") *out = m->steps0 * m->steps0 + m->steps1 * m->steps1 + 1;
+  else if (k == "seq_stride") *out = m->SS;
+  else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
+  return MD_OK;
+}
+
+int md_model_enable_taps(md_model_t m, int enable) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  m->taps_enabled = enable != 0;
+  return MD_OK;
+}
+
+int md_model_read_tap(md_model_t m, const char* name, float* host_data, size_t capacity, int64_t dims[4]) {
+  if (!m || !name) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  auto it = m->taps.find(name);
+  if (it == m->taps.end() || !it->second.dev) MD_FAIL(MD_ERR_INVALID_ARG, "tap `%s` was not captured", name);
+  if (dims) memcpy(dims, it->second.dims, sizeof(int64_t) * 4);
+  if (!host_data) return MD_OK;
+  if (capacity < it->second.count) MD_FAIL(MD_ERR_SHAPE, "tap `%s` needs %zu floats, capacity %zu", name, it->second.count, capacity);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  MD_HIP(hipDeviceSynchronize());
+  MD_HIP(hipMemcpy(host_data, it->second.dev, it->second.count * 4, hipMemcpyDeviceToHost));
+  return MD_OK;
+}
+
+int md_model_enable_timing(md_model_t m, int enable) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  m->timing_enabled = enable != 0;
+  return MD_OK;
+}
+
+int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls, int cap, int* n) {
+  if (!m || !n) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  MD_HIP(hipDeviceSynchronize());
+  m->timing_names_out.clear();
+  std::vector<float> tot;
+  std::vector<int> cnt;
+  for (auto& t : m->timing) {
+    float e = 0.f;
+    if (hipEventElapsedTime(&e, t.a, t.b) != hipSuccess) continue;
+    size_t i = 0;
+    for (; i < m->timing_names_out.size(); ++i)
+      if (m->timing_names_out[i] == t.name) break;
+    if (i == m->timing_names_out.size()) {
+      m->timing_names_out.push_back(t.name);
+      tot.push_back(0.f);
+      cnt.push_back(0);
+    }
+    tot[i] += e;
+    cnt[i] += 1;
+  }
+  *n = (int)m->timing_names_out.size();
+  for (int i = 0; i < *n && i < cap; ++i) {
+    if (names) names[i] = m->timing_names_out[i].c_str();
+    if (ms) ms[i] = tot[i];
+    if (calls) calls[i] = cnt[i];
+  }
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone operators
+// ------------------------------------------------------------------------------------------------
+int md_op_rgb_to_input(md_device_t dev, const uint8_t* rgb_dev, size_t rgb_len, int w, int h, float* out_dev, void* stream) {
+  if (!dev || !rgb_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (w <= 0 || h <= 0 || rgb_len != (size_t)w * h * 3)
+    MD_FAIL(MD_ERR_SHAPE, "expected %zu RGB bytes for %dx%d, got %zu", (size_t)w * h * 3, w, h, rgb_len);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  return launch_rgb_to_input(rgb_dev, w, h, out_dev, pick_stream(dev, stream));
+}
+
+int md_op_resize_bilinear(md_device_t dev, const float* in_dev, int B, int C, int H, int W, float* out_dev, int OH, int OW,
+                          int method, void* stream) {
+  if (!dev || !in_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape");
+  if (method != MD_INTERP_CUSTOM && method != MD_INTERP_BURN) MD_FAIL(MD_ERR_INVALID_ARG, "unknown interpolation method %d", method);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  return launch_resize_bilinear(in_dev, B * C, H, W, out_dev, OH, OW, method, 0, pick_stream(dev, stream));
+}
+
+int md_op_resize_output_size(int H, int W, float scale_h, float scale_w, int* oh, int* ow) {
+  if (!oh || !ow) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  // interpolate.rs:24-27
+  const long a = (long)std::floor((float)H * scale_h), b = (long)std::floor((float)W * scale_w);
+  *oh = (int)(a > 1 ? a : 1);
+  *ow = (int)(b > 1 ? b : 1);
+  return MD_OK;
+}
+
+int md_op_split(md_device_t dev, const float* in_dev, int B, int C, int S, int window, float overlap, float* out_dev,
+                int* steps_out, void* stream) {
+  if (!dev || !in_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || C <= 0 || S <= 0 || window <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  int stride, steps;
+  split_geometry(S, window, overlap, &stride, &steps);
+  if (steps_out) *steps_out = steps;
+  if (!out_dev) return MD_OK;  // geometry query
+  if ((steps - 1) * stride + window > S) MD_FAIL(MD_ERR_SHAPE, "window %d with stride %d does not tile %d", window, stride, S);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  return launch_split(in_dev, B, C, S, window, stride, steps, out_dev, pick_stream(dev, stream));
+}
+
+int md_op_merge(md_device_t dev, const float* in_dev, int tiles, int C, int h, int w, int batch, int padding, float* out_dev,
+                int* out_h, int* out_w, void* stream) {
+  if (!dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (tiles <= 0 || batch <= 0 || C <= 0 || h <= 0 || w <= 0 || padding < 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  const int steps = (int)std::lround(std::sqrt((double)(tiles / batch)));  // encoder.rs:240
+  if (steps <= 0 || steps * steps * batch != tiles) MD_FAIL(MD_ERR_SHAPE, "%d tiles is not steps^2 * batch(%d)", tiles, batch);
+  if (steps > 1 && (h - 2 * padding <= 0 || w - 2 * padding <= 0)) MD_FAIL(MD_ERR_SHAPE, "padding %d too large for %dx%d tiles", padding, h, w);
+  const int OH = merged_extent(h, steps, padding), OW = merged_extent(w, steps, padding);
+  if (out_h) *out_h = OH;
+  if (out_w) *out_w = OW;
+  if (!out_dev || !in_dev) return MD_OK;
+  MD_HIP(hipSetDevice(dev->ordinal));
+  return launch_merge(in_dev, batch, C, h, w, steps, padding, out_dev, OH, OW, pick_stream(dev, stream));
+}
+
+int md_op_layernorm(md_device_t dev, const float* x_dev, const float* gamma_dev, const float* beta_dev, int rows, int D,
+                    float eps, float* out_dev, void* stream) {
+  if (!dev || !x_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (rows <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid rows");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  SeqGroups g;
+  memset(&g, 0, sizeof(g));
+  g.ngroups = 1;
+  g.nseq[0] = rows;
+  g.a[0] = gamma_dev;
+  g.b[0] = beta_dev;
+  return launch_layernorm(x_dev, out_dev, rows, D, eps, 1, g, MD_PREC_F32, 1, pick_stream(dev, stream));
+}
+
+int md_op_linear(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int M, int N, int K, int act,
+                 int precision, float* out_dev, void* stream) {
+  if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = pick_stream(dev, stream);
+  DevBuf xa, wa;
+  MD_TRY(xa.alloc((size_t)M * K * esz_of(precision)));
+  MD_TRY(wa.alloc((size_t)N * K * esz_of(precision)));
+  MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st));
+  MD_TRY(launch_f32_to_rows(w_dev, (long)N * K, wa.p, precision, st));
+  GemmParams p;
+  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = K;
+  p.epi = EPI_STORE; p.act = act; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = out_dev; p.ldo = N;
+  MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_AUTO, st));
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int M, int N, int K,
+                      int act, int precision, int tile, float* out_dev, void* stream) {
+  if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = pick_stream(dev, stream);
+  DevBuf xa, wa;
+  MD_TRY(xa.alloc((size_t)M * K * esz_of(precision)));
+  MD_TRY(wa.alloc((size_t)N * K * esz_of(precision)));
+  MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st));
+  MD_TRY(launch_f32_to_rows(w_dev, (long)N * K, wa.p, precision, st));
+  GemmParams p;
+  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = K;
+  p.epi = EPI_STORE; p.act = act; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = out_dev; p.ldo = N;
+  MD_TRY(launch_gemm(p, A_DENSE, precision, tile, st));
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int heads, int precision, float* out_dev, void* stream) {
+  if (!dev || !qkv_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (T <= 0 || N <= 0 || heads <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = pick_stream(dev, stream);
+  const int D = heads * 64, SS = (N + 3) / 4 * 4, kpad = (N + 63) / 64 * 64;
+  const size_t es = esz_of(precision);
+  DevBuf qk, vT, ao, sc;
+  MD_TRY(qk.alloc(((size_t)T * SS + 64) * 2 * D * es));
+  MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * es));
+  MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * es));
+  MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, precision, st));
+  if (precision == MD_PREC_BF16) {
+    MD_TRY(launch_attention_bf16(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, st));
+  } else {
+    MD_TRY(sc.alloc((size_t)T * heads * SS * kpad * 4));
+    GemmParams p;
+    p.N = SS; p.K = 64; p.ngroups = 1; p.g_rows[0] = N;
+    p.batch = T * heads; p.batch_inner = heads;
+    p.A = qk.p; p.lda = 2 * D; p.a_bs[0] = (long)SS * 2 * D; p.a_bs[1] = 64;
+    p.W[0] = (const float*)qk.p + D; p.ldw = 2 * D; p.w_bs[0] = (long)SS * 2 * D; p.w_bs[1] = 64;
+    p.epi = EPI_STORE; p.out_f32 = 1; p.out = sc.p; p.ldo = kpad;
+    p.o_bs[0] = (long)heads * SS * kpad; p.o_bs[1] = (long)SS * kpad;
+    MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_128x128, st));
+    MD_TRY(launch_softmax_rows((float*)sc.p, (long)T * heads * SS, N, kpad, 0.125f, st));
+    GemmParams q;
+    q.N = 64; q.K = kpad; q.ngroups = 1; q.g_rows[0] = N;
+    q.batch = T * heads; q.batch_inner = heads;
+    q.A = sc.p; q.lda = kpad; q.a_bs[0] = (long)heads * SS * kpad; q.a_bs[1] = (long)SS * kpad;
+    q.W[0] = vT.p; q.ldw = kpad; q.w_bs[0] = (long)heads * 64 * kpad; q.w_bs[1] = 64L * kpad;
+    q.epi = EPI_STORE; q.out = ao.p; q.ldo = D; q.o_bs[0] = (long)SS * D; q.o_bs[1] = 64;
+    MD_TRY(launch_gemm(q, A_DENSE, precision, TILE_128x128, st));
+  }
+  MD_TRY(launch_unpad_rows(ao.p, T, N, SS, D, out_dev, precision, st));
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+int md_op_conv3x3(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int B, int Cin, int H, int W,
+                  int Cout, int pre_relu, int precision, float* out_dev, void* stream) {
+  if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  if (Cin % ke_of(precision) != 0 || Cout % 4 != 0)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "conv3x3: Cin=%d must be a multiple of %d and Cout=%d of 4", Cin, ke_of(precision), Cout);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = pick_stream(dev, stream);
+  const size_t es = esz_of(precision);
+  DevBuf xa, wa, oa, zp;
+  MD_TRY(xa.alloc((size_t)B * H * W * Cin * es));
+  MD_TRY(wa.alloc((size_t)Cout * 9 * Cin * es));
+  MD_TRY(oa.alloc((size_t)B * H * W * Cout * 4));
+  MD_TRY(zp.alloc(4096));
+  MD_TRY(launch_nchw_to_nhwc(x_dev, B, Cin, H, W, xa.p, precision, pre_relu, st));
+  PackEntry e;
+  e.kind = PACK_CONV3; e.d0 = Cout; e.d1 = Cin; e.k = 3; e.kp = Cin; e.dst = wa.p;
+  MD_TRY(pack_weight(w_dev, e, precision, st));
+  GemmParams p;
+  p.N = Cout; p.K = 9 * Cin; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p;
+  p.A = xa.p; p.cH = H; p.cW = W; p.cC = Cin; p.zero_page = zp.p;
+  p.epi = EPI_STORE; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
+  MD_TRY(launch_gemm(p, A_CONV3, precision, TILE_AUTO, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, H, W, Cout, 0, out_dev, MD_PREC_F32, st));
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+int md_op_deconv2x2(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int B, int Cin, int H,
+                    int W, int Cout, int precision, float* out_dev, void* stream) {
+  if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  if (Cin % ke_of(precision) != 0 || Cout % 4 != 0)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "deconv: Cin=%d must be a multiple of %d and Cout=%d of 4", Cin, ke_of(precision), Cout);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = pick_stream(dev, stream);
+  const size_t es = esz_of(precision);
+  DevBuf xa, wa, oa;
+  MD_TRY(xa.alloc((size_t)B * H * W * Cin * es));
+  MD_TRY(wa.alloc((size_t)4 * Cout * Cin * es));
+  MD_TRY(oa.alloc((size_t)B * 4 * H * W * Cout * 4));
+  MD_TRY(launch_nchw_to_nhwc(x_dev, B, Cin, H, W, xa.p, precision, 0, st));
+  PackEntry e;
+  e.kind = PACK_DECONV; e.d0 = Cin; e.d1 = Cout; e.k = 2; e.kp = Cin; e.dst = wa.p;
+  MD_TRY(pack_weight(w_dev, e, precision, st));
+  GemmParams p;
+  p.N = 4 * Cout; p.K = Cin; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p; p.A = xa.p; p.lda = Cin;
+  p.epi = EPI_PIXSHUF; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
+  p.psH = H; p.psW = W; p.psC = Cout; p.ps_coff = 0;
+  MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_AUTO, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, 2 * H, 2 * W, Cout, 0, out_dev, MD_PREC_F32, st));
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+int md_op_conv2d_direct(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int B, int Cin, int H,
+                        int W, int Cout, int k, int stride, int pad, int relu, float* out_dev, void* stream) {
+  if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || k <= 0 || stride <= 0 || pad < 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+  if (H + 2 * pad < k || W + 2 * pad < k) MD_FAIL(MD_ERR_SHAPE, "input %dx%d smaller than kernel %d", H, W, k);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = pick_stream(dev, stream);
+  DevBuf xa, wa, oa;
+  MD_TRY(xa.alloc((size_t)B * H * W * Cin * 4));
+  MD_TRY(wa.alloc((size_t)Cout * k * k * Cin * 4));
+  MD_TRY(oa.alloc((size_t)B * OH * OW * Cout * 4));
+  MD_TRY(launch_nchw_to_nhwc(x_dev, B, Cin, H, W, xa.p, MD_PREC_F32, 0, st));
+  PackEntry e;
+  e.kind = PACK_DIRECT; e.d0 = Cout; e.d1 = Cin; e.k = k; e.kp = Cin; e.f32 = 1; e.dst = wa.p;
+  MD_TRY(pack_weight(w_dev, e, MD_PREC_F32, st));
+  MD_TRY(launch_conv_direct(xa.p, MD_PREC_F32, nullptr, B, H, W, Cin, (const float*)wa.p, bias_dev, Cout, k, stride, pad, relu,
+                            (float*)oa.p, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, OH, OW, Cout, 0, out_dev, MD_PREC_F32, st));
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+int md_op_fov_to_focal(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad) {
+  if (H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid image size");
+  fov_scalar_host(fovx_deg, H, W, focal_px, fovy_rad);
+  return MD_OK;
+}
+
+int md_param_inventory(const md_depth_pro_cfg* cfg, int init_scheme, int index, const char** name, size_t* count, float* lo,
+                       float* hi) {
+  ModelCfg mc;
+  MD_TRY(parse_cfg(cfg, &mc));
+  static thread_local std::vector<ParamSpec> specs;
+  specs = depth_pro_param_specs(mc, init_scheme);
+  if (index >= 0 && index < (int)specs.size()) {
+    if (name) *name = specs[index].name.c_str();
+    if (count) *count = specs[index].count();
+    if (lo) *lo = specs[index].lo;
+    if (hi) *hi = specs[index].hi;
+  }
+  return (int)specs.size();
+}
+
+int md_uniform_stream(const char* name, uint64_t seed, size_t count, float lo, float hi, float* out_host) {
+  if (!name || !out_host) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  uniform_stream(name, seed, count, lo, hi, out_host);
+  return MD_OK;
+}
+
+int md_split_geometry(int image_size, int window, float overlap, int* stride, int* steps) {
+  if (!stride || !steps || image_size <= 0 || window <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "invalid argument");
+  split_geometry(image_size, window, overlap, stride, steps);
+  return MD_OK;
+}
+
+int md_feature_padding(int window, int stride, int feature_size) { return feature_padding(window, stride, feature_size); }
+
+}  // extern "C"

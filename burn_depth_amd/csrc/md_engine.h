@@ -1,0 +1,132 @@
+// Depth Pro engine: device-resident weights, static workspace plan, forward schedule.
+#pragma once
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels/gemm.h"
+#include "kernels/ops.h"
+#include "md_common.h"
+#include "md_weights.h"
+
+struct md_device_s {
+  int ordinal = 0;
+  hipStream_t stream = nullptr;
+};
+
+namespace md {
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  void* take(size_t bytes) {
+    size_t o = align_up(off, 256);
+    if (o + bytes > cap) return nullptr;
+    off = o + bytes;
+    return base + o;
+  }
+};
+
+// split geometry (encoder.rs:196-206) and feature padding (encoder.rs:28-38)
+void split_geometry(int image_size, int patch_size, float overlap, int* stride, int* steps);
+int feature_padding(int patch_size, int stride, int feature_patch_size);
+// merged-map pixel -> (tile j, tile i, ty, tx) (encoder.rs:234-282 inverted)
+void merge_source(int Y, int X, int h, int w, int steps, int pad, int* j, int* i, int* ty, int* tx);
+int merged_extent(int h, int steps, int pad);
+
+enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT = 3 };
+
+struct PackEntry {
+  int param = -1;   // index into params
+  int kind = PACK_NK;
+  int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k
+  int kp = 0;       // padded contraction length per tap (elements)
+  int f32 = 0;      // packed as f32 regardless of precision (direct conv)
+  void* dst = nullptr;
+  size_t bytes = 0;
+};
+
+struct VitBlockW {
+  const float *n1g, *n1b, *n2g, *n2b, *qkv_b, *proj_b, *ls1, *fc1_b, *fc2_b, *ls2;
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct VitW {
+  const void* pe_w;
+  const float *pe_b, *cls, *pos, *norm_g, *norm_b;
+  std::vector<VitBlockW> blk;
+};
+
+struct Tap {
+  float* dev = nullptr;
+  int64_t dims[4] = {0, 0, 0, 0};
+  size_t count = 0;
+};
+
+struct TimingEntry {
+  std::string name;
+  hipEvent_t a, b;
+};
+
+}  // namespace md
+
+struct md_model_s {
+  md_device_t dev = nullptr;
+  md::ModelCfg cfg;
+  int prec = MD_PREC_BF16;
+  int esz = 2;  // bytes per operand element
+  int ke = 64;  // contraction elements per 128-byte LDS row
+
+  // ---- parameters ----
+  std::vector<md::ParamSpec> params;
+  std::unordered_map<std::string, int> pindex;
+  std::vector<float*> w32;  // fp32 master copy on device, one per param
+  char* w32_base = nullptr;
+  size_t w32_bytes = 0;
+  std::vector<md::PackEntry> packs;
+  std::unordered_map<std::string, int> pack_index;
+  char* wpk_base = nullptr;
+  size_t wpk_bytes = 0;
+  bool committed = false;
+  int ngroups = 2;
+  md::VitW vit[3];
+  float head_b_host = 0.f;
+
+  // ---- workspace ----
+  md::Arena ws;
+  struct Buffers;
+  Buffers* buf = nullptr;
+  void* zero_page = nullptr;
+  std::map<int, int*> index_tables;  // per batch size B: device int32 blob
+  struct IndexSet {
+    int *hi = nullptr, *mid = nullptr, *x2 = nullptr, *img = nullptr, *fov = nullptr;
+  };
+  std::map<int, IndexSet> index_sets;
+
+  // ---- debug ----
+  bool taps_enabled = false;
+  std::map<std::string, md::Tap> taps;
+  bool timing_enabled = false;
+  std::vector<md::TimingEntry> timing;
+  std::vector<std::string> timing_names_out;
+
+  // geometry shared by create/infer
+  int S = 0, win = 0, g = 0, P = 0, NT = 0, SS = 0, kpad = 0;
+  int steps0 = 0, stride0 = 0, steps1 = 0, stride1 = 0, pad_hi = 0, pad_mid = 0;
+  int mh_hi = 0, mh_mid = 0;  // merged extents
+};
+
+namespace md {
+
+int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out);
+int model_init_seeded(md_model_t m, uint64_t seed, int scheme);
+int model_load_container(md_model_t m, const char* path);
+int model_commit(md_model_t m);
+int model_destroy(md_model_t m);
+int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
+                float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
+int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s);
+void fov_scalar_host(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad);
+
+}  // namespace md

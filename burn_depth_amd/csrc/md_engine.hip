@@ -1,0 +1,1197 @@
+// Depth Pro engine for MI355X: weights resident in HBM (fp32 master + MFMA-operand copies),
+// a static workspace plan sized for max_batch, and the forward schedule of DepthPro::infer
+// (depth_pro/mod.rs:312-364) expressed as launches of the hand-written gfx950 kernels.
+//
+// Data layout in HBM:
+//   * ViT token tensors are row-major [sequence*SS + token, channels]; SS = tokens rounded up to 4
+//     (580 for 577).  The three ViT-L encoders (patch / image / fov; encoder.rs:346-348,409,
+//     fov.rs:203) are "row groups" of the same tensors and advance through ONE launch per op.
+//   * the residual stream is fp32; every GEMM operand is T (bf16 or f32 by precision mode).
+//   * feature maps are NHWC (pixel-major rows of channels): a 1x1 conv is a dense GEMM, a k2s2
+//     ConvTranspose a GEMM + pixel-shuffle epilogue, a 3x3 conv an implicit GEMM over taps, and
+//     the token->map reshape + overlap-trim merge (encoder.rs:234-319) a row-index table.
+#include "md_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace md {
+
+// ------------------------------------------------------------------------------------------------
+// geometry helpers
+// ------------------------------------------------------------------------------------------------
+void split_geometry(int image_size, int patch_size, float overlap, int* stride, int* steps) {
+  int st = (int)std::floor((float)patch_size * (1.0f - overlap));  // encoder.rs:196-197
+  st = std::max(st, 1);
+  st = std::min(st, patch_size);
+  *stride = st;
+  *steps = patch_size >= image_size ? 1 : 1 + (image_size - patch_size + st - 1) / st;
+}
+
+int feature_padding(int patch_size, int stride, int fps) {  // encoder.rs:28-38
+  if (fps == 0 || patch_size == 0) return 0;
+  const int denom = std::max(patch_size, 1);
+  const int fstride = (stride * fps + denom / 2) / denom;
+  return std::max(fps - fstride, 0) / 2;
+}
+
+int merged_extent(int h, int steps, int pad) { return steps > 1 ? steps * (h - 2 * pad) + 2 * pad : h; }
+
+void merge_source(int Y, int X, int h, int w, int steps, int pad, int* j, int* i, int* ty, int* tx) {
+  int jj = 0, ii = 0;
+  if (steps > 1) {
+    const int ih = h - 2 * pad, iw = w - 2 * pad;
+    jj = Y < pad ? 0 : std::min((Y - pad) / ih, steps - 1);
+    ii = X < pad ? 0 : std::min((X - pad) / iw, steps - 1);
+    *ty = Y - jj * ih;
+    *tx = X - ii * iw;
+  } else {
+    *ty = Y;
+    *tx = X;
+  }
+  *j = jj;
+  *i = ii;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing kernels: fp32 master -> MFMA operand layouts
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int kind, int d0, int d1, int k,
+                            int kp, long total) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (kind == PACK_NK) {  // [N][K] -> [N][kp]
+      const int kk = (int)(e % kp);
+      const long n = e / kp;
+      if (kk < d1) v = src[n * d1 + kk];
+    } else if (kind == PACK_CONV3) {  // [Cout][Cin][3][3] -> [Cout][9][kp]
+      const int ci = (int)(e % kp);
+      const long t = e / kp;
+      const int tap = (int)(t % 9);
+      const long co = t / 9;
+      if (ci < d1) v = src[(co * d1 + ci) * 9 + tap];
+    } else if (kind == PACK_DECONV) {  // [Cin][Cout][2][2] -> [4*Cout][kp], row = tap*Cout + co
+      const int ci = (int)(e % kp);
+      const long n = e / kp;
+      const int tap = (int)(n / d1);
+      const int co = (int)(n % d1);
+      if (ci < d0) v = src[((long)ci * d1 + co) * 4 + tap];
+    } else {  // PACK_DIRECT: [Cout][Cin][k][k] -> [Cout][k][k][Cin]
+      const int ci = (int)(e % d1);
+      long t = e / d1;
+      const int kx = (int)(t % k);
+      t /= k;
+      const int ky = (int)(t % k);
+      const long co = t / k;
+      v = src[((co * d1 + ci) * k + ky) * k + kx];
+    }
+    if constexpr (sizeof(T) == 4)
+      ((float*)dst)[e] = v;
+    else
+      *((__bf16*)dst + e) = (__bf16)v;
+  }
+}
+
+static size_t pack_elems(const PackEntry& e) {
+  switch (e.kind) {
+    case PACK_NK: return (size_t)e.d0 * e.kp;
+    case PACK_CONV3: return (size_t)e.d0 * 9 * e.kp;
+    case PACK_DECONV: return (size_t)4 * e.d1 * e.kp;
+    default: return (size_t)e.d0 * e.d1 * e.k * e.k;
+  }
+}
+
+int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s) {
+  const long total = (long)pack_elems(e);
+  const int grid = (int)std::min<long>((total + 255) / 256, 4096);
+  if (e.f32 || prec == MD_PREC_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)e.dst, e.kind, e.d0, e.d1, e.k,
+                       e.kp, total);
+  else
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)e.dst, e.kind, e.d0, e.d1, e.k,
+                       e.kp, total);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+}  // namespace md
+
+using namespace md;
+
+// ------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------
+struct md_model_s::Buffers {
+  float* xin = nullptr;       // [B,3,S,S] fp32 (resized / staged input)
+  float* xraw = nullptr;      // staged raw input when it arrives on the host or needs resizing
+  uint8_t* rgb = nullptr;     // staged RGB bytes
+  void* patches = nullptr;    // [nseq_p*P, Kpe] T
+  float* xres = nullptr;      // [nseq*SS, D] fp32 residual stream
+  void* xn = nullptr;         // [nseq*SS, D] T
+  void* qk = nullptr;         // [nseq*SS, 2D] T
+  void* vT = nullptr;         // [nseq][heads][64][kpad] T
+  void* ao = nullptr;         // [nseq*SS, D] T
+  void* hbuf = nullptr;       // [nseq*SS, 4D] T
+  float* scores = nullptr;    // fp32 attention only
+  void* hook[2] = {nullptr, nullptr};  // [n0*SS, D] T
+  void* tok = nullptr;        // [nseq*SS, D] T (final-norm tokens)
+  // encoder
+  void *l0p = nullptr, *l0a = nullptr, *l0b = nullptr, *enc0 = nullptr, *enc0r = nullptr;
+  void *l1p = nullptr, *l1a = nullptr, *enc1 = nullptr;
+  void *x0p = nullptr, *enc2 = nullptr;
+  void *x1p = nullptr, *enc3 = nullptr;
+  void *x2p = nullptr, *cat = nullptr, *enc4 = nullptr;
+  // decoder (per level l: proj/projr, t, x/xr, t2, y, up, f)
+  void *proj[5] = {0, 0, 0, 0, 0}, *projr[5] = {0, 0, 0, 0, 0};
+  void *dt[5] = {0, 0, 0, 0, 0}, *dx[5] = {0, 0, 0, 0, 0}, *dxr[5] = {0, 0, 0, 0, 0};
+  void *dy[5] = {0, 0, 0, 0, 0}, *dup[5] = {0, 0, 0, 0, 0}, *df[5] = {0, 0, 0, 0, 0};
+  // head
+  void *h0 = nullptr, *h1 = nullptr;
+  float* canonical = nullptr;  // [B, S*S]
+  float* inv = nullptr;        // [B, S*S] (resize path)
+  float* depth_stage = nullptr;  // device staging for host outputs [B, Hmax*Wmax]
+  // fov
+  float *fovproj = nullptr, *fv0 = nullptr, *fv1 = nullptr, *fv2 = nullptr, *fv3 = nullptr, *fvr = nullptr;
+  float *fov_deg = nullptr, *focal = nullptr, *fovy = nullptr, *ratio = nullptr;
+  size_t depth_stage_elems = 0;
+};
+
+namespace md {
+
+static int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static void level_sizes(const md_model_s* m, int lvl_hw[5]) {
+  // spatial size of encoder feature l (encoder.rs:416-434): latent0 x8, latent1 x4, x0 x2, x1 x2(mid), fused x2
+  lvl_hw[0] = m->mh_hi * 8;
+  lvl_hw[1] = m->mh_hi * 4;
+  lvl_hw[2] = m->mh_hi * 2;
+  lvl_hw[3] = m->mh_mid * 2;
+  lvl_hw[4] = m->g * 2;
+}
+
+static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
+  const ModelCfg& c = m->cfg;
+  const int B = c.max_batch, D = c.pv.D, F = c.F, P = m->P, SS = m->SS, esz = m->esz;
+  const int n0 = m->steps0 * m->steps0 * B, n1 = m->steps1 * m->steps1 * B;
+  const int nseq_p = n0 + n1 + B;
+  const int nseq = nseq_p + B * (m->ngroups - 1);
+  const int* dims = c.pv.feat_dims;
+  auto cp = [&](int ch) { return round_up(ch, m->ke); };
+  md_model_s::Buffers* b = m->buf;
+  size_t total = 0;
+  auto take = [&](size_t bytes) -> void* {
+    bytes = align_up(bytes + 256, 256);  // slack: clamped tile rows never cross an allocation
+    total += bytes;
+    if (dry) return nullptr;
+    return m->ws.take(bytes);
+  };
+#define MD_TAKE(field, type, bytes)                                         \
+  do {                                                                      \
+    void* _p = take(bytes);                                                 \
+    if (!dry) {                                                             \
+      if (!_p) MD_FAIL(MD_ERR_OOM, "workspace arena exhausted at " #field); \
+      b->field = (type)_p;                                                  \
+    }                                                                       \
+  } while (0)
+  const size_t S2 = (size_t)m->S * m->S;
+  const int Kpe = 3 * c.pv.ps * c.pv.ps;
+  MD_TAKE(xin, float*, (size_t)B * 3 * S2 * 4);
+  MD_TAKE(patches, void*, (size_t)nseq_p * P * Kpe * esz);
+  const size_t rows = (size_t)nseq * SS + 64;
+  MD_TAKE(xres, float*, rows * D * 4);
+  MD_TAKE(xn, void*, rows * D * esz);
+  MD_TAKE(qk, void*, rows * 2 * D * esz);
+  MD_TAKE(vT, void*, (size_t)nseq * c.pv.heads * 64 * m->kpad * esz);
+  MD_TAKE(ao, void*, rows * D * esz);
+  MD_TAKE(hbuf, void*, rows * 4 * D * esz);
+  if (m->prec == MD_PREC_F32) MD_TAKE(scores, float*, (size_t)nseq * c.pv.heads * SS * m->kpad * 4);
+  MD_TAKE(hook[0], void*, ((size_t)n0 * SS + 64) * D * esz);
+  MD_TAKE(hook[1], void*, ((size_t)n0 * SS + 64) * D * esz);
+  MD_TAKE(tok, void*, rows * D * esz);
+  const size_t hi = (size_t)B * m->mh_hi * m->mh_hi, mid = (size_t)B * m->mh_mid * m->mh_mid,
+               lo = (size_t)B * m->g * m->g;
+  MD_TAKE(l0p, void*, hi * cp(dims[0]) * esz);
+  MD_TAKE(l0a, void*, hi * 4 * cp(F) * esz);
+  MD_TAKE(l0b, void*, hi * 16 * cp(F) * esz);
+  MD_TAKE(enc0, void*, hi * 64 * cp(F) * esz);
+  MD_TAKE(enc0r, void*, hi * 64 * cp(F) * esz);
+  MD_TAKE(l1p, void*, hi * cp(dims[0]) * esz);
+  MD_TAKE(l1a, void*, hi * 4 * cp(dims[0]) * esz);
+  MD_TAKE(enc1, void*, hi * 16 * cp(dims[0]) * esz);
+  MD_TAKE(x0p, void*, hi * cp(dims[1]) * esz);
+  MD_TAKE(enc2, void*, hi * 4 * cp(dims[1]) * esz);
+  MD_TAKE(x1p, void*, mid * cp(dims[2]) * esz);
+  MD_TAKE(enc3, void*, mid * 4 * cp(dims[2]) * esz);
+  MD_TAKE(x2p, void*, lo * cp(dims[3]) * esz);
+  MD_TAKE(cat, void*, lo * 4 * 2 * cp(dims[3]) * esz);
+  MD_TAKE(enc4, void*, lo * 4 * cp(dims[3]) * esz);
+  int hw[5];
+  level_sizes(m, hw);
+  for (int l = 0; l < 5; ++l) {
+    const size_t px = (size_t)B * hw[l] * hw[l];
+    const size_t fb = px * cp(F) * esz;
+    if (l != 0) {
+      MD_TAKE(proj[l], void*, fb);
+      MD_TAKE(projr[l], void*, fb);
+    }
+    MD_TAKE(dt[l], void*, fb);
+    if (l != 4) {
+      MD_TAKE(dx[l], void*, fb);
+      MD_TAKE(dxr[l], void*, fb);
+    }
+    MD_TAKE(dy[l], void*, fb);
+    if (l != 0) MD_TAKE(dup[l], void*, fb * 4);
+    MD_TAKE(df[l], void*, (l != 0 ? fb * 4 : fb));
+  }
+  const size_t px0 = (size_t)B * hw[0] * hw[0];
+  MD_TAKE(h0, void*, px0 * cp(F / 2) * esz);
+  MD_TAKE(h1, void*, px0 * 4 * cp(F / 2) * esz);
+  MD_TAKE(canonical, float*, px0 * 4 * 4);
+  MD_TAKE(inv, float*, px0 * 4 * 4);
+  if (c.use_fov_head) {
+    const size_t l4 = (size_t)B * hw[4] * hw[4];
+    MD_TAKE(fovproj, float*, (size_t)B * P * (F / 2) * 4);
+    MD_TAKE(fv0, float*, l4 * F * 4);
+    MD_TAKE(fv1, float*, l4 * F * 4);
+    MD_TAKE(fv2, float*, l4 * F * 4);
+    MD_TAKE(fv3, float*, l4 * F * 4);
+    MD_TAKE(fvr, float*, (size_t)B * 36 * F * 4 + l4 * F * 4);
+  }
+  MD_TAKE(fov_deg, float*, (size_t)B * 4);
+  MD_TAKE(focal, float*, (size_t)B * 4);
+  MD_TAKE(fovy, float*, (size_t)B * 4);
+  MD_TAKE(ratio, float*, (size_t)B * 4);
+#undef MD_TAKE
+  if (total_out) *total_out = total + 4096;
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model construction
+// ------------------------------------------------------------------------------------------------
+static const float* P32(md_model_s* m, const std::string& name) {
+  auto it = m->pindex.find(name);
+  return it == m->pindex.end() ? nullptr : m->w32[it->second];
+}
+static const void* PK(md_model_s* m, const std::string& name) {
+  auto it = m->pack_index.find(name);
+  return it == m->pack_index.end() ? nullptr : m->packs[it->second].dst;
+}
+
+static void add_pack(md_model_s* m, const std::string& name, int kind, int d0, int d1, int k, bool f32 = false) {
+  auto it = m->pindex.find(name);
+  if (it == m->pindex.end()) return;
+  PackEntry e;
+  e.param = it->second;
+  e.kind = kind;
+  e.d0 = d0;
+  e.d1 = d1;
+  e.k = k;
+  e.f32 = f32 ? 1 : 0;
+  const int contraction = kind == PACK_NK ? d1 : kind == PACK_CONV3 ? d1 : kind == PACK_DECONV ? d0 : d1;
+  e.kp = f32 ? contraction : round_up(contraction, m->ke);
+  const size_t esz = (f32 || m->prec == MD_PREC_F32) ? 4 : 2;
+  e.bytes = pack_elems(e) * esz;
+  m->pack_index[name] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
+int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
+  if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/model pointer is null");
+  if (!cfg.iv.same_arch(cfg.pv) || (cfg.use_fov_head && cfg.has_fov_vit && !cfg.fv.same_arch(cfg.pv)))
+    MD_FAIL(MD_ERR_UNSUPPORTED,
+            "patch/image/fov encoders must share one ViT architecture (they run as row groups of one launch)");
+  if (cfg.pv.D != cfg.pv.heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "ViT head_dim must be 64");
+  if (cfg.pv.D % 64 != 0 || cfg.pv.D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "ViT width %d unsupported", cfg.pv.D);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  md_model_s* m = new md_model_s();
+  m->dev = dev;
+  m->cfg = cfg;
+  m->prec = cfg.precision;
+  m->esz = cfg.precision == MD_PREC_F32 ? 4 : 2;
+  m->ke = 128 / m->esz;
+  m->ngroups = 2 + ((cfg.use_fov_head && cfg.has_fov_vit) ? 1 : 0);
+  m->S = cfg.img_size();
+  m->win = cfg.pv.img;
+  m->g = cfg.pv.grid();
+  m->P = m->g * m->g;
+  m->NT = m->P + 1;
+  m->SS = round_up(m->NT, 4);
+  m->kpad = round_up(m->NT, 64);
+  split_geometry(m->S, m->win, 0.25f, &m->stride0, &m->steps0);      // encoder.rs:329
+  split_geometry(m->S / 2, m->win, 0.5f, &m->stride1, &m->steps1);   // encoder.rs:330
+  m->pad_hi = feature_padding(m->win, m->stride0, m->g);
+  m->pad_mid = feature_padding(m->win, m->stride1, m->g);
+  m->mh_hi = merged_extent(m->g, m->steps0, m->pad_hi);
+  m->mh_mid = merged_extent(m->g, m->steps1, m->pad_mid);
+  auto fail = [&](int code) {
+    model_destroy(m);
+    return code;
+  };
+  if ((m->steps0 - 1) * m->stride0 + m->win != m->S || (m->steps1 - 1) * m->stride1 + m->win != m->S / 2 ||
+      m->stride0 % 4 != 0 || m->stride1 % 4 != 0 || m->g - 2 * m->pad_hi <= 0 || m->g - 2 * m->pad_mid <= 0) {
+    set_error("split geometry of window %d at image %d is not tile-exact", m->win, m->S);
+    return fail(MD_ERR_UNSUPPORTED);
+  }
+  if (m->mh_mid * 2 != m->mh_hi || m->g * 4 != m->mh_hi) {
+    // decoder levels must nest by factors of two (encoder.rs:416-434 / decoder.rs:119-134)
+    set_error("merged feature maps %d / %d / %d do not nest by 2", m->mh_hi, m->mh_mid, m->g);
+    return fail(MD_ERR_UNSUPPORTED);
+  }
+
+  // ---- parameters: fp32 master arena ----
+  m->params = depth_pro_param_specs(cfg, MD_INIT_REFERENCE);
+  size_t off = 0;
+  std::vector<size_t> offs;
+  for (size_t i = 0; i < m->params.size(); ++i) {
+    m->pindex[m->params[i].name] = (int)i;
+    offs.push_back(off);
+    off += align_up(m->params[i].count() * 4, 256);
+  }
+  m->w32_bytes = off;
+  if (hipMalloc((void**)&m->w32_base, m->w32_bytes) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the fp32 weights failed", m->w32_bytes);
+    return fail(MD_ERR_OOM);
+  }
+  (void)hipMemset(m->w32_base, 0, m->w32_bytes);
+  for (size_t i = 0; i < m->params.size(); ++i) m->w32.push_back((float*)(m->w32_base + offs[i]));
+
+  // ---- pack plan ----
+  const int D = cfg.pv.D, F = cfg.F;
+  const int* dims = cfg.pv.feat_dims;
+  const char* vnames[3] = {"encoder.patch_encoder", "encoder.image_encoder", "fov.encoder"};
+  for (int gi = 0; gi < m->ngroups; ++gi) {
+    const std::string v = vnames[gi];
+    add_pack(m, v + ".patch_embed.proj.weight", PACK_NK, D, 3 * cfg.pv.ps * cfg.pv.ps, 1);
+    for (int i = 0; i < cfg.pv.depth; ++i) {
+      const std::string b = v + ".blocks." + std::to_string(i);
+      add_pack(m, b + ".attn.qkv.weight", PACK_NK, 3 * D, D, 1);
+      add_pack(m, b + ".attn.proj.weight", PACK_NK, D, D, 1);
+      add_pack(m, b + ".mlp.fc1.weight", PACK_NK, 4 * D, D, 1);
+      add_pack(m, b + ".mlp.fc2.weight", PACK_NK, D, 4 * D, 1);
+    }
+  }
+  auto pub = [&](const std::string& n, int din, int dout, int layers, int dint) {
+    const int inter = dint > 0 ? dint : dout;
+    add_pack(m, n + ".projection.weight", PACK_NK, inter, din, 1);
+    for (int l = 0; l < layers; ++l)
+      add_pack(m, n + ".upsample." + std::to_string(l) + ".weight", PACK_DECONV, l == 0 ? inter : dout, dout, 2);
+  };
+  pub("encoder.upsample_latent0", D, F, 3, dims[0]);
+  pub("encoder.upsample_latent1", D, dims[0], 2, 0);
+  pub("encoder.upsample0", D, dims[1], 1, 0);
+  pub("encoder.upsample1", D, dims[2], 1, 0);
+  pub("encoder.upsample2", D, dims[3], 1, 0);
+  add_pack(m, "encoder.upsample_lowres.weight", PACK_DECONV, cfg.iv.D, dims[3], 2);
+  add_pack(m, "encoder.fuse_lowres.weight", PACK_NK, dims[3], 2 * dims[3], 1);
+  const int ddims[5] = {F, dims[0], dims[1], dims[2], dims[3]};
+  for (int l = 1; l < 5; ++l) add_pack(m, "decoder.convs." + std::to_string(l) + ".conv.weight", PACK_CONV3, F, ddims[l], 3);
+  for (int l = 0; l < 5; ++l) {
+    const std::string f = "decoder.fusions." + std::to_string(l);
+    for (const char* r : {"resnet1", "resnet2"}) {
+      add_pack(m, f + "." + r + ".conv1.weight", PACK_CONV3, F, F, 3);
+      add_pack(m, f + "." + r + ".conv2.weight", PACK_CONV3, F, F, 3);
+    }
+    if (l != 0) add_pack(m, f + ".deconv.weight", PACK_DECONV, F, F, 2);
+    add_pack(m, f + ".out_conv.weight", PACK_NK, F, F, 1);
+  }
+  add_pack(m, "head.conv0.weight", PACK_CONV3, F / 2, F, 3);
+  add_pack(m, "head.deconv.weight", PACK_DECONV, F / 2, F / 2, 2);
+  add_pack(m, "head.conv1.weight", PACK_CONV3, 32, F / 2, 3);
+  if (cfg.use_fov_head) {
+    if (cfg.has_fov_vit) {
+      add_pack(m, "fov.encoder_proj.weight", PACK_NK, F / 2, cfg.fv.D, 1);
+      add_pack(m, "fov.downsample_blocks.0.conv.weight", PACK_DIRECT, F / 2, F, 3, true);
+      add_pack(m, "fov.head_blocks.0.conv.weight", PACK_DIRECT, F / 4, F / 2, 3, true);
+      add_pack(m, "fov.head_blocks.1.conv.weight", PACK_DIRECT, F / 8, F / 4, 3, true);
+      add_pack(m, "fov.head_blocks.2.conv.weight", PACK_DIRECT, 1, F / 8, 6, true);
+    } else {
+      add_pack(m, "fov.head_blocks.0.conv.weight", PACK_DIRECT, F / 2, F, 3, true);
+      add_pack(m, "fov.head_blocks.1.conv.weight", PACK_DIRECT, F / 4, F / 2, 3, true);
+      add_pack(m, "fov.head_blocks.2.conv.weight", PACK_DIRECT, F / 8, F / 4, 3, true);
+      add_pack(m, "fov.head_blocks.3.conv.weight", PACK_DIRECT, 1, F / 8, 6, true);
+    }
+  }
+  size_t poff = 0;
+  for (auto& e : m->packs) {
+    e.dst = (void*)poff;  // offset for now
+    poff += align_up(e.bytes + 256, 256);
+  }
+  m->wpk_bytes = poff;
+  if (hipMalloc((void**)&m->wpk_base, m->wpk_bytes) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the packed weights failed", m->wpk_bytes);
+    return fail(MD_ERR_OOM);
+  }
+  (void)hipMemset(m->wpk_base, 0, m->wpk_bytes);
+  for (auto& e : m->packs) e.dst = m->wpk_base + (size_t)e.dst;
+
+  // ---- ViT weight tables ----
+  for (int gi = 0; gi < m->ngroups; ++gi) {
+    const std::string v = vnames[gi];
+    VitW& w = m->vit[gi];
+    w.pe_w = PK(m, v + ".patch_embed.proj.weight");
+    w.pe_b = P32(m, v + ".patch_embed.proj.bias");
+    w.cls = P32(m, v + ".cls_token");
+    w.pos = P32(m, v + ".pos_embed");
+    w.norm_g = P32(m, v + ".norm.gamma");
+    w.norm_b = P32(m, v + ".norm.beta");
+    for (int i = 0; i < cfg.pv.depth; ++i) {
+      const std::string b = v + ".blocks." + std::to_string(i);
+      VitBlockW k;
+      k.n1g = P32(m, b + ".norm1.gamma"); k.n1b = P32(m, b + ".norm1.beta");
+      k.n2g = P32(m, b + ".norm2.gamma"); k.n2b = P32(m, b + ".norm2.beta");
+      k.qkv_w = PK(m, b + ".attn.qkv.weight"); k.qkv_b = P32(m, b + ".attn.qkv.bias");
+      k.proj_w = PK(m, b + ".attn.proj.weight"); k.proj_b = P32(m, b + ".attn.proj.bias");
+      k.ls1 = P32(m, b + ".ls1.gamma"); k.ls2 = P32(m, b + ".ls2.gamma");
+      k.fc1_w = PK(m, b + ".mlp.fc1.weight"); k.fc1_b = P32(m, b + ".mlp.fc1.bias");
+      k.fc2_w = PK(m, b + ".mlp.fc2.weight"); k.fc2_b = P32(m, b + ".mlp.fc2.bias");
+      w.blk.push_back(k);
+    }
+  }
+
+  // ---- workspace ----
+  m->buf = new md_model_s::Buffers();
+  size_t need = 0;
+  plan_workspace(m, true, &need);
+  if (hipMalloc((void**)&m->ws.base, need) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the workspace failed (max_batch=%d)", need, cfg.max_batch);
+    return fail(MD_ERR_OOM);
+  }
+  m->ws.cap = need;
+  if (hipMemset(m->ws.base, 0, need) != hipSuccess) {  // padding rows/channels/keys must be finite zeros
+    set_error("hipMemset of the workspace failed");
+    return fail(MD_ERR_HIP);
+  }
+  int st = plan_workspace(m, false, nullptr);
+  if (st != MD_OK) return fail(st);
+  if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
+  (void)hipMemset(m->zero_page, 0, 4096);
+  (void)hipDeviceSynchronize();
+  *out = m;
+  return MD_OK;
+}
+
+int model_destroy(md_model_t m) {
+  if (!m) return MD_OK;
+  if (m->dev) (void)hipSetDevice(m->dev->ordinal);
+  (void)hipDeviceSynchronize();
+  if (m->w32_base) (void)hipFree(m->w32_base);
+  if (m->wpk_base) (void)hipFree(m->wpk_base);
+  if (m->ws.base) (void)hipFree(m->ws.base);
+  if (m->zero_page) (void)hipFree(m->zero_page);
+  for (auto& kv : m->index_tables) (void)hipFree(kv.second);
+  for (auto& kv : m->taps) (void)hipFree(kv.second.dev);
+  for (auto& t : m->timing) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  if (m->buf) {
+    if (m->buf->xraw) (void)hipFree(m->buf->xraw);
+    if (m->buf->rgb) (void)hipFree(m->buf->rgb);
+    if (m->buf->depth_stage) (void)hipFree(m->buf->depth_stage);
+    delete m->buf;
+  }
+  delete m;
+  return MD_OK;
+}
+
+int model_init_seeded(md_model_t m, uint64_t seed, int scheme) {
+  if (scheme != MD_INIT_REFERENCE && scheme != MD_INIT_PARITY) MD_FAIL(MD_ERR_INVALID_ARG, "unknown init scheme %d", scheme);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  std::vector<ParamSpec> specs = depth_pro_param_specs(m->cfg, scheme);
+  if (specs.size() != m->params.size()) MD_FAIL(MD_ERR_FORMAT, "internal: inventory mismatch");
+  std::vector<float> tmp;
+  for (size_t i = 0; i < specs.size(); ++i) {
+    const size_t n = specs[i].count();
+    tmp.resize(n);
+    uniform_stream(specs[i].name, seed, n, specs[i].lo, specs[i].hi, tmp.data());
+    MD_HIP(hipMemcpy(m->w32[i], tmp.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  return model_commit(m);
+}
+
+int model_load_container(md_model_t m, const char* path) {
+  Container c;
+  MD_TRY(read_container(path, &c));
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  std::vector<float> tmp;
+  for (size_t i = 0; i < m->params.size(); ++i) {
+    const ParamSpec& s = m->params[i];
+    auto it = c.tensors.find(s.name);
+    if (it == c.tensors.end()) MD_FAIL(MD_ERR_FORMAT, "checkpoint `%s` has no tensor `%s`", path, s.name.c_str());
+    size_t n = 1;
+    for (auto d : it->second.shape) n *= (size_t)d;
+    if (n != s.count()) {
+      MD_FAIL(MD_ERR_FORMAT, "tensor `%s` has %zu elements, the model expects %zu", s.name.c_str(), n, s.count());
+    }
+    // ConvTranspose weights may arrive [out,in,..] (maybe_fix_conv_transpose2d, mod.rs:416-431)
+    bool swap = false;
+    if (s.shape.size() == 4 && it->second.shape.size() == 4 && s.shape[2] == 2 && s.shape[3] == 2 &&
+        s.shape[0] != s.shape[1] && it->second.shape[0] == s.shape[1] && it->second.shape[1] == s.shape[0])
+      swap = true;
+    tmp.resize(n);
+    MD_TRY(container_tensor_to_f32(c, it->second, tmp.data(), n));
+    if (swap) {
+      std::vector<float> t2(n);
+      const size_t a = (size_t)s.shape[0], b2 = (size_t)s.shape[1];
+      for (size_t o = 0; o < b2; ++o)
+        for (size_t ii = 0; ii < a; ++ii)
+          for (int q = 0; q < 4; ++q) t2[(ii * b2 + o) * 4 + q] = tmp[(o * a + ii) * 4 + q];
+      tmp.swap(t2);
+    }
+    MD_HIP(hipMemcpy(m->w32[i], tmp.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  return model_commit(m);
+}
+
+int model_commit(md_model_t m) {
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t s = m->dev->stream;
+  for (auto& e : m->packs) MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
+  auto it = m->pindex.find("head.conv_out.bias");
+  if (it != m->pindex.end()) MD_HIP(hipMemcpyAsync(&m->head_b_host, m->w32[it->second], 4, hipMemcpyDeviceToHost, s));
+  MD_HIP(hipStreamSynchronize(s));
+  m->committed = true;
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index tables (token -> merged map gather, encoder.rs:234-319)
+// ------------------------------------------------------------------------------------------------
+static int get_index_set(md_model_s* m, int B, md_model_s::IndexSet* out) {
+  auto it = m->index_sets.find(B);
+  if (it != m->index_sets.end()) {
+    *out = it->second;
+    return MD_OK;
+  }
+  const int g = m->g, SS = m->SS, P = m->P;
+  const int n0 = m->steps0 * m->steps0 * B, n1 = m->steps1 * m->steps1 * B;
+  const int nseq_p = n0 + n1 + B;
+  const size_t nhi = (size_t)B * m->mh_hi * m->mh_hi, nmid = (size_t)B * m->mh_mid * m->mh_mid, nlo = (size_t)B * P;
+  std::vector<int> h(nhi + nmid + 3 * nlo);
+  size_t o = 0;
+  for (int b = 0; b < B; ++b)
+    for (int Y = 0; Y < m->mh_hi; ++Y)
+      for (int X = 0; X < m->mh_hi; ++X) {
+        int j, i, ty, tx;
+        merge_source(Y, X, g, g, m->steps0, m->pad_hi, &j, &i, &ty, &tx);
+        h[o++] = ((j * m->steps0 + i) * B + b) * SS + 1 + ty * g + tx;
+      }
+  for (int b = 0; b < B; ++b)
+    for (int Y = 0; Y < m->mh_mid; ++Y)
+      for (int X = 0; X < m->mh_mid; ++X) {
+        int j, i, ty, tx;
+        merge_source(Y, X, g, g, m->steps1, m->pad_mid, &j, &i, &ty, &tx);
+        h[o++] = (n0 + (j * m->steps1 + i) * B + b) * SS + 1 + ty * g + tx;
+      }
+  for (int which = 0; which < 3; ++which)
+    for (int b = 0; b < B; ++b)
+      for (int p = 0; p < P; ++p) {
+        const int seq = which == 0 ? n0 + n1 + b : which == 1 ? nseq_p + b : nseq_p + B + b;
+        h[o++] = seq * SS + 1 + p;
+      }
+  int* d = nullptr;
+  MD_HIP(hipMalloc((void**)&d, h.size() * 4));
+  MD_HIP(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  m->index_tables[B] = d;
+  md_model_s::IndexSet s;
+  s.hi = d;
+  s.mid = d + nhi;
+  s.x2 = s.mid + nmid;
+  s.img = s.x2 + nlo;
+  s.fov = s.img + nlo;
+  m->index_sets[B] = s;
+  *out = s;
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward schedule
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Run {
+  md_model_s* m;
+  hipStream_t st;
+  int B;
+  int pending = -1;
+  void begin(const char* name) {
+    if (!m->timing_enabled) return;
+    TimingEntry t;
+    t.name = name;
+    (void)hipEventCreate(&t.a);
+    (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, st);
+    m->timing.push_back(t);
+    pending = (int)m->timing.size() - 1;
+  }
+  void end() {
+    if (!m->timing_enabled || pending < 0) return;
+    (void)hipEventRecord(m->timing[pending].b, st);
+    pending = -1;
+  }
+  // NHWC T tensor -> NCHW fp32 tap
+  int tap_nhwc(const char* name, const void* p, int C, int H, int W, long ld, int coff = 0) {
+    if (!m->taps_enabled) return MD_OK;
+    Tap& t = m->taps[name];
+    const size_t n = (size_t)B * C * H * W;
+    if (t.count != n) {
+      if (t.dev) (void)hipFree(t.dev);
+      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
+      t.count = n;
+    }
+    t.dims[0] = B; t.dims[1] = C; t.dims[2] = H; t.dims[3] = W;
+    return launch_nhwc_to_nchw(p, B, C, H, W, ld, coff, t.dev, m->prec, st);
+  }
+  int tap_f32(const char* name, const float* p, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
+    if (!m->taps_enabled) return MD_OK;
+    Tap& t = m->taps[name];
+    const size_t n = (size_t)d0 * std::max<int64_t>(d1, 1) * std::max<int64_t>(d2, 1) * std::max<int64_t>(d3, 1);
+    if (t.count != n) {
+      if (t.dev) (void)hipFree(t.dev);
+      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
+      t.count = n;
+    }
+    t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = d3;
+    MD_HIP(hipMemcpyAsync(t.dev, p, n * 4, hipMemcpyDeviceToDevice, st));
+    return MD_OK;
+  }
+};
+
+inline int cpad(const md_model_s* m, int ch) { return (ch + m->ke - 1) / m->ke * m->ke; }
+
+// 1x1 conv / linear over NHWC rows.  A may be gathered through `idx`.
+int gemm_rows(Run& r, const char* name, const void* A, long lda, const int* idx, long M, const void* W, int N, int K,
+              const float* bias, void* out, long ldo, int out_f32 = 0, int act = ACT_NONE) {
+  GemmParams p;
+  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = (int)M; p.W[0] = W;
+  p.A = A; p.lda = lda; p.a_index = idx;
+  p.epi = EPI_STORE; p.act = act; p.out_f32 = out_f32; p.bias[0] = bias; p.out = out; p.ldo = ldo;
+  r.begin(name);
+  int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
+  r.end();
+  return s;
+}
+
+// ConvTranspose2d k=2 s=2 as GEMM + pixel shuffle (encoder.rs:61-69, decoder.rs:100-105, mod.rs:81-84)
+int deconv2(Run& r, const char* name, const void* A, long lda, const int* idx, int h, int w, const void* W, int Cin_p,
+            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr) {
+  GemmParams p;
+  p.N = 4 * Cout; p.K = Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W;
+  p.A = A; p.lda = lda; p.a_index = idx;
+  p.epi = EPI_PIXSHUF; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
+  p.psH = h; p.psW = w; p.psC = Cout; p.ps_coff = coff;
+  r.begin(name);
+  int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
+  r.end();
+  return s;
+}
+
+// Conv2d 3x3 s1 p1 over NHWC as implicit GEMM (decoder.rs:55-72,167-175; mod.rs:78-87)
+int conv3(Run& r, const char* name, const void* in, int H, int W, int Cin_p, const void* Wp, const float* bias,
+          int Cout, void* out, long ldo, int act, const void* res1, const void* res2, void* out2) {
+  GemmParams p;
+  p.N = Cout; p.K = 9 * Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * H * W; p.W[0] = Wp;
+  p.A = in; p.cH = H; p.cW = W; p.cC = Cin_p; p.zero_page = r.m->zero_page;
+  p.epi = EPI_STORE; p.act = act; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
+  p.res1 = res1; p.res2 = res2; p.ldr = ldo;
+  r.begin(name);
+  int s = launch_gemm(p, A_CONV3, r.m->prec, TILE_AUTO, r.st);
+  r.end();
+  return s;
+}
+
+}  // namespace
+
+static int run_vit(Run& r, int nseq_p, int nseq) {
+  md_model_s* m = r.m;
+  md_model_s::Buffers* b = m->buf;
+  const ModelCfg& c = m->cfg;
+  const int B = r.B, D = c.pv.D, P = m->P, SS = m->SS, NT = m->NT, heads = c.pv.heads, G = m->ngroups;
+  const int n0 = m->steps0 * m->steps0 * B, n1 = m->steps1 * m->steps1 * B;
+  const int Kpe = 3 * c.pv.ps * c.pv.ps;
+  const int gseq0[3] = {0, nseq_p, nseq_p + B};
+  const int gnseq[3] = {nseq_p, B, B};
+
+  SeqGroups sg;
+  sg.ngroups = G;
+  for (int g = 0; g < 4; ++g) { sg.seq0[g] = 0; sg.nseq[g] = 0; sg.a[g] = nullptr; sg.b[g] = nullptr; }
+  for (int g = 0; g < G; ++g) { sg.seq0[g] = gseq0[g]; sg.nseq[g] = gnseq[g]; }
+
+  // cls + pos[0], padding rows
+  for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].cls; sg.b[g] = m->vit[g].pos; }
+  r.begin("cls_init");
+  MD_TRY(launch_cls_init(b->xres, nseq, SS, NT, D, sg, r.st));
+  r.end();
+
+  // patch embed (conv 16x16 s16 as GEMM, + bias + pos_embed)
+  {
+    GemmParams p;
+    p.N = D; p.K = Kpe; p.ngroups = G;
+    for (int g = 0; g < G; ++g) {
+      p.g_row0[g] = gseq0[g] * P;
+      p.g_rows[g] = gnseq[g] * P;
+      p.g_arow0[g] = g == 0 ? 0 : (n0 + n1) * P;  // image/fov encoders read the x2 tiles (encoder.rs:409, fov.rs:202)
+      p.W[g] = m->vit[g].pe_w;
+      p.bias[g] = m->vit[g].pe_b;
+      p.pos[g] = m->vit[g].pos;
+    }
+    p.A = b->patches; p.lda = Kpe;
+    p.epi = EPI_PATCH_EMBED; p.out = b->xres; p.ldo = D; p.seq_stride = SS; p.seq_patches = P; p.embed = D;
+    r.begin("patch_embed");
+    MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+    r.end();
+  }
+  const long rows = (long)nseq * SS;
+  auto group_rows = [&](GemmParams& p) {
+    p.ngroups = G;
+    for (int g = 0; g < G; ++g) {
+      p.g_row0[g] = gseq0[g] * SS;
+      p.g_arow0[g] = gseq0[g] * SS;
+      p.g_rows[g] = gnseq[g] * SS;
+    }
+  };
+  for (int i = 0; i < c.pv.depth; ++i) {
+    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].blk[i].n1g; sg.b[g] = m->vit[g].blk[i].n1b; }
+    r.begin("layernorm");
+    MD_TRY(launch_layernorm(b->xres, b->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+    r.end();
+    {
+      GemmParams p;
+      p.N = 3 * D; p.K = D; group_rows(p);
+      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].qkv_w; p.bias[g] = m->vit[g].blk[i].qkv_b; }
+      p.A = b->xn; p.lda = D;
+      p.epi = EPI_QKV; p.out = b->qk; p.vT = b->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = m->kpad;
+      r.begin("qkv_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      r.end();
+    }
+    if (m->prec == MD_PREC_BF16) {
+      r.begin("attention");
+      MD_TRY(launch_attention_bf16(b->qk, b->vT, b->ao, nseq, SS, NT, heads, D, m->kpad, r.st));
+      r.end();
+    } else {
+      // fp32: scores = q k^T (batched GEMM) -> row softmax -> P V^T^T (batched GEMM)
+      GemmParams p;
+      p.N = SS; p.K = 64; p.ngroups = 1; p.g_rows[0] = NT;
+      p.batch = nseq * heads; p.batch_inner = heads;
+      p.A = b->qk; p.lda = 2 * D; p.a_bs[0] = (long)SS * 2 * D; p.a_bs[1] = 64;
+      p.W[0] = (const float*)b->qk + D; p.ldw = 2 * D; p.w_bs[0] = (long)SS * 2 * D; p.w_bs[1] = 64;
+      p.epi = EPI_STORE; p.out_f32 = 1; p.out = b->scores; p.ldo = m->kpad;
+      p.o_bs[0] = (long)heads * SS * m->kpad; p.o_bs[1] = (long)SS * m->kpad;
+      r.begin("attn_scores_f32");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_128x128, r.st));
+      r.end();
+      r.begin("attn_softmax_f32");
+      MD_TRY(launch_softmax_rows(b->scores, (long)nseq * heads * SS, NT, m->kpad, 0.125f, r.st));
+      r.end();
+      GemmParams q;
+      q.N = 64; q.K = m->kpad; q.ngroups = 1; q.g_rows[0] = NT;
+      q.batch = nseq * heads; q.batch_inner = heads;
+      q.A = b->scores; q.lda = m->kpad; q.a_bs[0] = (long)heads * SS * m->kpad; q.a_bs[1] = (long)SS * m->kpad;
+      q.W[0] = b->vT; q.ldw = m->kpad; q.w_bs[0] = (long)heads * 64 * m->kpad; q.w_bs[1] = 64L * m->kpad;
+      q.epi = EPI_STORE; q.out = b->ao; q.ldo = D; q.o_bs[0] = (long)SS * D; q.o_bs[1] = 64;
+      r.begin("attn_pv_f32");
+      MD_TRY(launch_gemm(q, A_DENSE, m->prec, TILE_128x128, r.st));
+      r.end();
+    }
+    {
+      GemmParams p;
+      p.N = D; p.K = D; group_rows(p);
+      for (int g = 0; g < G; ++g) {
+        p.W[g] = m->vit[g].blk[i].proj_w; p.bias[g] = m->vit[g].blk[i].proj_b; p.scale[g] = m->vit[g].blk[i].ls1;
+      }
+      p.A = b->ao; p.lda = D; p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
+      r.begin("proj_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      r.end();
+    }
+    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].blk[i].n2g; sg.b[g] = m->vit[g].blk[i].n2b; }
+    r.begin("layernorm");
+    MD_TRY(launch_layernorm(b->xres, b->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+    r.end();
+    {
+      GemmParams p;
+      p.N = 4 * D; p.K = D; group_rows(p);
+      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].fc1_w; p.bias[g] = m->vit[g].blk[i].fc1_b; }
+      p.A = b->xn; p.lda = D; p.epi = EPI_STORE; p.act = ACT_GELU; p.out = b->hbuf; p.ldo = 4 * D;
+      r.begin("fc1_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      r.end();
+    }
+    {
+      GemmParams p;
+      p.N = D; p.K = 4 * D; group_rows(p);
+      for (int g = 0; g < G; ++g) {
+        p.W[g] = m->vit[g].blk[i].fc2_w; p.bias[g] = m->vit[g].blk[i].fc2_b; p.scale[g] = m->vit[g].blk[i].ls2;
+      }
+      p.A = b->hbuf; p.lda = 4 * D; p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
+      r.begin("fc2_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      r.end();
+    }
+    // hooks: un-normalised tokens incl. cls after blocks hook_ids[0], hook_ids[1] (vit.rs:30,63)
+    for (int hk = 0; hk < 2; ++hk)
+      if (c.pv.hook_ids[hk] == i) {
+        r.begin("hook_copy");
+        MD_TRY(launch_convert_rows(b->xres, b->hook[hk], (long)n0 * SS * D, m->prec, r.st));
+        r.end();
+      }
+  }
+  for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].norm_g; sg.b[g] = m->vit[g].norm_b; }
+  r.begin("layernorm");
+  MD_TRY(launch_layernorm(b->xres, b->tok, rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+  r.end();
+  return MD_OK;
+}
+
+static int run_encoder_tail(Run& r, const md_model_s::IndexSet& ix) {
+  md_model_s* m = r.m;
+  md_model_s::Buffers* b = m->buf;
+  const ModelCfg& c = m->cfg;
+  const int B = r.B, D = c.pv.D, F = c.F, g = m->g;
+  const int* dims = c.pv.feat_dims;
+  const int hi = m->mh_hi, mid = m->mh_mid;
+  const long Mhi = (long)B * hi * hi, Mmid = (long)B * mid * mid, Mlo = (long)B * g * g;
+  auto W = [&](const char* n) { return PK(m, n); };
+  // latent0: 1x1 (D -> dims0) then 3 deconvs -> F @ 8x (encoder.rs:146-151,423)
+  MD_TRY(gemm_rows(r, "enc_proj", b->hook[0], D, ix.hi, Mhi, W("encoder.upsample_latent0.projection.weight"), dims[0], D,
+                   nullptr, b->l0p, cpad(m, dims[0])));
+  MD_TRY(deconv2(r, "enc_deconv", b->l0p, cpad(m, dims[0]), nullptr, hi, hi, W("encoder.upsample_latent0.upsample.0.weight"),
+                 cpad(m, dims[0]), F, nullptr, b->l0a, cpad(m, F), 0));
+  MD_TRY(deconv2(r, "enc_deconv", b->l0a, cpad(m, F), nullptr, 2 * hi, 2 * hi, W("encoder.upsample_latent0.upsample.1.weight"),
+                 cpad(m, F), F, nullptr, b->l0b, cpad(m, F), 0));
+  MD_TRY(deconv2(r, "enc_deconv", b->l0b, cpad(m, F), nullptr, 4 * hi, 4 * hi, W("encoder.upsample_latent0.upsample.2.weight"),
+                 cpad(m, F), F, nullptr, b->enc0, cpad(m, F), 0, b->enc0r));
+  // latent1: 1x1 (D -> dims0), 2 deconvs @ 4x (encoder.rs:152,424)
+  MD_TRY(gemm_rows(r, "enc_proj", b->hook[1], D, ix.hi, Mhi, W("encoder.upsample_latent1.projection.weight"), dims[0], D,
+                   nullptr, b->l1p, cpad(m, dims[0])));
+  MD_TRY(deconv2(r, "enc_deconv", b->l1p, cpad(m, dims[0]), nullptr, hi, hi, W("encoder.upsample_latent1.upsample.0.weight"),
+                 cpad(m, dims[0]), dims[0], nullptr, b->l1a, cpad(m, dims[0]), 0));
+  MD_TRY(deconv2(r, "enc_deconv", b->l1a, cpad(m, dims[0]), nullptr, 2 * hi, 2 * hi,
+                 W("encoder.upsample_latent1.upsample.1.weight"), cpad(m, dims[0]), dims[0], nullptr, b->enc1,
+                 cpad(m, dims[0]), 0));
+  // x0 (encoder.rs:153,425)
+  MD_TRY(gemm_rows(r, "enc_proj", b->tok, D, ix.hi, Mhi, W("encoder.upsample0.projection.weight"), dims[1], D, nullptr,
+                   b->x0p, cpad(m, dims[1])));
+  MD_TRY(deconv2(r, "enc_deconv", b->x0p, cpad(m, dims[1]), nullptr, hi, hi, W("encoder.upsample0.upsample.0.weight"),
+                 cpad(m, dims[1]), dims[1], nullptr, b->enc2, cpad(m, dims[1]), 0));
+  // x1 (encoder.rs:154,426)
+  MD_TRY(gemm_rows(r, "enc_proj", b->tok, D, ix.mid, Mmid, W("encoder.upsample1.projection.weight"), dims[2], D, nullptr,
+                   b->x1p, cpad(m, dims[2])));
+  MD_TRY(deconv2(r, "enc_deconv", b->x1p, cpad(m, dims[2]), nullptr, mid, mid, W("encoder.upsample1.upsample.0.weight"),
+                 cpad(m, dims[2]), dims[2], nullptr, b->enc3, cpad(m, dims[2]), 0));
+  // x2 + global image features -> cat -> fuse (encoder.rs:409-421)
+  const int catld = 2 * cpad(m, dims[3]);
+  MD_TRY(gemm_rows(r, "enc_proj", b->tok, D, ix.x2, Mlo, W("encoder.upsample2.projection.weight"), dims[3], D, nullptr,
+                   b->x2p, cpad(m, dims[3])));
+  MD_TRY(deconv2(r, "enc_deconv", b->x2p, cpad(m, dims[3]), nullptr, g, g, W("encoder.upsample2.upsample.0.weight"),
+                 cpad(m, dims[3]), dims[3], nullptr, b->cat, catld, 0));
+  MD_TRY(deconv2(r, "enc_deconv", b->tok, D, ix.img, g, g, W("encoder.upsample_lowres.weight"), D, dims[3],
+                 P32(m, "encoder.upsample_lowres.bias"), b->cat, catld, cpad(m, dims[3])));
+  MD_TRY(gemm_rows(r, "enc_fuse", b->cat, catld, nullptr, Mlo * 4, W("encoder.fuse_lowres.weight"), dims[3], catld,
+                   P32(m, "encoder.fuse_lowres.bias"), b->enc4, cpad(m, dims[3])));
+  if (m->taps_enabled) {
+    MD_TRY(r.tap_nhwc("encoder_feature_0", b->enc0, F, 8 * hi, 8 * hi, cpad(m, F)));
+    MD_TRY(r.tap_nhwc("encoder_feature_1", b->enc1, dims[0], 4 * hi, 4 * hi, cpad(m, dims[0])));
+    MD_TRY(r.tap_nhwc("encoder_feature_2", b->enc2, dims[1], 2 * hi, 2 * hi, cpad(m, dims[1])));
+    MD_TRY(r.tap_nhwc("encoder_feature_3", b->enc3, dims[2], 2 * mid, 2 * mid, cpad(m, dims[2])));
+    MD_TRY(r.tap_nhwc("encoder_feature_4", b->enc4, dims[3], 2 * g, 2 * g, cpad(m, dims[3])));
+  }
+  return MD_OK;
+}
+
+static int run_decoder_head(Run& r) {
+  md_model_s* m = r.m;
+  md_model_s::Buffers* b = m->buf;
+  const ModelCfg& c = m->cfg;
+  const int F = c.F, Fp = cpad(m, F);
+  const int* dims = c.pv.feat_dims;
+  int hw[5];
+  level_sizes(m, hw);
+  const int ddims[5] = {F, dims[0], dims[1], dims[2], dims[3]};
+  const void* enc[5] = {b->enc0, b->enc1, b->enc2, b->enc3, b->enc4};
+  auto W = [&](const std::string& n) { return PK(m, n); };
+  auto Bi = [&](const std::string& n) { return P32(m, n); };
+  // ResidualBlock (decoder.rs:74-87): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
+  auto resblock = [&](const std::string& name, int l, const void* x, const void* xr, const void* extra, void* t,
+                      void* out, void* out_relu) -> int {
+    MD_TRY(conv3(r, "dec_conv3x3", xr, hw[l], hw[l], Fp, W(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, t, Fp,
+                 ACT_RELU, nullptr, nullptr, nullptr));
+    return conv3(r, "dec_conv3x3", t, hw[l], hw[l], Fp, W(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp,
+                 ACT_NONE, x, extra, out_relu);
+  };
+  const void* feats = nullptr;
+  for (int l = 4; l >= 0; --l) {
+    const std::string f = "decoder.fusions." + std::to_string(l);
+    const void *pj, *pjr;
+    if (l == 0) {  // convs[0] is the identity (decoder.rs:155-165)
+      pj = b->enc0;
+      pjr = b->enc0r;
+    } else {
+      MD_TRY(conv3(r, "dec_conv3x3", enc[l], hw[l], hw[l], cpad(m, ddims[l]), W("decoder.convs." + std::to_string(l) + ".conv.weight"),
+                   nullptr, F, b->proj[l], Fp, ACT_NONE, nullptr, nullptr, b->projr[l]));
+      pj = b->proj[l];
+      pjr = b->projr[l];
+    }
+    const void *x, *xr;
+    if (l == 4) {  // top level: no skip input, resnet1 unused (decoder.rs:207-210)
+      if (m->taps_enabled) MD_TRY(r.tap_nhwc("decoder_lowres_feature", pj, F, hw[4], hw[4], Fp));
+      x = pj;
+      xr = pjr;
+    } else {
+      MD_TRY(resblock(f + ".resnet1", l, pj, pjr, feats, b->dt[l], b->dx[l], b->dxr[l]));
+      x = b->dx[l];
+      xr = b->dxr[l];
+    }
+    MD_TRY(resblock(f + ".resnet2", l, x, xr, nullptr, b->dt[l], b->dy[l], nullptr));
+    const void* pre = b->dy[l];
+    int ohw = hw[l];
+    if (l != 0) {
+      MD_TRY(deconv2(r, "dec_deconv", b->dy[l], Fp, nullptr, hw[l], hw[l], W(f + ".deconv.weight"), Fp, F, nullptr,
+                     b->dup[l], Fp, 0));
+      pre = b->dup[l];
+      ohw = 2 * hw[l];
+    }
+    MD_TRY(gemm_rows(r, "dec_out_conv", pre, Fp, nullptr, (long)r.B * ohw * ohw, W(f + ".out_conv.weight"), F, Fp,
+                     Bi(f + ".out_conv.bias"), b->df[l], Fp));
+    feats = b->df[l];
+    if (m->taps_enabled) {
+      const std::string tn = "decoder_fusion_" + std::to_string(l);
+      MD_TRY(r.tap_nhwc(tn.c_str(), feats, F, ohw, ohw, Fp));
+    }
+  }
+  if (m->taps_enabled) MD_TRY(r.tap_nhwc("decoder_feature", feats, F, hw[0], hw[0], Fp));
+  // depth head (mod.rs:105-112)
+  const int F2 = F / 2, F2p = cpad(m, F2);
+  MD_TRY(conv3(r, "head_conv0", feats, hw[0], hw[0], Fp, W("head.conv0.weight"), Bi("head.conv0.bias"), F2, b->h0, F2p,
+               ACT_NONE, nullptr, nullptr, nullptr));
+  MD_TRY(deconv2(r, "head_deconv", b->h0, F2p, nullptr, hw[0], hw[0], W("head.deconv.weight"), F2p, F2,
+                 Bi("head.deconv.bias"), b->h1, F2p, 0));
+  if (m->taps_enabled) {
+    MD_TRY(r.tap_nhwc("head_conv0", b->h0, F2, hw[0], hw[0], F2p));
+    MD_TRY(r.tap_nhwc("head_deconv", b->h1, F2, 2 * hw[0], 2 * hw[0], F2p));
+  }
+  {
+    GemmParams p;
+    p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = r.B * 4 * hw[0] * hw[0]; p.W[0] = W("head.conv1.weight");
+    p.A = b->h1; p.cH = 2 * hw[0]; p.cW = 2 * hw[0]; p.cC = F2p; p.zero_page = m->zero_page;
+    p.epi = EPI_HEAD; p.bias[0] = Bi("head.conv1.bias"); p.head_w = Bi("head.conv_out.weight"); p.head_b = m->head_b_host;
+    p.out = b->canonical;
+    r.begin("head_conv1_fused");
+    MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, r.st));
+    r.end();
+  }
+  MD_TRY(r.tap_f32("canonical_inverse_depth", b->canonical, r.B, 1, 2 * hw[0], 2 * hw[0]));
+  return MD_OK;
+}
+
+// NHWC f32 bilinear (ensure_min_spatial, fov.rs:238-246) -- tiny maps only, so go through NCHW
+static int fov_min_spatial(Run& r, float** cur, int* h, int C, int kmin, float* scratch_a, float* scratch_b) {
+  if (*h >= kmin) return MD_OK;
+  md_model_s* m = r.m;
+  const int B = r.B, oh = kmin;
+  // NHWC f32 -> NCHW f32
+  MD_TRY(launch_nhwc_to_nchw(*cur, B, C, *h, *h, C, 0, scratch_a, MD_PREC_F32, r.st));
+  MD_TRY(launch_resize_bilinear(scratch_a, B * C, *h, *h, scratch_b, oh, oh, m->cfg.interpolation, 0, r.st));
+  MD_TRY(launch_nchw_to_nhwc(scratch_b, B, C, oh, oh, scratch_a, MD_PREC_F32, 0, r.st));
+  *cur = scratch_a;
+  *h = oh;
+  return MD_OK;
+}
+
+static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
+  md_model_s* m = r.m;
+  md_model_s::Buffers* b = m->buf;
+  const ModelCfg& c = m->cfg;
+  const int B = r.B, F = c.F, g = m->g;
+  int hw[5];
+  level_sizes(m, hw);
+  const void* lowres = b->proj[4];  // convs[4](enc[4]) (decoder.rs:207-208)
+  const int Fp = cpad(m, F);
+  auto Wd = [&](const std::string& n) { return (const float*)PK(m, n); };
+  auto Bi = [&](const std::string& n) { return P32(m, n); };
+  if (Fp != F) MD_FAIL(MD_ERR_UNSUPPORTED, "fov: decoder_features must be a multiple of the MFMA k-tile");
+  float* stage[4] = {b->fv0, b->fv1, b->fv2, b->fv3};
+  float* sa = b->fvr;
+  float* sb = b->fvr + (size_t)B * 36 * F;
+  r.begin("fov_head");
+  if (c.has_fov_vit) {
+    // fov.rs:178-227: downsample(lowres) + Linear(tokens) -> head convs
+    MD_TRY(launch_conv_direct(lowres, m->prec, nullptr, B, hw[4], hw[4], F, Wd("fov.downsample_blocks.0.conv.weight"),
+                              Bi("fov.downsample_blocks.0.conv.bias"), F / 2, 3, 2, 1, 1, stage[0], r.st));
+    int h = (hw[4] + 2 - 3) / 2 + 1;
+    if (h != g) MD_FAIL(MD_ERR_UNSUPPORTED, "fov: downsampled lowres %d does not match the token grid %d", h, g);
+    r.end();
+    MD_TRY(gemm_rows(r, "fov_proj", b->tok, c.pv.D, ix.fov, (long)B * m->P, PK(m, "fov.encoder_proj.weight"), F / 2, c.pv.D,
+                     Bi("fov.encoder_proj.bias"), b->fovproj, F / 2, 1));
+    r.begin("fov_head");
+    float* cur = stage[0];
+    int ch = F / 2;
+    const float* add = b->fovproj;
+    const char* names[3] = {"fov.head_blocks.0.conv", "fov.head_blocks.1.conv", "fov.head_blocks.2.conv"};
+    const int couts[3] = {F / 4, F / 8, 1}, ks[3] = {3, 3, 6}, strides[3] = {2, 2, 1}, pads[3] = {1, 1, 0},
+              relus[3] = {1, 1, 0};
+    for (int i = 0; i < 3; ++i) {
+      if (h < ks[i]) {
+        if (add) MD_FAIL(MD_ERR_UNSUPPORTED, "fov: resize before the fused add is not supported");
+        MD_TRY(fov_min_spatial(r, &cur, &h, ch, ks[i], sa, sb));
+      }
+      float* out = i == 2 ? b->fov_deg : stage[i + 1];
+      MD_TRY(launch_conv_direct(cur, MD_PREC_F32, add, B, h, h, ch, Wd(std::string(names[i]) + ".weight"),
+                                Bi(std::string(names[i]) + ".bias"), couts[i], ks[i], strides[i], pads[i], relus[i], out,
+                                r.st));
+      add = nullptr;
+      h = (h + 2 * pads[i] - ks[i]) / strides[i] + 1;
+      ch = couts[i];
+      cur = out;
+    }
+    if (h != 1) MD_FAIL(MD_ERR_UNSUPPORTED, "fov head ends at %dx%d, expected 1x1", h, h);
+  } else {
+    // fov.rs:118-155: four head blocks straight on the lowres feature
+    const char* names[4] = {"fov.head_blocks.0.conv", "fov.head_blocks.1.conv", "fov.head_blocks.2.conv",
+                            "fov.head_blocks.3.conv"};
+    const int couts[4] = {F / 2, F / 4, F / 8, 1}, ks[4] = {3, 3, 3, 6}, strides[4] = {2, 2, 2, 1}, pads[4] = {1, 1, 1, 0},
+              relus[4] = {1, 1, 1, 0};
+    const void* cur = lowres;
+    int cur_prec = m->prec, h = hw[4], ch = F;
+    for (int i = 0; i < 4; ++i) {
+      if (h < ks[i]) {
+        if (cur_prec != MD_PREC_F32) MD_FAIL(MD_ERR_UNSUPPORTED, "fov: lowres smaller than the first kernel");
+        float* cf = (float*)cur;
+        MD_TRY(fov_min_spatial(r, &cf, &h, ch, ks[i], sa, sb));
+        cur = cf;
+      }
+      float* out = i == 3 ? b->fov_deg : stage[i];
+      MD_TRY(launch_conv_direct(cur, cur_prec, nullptr, B, h, h, ch, Wd(std::string(names[i]) + ".weight"),
+                                Bi(std::string(names[i]) + ".bias"), couts[i], ks[i], strides[i], pads[i], relus[i], out,
+                                r.st));
+      h = (h + 2 * pads[i] - ks[i]) / strides[i] + 1;
+      ch = couts[i];
+      cur = out;
+      cur_prec = MD_PREC_F32;
+    }
+    if (h != 1) MD_FAIL(MD_ERR_UNSUPPORTED, "fov head ends at %dx%d, expected 1x1", h, h);
+  }
+  r.end();
+  MD_TRY(r.tap_f32("fov_deg", b->fov_deg, r.B, 1, 1, 1));
+  return MD_OK;
+}
+
+int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
+                float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
+  if (!nchw && !rgb) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");
+  if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
+  if (B > m->cfg.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
+  if (!m->cfg.use_fov_head) MD_FAIL(MD_ERR_NO_FOV, "FOV head required for focal length");  // mod.rs:329
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : m->dev->stream;
+  md_model_s::Buffers* b = m->buf;
+  Run r{m, st, B};
+  if (m->timing_enabled) {
+    for (auto& t : m->timing) {
+      (void)hipEventDestroy(t.a);
+      (void)hipEventDestroy(t.b);
+    }
+    m->timing.clear();
+  }
+  const int S = m->S;
+  const size_t in_elems = (size_t)B * 3 * H * W;
+  const bool resize_needed = H != S || W != S;  // mod.rs:317
+  const float* x_dev = nullptr;
+  // ---- stage the input ----
+  if (rgb) {
+    if (rgb_len != (size_t)W * H * 3) MD_FAIL(MD_ERR_SHAPE, "expected %zu RGB bytes for %dx%d, got %zu", (size_t)W * H * 3, W, H, rgb_len);
+    const uint8_t* rgb_dev = rgb;
+    if (in_kind == MD_MEM_HOST) {
+      if (b->rgb) (void)hipFree(b->rgb);
+      MD_HIP(hipMalloc((void**)&b->rgb, rgb_len));
+      MD_HIP(hipMemcpyAsync(b->rgb, rgb, rgb_len, hipMemcpyHostToDevice, st));
+      rgb_dev = b->rgb;
+    }
+    float* dst = b->xin;
+    if (resize_needed) {
+      if (b->xraw) (void)hipFree(b->xraw);
+      MD_HIP(hipMalloc((void**)&b->xraw, in_elems * 4));
+      dst = b->xraw;
+    }
+    r.begin("rgb_to_input");
+    MD_TRY(launch_rgb_to_input(rgb_dev, W, H, dst, st));
+    r.end();
+    x_dev = dst;
+  } else if (in_kind == MD_MEM_HOST) {
+    float* dst = b->xin;
+    if (resize_needed) {
+      if (b->xraw) (void)hipFree(b->xraw);
+      MD_HIP(hipMalloc((void**)&b->xraw, in_elems * 4));
+      dst = b->xraw;
+    }
+    MD_HIP(hipMemcpyAsync(dst, nchw, in_elems * 4, hipMemcpyHostToDevice, st));
+    x_dev = dst;
+  } else {
+    x_dev = nchw;
+  }
+  if (resize_needed) {
+    r.begin("resize_in");
+    MD_TRY(launch_resize_bilinear(x_dev, B * 3, H, W, b->xin, S, S, m->cfg.interpolation, 0, st));
+    r.end();
+    x_dev = b->xin;
+  }
+  // ---- encoder ----
+  const int n0 = m->steps0 * m->steps0 * B, n1 = m->steps1 * m->steps1 * B;
+  const int nseq_p = n0 + n1 + B;
+  const int nseq = nseq_p + B * (m->ngroups - 1);
+  PyramidGeom pg{B, S, m->win, m->cfg.pv.ps, m->steps0, m->stride0, m->steps1, m->stride1, m->cfg.interpolation};
+  r.begin("pyramid_patchify");
+  MD_TRY(launch_pyramid_patchify(x_dev, pg, b->patches, m->prec, st));
+  r.end();
+  md_model_s::IndexSet ix;
+  MD_TRY(get_index_set(m, B, &ix));
+  MD_TRY(run_vit(r, nseq_p, nseq));
+  MD_TRY(run_encoder_tail(r, ix));
+  MD_TRY(run_decoder_head(r));
+  MD_TRY(run_fov(r, ix));
+  // ---- tail (mod.rs:330-363) ----
+  r.begin("fov_post");
+  MD_TRY(launch_fov_post(b->fov_deg, B, H, W, b->focal, b->fovy, b->ratio, st));
+  r.end();
+  const size_t out_elems = (size_t)B * H * W;
+  float* depth_dev = nullptr;
+  if (depth) {
+    if (out_kind == MD_MEM_DEVICE) {
+      depth_dev = depth;
+    } else {
+      if (b->depth_stage_elems < out_elems) {
+        if (b->depth_stage) (void)hipFree(b->depth_stage);
+        MD_HIP(hipMalloc((void**)&b->depth_stage, out_elems * 4));
+        b->depth_stage_elems = out_elems;
+      }
+      depth_dev = b->depth_stage;
+    }
+    r.begin("depth_post");
+    if (!resize_needed) {
+      MD_TRY(launch_depth_post(b->canonical, b->ratio, B, (long)S * S, depth_dev, 1, st));
+    } else {
+      MD_TRY(launch_depth_post(b->canonical, b->ratio, B, (long)S * S, b->inv, 0, st));
+      MD_TRY(launch_resize_bilinear(b->inv, B, S, S, depth_dev, H, W, m->cfg.interpolation, 1, st));
+    }
+    r.end();
+  }
+  auto copy_out = [&](float* dst, const float* src, size_t n) -> int {
+    if (!dst) return MD_OK;
+    MD_HIP(hipMemcpyAsync(dst, src, n * 4, out_kind == MD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    return MD_OK;
+  };
+  if (depth && out_kind == MD_MEM_HOST) MD_TRY(copy_out(depth, depth_dev, out_elems));
+  MD_TRY(copy_out(focal, b->focal, B));
+  MD_TRY(copy_out(fovx, b->fov_deg, B));
+  MD_TRY(copy_out(fovy, b->fovy, B));
+  if (out_kind == MD_MEM_HOST || m->timing_enabled) MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+
+}  // namespace md

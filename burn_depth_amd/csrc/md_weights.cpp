@@ -1,0 +1,377 @@
+// Host-side parameter inventory / seeded init / container reader. Compiled with
+// -ffp-contract=off so that the generator matches burn_depth_amd/weights.py bit for bit.
+#include "md_weights.h"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+
+namespace md {
+
+// ------------------------------------------------------------------------------------------------
+// presets (layers/vit.rs:23-43)
+// ------------------------------------------------------------------------------------------------
+bool vit_dims_from_preset(const char* preset, ViTDims* out) {
+  if (!preset) return false;
+  ViTDims v;
+  v.preset = preset;
+  if (v.preset == "dinov2l16_384" || v.preset == "dinov2l16_128") {
+    v.D = 1024; v.depth = 24; v.heads = 16; v.mlp_ratio = 4; v.ps = 16;
+    v.img = v.preset == "dinov2l16_384" ? 384 : 128;
+    const int h[4] = {5, 11, 17, 23}, d[4] = {256, 512, 1024, 1024};
+    for (int i = 0; i < 4; ++i) { v.hook_ids[i] = h[i]; v.feat_dims[i] = d[i]; }
+  } else if (v.preset == "tiny16_128") {
+    v.D = 256; v.depth = 4; v.heads = 4; v.mlp_ratio = 4; v.ps = 16; v.img = 128;
+    const int h[4] = {1, 2, 3, 3}, d[4] = {64, 128, 256, 256};
+    for (int i = 0; i < 4; ++i) { v.hook_ids[i] = h[i]; v.feat_dims[i] = d[i]; }
+  } else {
+    return false;
+  }
+  *out = v;
+  return true;
+}
+
+int parse_cfg(const md_depth_pro_cfg* c, ModelCfg* out) {
+  if (!c) MD_FAIL(MD_ERR_INVALID_ARG, "config is null");
+  ModelCfg m;
+  if (!vit_dims_from_preset(c->patch_encoder_preset, &m.pv))
+    MD_FAIL(MD_ERR_INVALID_ARG, "unsupported ViT preset `%s`", c->patch_encoder_preset ? c->patch_encoder_preset : "(null)");
+  if (!vit_dims_from_preset(c->image_encoder_preset, &m.iv))
+    MD_FAIL(MD_ERR_INVALID_ARG, "unsupported ViT preset `%s`", c->image_encoder_preset ? c->image_encoder_preset : "(null)");
+  m.has_fov_vit = c->fov_encoder_preset != nullptr && c->fov_encoder_preset[0] != 0;
+  if (m.has_fov_vit && !vit_dims_from_preset(c->fov_encoder_preset, &m.fv))
+    MD_FAIL(MD_ERR_INVALID_ARG, "unsupported ViT preset `%s`", c->fov_encoder_preset);
+  m.use_fov_head = c->use_fov_head != 0;
+  m.F = c->decoder_features;
+  m.interpolation = c->interpolation;
+  m.precision = c->precision;
+  m.max_batch = c->max_batch > 0 ? c->max_batch : 1;
+  m.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
+  if (m.F <= 0 || m.F % 64 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "decoder_features=%d must be a positive multiple of 64", m.F);
+  if (m.interpolation != MD_INTERP_CUSTOM && m.interpolation != MD_INTERP_BURN)
+    MD_FAIL(MD_ERR_INVALID_ARG, "unknown interpolation method %d", m.interpolation);
+  if (m.precision != MD_PREC_BF16 && m.precision != MD_PREC_F32)
+    MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", m.precision);
+  *out = m;
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inventory -- keep in lock-step with weights.py::depth_pro_param_specs
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct SpecBuilder {
+  std::vector<ParamSpec>& out;
+  bool par;
+  void add(const std::string& name, std::vector<int64_t> shape, double lo, double hi) {
+    out.push_back(ParamSpec{name, std::move(shape), (float)lo, (float)hi});
+  }
+  void sym(const std::string& name, std::vector<int64_t> shape, double b) { add(name, std::move(shape), -b, b); }
+  void lin(const std::string& name, int fan_out, int fan_in) {
+    const double b = par ? std::sqrt(3.0 / fan_in) : std::sqrt(1.0 / fan_in);
+    sym(name + ".weight", {fan_out, fan_in}, b);
+    sym(name + ".bias", {fan_out}, par ? 0.1 : std::sqrt(1.0 / fan_in));
+  }
+  void conv(const std::string& name, int cout, int cin, int k, bool bias, bool relu_after = false, double gain = 0.0) {
+    const int fan = cin * k * k;
+    double b;
+    if (par) {
+      b = std::sqrt((relu_after ? 6.0 : 3.0) / fan);
+      if (gain != 0.0) b *= gain;
+    } else {
+      b = std::sqrt(1.0 / fan);
+    }
+    sym(name + ".weight", {cout, cin, k, k}, b);
+    if (bias) sym(name + ".bias", {cout}, par ? 0.1 : b);
+  }
+  void deconv(const std::string& name, int cin, int cout, bool bias) {
+    const double b = par ? std::sqrt(3.0 / cin) : std::sqrt(1.0 / (cout * 4));
+    sym(name + ".weight", {cin, cout, 2, 2}, b);
+    if (bias) sym(name + ".bias", {cout}, par ? 0.1 : b);
+  }
+  void vit(const std::string& prefix, const ViTDims& v) {
+    const int D = v.D, P = v.ps, C = v.in_chans, hidden = D * v.mlp_ratio;
+    const int fan = C * P * P;
+    const double b = par ? std::sqrt(3.0 / fan) : std::sqrt(1.0 / fan);
+    sym(prefix + ".patch_embed.proj.weight", {D, C, P, P}, b);
+    sym(prefix + ".patch_embed.proj.bias", {D}, par ? 0.1 : b);
+    sym(prefix + ".cls_token", {1, 1, D}, par ? 0.5 : 1e-6);
+    sym(prefix + ".pos_embed", {1, v.ntok(), D}, par ? 0.3 : 0.02 * std::sqrt(3.0));
+    for (int i = 0; i < v.depth; ++i) {
+      const std::string blk = prefix + ".blocks." + std::to_string(i);
+      for (const char* n : {"norm1", "norm2"}) {
+        if (par) add(blk + "." + n + ".gamma", {D}, 0.5, 1.5); else add(blk + "." + n + ".gamma", {D}, 1.0, 1.0);
+        if (par) sym(blk + "." + n + ".beta", {D}, 0.1); else add(blk + "." + n + ".beta", {D}, 0.0, 0.0);
+      }
+      lin(blk + ".attn.qkv", 3 * D, D);
+      lin(blk + ".attn.proj", D, D);
+      if (par) add(blk + ".ls1.gamma", {D}, 0.05, 0.3); else add(blk + ".ls1.gamma", {D}, 1.0, 1.0);
+      lin(blk + ".mlp.fc1", hidden, D);
+      lin(blk + ".mlp.fc2", D, hidden);
+      if (par) add(blk + ".ls2.gamma", {D}, 0.05, 0.3); else add(blk + ".ls2.gamma", {D}, 1.0, 1.0);
+    }
+    if (par) add(prefix + ".norm.gamma", {D}, 0.5, 1.5); else add(prefix + ".norm.gamma", {D}, 1.0, 1.0);
+    if (par) sym(prefix + ".norm.beta", {D}, 0.1); else add(prefix + ".norm.beta", {D}, 0.0, 0.0);
+  }
+  void pub(const std::string& name, int dim_in, int dim_out, int layers, int dim_int) {
+    const int inter = dim_int > 0 ? dim_int : dim_out;
+    conv(name + ".projection", inter, dim_in, 1, false);
+    for (int l = 0; l < layers; ++l) deconv(name + ".upsample." + std::to_string(l), l == 0 ? inter : dim_out, dim_out, false);
+  }
+};
+}  // namespace
+
+std::vector<ParamSpec> depth_pro_param_specs(const ModelCfg& cfg, int scheme) {
+  std::vector<ParamSpec> specs;
+  SpecBuilder sb{specs, scheme == MD_INIT_PARITY};
+  const bool par = sb.par;
+  const int* dims = cfg.pv.feat_dims;
+  const int F = cfg.F, E = cfg.pv.D;
+  sb.vit("encoder.patch_encoder", cfg.pv);
+  sb.vit("encoder.image_encoder", cfg.iv);
+  sb.pub("encoder.upsample_latent0", E, F, 3, dims[0]);
+  sb.pub("encoder.upsample_latent1", E, dims[0], 2, 0);
+  sb.pub("encoder.upsample0", E, dims[1], 1, 0);
+  sb.pub("encoder.upsample1", E, dims[2], 1, 0);
+  sb.pub("encoder.upsample2", E, dims[3], 1, 0);
+  sb.deconv("encoder.upsample_lowres", cfg.iv.D, dims[3], true);
+  sb.conv("encoder.fuse_lowres", dims[3], dims[3] * 2, 1, true);
+  const int ddims[5] = {F, dims[0], dims[1], dims[2], dims[3]};
+  for (int l = 1; l < 5; ++l) sb.conv("decoder.convs." + std::to_string(l) + ".conv", F, ddims[l], 3, false);
+  for (int l = 0; l < 5; ++l) {
+    const std::string f = "decoder.fusions." + std::to_string(l);
+    for (const char* r : {"resnet1", "resnet2"}) {
+      sb.conv(f + "." + r + ".conv1", F, F, 3, true, true);
+      sb.conv(f + "." + r + ".conv2", F, F, 3, true, true, 0.5);
+    }
+    if (l != 0) sb.deconv(f + ".deconv", F, F, false);
+    sb.conv(f + ".out_conv", F, F, 1, true);
+  }
+  sb.conv("head.conv0", F / 2, F, 3, true);
+  sb.deconv("head.deconv", F / 2, F / 2, true);
+  sb.conv("head.conv1", 32, F / 2, 3, true, true);
+  if (par) {
+    sb.add("head.conv_out.weight", {1, 32, 1, 1}, 0.0, 0.08);
+    sb.add("head.conv_out.bias", {1}, 0.05, 0.05);
+  } else {
+    sb.sym("head.conv_out.weight", {1, 32, 1, 1}, std::sqrt(1.0 / 32));
+    sb.add("head.conv_out.bias", {1}, 0.0, 0.0);  // depth_pro/mod.rs:92-95
+  }
+  if (cfg.use_fov_head) {
+    std::string last;
+    int last_cin;
+    if (cfg.has_fov_vit) {
+      sb.vit("fov.encoder", cfg.fv);
+      const int fan = cfg.fv.D;
+      const double b = par ? std::sqrt(3.0 / fan) : std::sqrt(1.0 / fan);
+      sb.sym("fov.encoder_proj.weight", {F / 2, fan}, b);
+      sb.sym("fov.encoder_proj.bias", {F / 2}, par ? 0.1 : b);
+      sb.conv("fov.downsample_blocks.0.conv", F / 2, F, 3, true, true);
+      sb.conv("fov.head_blocks.0.conv", F / 4, F / 2, 3, true, true);
+      sb.conv("fov.head_blocks.1.conv", F / 8, F / 4, 3, true, true);
+      last = "fov.head_blocks.2.conv";
+    } else {
+      sb.conv("fov.head_blocks.0.conv", F / 2, F, 3, true, true);
+      sb.conv("fov.head_blocks.1.conv", F / 4, F / 2, 3, true, true);
+      sb.conv("fov.head_blocks.2.conv", F / 8, F / 4, 3, true, true);
+      last = "fov.head_blocks.3.conv";
+    }
+    last_cin = F / 8;
+    const int fan = last_cin * 36;
+    const double b = par ? std::sqrt(3.0 / fan) : std::sqrt(1.0 / fan);
+    sb.sym(last + ".weight", {1, last_cin, 6, 6}, b);
+    if (par) sb.add(last + ".bias", {1}, 55.0, 55.0); else sb.sym(last + ".bias", {1}, b);
+  }
+  return specs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// counter-based generator
+// ------------------------------------------------------------------------------------------------
+uint64_t fnv1a64(const std::string& s) {
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (unsigned char ch : s) {
+    h ^= ch;
+    h *= 0x100000001B3ull;
+  }
+  return h;
+}
+
+void uniform_stream(const std::string& name, uint64_t seed, size_t count, float lo, float hi, float* out) {
+  if (lo == hi) {
+    for (size_t i = 0; i < count; ++i) out[i] = lo;
+    return;
+  }
+  const uint64_t golden = 0x9E3779B97F4A7C15ull;
+  const uint64_t key = fnv1a64(name) ^ (seed * golden);
+  const double w = (double)hi - (double)lo;
+  const double dlo = (double)lo;
+  for (size_t i = 0; i < count; ++i) {
+    uint64_t z = key + (uint64_t)(i + 1) * golden;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const double u = ((double)(z >> 40) + 0.5) * (1.0 / 16777216.0);
+    volatile double prod = w * u;  // one rounding, never fused with the add
+    out[i] = (float)(dlo + prod);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// safetensors subset reader
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Json {
+  const char* p;
+  const char* e;
+  bool ok = true;
+  void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+  bool eat(char c) { ws(); if (p < e && *p == c) { ++p; return true; } return false; }
+  std::string str() {
+    ws();
+    std::string s;
+    if (p >= e || *p != '"') { ok = false; return s; }
+    ++p;
+    while (p < e && *p != '"') {
+      if (*p == '\\' && p + 1 < e) {
+        ++p;
+        switch (*p) {
+          case 'n': s += '\n'; break;
+          case 't': s += '\t'; break;
+          case 'u': p += 4; s += '?'; break;
+          default: s += *p; break;
+        }
+        ++p;
+      } else {
+        s += *p++;
+      }
+    }
+    if (p >= e) { ok = false; return s; }
+    ++p;
+    return s;
+  }
+  double num() {
+    ws();
+    char* end = nullptr;
+    double v = strtod(p, &end);
+    if (end == p) ok = false;
+    p = end;
+    return v;
+  }
+  void skip() {  // skip any value
+    ws();
+    if (p >= e) { ok = false; return; }
+    if (*p == '"') { str(); return; }
+    if (*p == '{') { ++p; if (eat('}')) return; do { str(); if (!eat(':')) { ok = false; return; } skip(); } while (ok && eat(',')); if (!eat('}')) ok = false; return; }
+    if (*p == '[') { ++p; if (eat(']')) return; do { skip(); } while (ok && eat(',')); if (!eat(']')) ok = false; return; }
+    while (p < e && *p != ',' && *p != '}' && *p != ']') ++p;
+  }
+};
+}  // namespace
+
+int read_container(const char* path, Container* out) {
+  if (!path) MD_FAIL(MD_ERR_INVALID_ARG, "checkpoint path is null");
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) MD_FAIL(MD_ERR_IO, "cannot open checkpoint `%s`", path);
+  const std::streamsize sz = f.tellg();
+  if (sz < 8) MD_FAIL(MD_ERR_FORMAT, "checkpoint `%s` is too short (%ld bytes)", path, (long)sz);
+  f.seekg(0);
+  out->bytes.resize((size_t)sz);
+  if (!f.read((char*)out->bytes.data(), sz)) MD_FAIL(MD_ERR_IO, "short read on `%s`", path);
+  uint64_t hlen = 0;
+  memcpy(&hlen, out->bytes.data(), 8);
+  if (hlen > (uint64_t)sz - 8) MD_FAIL(MD_ERR_FORMAT, "container header length %llu exceeds file size", (unsigned long long)hlen);
+  out->data_off = 8 + (size_t)hlen;
+  const size_t data_len = (size_t)sz - out->data_off;
+  Json j{(const char*)out->bytes.data() + 8, (const char*)out->bytes.data() + 8 + hlen};
+  if (!j.eat('{')) MD_FAIL(MD_ERR_FORMAT, "container header is not a JSON object");
+  if (!j.eat('}')) {
+    do {
+      std::string key = j.str();
+      if (!j.ok || !j.eat(':')) MD_FAIL(MD_ERR_FORMAT, "malformed container header near `%s`", key.c_str());
+      if (key == "__metadata__") {
+        if (!j.eat('{')) MD_FAIL(MD_ERR_FORMAT, "malformed __metadata__");
+        if (!j.eat('}')) {
+          do {
+            std::string k = j.str();
+            if (!j.eat(':')) MD_FAIL(MD_ERR_FORMAT, "malformed __metadata__");
+            out->metadata[k] = j.str();
+          } while (j.ok && j.eat(','));
+          if (!j.eat('}')) MD_FAIL(MD_ERR_FORMAT, "malformed __metadata__");
+        }
+      } else {
+        ContainerTensor t;
+        if (!j.eat('{')) MD_FAIL(MD_ERR_FORMAT, "malformed entry `%s`", key.c_str());
+        do {
+          std::string k = j.str();
+          if (!j.eat(':')) MD_FAIL(MD_ERR_FORMAT, "malformed entry `%s`", key.c_str());
+          if (k == "dtype") {
+            t.dtype = j.str();
+          } else if (k == "shape") {
+            if (!j.eat('[')) MD_FAIL(MD_ERR_FORMAT, "malformed shape of `%s`", key.c_str());
+            if (!j.eat(']')) {
+              do { t.shape.push_back((int64_t)j.num()); } while (j.ok && j.eat(','));
+              if (!j.eat(']')) MD_FAIL(MD_ERR_FORMAT, "malformed shape of `%s`", key.c_str());
+            }
+          } else if (k == "data_offsets") {
+            if (!j.eat('[')) MD_FAIL(MD_ERR_FORMAT, "malformed offsets of `%s`", key.c_str());
+            t.begin = (size_t)j.num();
+            if (!j.eat(',')) MD_FAIL(MD_ERR_FORMAT, "malformed offsets of `%s`", key.c_str());
+            t.end = (size_t)j.num();
+            if (!j.eat(']')) MD_FAIL(MD_ERR_FORMAT, "malformed offsets of `%s`", key.c_str());
+          } else {
+            j.skip();
+          }
+        } while (j.ok && j.eat(','));
+        if (!j.ok || !j.eat('}')) MD_FAIL(MD_ERR_FORMAT, "malformed entry `%s`", key.c_str());
+        if (t.begin > t.end || t.end > data_len)
+          MD_FAIL(MD_ERR_FORMAT, "tensor `%s` data range [%zu,%zu) outside the file", key.c_str(), t.begin, t.end);
+        out->tensors[key] = t;
+      }
+    } while (j.ok && j.eat(','));
+    if (!j.ok || !j.eat('}')) MD_FAIL(MD_ERR_FORMAT, "malformed container header");
+  }
+  return MD_OK;
+}
+
+static float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ffu;
+  uint32_t u;
+  if (exp == 0) {
+    if (man == 0) {
+      u = sign;
+    } else {
+      int e = -1;
+      do { ++e; man <<= 1; } while (!(man & 0x400u));
+      u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) {
+    u = sign | 0x7f800000u | (man << 13);
+  } else {
+    u = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int container_tensor_to_f32(const Container& c, const ContainerTensor& t, float* dst, size_t count) {
+  const uint8_t* src = c.bytes.data() + c.data_off + t.begin;
+  const size_t nbytes = t.end - t.begin;
+  if (t.dtype == "F32") {
+    if (nbytes != count * 4) MD_FAIL(MD_ERR_FORMAT, "F32 tensor has %zu bytes, expected %zu", nbytes, count * 4);
+    memcpy(dst, src, nbytes);
+  } else if (t.dtype == "F16") {
+    if (nbytes != count * 2) MD_FAIL(MD_ERR_FORMAT, "F16 tensor has %zu bytes, expected %zu", nbytes, count * 2);
+    for (size_t i = 0; i < count; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); dst[i] = f16_to_f32(h); }
+  } else if (t.dtype == "BF16") {
+    if (nbytes != count * 2) MD_FAIL(MD_ERR_FORMAT, "BF16 tensor has %zu bytes, expected %zu", nbytes, count * 2);
+    for (size_t i = 0; i < count; ++i) { uint16_t h; memcpy(&h, src + 2 * i, 2); uint32_t u = (uint32_t)h << 16; memcpy(&dst[i], &u, 4); }
+  } else {
+    MD_FAIL(MD_ERR_FORMAT, "unsupported container dtype `%s`", t.dtype.c_str());
+  }
+  return MD_OK;
+}
+
+}  // namespace md

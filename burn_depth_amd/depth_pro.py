@@ -1,0 +1,225 @@
+"""Host-side mirror of the reference's Depth Pro interface over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference (file:line under the
+reference repository):
+
+* ``DepthPro.new(device, config)``            -- depth_pro/mod.rs:145-191
+* ``DepthPro.load(device, path)``             -- depth_pro/mod.rs:193-198
+* ``DepthPro.load_with_config``               -- depth_pro/mod.rs:200-208
+* ``DepthPro.infer(x) -> DepthProInference``  -- depth_pro/mod.rs:312-364
+* ``img_size`` / ``interpolation_method``     -- depth_pro/mod.rs:296,308
+* debug taps                                  -- encoder.rs:106-123, mod.rs:135-142,285-287
+
+PyTorch is used only as plumbing: device buffers (``torch.empty(..., device="cuda")``), the
+current HIP stream, and ``torch.distributed``.  All arithmetic happens in libmi_depth.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import DepthProConfig, InterpolationMethod, Precision
+
+
+class Device:
+    """`<B as Backend>::Device::default()` (README.md:21): one engine device = one GPU."""
+
+    def __init__(self, ordinal: int = 0):
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.md_device_open(int(ordinal), C.byref(h)))
+        self.handle = h
+        self.ordinal = int(ordinal)
+        torch.cuda.set_device(self.ordinal)
+
+    @staticmethod
+    def default() -> "Device":
+        return Device(int(os.environ.get("LOCAL_RANK", "0")))
+
+    def synchronize(self) -> None:
+        _lib.check(_lib.load().md_device_synchronize(self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            _lib.load().md_device_close(self.handle)
+            self.handle = None
+
+
+@dataclass
+class DepthProInference:
+    """depth_pro/mod.rs:128-133."""
+    depth: torch.Tensor           # [B, H, W]
+    focallength_px: torch.Tensor  # [B]
+    fovx_deg: torch.Tensor        # [B]
+    fovy_rad: torch.Tensor        # [B]
+
+
+def _c_cfg(cfg: DepthProConfig) -> Tuple[_lib.MdDepthProCfg, list]:
+    keep = [cfg.patch_encoder_preset.encode(), cfg.image_encoder_preset.encode(),
+            cfg.fov_encoder_preset.encode() if cfg.fov_encoder_preset else None]
+    c = _lib.MdDepthProCfg(keep[0], keep[1], keep[2], int(cfg.decoder_features), int(bool(cfg.use_fov_head)),
+                           int(cfg.interpolation), int(cfg.precision), int(cfg.max_batch), float(cfg.ln_eps))
+    return c, keep
+
+
+def _stream_ptr(device_ordinal: int) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device_ordinal).cuda_stream)
+
+
+class DepthPro:
+    def __init__(self, device: Device, handle: C.c_void_p, config: DepthProConfig):
+        self.device = device
+        self._h = handle
+        self.config = config
+        self._lib = _lib.load()
+
+    # ---- construction ---------------------------------------------------------------------
+    @staticmethod
+    def new(device: Device, config: Optional[DepthProConfig] = None, seed: int = 0, init_scheme: int = 0) -> "DepthPro":
+        config = config or DepthProConfig()
+        c, keep = _c_cfg(config)
+        h = C.c_void_p()
+        _lib.check(_lib.load().md_depth_pro_create(device.handle, C.byref(c), C.c_uint64(seed), int(init_scheme), C.byref(h)))
+        return DepthPro(device, h, config)
+
+    @staticmethod
+    def load(device: Device, checkpoint_path: str) -> "DepthPro":
+        return DepthPro.load_with_config(device, DepthProConfig(), checkpoint_path)
+
+    @staticmethod
+    def load_with_config(device: Device, config: DepthProConfig, checkpoint_path: str) -> "DepthPro":
+        c, keep = _c_cfg(config)
+        h = C.c_void_p()
+        _lib.check(_lib.load().md_depth_pro_load_with_config(device.handle, C.byref(c), os.fspath(checkpoint_path).encode(),
+                                                             C.byref(h)))
+        return DepthPro(device, h, config)
+
+    def destroy(self) -> None:
+        if self._h:
+            self._lib.md_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- introspection --------------------------------------------------------------------
+    def query(self, key: str) -> int:
+        v = C.c_int64()
+        _lib.check(self._lib.md_model_query(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def img_size(self) -> int:
+        return self.query("img_size")
+
+    def interpolation_method(self) -> int:
+        return self.query("interpolation")
+
+    def param_names(self) -> List[Tuple[str, int]]:
+        out = []
+        for i in range(self._lib.md_model_param_count(self._h)):
+            name, n = C.c_char_p(), C.c_size_t()
+            _lib.check(self._lib.md_model_param_info(self._h, i, C.byref(name), C.byref(n)))
+            out.append((name.value.decode(), int(n.value)))
+        return out
+
+    # ---- records (Module::into_record / load_record, src/lib.rs:163-177) -------------------
+    def get_tensor(self, name: str, count: int) -> np.ndarray:
+        buf = np.empty(count, dtype=np.float32)
+        _lib.check(self._lib.md_model_get_tensor(self._h, name.encode(), buf.ctypes.data_as(C.c_void_p), count))
+        return buf
+
+    def set_tensor(self, name: str, values: np.ndarray) -> None:
+        v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+        _lib.check(self._lib.md_model_set_tensor(self._h, name.encode(), v.ctypes.data_as(C.c_void_p), v.size))
+
+    def commit_weights(self) -> None:
+        _lib.check(self._lib.md_model_commit_weights(self._h))
+
+    def into_record(self) -> Dict[str, np.ndarray]:
+        return {n: self.get_tensor(n, c) for n, c in self.param_names()}
+
+    def load_record(self, record: Dict[str, np.ndarray]) -> "DepthPro":
+        for n, _ in self.param_names():
+            self.set_tensor(n, record[n])
+        self.commit_weights()
+        return self
+
+    def weight_arena(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(self._lib.md_model_weight_arena(self._h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    # ---- inference ------------------------------------------------------------------------
+    def infer(self, x: torch.Tensor) -> DepthProInference:
+        """x: [B,3,H,W] fp32, ImageNet-normalised (any H, W), on the GPU or the host."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
+        x = x.contiguous().to(torch.float32)
+        B, _, H, W = x.shape
+        dev = torch.device("cuda", self.device.ordinal)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        focal = torch.empty((B,), dtype=torch.float32, device=dev)
+        fovx = torch.empty((B,), dtype=torch.float32, device=dev)
+        fovy = torch.empty((B,), dtype=torch.float32, device=dev)
+        in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_depth_pro_infer(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind,
+                                                C.c_void_p(depth.data_ptr()), C.c_void_p(focal.data_ptr()),
+                                                C.c_void_p(fovx.data_ptr()), C.c_void_p(fovy.data_ptr()),
+                                                _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
+        return DepthProInference(depth, focal, fovx, fovy)
+
+    def infer_into(self, x: torch.Tensor, depth: torch.Tensor, focal: torch.Tensor, fovx: torch.Tensor,
+                   fovy: torch.Tensor) -> None:
+        """Allocation-free variant used by the benchmark loop (all tensors on this GPU)."""
+        B, _, H, W = x.shape
+        _lib.check(self._lib.md_depth_pro_infer(self._h, C.c_void_p(x.data_ptr()), B, H, W, _lib.MD_MEM_DEVICE,
+                                                C.c_void_p(depth.data_ptr()), C.c_void_p(focal.data_ptr()),
+                                                C.c_void_p(fovx.data_ptr()), C.c_void_p(fovy.data_ptr()),
+                                                _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
+
+    def infer_from_rgb(self, rgb: bytes, width: int, height: int) -> DepthProInference:
+        """`infer_from_rgb` (src/inference.rs:128-137); raises MdError(MD_ERR_SHAPE) on a bad length."""
+        dev = torch.device("cuda", self.device.ordinal)
+        depth = torch.empty((1, height, width), dtype=torch.float32, device=dev) if width > 0 and height > 0 else None
+        focal = torch.empty((1,), dtype=torch.float32, device=dev)
+        fovy = torch.empty((1,), dtype=torch.float32, device=dev)
+        buf = (C.c_uint8 * len(rgb)).from_buffer_copy(rgb) if len(rgb) else (C.c_uint8 * 1)()
+        _lib.check(self._lib.md_infer_from_rgb(self._h, C.cast(buf, C.c_void_p), len(rgb), int(width), int(height),
+                                               _lib.MD_MEM_HOST, C.c_void_p(depth.data_ptr() if depth is not None else 0),
+                                               C.c_void_p(focal.data_ptr()), C.c_void_p(fovy.data_ptr()),
+                                               _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
+        return DepthProInference(depth, focal, torch.empty(0), fovy)
+
+    # ---- debug taps / timing --------------------------------------------------------------
+    def enable_taps(self, enable: bool = True) -> None:
+        _lib.check(self._lib.md_model_enable_taps(self._h, int(enable)))
+
+    def read_tap(self, name: str) -> np.ndarray:
+        dims = (C.c_int64 * 4)()
+        _lib.check(self._lib.md_model_read_tap(self._h, name.encode(), None, 0, C.byref(dims)))
+        shape = [int(d) for d in dims]
+        n = int(np.prod([max(d, 1) for d in shape]))
+        out = np.empty(n, dtype=np.float32)
+        _lib.check(self._lib.md_model_read_tap(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), n, C.byref(dims)))
+        return out.reshape([max(d, 1) for d in shape])
+
+    def enable_timing(self, enable: bool = True) -> None:
+        _lib.check(self._lib.md_model_enable_timing(self._h, int(enable)))
+
+    def read_timing(self) -> Dict[str, Tuple[float, int]]:
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        calls = (C.c_int * cap)()
+        n = C.c_int()
+        _lib.check(self._lib.md_model_read_timing(self._h, names, ms, calls, cap, C.byref(n)))
+        return {names[i].decode(): (float(ms[i]), int(calls[i])) for i in range(min(n.value, cap))}

@@ -22,6 +22,7 @@ dtype F32 / F16 / BF16, keyed by the names above, plus ``__metadata__`` carrying
 from __future__ import annotations
 
 import json
+import math
 import struct
 from typing import Dict, Iterable, List, NamedTuple, Optional, Tuple
 
@@ -55,19 +56,19 @@ def _vit_specs(prefix: str, v: ViTConfig, scheme: int) -> List[ParamSpec]:
     par = scheme == INIT_PARITY
 
     def lin(name, fan_out, fan_in, bias=True):
-        b = (3.0 / fan_in) ** 0.5 if par else (1.0 / fan_in) ** 0.5
+        b = math.sqrt(3.0 / fan_in) if par else math.sqrt(1.0 / fan_in)
         out.append(ParamSpec(f"{name}.weight", (fan_out, fan_in), *_sym(b)))
         if bias:
-            bb = 0.1 if par else (1.0 / fan_in) ** 0.5
+            bb = 0.1 if par else math.sqrt(1.0 / fan_in)
             out.append(ParamSpec(f"{name}.bias", (fan_out,), *_sym(bb)))
 
     fan = C * P * P
-    b = (3.0 / fan) ** 0.5 if par else (1.0 / fan) ** 0.5
+    b = math.sqrt(3.0 / fan) if par else math.sqrt(1.0 / fan)
     out.append(ParamSpec(f"{prefix}.patch_embed.proj.weight", (D, C, P, P), *_sym(b)))
     out.append(ParamSpec(f"{prefix}.patch_embed.proj.bias", (D,), *_sym(0.1 if par else b)))
     out.append(ParamSpec(f"{prefix}.cls_token", (1, 1, D), *_sym(0.5 if par else 1e-6)))
     # N(0, 0.02) in DINOv2; a uniform of the same std keeps the generator transcendental-free
-    s = 0.02 * 3.0 ** 0.5
+    s = 0.02 * math.sqrt(3.0)
     out.append(ParamSpec(f"{prefix}.pos_embed", (1, v.num_tokens, D), *_sym(0.3 if par else s)))
     for i in range(v.depth):
         blk = f"{prefix}.blocks.{i}"
@@ -99,11 +100,11 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
     def conv(name, cout, cin, k, bias, relu_after=False, gain=None):
         fan = cin * k * k
         if par:
-            b = ((6.0 if relu_after else 3.0) / fan) ** 0.5
+            b = math.sqrt((6.0 if relu_after else 3.0) / fan)
             if gain is not None:
                 b *= gain
         else:
-            b = (1.0 / fan) ** 0.5
+            b = math.sqrt(1.0 / fan)
         specs.append(ParamSpec(f"{name}.weight", (cout, cin, k, k), *_sym(b)))
         if bias:
             specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
@@ -111,7 +112,7 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
     def deconv(name, cin, cout, bias):
         # Burn's ConvTranspose2d fan_in uses channels[1]*k*k (out channels); only the range matters
         fan = cin
-        b = (3.0 / fan) ** 0.5 if par else (1.0 / (cout * 4)) ** 0.5
+        b = math.sqrt(3.0 / fan) if par else math.sqrt(1.0 / (cout * 4))
         specs.append(ParamSpec(f"{name}.weight", (cin, cout, 2, 2), *_sym(b)))
         if bias:
             specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
@@ -154,7 +155,7 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
         specs.append(ParamSpec("head.conv_out.weight", (1, 32, 1, 1), 0.0, 0.08))
         specs.append(ParamSpec("head.conv_out.bias", (1,), 0.05, 0.05))
     else:
-        b = (1.0 / 32) ** 0.5
+        b = math.sqrt(1.0 / 32)
         specs.append(ParamSpec("head.conv_out.weight", (1, 32, 1, 1), *_sym(b)))
         specs.append(ParamSpec("head.conv_out.bias", (1,), 0.0, 0.0))  # mod.rs:92-95
 
@@ -162,7 +163,7 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
         if fv is not None:
             specs += _vit_specs("fov.encoder", fv, scheme)
             fan = fv.embed_dim
-            b = (3.0 / fan) ** 0.5 if par else (1.0 / fan) ** 0.5
+            b = math.sqrt(3.0 / fan) if par else math.sqrt(1.0 / fan)
             specs.append(ParamSpec("fov.encoder_proj.weight", (F // 2, fan), *_sym(b)))
             specs.append(ParamSpec("fov.encoder_proj.bias", (F // 2,), *_sym(0.1 if par else b)))
             conv("fov.downsample_blocks.0.conv", F // 2, F, 3, True, relu_after=True)
@@ -176,7 +177,7 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
             last = ("fov.head_blocks.3.conv", 1, F // 8, 6)
         name, cout, cin, k = last
         fan = cin * k * k
-        b = (3.0 / fan) ** 0.5 if par else (1.0 / fan) ** 0.5
+        b = math.sqrt(3.0 / fan) if par else math.sqrt(1.0 / fan)
         specs.append(ParamSpec(f"{name}.weight", (cout, cin, k, k), *_sym(b)))
         # parity scheme: field of view around 55 degrees so tan(fov/2) is well conditioned
         specs.append(ParamSpec(f"{name}.bias", (cout,), *((55.0, 55.0) if par else _sym(b))))

@@ -1,0 +1,191 @@
+/*
+ * mi_depth.h -- C ABI of libmi_depth.so, the MI355X-native (gfx950) drop-in for the hot path
+ * of mosure/burn_depth: DepthPro::load / DepthPro::infer (and the helpers either side of it).
+ *
+ * Every entry point cites the reference interface it replaces (path:line under the reference
+ * repository).  Plain pointers and sizes only; no torch / HIP types in the signatures (a
+ * hipStream_t is passed as void*).  All functions return 0 (MD_OK) or a negative md_status and
+ * record a message retrievable with md_last_error() -- the reference's panics
+ * (expect!/assert!/panic!) become checked preconditions with distinct codes, never aborts.
+ *
+ * Threading: one in-flight infer per md_model_t (the workspace arena is per model), matching
+ * the reference's `infer(&self)` + per-caller Mutex usage (crates/bevy_burn_depth/src/lib.rs:18,29).
+ */
+#ifndef MI_DEPTH_H
+#define MI_DEPTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct md_device_s* md_device_t;
+typedef struct md_model_s* md_model_t;
+
+typedef enum md_status {
+  MD_OK = 0,
+  MD_ERR_INVALID_ARG = -1, /* null pointer, unknown preset/key (vit.rs:49-50 panic)            */
+  MD_ERR_SHAPE = -2,       /* bad B/H/W, RGB length mismatch (inference.rs:90-95 Err)           */
+  MD_ERR_IO = -3,          /* file cannot be read (RecorderError, mod.rs:193-208)               */
+  MD_ERR_FORMAT = -4,      /* container malformed / tensor missing or wrong shape               */
+  MD_ERR_HIP = -5,         /* HIP runtime failure                                               */
+  MD_ERR_UNSUPPORTED = -6, /* configuration outside what the kernels support                    */
+  MD_ERR_NO_FOV = -7,      /* "FOV head required for focal length" (mod.rs:329 expect)          */
+  MD_ERR_OOM = -8,         /* workspace arena exhausted                                         */
+  MD_ERR_LEVELS = -9       /* decoder level-count mismatch (decoder.rs:200-205 panic)           */
+} md_status;
+
+typedef enum md_mem_kind { MD_MEM_HOST = 0, MD_MEM_DEVICE = 1 } md_mem_kind;
+/* Arithmetic type of the MFMA operands; accumulation, LayerNorm, softmax and the final
+ * focal/clamp/reciprocal are fp32 in both modes. */
+typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1 } md_precision;
+/* depth_pro/interpolate.rs:11-22 */
+typedef enum md_interp { MD_INTERP_CUSTOM = 0, MD_INTERP_BURN = 1 } md_interp;
+/* synthetic initialisation (no trained weights exist in the reference tree) */
+typedef enum md_init_scheme { MD_INIT_REFERENCE = 0, MD_INIT_PARITY = 1 } md_init_scheme;
+
+/* DepthProConfig, depth_pro/mod.rs:35-66 (same fields, same defaults via md_depth_pro_cfg_default). */
+typedef struct md_depth_pro_cfg {
+  const char* patch_encoder_preset; /* "dinov2l16_384" | "dinov2l16_128" | "tiny16_128" */
+  const char* image_encoder_preset;
+  const char* fov_encoder_preset;   /* NULL = FOV head without its own ViT (fov.rs:118-155) */
+  int decoder_features;             /* 256 */
+  int use_fov_head;                 /* 1 */
+  int interpolation;                /* md_interp, default CUSTOM */
+  int precision;                    /* md_precision, engine-side addition */
+  int max_batch;                    /* images per infer call the workspace is sized for */
+  float ln_eps;                     /* burn_dino's LayerNorm eps is not visible; default 1e-6 */
+} md_depth_pro_cfg;
+
+/* Last error message of the calling thread ("" if none). Maps RecorderError / String errors. */
+const char* md_last_error(void);
+/* Library version string. */
+const char* md_version(void);
+
+/* `<B as Backend>::Device::default()` (README.md:21, src/lib.rs:15-22): one device = one GPU. */
+int md_device_open(int hip_ordinal, md_device_t* out);
+int md_device_close(md_device_t dev);
+int md_device_synchronize(md_device_t dev); /* `B::sync(&device)` (bench/inference.rs:46) */
+
+/* `DepthProConfig::default()` (depth_pro/mod.rs:54-66). */
+void md_depth_pro_cfg_default(md_depth_pro_cfg* cfg);
+
+/* `DepthPro::new(&device, cfg)` (depth_pro/mod.rs:145-191): seeded synthetic initialisation. */
+int md_depth_pro_create(md_device_t dev, const md_depth_pro_cfg* cfg, uint64_t seed, int init_scheme,
+                        md_model_t* out);
+/* `DepthPro::load(&device, path)` (depth_pro/mod.rs:193-198): default config. The container is
+ * safetensors keyed by the reference's Burn field paths. */
+int md_depth_pro_load(md_device_t dev, const char* path, md_model_t* out);
+/* `DepthPro::load_with_config` (depth_pro/mod.rs:200-208). */
+int md_depth_pro_load_with_config(md_device_t dev, const md_depth_pro_cfg* cfg, const char* path,
+                                  md_model_t* out);
+/* `Module::load_record` / `into_record` (src/lib.rs:163-177): read or replace one named
+ * parameter with host fp32 data. `count` = number of elements and must match. */
+int md_model_set_tensor(md_model_t m, const char* name, const float* host_data, size_t count);
+int md_model_get_tensor(md_model_t m, const char* name, float* host_data, size_t count);
+/* Number of parameters / name+element count of the i-th one (fixed inventory order). */
+int md_model_param_count(md_model_t m);
+int md_model_param_info(md_model_t m, int index, const char** name, size_t* count);
+/* Must be called after md_model_set_tensor calls and before the next infer: re-packs the
+ * MFMA operand copies (bf16, [N][K] / tap-major layouts) from the fp32 master weights. */
+int md_model_commit_weights(md_model_t m);
+/* The packed device-resident weight arena (for an RCCL broadcast from rank 0). */
+int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes);
+int md_model_destroy(md_model_t m);
+
+/* `DepthPro::infer(&self, x)` (depth_pro/mod.rs:312-364). Input NCHW fp32, ImageNet-normalised,
+ * any H x W (resized to img_size^2 and back like the reference). Outputs (DepthProInference,
+ * mod.rs:128-133): depth[B*H*W], focallength_px[B], fovx_deg[B], fovy_rad[B]; any output pointer
+ * may be NULL to skip it. in_kind/out_kind say whether the pointers are host or device memory.
+ * `stream` is a hipStream_t (NULL = the model's own stream); the call is asynchronous for
+ * device outputs and synchronises for host outputs. */
+int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
+                       float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream);
+
+/* `infer_from_rgb` + `rgb_to_input_tensor` (src/inference.rs:79-137): packed RGB bytes,
+ * row-major, `rgb_len` must equal w*h*3 (else MD_ERR_SHAPE, as the reference's Err). B = 1. */
+int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, int h, int in_kind,
+                      float* depth, float* focallength_px, float* fovy_rad, int out_kind, void* stream);
+
+/* `img_size()` (mod.rs:296), `interpolation_method()` (mod.rs:308) and friends.
+ * keys: "img_size", "patch_window", "interpolation", "precision", "max_batch", "num_params",
+ *       "workspace_bytes", "weight_bytes", "tiles_per_image". */
+int md_model_query(md_model_t m, const char* key, int64_t* out);
+
+/* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs
+ * mod.rs:285-287). After an infer, copy the named intermediate (converted to NCHW fp32, the
+ * reference's layout) to host memory. `dims` receives up to 4 dims. Names follow
+ * example/correctness.rs:98-122: encoder_feature_{0..4}, encoder_merge_latent{0,1},
+ * encoder_merge_x{0,1,2}, decoder_fusion_{0..4}, decoder_feature, decoder_lowres_feature,
+ * head_conv0, head_deconv, canonical_inverse_depth, fov_deg, split_x{0,1,2}.
+ * Pass host_data = NULL to query dims only. Taps must be enabled before the infer. */
+int md_model_enable_taps(md_model_t m, int enable);
+int md_model_read_tap(md_model_t m, const char* name, float* host_data, size_t capacity, int64_t dims[4]);
+
+/* ---- stand-alone operators on device pointers (the reference's public helpers; used by the
+ * parity tests to check each kernel against the oracle) ------------------------------------ */
+/* `rgb_to_input_tensor` (src/inference.rs:79-121) on device: u8 HWC -> fp32 NCHW. */
+int md_op_rgb_to_input(md_device_t dev, const uint8_t* rgb_dev, size_t rgb_len, int w, int h, float* out_dev,
+                       void* stream);
+/* `resize_bilinear_align_corners_false(x, [oh,ow], method)` (interpolate.rs:123-134), fp32 NCHW. */
+int md_op_resize_bilinear(md_device_t dev, const float* in_dev, int B, int C, int H, int W, float* out_dev,
+                          int OH, int OW, int method, void* stream);
+/* `resize_bilinear_scale` (interpolate.rs:136-145): writes the output dims to oh/ow. */
+int md_op_resize_output_size(int H, int W, float scale_h, float scale_w, int* oh, int* ow);
+/* `DepthProEncoder::split` (encoder.rs:190-232): fp32 NCHW [B,C,S,S] -> [steps^2*B,C,win,win]. */
+int md_op_split(md_device_t dev, const float* in_dev, int B, int C, int S, int window, float overlap,
+                float* out_dev, int* steps_out, void* stream);
+/* `DepthProEncoder::merge` (encoder.rs:234-282): fp32 NCHW tiles -> stitched map. */
+int md_op_merge(md_device_t dev, const float* in_dev, int tiles, int C, int h, int w, int batch, int padding,
+                float* out_dev, int* out_h, int* out_w, void* stream);
+/* LayerNorm over the last dim (burn nn::LayerNorm as used by burn_dino): x[rows,D] fp32 -> fp32. */
+int md_op_layernorm(md_device_t dev, const float* x_dev, const float* gamma_dev, const float* beta_dev, int rows,
+                    int D, float eps, float* out_dev, void* stream);
+/* Linear: out[M,N] = act(x[M,K] @ w[N,K]^T + bias), fp32 in/out; operands rounded per
+ * `precision`. act: 0 none, 1 relu, 2 gelu(erf). (burn nn::Linear) */
+int md_op_linear(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int M, int N,
+                 int K, int act, int precision, float* out_dev, void* stream);
+/* Same with an explicit GEMM tile configuration (0 = 256x256, 1 = 128x128, 2 = 256x32, 99 = auto);
+ * lets the parity tests and the bench exercise every tile shape. */
+int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int M, int N,
+                      int K, int act, int precision, int tile, float* out_dev, void* stream);
+/* Multi-head attention core on a fused qkv tensor [T, N, 3*heads*64] (timm layout), fp32 in/out:
+ * softmax(q k^T / 8) v -> [T, N, heads*64]. (burn_dino attention, quiet_softmax=false) */
+int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int heads, int precision, float* out_dev,
+                    void* stream);
+/* Conv2d 3x3 stride 1 pad 1 (burn nn::Conv2d): fp32 NCHW in/out, w [Cout,Cin,3,3]. */
+int md_op_conv3x3(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int B, int Cin,
+                  int H, int W, int Cout, int pre_relu, int precision, float* out_dev, void* stream);
+/* ConvTranspose2d k=2 s=2 (burn nn::ConvTranspose2d): fp32 NCHW, w [Cin,Cout,2,2]. */
+int md_op_deconv2x2(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int B, int Cin,
+                    int H, int W, int Cout, int precision, float* out_dev, void* stream);
+/* Generic small Conv2d (any k/stride/pad), fp32 exact; the FOV head path (fov.rs:16-49). */
+int md_op_conv2d_direct(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int B,
+                        int Cin, int H, int W, int Cout, int k, int stride, int pad, int relu, float* out_dev,
+                        void* stream);
+/* `fovy_from_fovx_rad` (mod.rs:370-414) + focal length (mod.rs:330-336) on host scalars. */
+int md_op_fov_to_focal(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad);
+
+/* ---- host-only utilities (no GPU needed) ---------------------------------------------------- */
+/* The parameter inventory of `DepthPro::new` for a config: returns the number of parameters; for
+ * 0 <= index < count also the name (static storage, valid until the next call from this thread),
+ * element count and the uniform range [lo, hi) the seeded initialiser draws from. */
+int md_param_inventory(const md_depth_pro_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,
+                       float* lo, float* hi);
+/* The seeded generator itself: `count` values of stream (name, seed) in [lo, hi). */
+int md_uniform_stream(const char* name, uint64_t seed, size_t count, float lo, float hi, float* out_host);
+/* Split geometry (encoder.rs:196-206) and feature padding (encoder.rs:28-38). */
+int md_split_geometry(int image_size, int window, float overlap, int* stride, int* steps);
+int md_feature_padding(int window, int stride, int feature_size);
+
+/* Per-kernel timing of the last infer (HIP events on the model stream; enable first).
+ * names/ms arrays of capacity `cap`; returns the number of entries in *n. */
+int md_model_enable_timing(md_model_t m, int enable);
+int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_DEPTH_H */

@@ -1,0 +1,127 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/mi_depth.h declares,
+and its host-side logic (inventory, seeded generator, geometry, scalar tail) agrees with the Python
+host code and the oracle.  No compute kernel is launched here."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from burn_depth_amd import _lib
+from burn_depth_amd import weights as Wt
+from burn_depth_amd.config import DepthProConfig
+from burn_depth_amd.depth_pro import _c_cfg
+from oracle import depth_pro_ref as R
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib, repo_root):
+    header = open(os.path.join(repo_root, "include", "mi_depth.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(md_[a-z0-9_]+)\s*\(", header, re.M))
+    assert declared, "no symbols parsed from the header"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libmi_depth.so does not export {name}"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+
+
+def test_cfg_default_matches_reference(lib):
+    c = _lib.MdDepthProCfg()
+    lib.md_depth_pro_cfg_default(C.byref(c))
+    # depth_pro/mod.rs:54-66
+    assert c.patch_encoder_preset == b"dinov2l16_384" and c.image_encoder_preset == b"dinov2l16_384"
+    assert c.fov_encoder_preset == b"dinov2l16_384"
+    assert c.decoder_features == 256 and c.use_fov_head == 1 and c.interpolation == 0
+
+
+@pytest.mark.parametrize("cfg", [DepthProConfig(), DepthProConfig.small_test(), DepthProConfig.tiny_test()])
+@pytest.mark.parametrize("scheme", [Wt.INIT_REFERENCE, Wt.INIT_PARITY])
+def test_inventory_matches_python(lib, cfg, scheme):
+    specs = Wt.depth_pro_param_specs(cfg, scheme)
+    c, keep = _c_cfg(cfg)
+    n = lib.md_param_inventory(C.byref(c), scheme, -1, None, None, None, None)
+    assert n == len(specs)
+    for i, s in enumerate(specs):
+        name, cnt, lo, hi = C.c_char_p(), C.c_size_t(), C.c_float(), C.c_float()
+        lib.md_param_inventory(C.byref(c), scheme, i, C.byref(name), C.byref(cnt), C.byref(lo), C.byref(hi))
+        assert name.value.decode() == s.name
+        assert cnt.value == int(np.prod(s.shape))
+        assert lo.value == np.float32(s.lo) and hi.value == np.float32(s.hi), s.name
+
+
+def test_unknown_preset_is_an_error_not_a_panic(lib):
+    # layers/vit.rs:49-50 panics on an unknown preset; the ABI returns MD_ERR_INVALID_ARG
+    cfg = DepthProConfig()
+    cfg.patch_encoder_preset = "vit_h_14"
+    c, keep = _c_cfg(cfg)
+    assert lib.md_param_inventory(C.byref(c), 0, -1, None, None, None, None) == _lib.MD_ERR_INVALID_ARG
+    assert b"unsupported ViT preset" in lib.md_last_error()
+
+
+def test_seeded_generator_is_bit_identical(lib):
+    for name, seed, n, lo, hi in [("encoder.patch_encoder.blocks.3.attn.qkv.weight", 0, 4099, -0.03125, 0.03125),
+                                  ("head.conv_out.weight", 7, 32, 0.0, 0.08),
+                                  ("fov.encoder.pos_embed", 123456789, 1000, -0.3, 0.3),
+                                  ("x", 1, 17, 0.5, 1.5), ("const", 0, 5, 1.0, 1.0)]:
+        got = np.empty(n, dtype=np.float32)
+        assert lib.md_uniform_stream(name.encode(), seed, n, lo, hi, got.ctypes.data_as(C.c_void_p)) == 0
+        want = Wt.uniform_stream(name, seed, n, lo, hi)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+        if lo != hi:
+            assert (want >= np.float32(lo)).all() and (want <= np.float32(hi)).all()
+
+
+def test_split_geometry_and_padding(lib):
+    for size, win, ov in [(1536, 384, 0.25), (768, 384, 0.5), (512, 128, 0.25), (256, 128, 0.5), (512, 128, 0.0), (128, 128, 0.5)]:
+        st, sp = C.c_int(), C.c_int()
+        assert lib.md_split_geometry(size, win, C.c_float(ov), C.byref(st), C.byref(sp)) == 0
+        assert (st.value, sp.value) == R.split_geometry(size, win, ov)
+        for fs in (8, 24):
+            assert lib.md_feature_padding(win, st.value, fs) == R.feature_padding(win, st.value, fs)
+
+
+def test_resize_output_size(lib):
+    for h, w, sh, sw in [(2, 2, 1.5, 0.5), (1536, 1536, 0.5, 0.25), (1, 3, 0.25, 0.25), (360, 540, 0.5, 0.5)]:
+        oh, ow = C.c_int(), C.c_int()
+        assert lib.md_op_resize_output_size(h, w, C.c_float(sh), C.c_float(sw), C.byref(oh), C.byref(ow)) == 0
+        assert (oh.value, ow.value) == (R.compute_output_size(h, sh), R.compute_output_size(w, sw))
+
+
+def test_fov_scalar_tail_matches_oracle(lib):
+    # depth_pro/mod.rs:330-336 and 370-414
+    for deg, h, w in [(56.4, 512, 512), (30.0, 360, 540), (100.0, 540, 360), (75.5, 1536, 1536)]:
+        f, y = C.c_float(), C.c_float()
+        assert lib.md_op_fov_to_focal(C.c_float(deg), h, w, C.byref(f), C.byref(y)) == 0
+        fx = torch.tensor([deg], dtype=torch.float32) * torch.tensor(math.pi / 180.0, dtype=torch.float32)
+        focal = (w * 0.5) / torch.tan(fx * 0.5)
+        fovy = R.fovy_from_fovx_rad(fx, h, w)
+        assert abs(f.value - focal.item()) <= 2e-6 * abs(focal.item())
+        assert abs(y.value - fovy.item()) <= 1e-6
+
+
+def test_load_missing_file_is_io_error(lib):
+    # RecorderError path of DepthPro::load (depth_pro/mod.rs:193-208): reported before touching the GPU
+    h = C.c_void_p()
+    fake_dev = C.c_void_p(1)
+    code = lib.md_depth_pro_load(fake_dev, b"/nonexistent/depth_pro.safetensors", C.byref(h))
+    assert code == _lib.MD_ERR_IO
+    assert b"cannot open" in lib.md_last_error()
+
+
+def test_container_roundtrip(tmp_path):
+    cfg = DepthProConfig.tiny_test()
+    W = Wt.generate_depth_pro_weights(cfg, 3)
+    for dt, tol in [("F32", 0.0), ("F16", 1e-3), ("BF16", 8e-3)]:
+        p = str(tmp_path / f"w_{dt}.safetensors")
+        Wt.save_container(p, W, Wt.config_metadata(cfg), dt)
+        W2, meta = Wt.load_container(p)
+        assert meta["model"] == "depth_pro" and set(W2) == set(W)
+        k = "encoder.patch_encoder.blocks.0.attn.qkv.weight"
+        assert W2[k].shape == W[k].shape
+        assert np.abs(W2[k] - W[k]).max() <= tol * np.abs(W[k]).max() + (0 if tol else 0)

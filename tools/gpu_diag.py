@@ -1,0 +1,314 @@
+"""One-shot GPU diagnostic: runs every stand-alone operator and the end-to-end Depth Pro path
+against the CPU oracle and prints an error table (never raises; meant for `gpurun` logs).
+
+usage: python tools/gpu_diag.py [--skip-small] [--full]
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from burn_depth_amd import _lib, ops  # noqa: E402
+from burn_depth_amd import weights as Wt  # noqa: E402
+from burn_depth_amd.config import DepthProConfig, Precision  # noqa: E402
+from burn_depth_amd.depth_pro import DepthPro, Device  # noqa: E402
+from oracle import depth_pro_ref as R  # noqa: E402
+
+RESULTS = []
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if a.shape != b.shape:
+        return float("inf")
+    if not torch.isfinite(a).all():
+        return float("nan")
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def record(name, err, tol, extra=""):
+    ok = err == err and err <= tol
+    RESULTS.append((name, err, tol, ok, extra))
+    print(f"[{'OK ' if ok else 'BAD'}] {name:58s} err={err:.3e} tol={tol:.1e} {extra}", flush=True)
+
+
+def guarded(name):
+    def deco(fn):
+        def run(*a, **k):
+            try:
+                t = time.time()
+                fn(*a, **k)
+                torch.cuda.synchronize()
+                print(f"      ({name}: {time.time() - t:.2f}s)", flush=True)
+            except Exception as e:  # noqa: BLE001
+                traceback.print_exc()
+                RESULTS.append((name, float("nan"), 0.0, False, f"EXC {type(e).__name__}: {e}"))
+                print(f"[BAD] {name}: exception {e}", flush=True)
+        return run
+    return deco
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@guarded("resize")
+def check_resize(dev):
+    g = torch.Generator().manual_seed(1)
+    for (shape, out, m) in [((1, 1, 2, 2), (4, 4), 0), ((1, 1, 2, 2), (4, 4), 1), ((1, 1, 2, 2), (3, 1), 0), ((1, 1, 2, 2), (3, 1), 1),
+                            ((2, 3, 36, 54), (96, 96), 0), ((2, 3, 96, 96), (48, 48), 0), ((1, 3, 96, 96), (24, 24), 0),
+                            ((1, 1, 96, 96), (36, 54), 0), ((1, 2, 7, 5), (13, 17), 1), ((1, 2, 5, 5), (5, 5), 0)]:
+        x = torch.rand(shape, generator=g)
+        if shape == (1, 1, 2, 2):
+            x = torch.tensor([1.0, 2.0, 3.0, 4.0]).reshape(shape) if out == (4, 4) else torch.tensor([4.0, 1.0, 0.0, 2.0]).reshape(shape)
+        want = R.resize_bilinear(x, out, m)
+        got = ops.resize_bilinear(dev, x.cuda(), out, m).cpu()
+        exact = torch.equal(got, want)
+        record(f"resize {shape}->{out} m{m}", rel_err(got, want), 0.0 if m == 0 else 1e-6, "bit-exact" if exact else "")
+
+
+@guarded("rgb")
+def check_rgb(dev):
+    from burn_depth_amd.inference import rgb_to_input_tensor
+    rgb = bytes(np.random.RandomState(0).randint(0, 256, size=37 * 21 * 3, dtype=np.uint8).tolist())
+    want = R.rgb_to_input_tensor(rgb, 37, 21)
+    got = rgb_to_input_tensor(rgb, 37, 21, dev).cpu()
+    record("rgb_to_input 37x21", rel_err(got, want), 0.0, "bit-exact" if torch.equal(got, want) else "")
+    kat = rgb_to_input_tensor(bytes([0, 255, 128, 255, 0, 128]), 1, 2, dev).cpu().flatten()
+    exp = torch.tensor([-2.1179039, 2.2489083, 2.4285715, -2.0357141, 0.42649257, 0.42649257])
+    record("rgb_to_input KAT", (kat - exp).abs().max().item(), 1e-6)
+
+
+@guarded("split/merge")
+def check_split_merge(dev):
+    x = torch.arange(2 * 3 * 512 * 512, dtype=torch.float32).reshape(2, 3, 512, 512)
+    for ov in (0.25, 0.5, 0.0):
+        want, steps, stride = R.split(x, 128, ov)
+        got, st = ops.split(dev, x.cuda(), 128, ov)
+        record(f"split ov={ov} steps={st}", rel_err(got, want), 0.0)
+    tiles = torch.rand(25 * 2, 5, 8, 8)
+    record("merge 5x5 pad1", rel_err(ops.merge(dev, tiles.cuda(), 2, 1), R.merge(tiles, 2, 1)), 0.0)
+    tiles = torch.rand(9 * 2, 4, 24, 24)
+    record("merge 3x3 pad6", rel_err(ops.merge(dev, tiles.cuda(), 2, 6), R.merge(tiles, 2, 6)), 0.0)
+    tiles = torch.rand(25, 4, 24, 24)
+    record("merge 5x5 pad3", rel_err(ops.merge(dev, tiles.cuda(), 1, 3), R.merge(tiles, 1, 3)), 0.0)
+    tiles = torch.rand(3, 4, 8, 8)
+    record("merge 1x1", rel_err(ops.merge(dev, tiles.cuda(), 3, 2), R.merge(tiles, 3, 2)), 0.0)
+
+
+@guarded("layernorm")
+def check_layernorm(dev):
+    g = torch.Generator().manual_seed(2)
+    for rows, D in [(7, 1024), (580, 1024), (33, 256), (5, 384), (3, 64)]:
+        x = torch.randn(rows, D, generator=g) * 3 + 0.5
+        ga, be = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+        want = F.layer_norm(x, (D,), ga, be, 1e-6)
+        got = ops.layernorm(dev, x.cuda(), ga.cuda(), be.cuda(), 1e-6)
+        record(f"layernorm {rows}x{D}", rel_err(got, want), 2e-6)
+    x = torch.randn(9, 256, generator=g)
+    record("layernorm non-affine", rel_err(ops.layernorm(dev, x.cuda(), None, None, 1e-5), F.layer_norm(x, (256,), None, None, 1e-5)), 2e-6)
+
+
+@guarded("linear")
+def check_linear(dev):
+    g = torch.Generator().manual_seed(3)
+    cases = [(300, 256, 128, _lib.TILE_128x128), (300, 256, 128, _lib.TILE_256x256), (577, 3072, 1024, _lib.TILE_AUTO),
+             (1160, 1024, 4096, _lib.TILE_AUTO), (64, 32, 192, _lib.TILE_256x32), (1000, 32, 128, _lib.TILE_256x32),
+             (129, 132, 64, _lib.TILE_128x128), (513, 260, 320, _lib.TILE_256x256), (2000, 1024, 1024, _lib.TILE_256x256),
+             (2000, 1024, 1024, _lib.TILE_128x128)]
+    for prec, pname in [(0, "bf16"), (1, "f32")]:
+        for (M, N, K, tile) in cases:
+            x = torch.randn(M, K, generator=g)
+            w = torch.randn(N, K, generator=g) / math.sqrt(K)
+            b = torch.randn(N, generator=g)
+            if prec == 0:
+                x, w = bf(x), bf(w)
+            want = F.linear(x.double(), w.double(), b.double()).float()
+            got = ops.linear(dev, x.cuda(), w.cuda(), b.cuda(), 0, prec, tile)
+            record(f"linear {pname} M{M} N{N} K{K} tile{tile}", rel_err(got, want), 2e-5)
+        x = bf(torch.randn(200, 256, generator=g))
+        w = bf(torch.randn(512, 256, generator=g) / 16)
+        b = torch.randn(512, generator=g)
+        record(f"linear {pname} gelu", rel_err(ops.linear(dev, x.cuda(), w.cuda(), b.cuda(), 2, prec), F.gelu(F.linear(x, w, b))), 2e-5)
+        record(f"linear {pname} relu nobias", rel_err(ops.linear(dev, x.cuda(), w.cuda(), None, 1, prec), F.relu(F.linear(x, w))), 2e-5)
+
+
+def attn_ref(qkv, heads, quant):
+    T, N, _ = qkv.shape
+    q, k, v = qkv.reshape(T, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * 0.125
+    pu = torch.exp(s - s.amax(-1, keepdim=True))
+    o = (quant(pu) @ v) / pu.sum(-1, keepdim=True)
+    return o.transpose(1, 2).reshape(T, N, heads * 64)
+
+
+@guarded("attention")
+def check_attention(dev):
+    g = torch.Generator().manual_seed(4)
+    for (T, N, heads) in [(2, 65, 4), (3, 577, 2), (1, 577, 16), (2, 64, 1), (1, 130, 3), (1, 1370, 2)]:
+        qkv = torch.randn(T, N, 3 * heads * 64, generator=g)
+        qkv[..., :heads * 64] *= 2.0
+        want = attn_ref(bf(qkv), heads, R.identity)
+        got = ops.attention(dev, bf(qkv).cuda(), heads, 0)
+        record(f"attention bf16 T{T} N{N} h{heads}", rel_err(got, want), 1.5e-2)
+        want32 = attn_ref(qkv, heads, R.identity)
+        got32 = ops.attention(dev, qkv.cuda(), heads, 1)
+        record(f"attention f32  T{T} N{N} h{heads}", rel_err(got32, want32), 2e-5)
+    # online-softmax rescale stress: one key dominates late in the sequence
+    qkv = torch.randn(1, 577, 3 * 64, generator=g)
+    qkv[0, 500, 64:128] = qkv[0, 3, :64] * 6.0
+    want = attn_ref(bf(qkv), 1, R.identity)
+    record("attention bf16 spike", rel_err(ops.attention(dev, bf(qkv).cuda(), 1, 0), want), 1.5e-2)
+
+
+@guarded("conv")
+def check_convs(dev):
+    g = torch.Generator().manual_seed(5)
+    for prec, pname, tol in [(0, "bf16", 2e-5), (1, "f32", 2e-5)]:
+        for (B, Cin, H, W, Cout) in [(1, 64, 16, 16, 64), (2, 128, 24, 20, 256), (1, 256, 48, 48, 256), (1, 64, 33, 17, 32)]:
+            x = torch.randn(B, Cin, H, W, generator=g)
+            w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+            b = torch.randn(Cout, generator=g)
+            if prec == 0:
+                x, w = bf(x), bf(w)
+            want = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+            got = ops.conv3x3(dev, x.cuda(), w.cuda(), b.cuda(), False, prec)
+            record(f"conv3x3 {pname} B{B} {Cin}->{Cout} {H}x{W}", rel_err(got, want), tol)
+        x = bf(torch.randn(1, 64, 12, 12, generator=g))
+        w = bf(torch.randn(64, 64, 3, 3, generator=g) / 24)
+        record(f"conv3x3 {pname} pre-relu nobias", rel_err(ops.conv3x3(dev, x.cuda(), w.cuda(), None, True, prec), F.conv2d(F.relu(x), w, None, padding=1)), tol)
+        for (B, Cin, H, W, Cout) in [(1, 64, 8, 8, 64), (2, 256, 12, 10, 128), (1, 1024, 24, 24, 256)]:
+            x = torch.randn(B, Cin, H, W, generator=g)
+            w = torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin)
+            b = torch.randn(Cout, generator=g)
+            if prec == 0:
+                x, w = bf(x), bf(w)
+            want = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2).float()
+            got = ops.deconv2x2(dev, x.cuda(), w.cuda(), b.cuda(), prec)
+            record(f"deconv2x2 {pname} B{B} {Cin}->{Cout} {H}x{W}", rel_err(got, want), tol)
+    for (B, Cin, H, W, Cout, k, s, p, relu) in [(2, 64, 16, 16, 32, 3, 2, 1, True), (1, 32, 8, 8, 16, 3, 2, 1, True), (2, 8, 6, 6, 1, 6, 1, 0, False),
+                                                  (1, 256, 48, 48, 128, 3, 2, 1, True)]:
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(k * k * Cin)
+        b = torch.randn(Cout, generator=g)
+        want = F.conv2d(x, w, b, stride=s, padding=p)
+        if relu:
+            want = F.relu(want)
+        record(f"conv_direct {Cin}->{Cout} k{k}s{s}p{p}", rel_err(ops.conv2d_direct(dev, x.cuda(), w.cuda(), b.cuda(), s, p, relu), want), 2e-5)
+
+
+def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY, tols=None):
+    cfg.precision = precision
+    cfg.max_batch = max(B, 1)
+    t0 = time.time()
+    model = DepthPro.new(dev, cfg, seed=0, init_scheme=scheme)
+    print(f"      model created in {time.time() - t0:.1f}s  workspace={model.query('workspace_bytes') / 1e9:.2f} GB weights={model.query('weight_bytes') / 1e9:.2f} GB", flush=True)
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
+    # spot-check that the C++ generator produced the same weights
+    for n in ("encoder.patch_encoder.blocks.0.attn.qkv.weight", "head.conv_out.weight", "fov.encoder_proj.bias"):
+        if n in W:
+            got = model.get_tensor(n, W[n].numel())
+            record(f"{label} seeded weight {n.split('.')[-3]}.{n.split('.')[-1]}", float(np.abs(got - W[n].numpy().reshape(-1)).max()), 0.0)
+    torch.manual_seed(0)
+    H, Wd = hw
+    img = torch.rand(B, 3, H, Wd)
+    x = (img - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
+    if taps:
+        model.enable_taps(True)
+    t0 = time.time()
+    out = model.infer(x.cuda())
+    torch.cuda.synchronize()
+    print(f"      first infer {time.time() - t0:.2f}s", flush=True)
+    q = R.bf16_round if precision == Precision.BF16 else R.identity
+    t0 = time.time()
+    ref = R.infer(x, W, cfg, q=R.identity, debug=True)
+    print(f"      oracle fp32 {time.time() - t0:.1f}s", flush=True)
+    tol = tols or ((5e-2, 5e-3) if precision == Precision.BF16 else (1e-3, 1e-3))
+    d, rd = out.depth.cpu(), ref["depth"]
+    relmax = ((d - rd).abs() / rd.abs()).max().item()
+    relmean = ((d - rd).abs() / rd.abs()).mean().item()
+    record(f"{label} depth max-rel vs fp32 oracle", relmax, tol[0], f"mean-rel={relmean:.2e} L_inf={(d - rd).abs().max().item():.2e} depth in [{rd.min():.3f},{rd.max():.3f}]")
+    record(f"{label} fovx_deg abs", (out.fovx_deg.cpu() - ref['fovx_deg']).abs().max().item(), 0.05 if precision == Precision.BF16 else 1e-3, f"fov={ref['fovx_deg'].tolist()}")
+    record(f"{label} focallength rel", rel_err(out.focallength_px, ref["focallength_px"]), tol[1])
+    record(f"{label} fovy_rad abs", (out.fovy_rad.cpu() - ref['fovy_rad']).abs().max().item(), 2e-3 if precision == Precision.BF16 else 2e-5)
+    if precision == Precision.BF16:
+        refq = R.infer(x, W, cfg, q=q, debug=True)
+        rq = refq["depth"]
+        record(f"{label} depth max-rel vs bf16-emulated oracle", ((d - rq).abs() / rq.abs()).max().item(), 3e-2,
+               f"mean-rel={((d - rq).abs() / rq.abs()).mean().item():.2e}")
+    else:
+        refq = ref
+    if taps:
+        dbg = refq["debug"]
+        names = {f"encoder_feature_{i}": dbg["encoder"]["features"][i] for i in range(5)}
+        names.update({f"decoder_fusion_{i}": dbg["fusions"][i] for i in range(5)})
+        names.update(decoder_lowres_feature=dbg["decoder_lowres"], decoder_feature=dbg["decoder_features"],
+                     head_conv0=dbg["head"]["conv0"], head_deconv=dbg["head"]["deconv"], canonical_inverse_depth=dbg["canonical"])
+        ttol = 3e-2 if precision == Precision.BF16 else 2e-4
+        for n, t in names.items():
+            try:
+                got = torch.from_numpy(model.read_tap(n))
+                record(f"{label} tap {n}", rel_err(got, t), ttol, f"shape={tuple(got.shape)}")
+            except Exception as e:  # noqa: BLE001
+                record(f"{label} tap {n}", float("nan"), ttol, f"EXC {e}")
+    # timing
+    model.enable_taps(False)
+    model.enable_timing(True)
+    model.infer(x.cuda())
+    tm = model.read_timing()
+    tot = sum(v[0] for v in tm.values())
+    print(f"      kernel time {tot:.2f} ms/batch: " + ", ".join(f"{k}={v[0]:.2f}ms/{v[1]}" for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0])[:12]), flush=True)
+    model.enable_timing(False)
+    model.destroy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-small", action="store_true")
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = Device.default()
+    print("device:", torch.cuda.get_device_name(0), "| lib:", _lib.load().md_version().decode(), flush=True)
+    only = set(args.only.split(",")) if args.only else None
+
+    def want(k):
+        return only is None or k in only
+    if want("ops"):
+        check_rgb(dev)
+        check_resize(dev)
+        check_split_merge(dev)
+        check_layernorm(dev)
+        check_linear(dev)
+        check_attention(dev)
+        check_convs(dev)
+    if want("tiny"):
+        guarded("tiny f32")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f32", 1, (512, 512), Precision.F32)
+        guarded("tiny bf16")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/bf16", 1, (512, 512), Precision.BF16)
+        guarded("tiny bf16 B2 resize")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/bf16/B2/360x540", 2, (360, 540), Precision.BF16, taps=False)
+        guarded("tiny f32 B2 resize")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f32/B2/360x540", 2, (360, 540), Precision.F32, taps=False)
+    if want("small") and not args.skip_small:
+        guarded("small bf16")(run_e2e)(dev, DepthProConfig.small_test(), "small/bf16", 1, (512, 512), Precision.BF16)
+        guarded("small f32")(run_e2e)(dev, DepthProConfig.small_test(), "small/f32", 1, (512, 512), Precision.F32)
+    if args.full or want("full") and only is not None:
+        guarded("full bf16")(run_e2e)(dev, DepthProConfig(), "full/bf16", 1, (1536, 1536), Precision.BF16, taps=False)
+    bad = [r for r in RESULTS if not r[3]]
+    print(f"\n==== {len(RESULTS) - len(bad)}/{len(RESULTS)} checks within tolerance ====")
+    for r in bad:
+        print("BAD:", r[0], f"err={r[1]:.3e} tol={r[2]:.1e}", r[4])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
