@@ -39,7 +39,9 @@ int md_device_open(int hip_ordinal, md_device_t* out) {
   MD_HIP(hipSetDevice(hip_ordinal));
   md_device_s* d = new md_device_s();
   d->ordinal = hip_ordinal;
-  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+  // a BLOCKING stream: implicitly ordered with the legacy default stream, so a caller that hands over
+  // buffers produced on the null stream (and passes stream = NULL) needs no extra synchronisation
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamDefault) != hipSuccess) {
     delete d;
     MD_FAIL(MD_ERR_HIP, "hipStreamCreate failed");
   }
@@ -247,6 +249,11 @@ int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls
     tot[i] += e;
     cnt[i] += 1;
   }
+  for (auto& t : m->timing) {  // entries accumulate across infers until they are read
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  m->timing.clear();
   *n = (int)m->timing_names_out.size();
   for (int i = 0; i < *n && i < cap; ++i) {
     if (names) names[i] = m->timing_names_out[i].c_str();

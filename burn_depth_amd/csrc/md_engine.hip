@@ -1092,13 +1092,6 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
   hipStream_t st = stream ? stream : m->dev->stream;
   md_model_s::Buffers* b = m->buf;
   Run r{m, st, B};
-  if (m->timing_enabled) {
-    for (auto& t : m->timing) {
-      (void)hipEventDestroy(t.a);
-      (void)hipEventDestroy(t.b);
-    }
-    m->timing.clear();
-  }
   const int S = m->S;
   const size_t in_elems = (size_t)B * 3 * H * W;
   const bool resize_needed = H != S || W != S;  // mod.rs:317
@@ -1190,7 +1183,7 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
   MD_TRY(copy_out(focal, b->focal, B));
   MD_TRY(copy_out(fovx, b->fov_deg, B));
   MD_TRY(copy_out(fovy, b->fovy, B));
-  if (out_kind == MD_MEM_HOST || m->timing_enabled) MD_HIP(hipStreamSynchronize(st));
+  if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
 

@@ -1,0 +1,58 @@
+"""Multi-GPU plumbing for the data-parallel hot path: one process per GPU,
+torch.distributed over RCCL ("nccl" backend on ROCm) / xGMI.
+
+Images of a batch never interact (B is a pure batch dimension through split, ViT, merge and
+decoder; encoder.rs:216-225,249-255), so the path shards by image with NO collective inside the
+model.  The only exchanges are
+  * a one-time broadcast of the fp32 weight arena from rank 0 (then every rank re-packs its own
+    MFMA operand copies), and
+  * a gather of the finished depth maps to rank 0.
+Both also run on the gloo backend (CPU tensors), which is how the N>1 path is tested without GPUs.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced split of `n_items` images over `world` ranks: [begin, end)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class _ArenaView:
+    """Zero-copy torch view of raw device memory through __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_weights(model, src: int = 0) -> None:
+    """RCCL broadcast of the fp32 master weights (in place), then re-pack on every rank."""
+    ptr, nbytes = model.weight_arena()
+    view = torch.as_tensor(_ArenaView(ptr, nbytes), device=torch.device("cuda", model.device.ordinal))
+    chunk = 1 << 30  # 1 GiB buckets: large enough to be link-bound, small enough for the int32 counts
+    for off in range(0, nbytes, chunk):
+        dist.broadcast(view[off:off + chunk], src=src)
+    torch.cuda.synchronize()
+    model.commit_weights()
+
+
+def gather_depth(depth: torch.Tensor, gathered: Optional[List[torch.Tensor]], dst: int = 0) -> None:
+    """Depth maps of every rank -> rank `dst` (works for nccl and gloo)."""
+    dist.gather(depth, gathered if dist.get_rank() == dst else None, dst=dst)
+
+
+def scatter_images(images: Optional[torch.Tensor], n_total: int, like: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Rank `src` holds [n_total,3,H,W]; every rank receives its shard (equal shards required)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert n_total % world == 0, "scatter_images needs equal shards"
+    per = n_total // world
+    out = torch.empty((per,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+    chunks = list(images.split(per, 0)) if rank == src else None
+    dist.scatter(out, chunks, src=src)
+    return out

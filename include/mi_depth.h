@@ -180,8 +180,9 @@ int md_uniform_stream(const char* name, uint64_t seed, size_t count, float lo, f
 int md_split_geometry(int image_size, int window, float overlap, int* stride, int* steps);
 int md_feature_padding(int window, int stride, int feature_size);
 
-/* Per-kernel timing of the last infer (HIP events on the model stream; enable first).
- * names/ms arrays of capacity `cap`; returns the number of entries in *n. */
+/* Per-kernel-family timing (HIP events recorded on the stream each kernel is launched on; enable
+ * first). Entries accumulate over infer calls until read; reading sums them by family name into
+ * names/ms/calls (capacity `cap`, count in *n) and clears them. */
 int md_model_enable_timing(md_model_t m, int enable);
 int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls, int cap, int* n);
 

@@ -234,18 +234,19 @@ def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY,
     t0 = time.time()
     ref = R.infer(x, W, cfg, q=R.identity, debug=True)
     print(f"      oracle fp32 {time.time() - t0:.1f}s", flush=True)
-    tol = tols or ((5e-2, 5e-3) if precision == Precision.BF16 else (1e-3, 1e-3))
+    tol = tols or ((8e-2, 5e-3, 8e-3) if precision == Precision.BF16 else (1e-3, 1e-3, 1e-4))
     d, rd = out.depth.cpu(), ref["depth"]
     relmax = ((d - rd).abs() / rd.abs()).max().item()
     relmean = ((d - rd).abs() / rd.abs()).mean().item()
     record(f"{label} depth max-rel vs fp32 oracle", relmax, tol[0], f"mean-rel={relmean:.2e} L_inf={(d - rd).abs().max().item():.2e} depth in [{rd.min():.3f},{rd.max():.3f}]")
+    record(f"{label} depth mean-rel vs fp32 oracle", relmean, tol[2])
     record(f"{label} fovx_deg abs", (out.fovx_deg.cpu() - ref['fovx_deg']).abs().max().item(), 0.05 if precision == Precision.BF16 else 1e-3, f"fov={ref['fovx_deg'].tolist()}")
     record(f"{label} focallength rel", rel_err(out.focallength_px, ref["focallength_px"]), tol[1])
     record(f"{label} fovy_rad abs", (out.fovy_rad.cpu() - ref['fovy_rad']).abs().max().item(), 2e-3 if precision == Precision.BF16 else 2e-5)
     if precision == Precision.BF16:
         refq = R.infer(x, W, cfg, q=q, debug=True)
         rq = refq["depth"]
-        record(f"{label} depth max-rel vs bf16-emulated oracle", ((d - rq).abs() / rq.abs()).max().item(), 3e-2,
+        record(f"{label} depth max-rel vs bf16-emulated oracle", ((d - rq).abs() / rq.abs()).max().item(), 8e-2,
                f"mean-rel={((d - rq).abs() / rq.abs()).mean().item():.2e}")
     else:
         refq = ref
