@@ -228,6 +228,13 @@ def cpu_baseline(cfg: DepthProConfig):
     ViT work is 73 % of a frame and the oracle runs every part through the same oneDNN/MKL GEMMs."""
     from oracle import depth_pro_ref as R
     import numpy as np
+    # use this process's CPU share (a 1-GPU box gets 16 cores of the host), not every core of the host
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
+    torch.set_num_threads(threads)
     v = cfg.patch_vit()
     torch.manual_seed(0)
     tiles = 6
