@@ -82,6 +82,8 @@ SYMBOLS = {
     "md_op_deconv2x2": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "md_op_conv2d_direct": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "md_op_fov_to_focal": (_I, [C.c_float, _I, _I, _F, _F]),
+    "md_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "md_bench_attention": (_I, [_P, _I, _I, _I, _I, _F]),
     "md_param_inventory": (_I, [C.POINTER(MdDepthProCfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_uniform_stream": (_I, [C.c_char_p, C.c_uint64, C.c_size_t, C.c_float, C.c_float, _P]),
     "md_split_geometry": (_I, [_I, _I, C.c_float, C.POINTER(_I), C.POINTER(_I)]),

@@ -96,7 +96,26 @@ __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
   *(__bf16*)p = (__bf16)v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (burn/DINOv2 `Gelu`). fp32 mode: libm erff. bf16 mode: Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below the bf16 output rounding of 2^-9) -- about 3x fewer VALU ops in
+// the fc1 epilogue, which evaluates 87 M GELUs per launch.
+template <typename T>
+__device__ __forceinline__ float gelu_erf(float x) {
+  if constexpr (sizeof(T) == 4) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  } else {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = 1.0f - poly * t * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+  }
+}
 
 __device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
   f32x4_t r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
@@ -117,10 +136,10 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       if (p.act == ACT_RELU) {
         v = relu4(v);
       } else if (p.act == ACT_GELU) {
-        v[0] = gelu_erf(v[0]);
-        v[1] = gelu_erf(v[1]);
-        v[2] = gelu_erf(v[2]);
-        v[3] = gelu_erf(v[3]);
+        v[0] = gelu_erf<T>(v[0]);
+        v[1] = gelu_erf<T>(v[1]);
+        v[2] = gelu_erf<T>(v[2]);
+        v[3] = gelu_erf<T>(v[3]);
       }
       if (p.out_f32)
         store4<float>((float*)p.out + boff + (long)m * p.ldo + n, v);
@@ -391,6 +410,290 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// v2: 256x256 tile, BK = 64, 8 waves (2 x 4, wave tile 128 x 64).  LDS is a ring of FIVE 32-KB
+// half-tile slots (160 KB): half-tile h = 2t is the A tile of k-tile t, h = 2t+1 its W tile, slot
+// = h mod 5.  While k-tile t is multiplied (2 slots busy) three more half-tiles (96 KB per CU) are
+// in flight; the loads are never drained inside the loop -- each iteration waits with a COUNTED
+// `s_waitcnt vmcnt(4)` (everything but the youngest half-tile) and one raw s_barrier.  MFMA operand
+// fragments are double-buffered in registers across the four k-steps of a tile.  The epilogue goes
+// through LDS (wave-private 64x64 fp32 sub-tiles, rows padded to 272 B) so that every global
+// load/store instruction of the epilogue covers 4 full 256-byte row segments.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int AMODE>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
+  constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int HALF_BYTES = 256 * 128;  // one half-tile slot
+  constexpr int NSLOT = 5;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int KE = 128 / ESZ;
+  constexpr int LPH = 4;  // glds wave-instructions per wave per half-tile (32 row groups / 8 waves)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int nwg = gridDim.x;
+  int id;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_n = id % tiles_n;
+  const int tile_mg = id / tiles_n;
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroups; ++i)
+    if (i < p.ngroups && tile_mg >= p.g_tile0[i]) g = i;
+  const int g_row0 = MD_SEL_G(p.g_row0, g);
+  const int g_arow0 = MD_SEL_G(p.g_arow0, g);
+  const int m_base = g_row0 + (tile_mg - MD_SEL_G(p.g_tile0, g)) * BM;
+  const int m_end = g_row0 + MD_SEL_G(p.g_rows, g);
+  const int n0 = tile_n * BN;
+  const char* Wg = (const char*)MD_SEL_G(p.W, g);
+  const char* Ab = (const char*)p.A;
+  long out_boff = 0;
+  if (p.batch > 1) {
+    const int by = blockIdx.y;
+    const int bo = by / p.batch_inner, bi = by - bo * p.batch_inner;
+    Ab += (bo * p.a_bs[0] + bi * p.a_bs[1]) * ESZ;
+    Wg += (bo * p.w_bs[0] + bi * p.w_bs[1]) * ESZ;
+    out_boff = bo * p.o_bs[0] + bi * p.o_bs[1];
+  }
+
+  const int lrow = lane >> 3, pc = lane & 7;
+  const char* srcA[LPH];
+  unsigned maskA[LPH];
+#pragma unroll
+  for (int i = 0; i < LPH; ++i) {
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int lc = pc ^ ((r >> 1) & 7);
+    int m = m_base + r;
+    m = m < m_end ? m : m_end - 1;
+    const long am = (long)g_arow0 + (m - g_row0);
+    if constexpr (AMODE == A_DENSE) {
+      srcA[i] = Ab + am * p.lda * ESZ + lc * 16;
+      maskA[i] = 0;
+    } else if constexpr (AMODE == A_INDEXED) {
+      srcA[i] = Ab + (long)p.a_index[am] * p.lda * ESZ + lc * 16;
+      maskA[i] = 0;
+    } else {
+      const int x = (int)(am % p.cW);
+      const int y = (int)((am / p.cW) % p.cH);
+      unsigned mk = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) mk |= 1u << (ky * 3 + kx);
+        }
+      maskA[i] = mk;
+      srcA[i] = Ab + am * p.cC * ESZ + lc * 16;
+    }
+  }
+  const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
+  const char* srcW[LPH];
+#pragma unroll
+  for (int i = 0; i < LPH; ++i) {
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int lc = pc ^ ((r >> 1) & 7);
+    int n = n0 + r;
+    n = n < p.N ? n : p.N - 1;
+    srcW[i] = Wg + (long)n * ldw * ESZ + lc * 16;
+  }
+  const char* zsrc = (const char*)p.zero_page + pc * 16;
+  const int KT = p.K / KE;
+  const int cblocks = (AMODE == A_CONV3) ? p.cC / KE : 1;
+
+  // issue the A / W half-tile of k-tile kt into ring slot `slot` (both wave-uniform)
+  auto issue_W = [&](int kt, int slot) {
+    char* sbase = smem + slot * HALF_BYTES;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) glds16(srcW[i] + (long)kt * 128, sbase + (i * NW + wave) * 1024);
+  };
+  auto issue_A = [&](int kt, int slot) {
+    char* sbase = smem + slot * HALF_BYTES;
+    long a_delta;
+    int tap = 0;
+    if constexpr (AMODE == A_CONV3) {
+      tap = kt / cblocks;
+      const int cb = kt - tap * cblocks;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * ESZ + (long)cb * 128;
+    } else {
+      a_delta = (long)kt * 128;
+    }
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) {
+      const char* s = srcA[i] + a_delta;
+      if constexpr (AMODE == A_CONV3) {
+        if (!((maskA[i] >> tap) & 1u)) s = zsrc;
+      }
+      glds16(s, sbase + (i * NW + wave) * 1024);
+    }
+  };
+
+  f32x16_t acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int h = lane >> 5;
+  const int lane_off = (lane & 31) * 128 + ((((lane >> 1) & 7) ^ h) << 4);
+
+  // half-tile order: A0 W0 A1 W1 A2 | W2 A3 | W3 A4 | ...   (slot = order index mod 5)
+  int issued = 2, slot_i = 2;
+  issue_A(0, 0);
+  issue_W(0, 1);
+  if (KT > 1) {
+    issue_A(1, 2);
+    issue_W(1, 3);
+    issued = 4;
+    slot_i = 4;
+  }
+  if (KT > 2) {
+    issue_A(2, 4);
+    issued = 5;
+    slot_i = 0;
+  }
+  int slot_c = 0;  // slot of the current tile's A half
+  for (int t = 0; t < KT; ++t) {
+    // wait for half-tiles 2t, 2t+1: everything except the `younger` most recent half-tiles
+    const int younger = issued - (2 * t + 2);
+    if (younger >= 3) {
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else if (younger == 2) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (younger == 1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t >= 1) {  // the two slots of tile t-1 are free now
+      if (t + 1 < KT) {
+        issue_W(t + 1, slot_i);
+        ++issued;
+        slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
+      }
+      if (t + 2 < KT) {
+        issue_A(t + 2, slot_i);
+        ++issued;
+        slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
+      }
+    }
+    const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+    const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+    const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+    slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+
+    i32x4_t af[2][TM], wf[2][TN];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) af[0][b] = *(const i32x4_t*)(As + b * 4096 + lane_off);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) wf[0][a] = *(const i32x4_t*)(Ws + a * 4096 + lane_off);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s < 3) {
+        const int off = lane_off ^ ((s + 1) << 5);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) af[nxt][b] = *(const i32x4_t*)(As + b * 4096 + off);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+      }
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[cur][a], af[cur][b], acc[a][b]);
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
+  if (direct) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = m_base + wm * WTM + b * 32 + (lane & 31);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int n = n0 + wn * WTN + a * 32 + 8 * q4 + 4 * h;
+          if (m < m_end && n < p.N) {
+            f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
+            epilogue4<T>(p, g, m, n, v, out_boff);
+          }
+        }
+      }
+    return;
+  }
+  // staged: wave-private region of 64 rows x 272 bytes (68 floats)
+  constexpr int SROW = 272;
+  char* st = smem + wave * (64 * SROW);
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the ring (its MFMAs consumed the fragments)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int b = half * 2 + bb;
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
+          *(f32x4_t*)(st + (bb * 32 + (lane & 31)) * SROW + (a * 32 + 8 * q4 + 4 * h) * 4) = v;
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    const int col = (lane & 15) * 4;
+    const int n = n0 + wn * WTN + col;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const int m = m_base + wm * WTM + half * 64 + row;
+      const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
+      if (m < m_end && n < p.N) epilogue4<T>(p, g, m, n, v, out_boff);
+    }
+  }
+}
+
+template <typename T, int AMODE>
+static int launch_256(GemmParams& p, hipStream_t stream) {
+  constexpr int BM = 256, BN = 256;
+  int tiles_m = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    p.g_tile0[g] = tiles_m;
+    tiles_m += cdiv(p.g_rows[g], BM);
+  }
+  p.g_tile0[p.ngroups] = tiles_m;
+  for (int g = p.ngroups + 1; g <= kMaxGroups; ++g) p.g_tile0[g] = tiles_m;
+  const long blocks = (long)tiles_m * cdiv(p.N, BN);
+  if (blocks <= 0) return MD_OK;
+  if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
+  constexpr int smem = 5 * 256 * 128;  // 160 KB: the whole LDS of a CU
+  auto kern = gemm256_kernel<T, AMODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(512), smem, stream, p);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WGM, int WGN, int AMODE>
 static int launch_cfg(GemmParams& p, hipStream_t stream) {
   int tiles_m = 0;
@@ -420,6 +723,8 @@ template <typename T, int AMODE>
 static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
     case TILE_256x256:
+      return launch_256<T, AMODE>(p, stream);
+    case TILE_256x256_V1:
       return launch_cfg<T, 256, 256, 2, 4, AMODE>(p, stream);
     case TILE_128x128:
       return launch_cfg<T, 128, 128, 2, 2, AMODE>(p, stream);

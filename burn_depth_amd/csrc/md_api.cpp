@@ -1,4 +1,5 @@
 // extern "C" surface of libmi_depth.so (include/mi_depth.h).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -492,6 +493,90 @@ int md_op_conv2d_direct(md_device_t dev, const float* x_dev, const float* w_dev,
 int md_op_fov_to_focal(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad) {
   if (H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid image size");
   fov_scalar_host(fovx_deg, H, W, focal_px, fovy_rad);
+  return MD_OK;
+}
+
+namespace {
+__attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, uint64_t seed, float scale, hipStream_t st) {
+  std::vector<float> h(std::min<size_t>(elems, (size_t)1 << 22));
+  uniform_stream("bench", seed, h.size(), -scale, scale, h.data());
+  DevBuf tmp;
+  MD_TRY(tmp.alloc(h.size() * 4));
+  MD_HIP(hipMemcpy(tmp.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  const size_t es = precision == MD_PREC_F32 ? 4 : 2;
+  for (size_t off = 0; off < elems; off += h.size()) {
+    const size_t n = std::min(h.size(), elems - off);
+    MD_TRY(launch_f32_to_rows((const float*)tmp.p, (long)n, (char*)dst + off * es, precision, st));
+  }
+  MD_HIP(hipStreamSynchronize(st));
+  return MD_OK;
+}
+}  // namespace
+
+int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int aux1, int precision, int tile, int iters,
+                  float* avg_ms) {
+  if (!dev || !avg_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "invalid argument");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = dev->stream;
+  const size_t es = esz_of(precision);
+  DevBuf a, w, o, zp;
+  const size_t kw = mode == 1 ? (size_t)9 * K : (size_t)K;
+  MD_TRY(a.alloc((size_t)M * K * es));
+  MD_TRY(w.alloc((size_t)N * kw * es));
+  MD_TRY(o.alloc((size_t)M * N * es));
+  MD_TRY(zp.alloc(4096));
+  MD_TRY(fill_random(a.p, (size_t)M * K, precision, 1, 1.0f, st));
+  MD_TRY(fill_random(w.p, (size_t)N * kw, precision, 2, 0.05f, st));
+  GemmParams p;
+  p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
+  p.epi = EPI_STORE; p.out = o.p; p.ldo = N;
+  int amode = A_DENSE;
+  if (mode == 1) {
+    if ((long)aux0 * aux1 != M) MD_FAIL(MD_ERR_SHAPE, "conv bench: H*W must equal M");
+    amode = A_CONV3; p.K = 9 * K; p.cH = aux0; p.cW = aux1; p.cC = K; p.zero_page = zp.p;
+  } else {
+    p.K = K; p.lda = K;
+  }
+  for (int i = 0; i < 2; ++i) MD_TRY(launch_gemm(p, amode, precision, tile, st));
+  hipEvent_t e0, e1;
+  MD_HIP(hipEventCreate(&e0));
+  MD_HIP(hipEventCreate(&e1));
+  MD_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) MD_TRY(launch_gemm(p, amode, precision, tile, st));
+  MD_HIP(hipEventRecord(e1, st));
+  MD_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
+  return MD_OK;
+}
+
+int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms) {
+  if (!dev || !avg_ms || T <= 0 || n_tokens <= 0 || heads <= 0 || iters <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "invalid argument");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = dev->stream;
+  const int D = heads * 64, SS = (n_tokens + 3) / 4 * 4, kpad = (n_tokens + 63) / 64 * 64;
+  DevBuf qk, vT, ao;
+  MD_TRY(qk.alloc(((size_t)T * SS + 64) * 2 * D * 2));
+  MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * 2));
+  MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * 2));
+  MD_TRY(fill_random(qk.p, (size_t)T * SS * 2 * D, MD_PREC_BF16, 3, 2.0f, st));
+  MD_TRY(fill_random(vT.p, (size_t)T * heads * 64 * kpad, MD_PREC_BF16, 4, 1.0f, st));
+  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention_bf16(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, st));
+  hipEvent_t e0, e1;
+  MD_HIP(hipEventCreate(&e0));
+  MD_HIP(hipEventCreate(&e1));
+  MD_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention_bf16(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, st));
+  MD_HIP(hipEventRecord(e1, st));
+  MD_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
   return MD_OK;
 }
 

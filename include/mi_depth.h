@@ -168,6 +168,15 @@ int md_op_conv2d_direct(md_device_t dev, const float* x_dev, const float* w_dev,
 /* `fovy_from_fovx_rad` (mod.rs:370-414) + focal length (mod.rs:330-336) on host scalars. */
 int md_op_fov_to_focal(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad);
 
+/* Kernel micro-benchmark: times `iters` launches of the GEMM kernel (random bf16/f32 operands resident
+ * in HBM, plain store epilogue, out element = operand type) with HIP events on the launch stream and
+ * returns the average milliseconds per launch. mode: 0 dense GEMM [M,K]x[N,K]^T; 1 conv3x3 over an
+ * NHWC [1,H,W,K] image with M = H*W (pass H in `aux0`, W in `aux1`), N = Cout. */
+int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int aux1, int precision, int tile, int iters,
+                  float* avg_ms);
+/* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
+int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
+
 /* ---- host-only utilities (no GPU needed) ---------------------------------------------------- */
 /* The parameter inventory of `DepthPro::new` for a config: returns the number of parameters; for
  * 0 <= index < count also the name (static storage, valid until the next call from this thread),

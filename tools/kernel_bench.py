@@ -1,0 +1,47 @@
+"""Micro-benchmark of the MFMA kernels on the Depth Pro shapes: interleaved rounds in ONE process
+(HIP events on the launch stream inside md_bench_gemm / md_bench_attention), random operands."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from burn_depth_amd import _lib  # noqa: E402
+from burn_depth_amd.depth_pro import Device  # noqa: E402
+
+
+def main():
+    dev = Device(0)
+    lib = _lib.load()
+    rows = 37 * 580
+    gemms = [("qkv", 0, rows, 3072, 1024, 0, 0), ("proj", 0, rows, 1024, 1024, 0, 0), ("fc1", 0, rows, 4096, 1024, 0, 0),
+             ("fc2", 0, rows, 1024, 4096, 0, 0), ("sq8k", 0, 8192, 8192, 8192, 0, 0),
+             ("conv768_256", 1, 768 * 768, 256, 256, 768, 768), ("conv384_256", 1, 384 * 384, 256, 256, 384, 384)]
+    tiles = [(0, "256v2"), (3, "256v1"), (1, "128v1")]
+    prec = int(os.environ.get("PREC", "0"))
+    only = os.environ.get("ONLY")
+    if only:
+        gemms = [g for g in gemms if g[0] in only.split(",")]
+    if os.environ.get("TILES"):
+        tiles = [t for t in tiles if t[1] in os.environ["TILES"].split(",")]
+    for name, mode, M, N, K, a0, a1 in gemms:
+        flops = 2.0 * M * N * K * (9 if mode == 1 else 1)
+        best = {}
+        for rnd in range(3):
+            for tile, tn in tiles:
+                ms = C.c_float()
+                _lib.check(lib.md_bench_gemm(dev.handle, mode, M, N, K, a0, a1, prec, tile, 10, C.byref(ms)))
+                best[tn] = min(best.get(tn, 1e9), ms.value)
+        print(f"{name:12s} M={M} N={N} K={K}: " + "  ".join(f"{k} {v:.4f} ms {flops / v / 1e9:.0f} TF" for k, v in best.items()), flush=True)
+    for (T, N, h) in ([] if only and 'attn' not in only else [(37, 577, 16), (296, 577, 16), (1, 1370, 16), (1, 5477, 16)]):
+        ms = C.c_float()
+        best = 1e9
+        for rnd in range(3):
+            _lib.check(lib.md_bench_attention(dev.handle, T, N, h, 10, C.byref(ms)))
+            best = min(best, ms.value)
+        fl = 4.0 * T * h * N * N * 64
+        print(f"attention T={T} N={N} h={h}: {best:.4f} ms {fl / best / 1e9:.0f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()
