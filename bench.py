@@ -89,11 +89,12 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (B of DepthPro::infer([B,3,S,S]))")
     ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--dump-launch-order", default="", help="write the per-launch kernel-family list of one infer (json)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +146,14 @@ def main() -> int:
         if do_gather:
             gather_depth(depth, gathered, dst=0)
 
+    if args.dump_launch_order and rank == 0:
+        model.enable_timing(True)
+        step()
+        torch.cuda.synchronize()
+        with open(args.dump_launch_order, "w") as f:
+            json.dump({"families": model.read_launch_order(), "infers": args.steps}, f)
+        model.read_timing()
+        model.enable_timing(False)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -190,7 +199,7 @@ def main() -> int:
         if dom:
             e = kernels[dom]
             roofline = {"kernel": dom, "bound": "mfma", "achieved": e["tflops"], "peak": peak, "unit": "TFLOP/s",
-                        "frac": e["frac_mfma_peak"], "traffic": None,
+                        "frac": e["frac_mfma_peak"], "traffic": pmc_traffic(dom, B, args),
                         "avg_launch_ms": round(e["ms_per_step"] / max(e["launches_per_step"], 1), 4),
                         "flops_per_launch": fl[dom] / max(e["launches_per_step"], 1)}
         gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
@@ -220,6 +229,22 @@ def main() -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def pmc_traffic(kernel: str, B: int, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
+    gfx950 corrections of MI355X_MICROARCH.md and writes profiles/r01_traffic.json). None if the
+    passes were made for another batch/precision."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("batch") == B and t.get("precision") == args.precision and t.get("preset") == args.preset:
+            return t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg: DepthProConfig):

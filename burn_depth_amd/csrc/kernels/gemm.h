@@ -65,12 +65,14 @@ struct GemmParams {
   void* vT = nullptr;
   // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = 4*psC; out NHWC [B, 2psH, 2psW, ldo] at +ps_coff
   int psH = 0, psW = 0, psC = 0, ps_coff = 0;
+  // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
+  int debug_flags = 0;
   // EPI_HEAD
   const float* head_w = nullptr;  // [32]
   float head_b = 0.f;
 };
 
-enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_AUTO = 99 };
+enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_256x256_V2 = 4, TILE_AUTO = 99 };
 
 // Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16) or MD_PREC_F32 (T = float).
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream);

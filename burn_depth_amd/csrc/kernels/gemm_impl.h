@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 // through LDS (wave-private 64x64 fp32 sub-tiles, rows padded to 272 B) so that every global
 // load/store instruction of the epilogue covers 4 full 256-byte row segments.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int AMODE>
+template <typename T, int AMODE, int PP>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
   constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
@@ -566,8 +566,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     slot_i = 0;
   }
   int slot_c = 0;  // slot of the current tile's A half
-  for (int t = 0; t < KT; ++t) {
-    // wait for half-tiles 2t, 2t+1: everything except the `younger` most recent half-tiles
+
+  // counted wait for the two half-tiles of k-tile `t`: all but the `younger` most recent half-tiles
+  auto wait_tile = [&](int t) {
     const int younger = issued - (2 * t + 2);
     if (younger >= 3) {
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -578,44 +579,112 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    if (t >= 1) {  // the two slots of tile t-1 are free now
-      if (t + 1 < KT) {
-        issue_W(t + 1, slot_i);
-        ++issued;
-        slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
-      }
-      if (t + 2 < KT) {
-        issue_A(t + 2, slot_i);
-        ++issued;
-        slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
-      }
+  };
+  const bool no_loads = (p.debug_flags & 1) != 0;
+  auto issue_next_W = [&](int t) {
+    if (t >= 1 && t + 1 < KT && !no_loads) {
+      issue_W(t + 1, slot_i);
+      ++issued;
+      slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
     }
-    const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
-    const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
-    const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
-    slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+  };
+  auto issue_next_A = [&](int t) {
+    if (t >= 1 && t + 2 < KT && !no_loads) {
+      issue_A(t + 2, slot_i);
+      ++issued;
+      slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
+    }
+  };
 
-    i32x4_t af[2][TM], wf[2][TN];
+  if constexpr (PP == 0) {
+    for (int t = 0; t < KT; ++t) {
+      wait_tile(t);
+      __builtin_amdgcn_s_barrier();
+      issue_next_W(t);  // the two slots of tile t-1 are free now
+      issue_next_A(t);
+      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+      i32x4_t af[2][TM], wf[2][TN];
 #pragma unroll
-    for (int b = 0; b < TM; ++b) af[0][b] = *(const i32x4_t*)(As + b * 4096 + lane_off);
+      for (int b = 0; b < TM; ++b) af[0][b] = *(const i32x4_t*)(As + b * 4096 + lane_off);
 #pragma unroll
-    for (int a = 0; a < TN; ++a) wf[0][a] = *(const i32x4_t*)(Ws + a * 4096 + lane_off);
+      for (int a = 0; a < TN; ++a) wf[0][a] = *(const i32x4_t*)(Ws + a * 4096 + lane_off);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int cur = s & 1, nxt = cur ^ 1;
-      if (s < 3) {
-        const int off = lane_off ^ ((s + 1) << 5);
+      for (int s = 0; s < 4; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s < 3) {
+          const int off = lane_off ^ ((s + 1) << 5);
 #pragma unroll
-        for (int b = 0; b < TM; ++b) af[nxt][b] = *(const i32x4_t*)(As + b * 4096 + off);
+          for (int b = 0; b < TM; ++b) af[nxt][b] = *(const i32x4_t*)(As + b * 4096 + off);
 #pragma unroll
-        for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+          for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[cur][a], af[cur][b], acc[a][b]);
       }
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[cur][a], af[cur][b], acc[a][b]);
     }
+  } else {
+    // ---- staggered two-group schedule ("ping-pong") ----
+    // Each k-step is a phase of two segments separated by raw barriers: R = issue the 6 ds_read_b128 of
+    // the k-step, M = the 8 MFMAs that consume them.  Waves 4..7 (group 1, wm == 1) run ONE barrier
+    // behind waves 0..3 (group 0), and every SIMD hosts one wave of each group: while group 0 is in
+    // its MFMA segment group 1 is reading LDS and vice versa, so the matrix pipe of each SIMD goes
+    // from one wave's MFMA cluster straight into the other's.  I_k = interval after physical barrier
+    // k; group 0 has R(p) in I_2p and M(p) in I_2p+1, group 1 has R(p) in I_2p+1 and M(p) in I_2p+2.
+    //  * reads of tile t finish (group 1's lgkmcnt) inside I_8t+8, so its two ring slots are
+    //    re-filled from I_8t+9 on: group 0 in M(4t+4), group 1 in R(4t+4)  (phase 0 of tile t+1);
+    //  * tile t+1 is first read in I_8t+8 (group 0), so every wave retires its loads of tile t+1
+    //    with a counted vmcnt inside I_8t+7: group 0 at the end of M(4t+3), group 1 in R(4t+3).
+    const bool g1 = wm == 1;  // wave-uniform
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < KT; ++t) {
+      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int off = lane_off ^ (s << 5);
+        i32x4_t af[TM], wf[TN];
+        // ---- R segment ----
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) af[b] = *(const i32x4_t*)(As + b * 4096 + off);
+        if (g1) {
+          if (s == 0) issue_next_W(t);
+          if (s == 1) issue_next_A(t);
+          if (s == 3 && t + 1 < KT) wait_tile(t + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- M segment ----
+        if (!g1) {
+          if (s == 0) issue_next_W(t);
+          if (s == 1) issue_next_A(t);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[a], af[b], acc[a][b]);
+        __builtin_amdgcn_s_setprio(0);
+        if (!g1) {
+          if (s == 3 && t + 1 < KT) wait_tile(t + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
   }
 
   // ---------------- epilogue ----------------
@@ -668,7 +737,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
 }
 
-template <typename T, int AMODE>
+template <typename T, int AMODE, int PP>
 static int launch_256(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 256, BN = 256;
   int tiles_m = 0;
@@ -682,7 +751,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   if (blocks <= 0) return MD_OK;
   if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
   constexpr int smem = 5 * 256 * 128;  // 160 KB: the whole LDS of a CU
-  auto kern = gemm256_kernel<T, AMODE>;
+  auto kern = gemm256_kernel<T, AMODE, PP>;
   static bool attr_set = false;
   if (!attr_set) {
     MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -723,7 +792,9 @@ template <typename T, int AMODE>
 static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
     case TILE_256x256:
-      return launch_256<T, AMODE>(p, stream);
+      return launch_256<T, AMODE, 1>(p, stream);
+    case TILE_256x256_V2:
+      return launch_256<T, AMODE, 0>(p, stream);
     case TILE_256x256_V1:
       return launch_cfg<T, 256, 256, 2, 4, AMODE>(p, stream);
     case TILE_128x128:

@@ -264,6 +264,14 @@ int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls
   return MD_OK;
 }
 
+int md_model_read_launch_order(md_model_t m, const char** names, int cap, int* n) {
+  if (!m || !n) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  *n = (int)m->timing.size();
+  for (int i = 0; i < *n && i < cap; ++i)
+    if (names) names[i] = m->timing[i].name.c_str();
+  return MD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // stand-alone operators
 // ------------------------------------------------------------------------------------------------
@@ -515,6 +523,8 @@ __attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, 
 
 int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int aux1, int precision, int tile, int iters,
                   float* avg_ms) {
+  const int dbg = tile >> 8;  // timing-only ablation flags ride in the upper bits of `tile`
+  tile &= 0xff;
   if (!dev || !avg_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "invalid argument");
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = dev->stream;
@@ -529,7 +539,7 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   MD_TRY(fill_random(w.p, (size_t)N * kw, precision, 2, 0.05f, st));
   GemmParams p;
   p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
-  p.epi = EPI_STORE; p.out = o.p; p.ldo = N;
+  p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = dbg;
   int amode = A_DENSE;
   if (mode == 1) {
     if ((long)aux0 * aux1 != M) MD_FAIL(MD_ERR_SHAPE, "conv bench: H*W must equal M");

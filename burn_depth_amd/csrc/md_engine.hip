@@ -994,9 +994,15 @@ static int fov_min_spatial(Run& r, float** cur, int* h, int C, int kmin, float* 
   md_model_s* m = r.m;
   const int B = r.B, oh = kmin;
   // NHWC f32 -> NCHW f32
+  r.begin("fov_resize");
   MD_TRY(launch_nhwc_to_nchw(*cur, B, C, *h, *h, C, 0, scratch_a, MD_PREC_F32, r.st));
+  r.end();
+  r.begin("fov_resize");
   MD_TRY(launch_resize_bilinear(scratch_a, B * C, *h, *h, scratch_b, oh, oh, m->cfg.interpolation, 0, r.st));
+  r.end();
+  r.begin("fov_resize");
   MD_TRY(launch_nchw_to_nhwc(scratch_b, B, C, oh, oh, scratch_a, MD_PREC_F32, 0, r.st));
+  r.end();
   *cur = scratch_a;
   *h = oh;
   return MD_OK;
@@ -1017,8 +1023,8 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
   float* stage[4] = {b->fv0, b->fv1, b->fv2, b->fv3};
   float* sa = b->fvr;
   float* sb = b->fvr + (size_t)B * 36 * F;
-  r.begin("fov_head");
   if (c.has_fov_vit) {
+    r.begin("fov_head");
     // fov.rs:178-227: downsample(lowres) + Linear(tokens) -> head convs
     MD_TRY(launch_conv_direct(lowres, m->prec, nullptr, B, hw[4], hw[4], F, Wd("fov.downsample_blocks.0.conv.weight"),
                               Bi("fov.downsample_blocks.0.conv.bias"), F / 2, 3, 2, 1, 1, stage[0], r.st));
@@ -1027,7 +1033,6 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
     r.end();
     MD_TRY(gemm_rows(r, "fov_proj", b->tok, c.pv.D, ix.fov, (long)B * m->P, PK(m, "fov.encoder_proj.weight"), F / 2, c.pv.D,
                      Bi("fov.encoder_proj.bias"), b->fovproj, F / 2, 1));
-    r.begin("fov_head");
     float* cur = stage[0];
     int ch = F / 2;
     const float* add = b->fovproj;
@@ -1040,9 +1045,11 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
         MD_TRY(fov_min_spatial(r, &cur, &h, ch, ks[i], sa, sb));
       }
       float* out = i == 2 ? b->fov_deg : stage[i + 1];
+      r.begin("fov_head");
       MD_TRY(launch_conv_direct(cur, MD_PREC_F32, add, B, h, h, ch, Wd(std::string(names[i]) + ".weight"),
                                 Bi(std::string(names[i]) + ".bias"), couts[i], ks[i], strides[i], pads[i], relus[i], out,
                                 r.st));
+      r.end();
       add = nullptr;
       h = (h + 2 * pads[i] - ks[i]) / strides[i] + 1;
       ch = couts[i];
@@ -1065,9 +1072,11 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
         cur = cf;
       }
       float* out = i == 3 ? b->fov_deg : stage[i];
+      r.begin("fov_head");
       MD_TRY(launch_conv_direct(cur, cur_prec, nullptr, B, h, h, ch, Wd(std::string(names[i]) + ".weight"),
                                 Bi(std::string(names[i]) + ".bias"), couts[i], ks[i], strides[i], pads[i], relus[i], out,
                                 r.st));
+      r.end();
       h = (h + 2 * pads[i] - ks[i]) / strides[i] + 1;
       ch = couts[i];
       cur = out;
@@ -1075,7 +1084,6 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
     }
     if (h != 1) MD_FAIL(MD_ERR_UNSUPPORTED, "fov head ends at %dx%d, expected 1x1", h, h);
   }
-  r.end();
   MD_TRY(r.tap_f32("fov_deg", b->fov_deg, r.B, 1, 1, 1));
   return MD_OK;
 }
@@ -1168,11 +1176,14 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
     r.begin("depth_post");
     if (!resize_needed) {
       MD_TRY(launch_depth_post(b->canonical, b->ratio, B, (long)S * S, depth_dev, 1, st));
+      r.end();
     } else {
       MD_TRY(launch_depth_post(b->canonical, b->ratio, B, (long)S * S, b->inv, 0, st));
+      r.end();
+      r.begin("resize_out");
       MD_TRY(launch_resize_bilinear(b->inv, B, S, S, depth_dev, H, W, m->cfg.interpolation, 1, st));
+      r.end();
     }
-    r.end();
   }
   auto copy_out = [&](float* dst, const float* src, size_t n) -> int {
     if (!dst) return MD_OK;

@@ -215,6 +215,13 @@ class DepthPro:
     def enable_timing(self, enable: bool = True) -> None:
         _lib.check(self._lib.md_model_enable_timing(self._h, int(enable)))
 
+    def read_launch_order(self) -> List[str]:
+        n = C.c_int()
+        _lib.check(self._lib.md_model_read_launch_order(self._h, None, 0, C.byref(n)))
+        names = (C.c_char_p * max(n.value, 1))()
+        _lib.check(self._lib.md_model_read_launch_order(self._h, names, n.value, C.byref(n)))
+        return [names[i].decode() for i in range(n.value)]
+
     def read_timing(self) -> Dict[str, Tuple[float, int]]:
         cap = 64
         names = (C.c_char_p * cap)()

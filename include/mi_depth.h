@@ -194,6 +194,9 @@ int md_feature_padding(int window, int stride, int feature_size);
  * names/ms/calls (capacity `cap`, count in *n) and clears them. */
 int md_model_enable_timing(md_model_t m, int enable);
 int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls, int cap, int* n);
+/* Family name of every kernel launch recorded since timing was enabled / last read, in launch order
+ * (one entry per kernel launch; does not clear). Lets a rocprofv3 trace be mapped to families. */
+int md_model_read_launch_order(md_model_t m, const char** names, int cap, int* n);
 
 #ifdef __cplusplus
 }
