@@ -37,17 +37,29 @@ __device__ __forceinline__ int pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(int, v);
 }
 
-// grid: (q blocks of 128, heads, sequences); block 256.
+// grid: 1-D, q blocks of 128 x heads x sequences; block 256. The block -> (unit, q block) map is
+// XCD-aware: blocks b and b+8 share an XCD, so logical ids are dealt in contiguous ranges per XCD and
+// the q blocks of one (sequence, head) run on ONE XCD -- its K and V^T (148 KB) are fetched into that
+// L2 once instead of once per q block (measured before the remap: 1.0 GB fetched per launch against
+// 0.27 GB of q/k/v).
 __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __restrict__ qk,
                                                              const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
-                                                             int S, int n_tokens, int heads, int D, int kpad) {
+                                                             int S, int n_tokens, int heads, int D, int kpad,
+                                                             int qblocks) {
   constexpr int STAGE = 16384;  // K tile 64x128B + V^T tile 64x128B
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, seq = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int id;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int unit = id / qblocks, qb = id - unit * qblocks;
+  const int seq = unit / heads, head = unit - seq * heads;
+  const int q0 = qb * 128 + wave * 32;
   const bool active = q0 < n_tokens;  // wave-uniform
   const int h = lane >> 5, c = lane & 31;
   const long two_d = 2L * D;
@@ -216,10 +228,11 @@ int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, i
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
     MD_FAIL(MD_ERR_INVALID_ARG, "attention: kpad=%d must be a multiple of 64 covering %d keys", kpad, n_tokens);
-  if (nseq <= 0 || nseq > 65535) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
-  dim3 grid((n_tokens + 127) / 128, heads, nseq);
-  hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out,
-                     S, n_tokens, heads, D, kpad);
+  const int qblocks = (n_tokens + 127) / 128;
+  const long blocks = (long)qblocks * heads * nseq;
+  if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
+  hipLaunchKernelGGL(attention_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+                     (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks);
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

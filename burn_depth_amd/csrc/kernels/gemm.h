@@ -65,6 +65,7 @@ struct GemmParams {
   void* vT = nullptr;
   // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = 4*psC; out NHWC [B, 2psH, 2psW, ldo] at +ps_coff
   int psH = 0, psW = 0, psC = 0, ps_coff = 0;
+  int raster_gn = 0;  // n-tiles per raster group (0 = all: plain n-fastest order); set by the launcher
   // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
   int debug_flags = 0;
   // EPI_HEAD

@@ -45,6 +45,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     if (!p.W[g]) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has no weights", g);
   }
   if (tile == TILE_AUTO) tile = pick_tile(p);
+  {
+    const int bn = (tile == TILE_128x128) ? 128 : (tile == TILE_256x32 ? 32 : 256);
+    const int tn = cdiv(p.N, bn);
+    p.raster_gn = tn <= 4 ? 0 : 4;
+  }
   if (p.epi == EPI_HEAD) tile = TILE_256x32;
   if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);
   return launch_gemm_bf16(p, amode, tile, stream);

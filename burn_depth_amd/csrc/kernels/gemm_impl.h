@@ -239,9 +239,26 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // L2-aware raster: n-tiles are walked in groups of `gn` (host-chosen, <= 4): the 32 blocks an XCD
+  // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
+  // the XCD's 4-MB L2 while the A panels stream past it.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_n = id % tiles_n;
-  const int tile_mg = id / tiles_n;
+  int tile_n, tile_mg;
+  {
+    const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
+    const int tiles_m = p.g_tile0[kMaxGroups];  // total m-tiles over all groups
+    const int gsz = tiles_m * gn;
+    const int full = tiles_n / gn;
+    if (id < full * gsz) {
+      const int ng = id / gsz, r = id - ng * gsz;
+      tile_mg = r / gn;
+      tile_n = ng * gn + (r - tile_mg * gn);
+    } else {
+      const int rn = tiles_n - full * gn, r = id - full * gsz;
+      tile_mg = r / rn;
+      tile_n = full * gn + (r - tile_mg * rn);
+    }
+  }
   int g = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroups; ++i)
@@ -443,9 +460,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // L2-aware raster: n-tiles are walked in groups of `gn` (host-chosen, <= 4): the 32 blocks an XCD
+  // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
+  // the XCD's 4-MB L2 while the A panels stream past it.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_n = id % tiles_n;
-  const int tile_mg = id / tiles_n;
+  int tile_n, tile_mg;
+  {
+    const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
+    const int tiles_m = p.g_tile0[kMaxGroups];  // total m-tiles over all groups
+    const int gsz = tiles_m * gn;
+    const int full = tiles_n / gn;
+    if (id < full * gsz) {
+      const int ng = id / gsz, r = id - ng * gsz;
+      tile_mg = r / gn;
+      tile_n = ng * gn + (r - tile_mg * gn);
+    } else {
+      const int rn = tiles_n - full * gn, r = id - full * gsz;
+      tile_mg = r / rn;
+      tile_n = full * gn + (r - tile_mg * rn);
+    }
+  }
   int g = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroups; ++i)
@@ -512,13 +546,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int cblocks = (AMODE == A_CONV3) ? p.cC / KE : 1;
 
   // issue the A / W half-tile of k-tile kt into ring slot `slot` (both wave-uniform)
+  const bool freeze_k = (p.debug_flags & 2) != 0;  // timing-only: every k-tile re-reads k-tile 0 (L2-resident)
   auto issue_W = [&](int kt, int slot) {
     char* sbase = smem + slot * HALF_BYTES;
+    if (freeze_k) kt = 0;
 #pragma unroll
     for (int i = 0; i < LPH; ++i) glds16(srcW[i] + (long)kt * 128, sbase + (i * NW + wave) * 1024);
   };
-  auto issue_A = [&](int kt, int slot) {
+  auto issue_A_part = [&](int kt, int slot, int i0, int i1) {
     char* sbase = smem + slot * HALF_BYTES;
+    if (freeze_k) kt = 0;
     long a_delta;
     int tap = 0;
     if constexpr (AMODE == A_CONV3) {
@@ -531,6 +568,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < LPH; ++i) {
+      if (i < i0 || i >= i1) continue;
       const char* s = srcA[i] + a_delta;
       if constexpr (AMODE == A_CONV3) {
         if (!((maskA[i] >> tap) & 1u)) s = zsrc;
@@ -538,6 +576,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       glds16(s, sbase + (i * NW + wave) * 1024);
     }
   };
+  auto issue_A = [&](int kt, int slot) { issue_A_part(kt, slot, 0, LPH); };
 
   f32x16_t acc[TN][TM];
 #pragma unroll
@@ -595,6 +634,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
     }
   };
+  auto issue_next_A_lo = [&](int t) {  // first two of the four A loads of k-tile t+2
+    if (t >= 1 && t + 2 < KT && !no_loads) issue_A_part(t + 2, slot_i, 0, 2);
+  };
+  auto issue_next_A_hi = [&](int t) {  // the other two; the half-tile now counts as issued
+    if (t >= 1 && t + 2 < KT && !no_loads) {
+      issue_A_part(t + 2, slot_i, 2, 4);
+      ++issued;
+      slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
+    }
+  };
 
   if constexpr (PP == 0) {
     for (int t = 0; t < KT; ++t) {
@@ -636,7 +685,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     // from one wave's MFMA cluster straight into the other's.  I_k = interval after physical barrier
     // k; group 0 has R(p) in I_2p and M(p) in I_2p+1, group 1 has R(p) in I_2p+1 and M(p) in I_2p+2.
     //  * reads of tile t finish (group 1's lgkmcnt) inside I_8t+8, so its two ring slots are
-    //    re-filled from I_8t+9 on: group 0 in M(4t+4), group 1 in R(4t+4)  (phase 0 of tile t+1);
+    //    re-filled from I_8t+9 on: group 1 from R(4t+4) = I_8t+9, group 0 from R(4t+5) = I_8t+10;
     //  * tile t+1 is first read in I_8t+8 (group 0), so every wave retires its loads of tile t+1
     //    with a counted vmcnt inside I_8t+7: group 0 at the end of M(4t+3), group 1 in R(4t+3).
     const bool g1 = wm == 1;  // wave-uniform
@@ -657,19 +706,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         for (int a = 0; a < TN; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 4096 + off);
 #pragma unroll
         for (int b = 0; b < TM; ++b) af[b] = *(const i32x4_t*)(As + b * 4096 + off);
+        // global->LDS loads are issued in R segments only (an LDS-DMA instruction costs ~60-100
+        // issue cycles: in front of an MFMA cluster it would idle the matrix pipe, here it hides under
+        // the other group's cluster). Group 1: W in R0, A in R1+R2; group 0 (one interval earlier, its
+        // R0 precedes the slot release): W in R1, A in R2+R3.
         if (g1) {
           if (s == 0) issue_next_W(t);
-          if (s == 1) issue_next_A(t);
+          if (s == 1) issue_next_A_lo(t);
+          if (s == 2) issue_next_A_hi(t);
           if (s == 3 && t + 1 < KT) wait_tile(t + 1);
+        } else {
+          if (s == 1) issue_next_W(t);
+          if (s == 2) issue_next_A_lo(t);
+          if (s == 3) issue_next_A_hi(t);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- M segment ----
-        if (!g1) {
-          if (s == 0) issue_next_W(t);
-          if (s == 1) issue_next_A(t);
-        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < TN; ++a)
