@@ -159,16 +159,30 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
         }
     }
     // ---- online softmax (one query per lane; the two lane halves share a query) ----
-    float mx = st[0][0];
+    // Deferred rescale: the running max m_run is only raised (and O, l rescaled) when some row of the
+    // wave saw a score more than 2^kDefer above it; otherwise exponentials stay relative to the old
+    // max (p <= 2^kDefer, harmless for bf16's floating-point rounding and the fp32 sums).  With
+    // softmax logits of O(1) spread this fires on the first tile and then almost never, which removes
+    // the 32-register O rescale from nearly every tile.  The final result is exact either way.
+    constexpr float kDefer = 6.0f;  // in log2 units
+    float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+    for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, st[0][r]), st[0][r + 1]);
+    mx = fmaxf(mx, st[0][15]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[1][r]), st[1][r + 1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
-    const float mc = m_new * cs;
-    m_run = m_new;
+    if (__any((mx - m_run) * cs > kDefer)) {  // wave-uniform branch
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float mc = m_run * cs;
     float psum = 0.f;
     i32x4_t pf[2][2];
 #pragma unroll
@@ -187,11 +201,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
         pf[sub][s2][3] = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
       }
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    l_run += psum;
     // ---- O^T[dt] += V^T[dt] . P^T ----
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)

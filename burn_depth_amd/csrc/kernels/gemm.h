@@ -73,7 +73,7 @@ struct GemmParams {
   float head_b = 0.f;
 };
 
-enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_256x256_V2 = 4, TILE_AUTO = 99 };
+enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_256x256_V2 = 4, TILE_256x256_PP32 = 5, TILE_AUTO = 99 };
 
 // Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16) or MD_PREC_F32 (T = float).
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream);

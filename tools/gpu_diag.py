@@ -126,7 +126,7 @@ def check_linear(dev):
     cases = [(300, 256, 128, _lib.TILE_128x128), (300, 256, 128, _lib.TILE_256x256), (577, 3072, 1024, _lib.TILE_AUTO),
              (1160, 1024, 4096, _lib.TILE_AUTO), (64, 32, 192, _lib.TILE_256x32), (1000, 32, 128, _lib.TILE_256x32),
              (129, 132, 64, _lib.TILE_128x128), (513, 260, 320, _lib.TILE_256x256), (2000, 1024, 1024, _lib.TILE_256x256),
-             (2000, 1024, 1024, _lib.TILE_128x128), (2000, 1024, 1024, 3), (513, 260, 320, 3), (2000, 1024, 1024, 4), (513, 260, 320, 4), (300, 256, 64, 4), (300, 256, 128, 0), (21349, 1024, 1024, _lib.TILE_256x256),
+             (2000, 1024, 1024, _lib.TILE_128x128), (2000, 1024, 1024, 3), (513, 260, 320, 3), (2000, 1024, 1024, 4), (513, 260, 320, 4), (300, 256, 64, 4), (300, 256, 128, 0), (2000, 1024, 1024, 5), (513, 260, 320, 5), (300, 256, 64, 5), (21349, 1024, 1024, _lib.TILE_256x256),
              (700, 3072, 64, _lib.TILE_256x256), (700, 512, 128, _lib.TILE_256x256), (700, 512, 192, _lib.TILE_256x256)]
     for prec, pname in [(0, "bf16"), (1, "f32")]:
         for (M, N, K, tile) in cases:
