@@ -42,7 +42,7 @@ __device__ __forceinline__ int pack_bf16x2(float a, float b) {
 // the q blocks of one (sequence, head) run on ONE XCD -- its K and V^T (148 KB) are fetched into that
 // L2 once instead of once per q block (measured before the remap: 1.0 GB fetched per launch against
 // 0.27 GB of q/k/v).
-__global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __restrict__ qk,
+__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ qk,
                                                              const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
                                                              int S, int n_tokens, int heads, int D, int kpad,
                                                              int qblocks) {
@@ -139,12 +139,11 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[sub][r] = 0.f;
-#pragma unroll
       for (int s = 0; s < 4; ++s) {
         const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
+        const f32x16_t cin = s == 0 ? (f32x16_t){0.f} : st[sub];  // first k-step: inline-constant 0 as C
         st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                          __builtin_bit_cast(bf16x8_t, qf[s]), st[sub], 0, 0, 0);
+                                                          __builtin_bit_cast(bf16x8_t, qf[s]), cin, 0, 0, 0);
       }
     }
     // register r of lane half h holds local key (r&7) + 8h + 16(r>>3) of the sub-tile
