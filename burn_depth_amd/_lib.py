@@ -27,6 +27,10 @@ class MdError(RuntimeError):
         self.message = message
 
 
+class MdDa3Cfg(C.Structure):
+    _fields_ = [("variant", C.c_char_p), ("precision", C.c_int), ("max_batch", C.c_int), ("ln_eps", C.c_float)]
+
+
 class MdDepthProCfg(C.Structure):
     _fields_ = [
         ("patch_encoder_preset", C.c_char_p),
@@ -64,6 +68,11 @@ SYMBOLS = {
     "md_model_destroy": (_I, [_P]),
     "md_depth_pro_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "md_infer_from_rgb": (_I, [_P, _P, C.c_size_t, _I, _I, _I, _P, _P, _P, _I, _P]),
+    "md_da3_cfg_default": (None, [C.POINTER(MdDa3Cfg)]),
+    "md_da3_create": (_I, [_P, C.POINTER(MdDa3Cfg), C.c_uint64, _I, C.POINTER(_P)]),
+    "md_da3_load": (_I, [_P, C.POINTER(MdDa3Cfg), C.c_char_p, C.POINTER(_P)]),
+    "md_da3_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "md_da3_param_inventory": (_I, [C.POINTER(MdDa3Cfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_model_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "md_model_enable_taps": (_I, [_P, _I]),
     "md_model_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int64 * 4)]),

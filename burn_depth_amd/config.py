@@ -122,3 +122,45 @@ class DepthProConfig:
     def img_size(self) -> int:
         """reference: encoder.rs:139-140 (img_size = 4 * patch window)."""
         return self.patch_vit().img_size * 4
+
+
+# ---------------------------------------------------------------------------------------------
+# Depth-Anything-v3 (reference: src/model/depth_anything3/mod.rs:124-172, dpt.rs:15-80)
+# ---------------------------------------------------------------------------------------------
+DA3_VITL14 = ViTConfig("da3_vitl14", 3, 1024, 24, 16, 4, 518, 14, (4, 11, 17, 23), (256, 512, 1024, 1024))
+DA3_TINY14 = ViTConfig("da3_tiny14", 3, 256, 4, 4, 4, 70, 14, (0, 1, 2, 3), (64, 128, 256, 256))  # test-only
+
+
+@dataclass
+class DepthAnything3Config:
+    """`DepthAnything3Config::metric_large()` (depth_anything3/mod.rs:153-156) + head
+    (`DepthAnything3HeadConfig::metric_large`, dpt.rs:41-58). Only the mono-head ("metric_large")
+    variant is built so far; `small` (dual head, camera decoder, RoPE/QK-norm backbone) is a next row."""
+
+    variant: str = "metric_large"
+    image_size: int = 518
+    patch_size: int = 14
+    hook_block_ids: tuple = (4, 11, 17, 23)
+    dim_in: int = 1024
+    features: int = 256
+    out_channels: tuple = (256, 512, 1024, 1024)
+    output_dim: int = 1
+    pos_embed: bool = True
+    precision: int = Precision.BF16
+    max_batch: int = 1
+    ln_eps: float = 1e-6
+
+    @staticmethod
+    def metric_large() -> "DepthAnything3Config":
+        return DepthAnything3Config()
+
+    @staticmethod
+    def tiny_test() -> "DepthAnything3Config":
+        return DepthAnything3Config("tiny", 70, 14, (0, 1, 2, 3), 256, 64, (64, 128, 256, 256))
+
+    def vit(self) -> ViTConfig:
+        base = DA3_VITL14 if self.variant == "metric_large" else DA3_TINY14
+        return dataclasses.replace(base, ln_eps=self.ln_eps, encoder_feature_layer_ids=tuple(self.hook_block_ids))
+
+    def img_size(self) -> int:
+        return self.image_size

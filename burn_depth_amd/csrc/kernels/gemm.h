@@ -41,7 +41,8 @@ struct GemmParams {
   const void* A = nullptr;
   long lda = 0;                 // elements between consecutive rows (dense / indexed)
   const int* a_index = nullptr; // A_INDEXED: logical row m reads physical row a_index[m]
-  int cH = 0, cW = 0, cC = 0;   // A_CONV3: NHWC [B, cH, cW, cC]; M = B*cH*cW; K = 9*cC (tap-major)
+  int cH = 0, cW = 0, cC = 0;   // A_CONV3: NHWC input [B, cH, cW, cC]; K = 9*cC (tap-major), pad 1
+  int cOH = 0, cOW = 0, cstride = 1;  // output grid (0 = same as input) and stride; M = B*cOH*cOW
   const void* zero_page = nullptr;  // >= 256 zero bytes (A_CONV3 halo)
   // ---- epilogue ----
   int epi = EPI_STORE;
@@ -56,6 +57,7 @@ struct GemmParams {
   const void* res1 = nullptr;   // optional residual inputs, element type T
   const void* res2 = nullptr;
   long ldr = 0;
+  int res_mod = 0;              // > 0: residual row = m % res_mod (a per-image table shared by the batch)
   // EPI_PATCH_EMBED / EPI_QKV
   int seq_stride = 0;           // rows per sequence in the token buffers (tokens padded to x4)
   int seq_patches = 0;          // patches per sequence (EPI_PATCH_EMBED input rows per sequence)
@@ -63,14 +65,15 @@ struct GemmParams {
   int heads = 0;
   int kpad = 0;                 // padded key count of V^T rows
   void* vT = nullptr;
-  // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = 4*psC; out NHWC [B, 2psH, 2psW, ldo] at +ps_coff
-  int psH = 0, psW = 0, psC = 0, ps_coff = 0;
+  // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = f*f*psC (f = ps_f, 2 or 4); out NHWC [B, f*psH, f*psW, ldo] at +ps_coff
+  int psH = 0, psW = 0, psC = 0, ps_coff = 0, ps_f = 2;
   int raster_gn = 0;  // n-tiles per raster group (0 = all: plain n-fastest order); set by the launcher
   // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
   int debug_flags = 0;
   // EPI_HEAD
   const float* head_w = nullptr;  // [32]
   float head_b = 0.f;
+  int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear
 };
 
 enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_256x256_V2 = 4, TILE_256x256_PP32 = 5, TILE_AUTO = 99 };

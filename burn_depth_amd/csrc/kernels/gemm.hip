@@ -32,6 +32,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   if (p.N <= 0 || p.N % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: N=%d must be a positive multiple of 4", p.N);
   if (p.K <= 0 || p.K % ke != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", p.K, ke);
   if (amode == A_CONV3) {
+    if (p.cstride < 1) MD_FAIL(MD_ERR_INVALID_ARG, "conv3x3: stride %d", p.cstride);
     if (p.cC % ke != 0 || p.K != 9 * p.cC)
       MD_FAIL(MD_ERR_UNSUPPORTED, "conv3x3: Cin=%d must be a multiple of %d (K=%d)", p.cC, ke, p.K);
     if (!p.zero_page) MD_FAIL(MD_ERR_INVALID_ARG, "conv3x3: zero page missing");

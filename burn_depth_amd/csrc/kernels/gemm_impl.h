@@ -155,8 +155,9 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
   switch (p.epi) {
     case EPI_STORE: {
       if (bias) v += *(const f32x4_t*)(bias + n);
-      if (p.res1) v += load4<T>((const T*)p.res1 + (long)m * p.ldr + n);
-      if (p.res2) v += load4<T>((const T*)p.res2 + (long)m * p.ldr + n);
+      const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+      if (p.res1) v += load4<T>((const T*)p.res1 + rm * p.ldr + n);
+      if (p.res2) v += load4<T>((const T*)p.res2 + rm * p.ldr + n);
       if (p.act == ACT_RELU) {
         v = relu4(v);
       } else if (p.act == ACT_GELU) {
@@ -214,12 +215,13 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
     case EPI_PIXSHUF: {
       int tap = n / p.psC;
       int co = n - tap * p.psC;
-      int dy = tap >> 1, dx = tap & 1;
+      const int f = p.ps_f;
+      int dy = tap / f, dx = tap - dy * f;
       int x = m % p.psW;
       int t = m / p.psW;
       int y = t % p.psH;
       int b = t / p.psH;
-      long orow = ((long)b * 2 * p.psH + 2 * y + dy) * (2L * p.psW) + 2 * x + dx;
+      long orow = ((long)b * f * p.psH + f * y + dy) * ((long)f * p.psW) + f * x + dx;
       if (bias) v += *(const f32x4_t*)(bias + co);
       long o = orow * p.ldo + p.ps_coff + co;
       if (p.out_f32)
@@ -322,8 +324,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
       srcA[i] = Ab + (long)p.a_index[am] * p.lda * ESZ + lc * 16;
       maskA[i] = 0;
     } else {
-      const int x = (int)(am % p.cW);
-      const int y = (int)((am / p.cW) % p.cH);
+      const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
+      const int ox = (int)(am % ow);
+      const long t2 = am / ow;
+      const int oy = (int)(t2 % oh);
+      const long bimg = t2 / oh;
+      const int x = ox * p.cstride, y = oy * p.cstride;  // centre tap in the input grid
       unsigned mk = 0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
           if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) mk |= 1u << (ky * 3 + kx);
         }
       maskA[i] = mk;
-      srcA[i] = Ab + am * p.cC * ESZ + lc * 16;
+      srcA[i] = Ab + ((bimg * p.cH + y) * p.cW + x) * p.cC * ESZ + lc * 16;
     }
   }
   const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
@@ -429,7 +435,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
         }
         part += __shfl_xor(part, 32);
         const int m = m_base + wm * WTM + b * 32 + (lane & 31);
-        if (h == 0 && m < m_end) ((float*)p.out)[m] = fmaxf(part + p.head_b, 0.f);
+        if (h == 0 && m < m_end) {
+          const float z = part + p.head_b;
+          ((float*)p.out)[m] = p.head_act == 1 ? expf(z) : (p.head_act == 2 ? z : fmaxf(z, 0.f));
+        }
       }
     }
     return;
@@ -541,8 +550,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       srcA[i] = Ab + (long)p.a_index[am] * p.lda * ESZ + lc * 16;
       maskA[i] = 0;
     } else {
-      const int x = (int)(am % p.cW);
-      const int y = (int)((am / p.cW) % p.cH);
+      const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
+      const int ox = (int)(am % ow);
+      const long t2 = am / ow;
+      const int oy = (int)(t2 % oh);
+      const long bimg = t2 / oh;
+      const int x = ox * p.cstride, y = oy * p.cstride;  // centre tap in the input grid
       unsigned mk = 0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -552,7 +565,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) mk |= 1u << (ky * 3 + kx);
         }
       maskA[i] = mk;
-      srcA[i] = Ab + am * p.cC * ESZ + lc * 16;
+      srcA[i] = Ab + ((bimg * p.cH + y) * p.cW + x) * p.cC * ESZ + lc * 16;
     }
   }
   const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;

@@ -25,6 +25,16 @@ struct PyramidGeom {
 };
 int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s);
 
+// Generic ViT patch extraction (any patch size, e.g. 14 for DA3): fp32 NCHW [B,3,H,W] ->
+// A[(b*ph + py)*pw + px][c*ps*ps + ky*ps + kx], row length Kp >= 3*ps*ps (tail zero-filled).
+int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s);
+
+// Bilinear resize of an NHWC tensor (element type by prec), align_corners per `method`
+// (MD_INTERP_BURN = align_corners=True, depth_anything3/interpolate.rs:7-47), optional per-pixel
+// fp32 addend table [OH*OW, C] (already scaled; the DA3 UV position embedding, dpt.rs:799-828).
+int launch_resize_nhwc(const void* in, int B, int H, int W, int C, long ld_in, void* out, int OH, int OW, long ld_out,
+                       int method, const float* addend, int prec, hipStream_t s);
+
 // a3 stand-alone split on fp32 NCHW (debug tap / md_op_split).
 int launch_split(const float* x, int B, int C, int S, int win, int stride, int steps, float* out, hipStream_t s);
 // a6 stand-alone merge on fp32 NCHW (encoder.rs:234-282).

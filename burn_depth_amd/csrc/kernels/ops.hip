@@ -202,6 +202,105 @@ int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches,
 }
 
 // ------------------------------------------------------------------------------------------------
+// generic patch extraction + NHWC bilinear resize (Depth-Anything-v3 path)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ x, int B, int H, int W, int ps, int Kp, T* __restrict__ out) {
+  const int ph = H / ps, pw = W / ps, K = 3 * ps * ps;
+  const long total = (long)B * ph * pw * Kp;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % Kp);
+    const long row = e / Kp;
+    float v = 0.f;
+    if (col < K) {
+      const int c = col / (ps * ps), r = col % (ps * ps);
+      const int ky = r / ps, kx = r % ps;
+      const int px = (int)(row % pw);
+      const long t = row / pw;
+      const int py = (int)(t % ph);
+      const int b = (int)(t / ph);
+      v = x[(((long)b * 3 + c) * H + py * ps + ky) * W + px * ps + kx];
+    }
+    if constexpr (sizeof(T) == 4)
+      ((float*)out)[e] = v;
+    else
+      *((__bf16*)out + e) = (__bf16)v;
+  }
+}
+
+int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s) {
+  if (ps <= 0 || H % ps || W % ps || Kp < 3 * ps * ps) MD_FAIL(MD_ERR_SHAPE, "patchify: %dx%d / patch %d / K %d", H, W, ps, Kp);
+  const long total = (long)B * (H / ps) * (W / ps) * Kp;
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (float*)out);
+  else
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (bf16_t*)out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+template <typename T>
+__device__ __forceinline__ void load8f(const T* p, float* v);
+template <>
+__device__ __forceinline__ void load8f<float>(const float* p, float* v) {
+  const f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <>
+__device__ __forceinline__ void load8f<bf16_t>(const bf16_t* p, float* v) {
+  const bf16x8_t a = *(const bf16x8_t*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+
+// one thread = 8 channels of one output pixel (16-byte bf16 / 32-byte f32 accesses)
+template <typename T>
+__global__ void resize_nhwc_kernel(const T* __restrict__ in, int B, int H, int W, int C, long ld_in, T* __restrict__ out,
+                                   int OH, int OW, long ld_out, int method, const float* __restrict__ addend) {
+#pragma clang fp contract(off)
+  const int C8 = C / 8;
+  const long total = (long)B * OH * OW * C8;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C8) * 8;
+    long t = e / C8;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    const AxisTap ty = axis_tap(oy, H, OH, method), tx = axis_tap(ox, W, OW, method);
+    const T* base = in + ((long)b * H * W) * ld_in + c;
+    float tl[8], tr[8], bl[8], br[8], o[8];
+    load8f<T>(base + ((long)ty.i0 * W + tx.i0) * ld_in, tl);
+    load8f<T>(base + ((long)ty.i0 * W + tx.i1) * ld_in, tr);
+    load8f<T>(base + ((long)ty.i1 * W + tx.i0) * ld_in, bl);
+    load8f<T>(base + ((long)ty.i1 * W + tx.i1) * ld_in, br);
+    const long opix = ((long)b * OH + oy) * OW + ox;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float top = tl[i] * (1.0f - tx.d) + tr[i] * tx.d;
+      const float bottom = bl[i] * (1.0f - tx.d) + br[i] * tx.d;
+      o[i] = top * (1.0f - ty.d) + bottom * ty.d;
+      if (addend) o[i] += addend[((long)oy * OW + ox) * C + c + i];
+    }
+    store8<T>(out + opix * ld_out + c, o);
+  }
+}
+
+int launch_resize_nhwc(const void* in, int B, int H, int W, int C, long ld_in, void* out, int OH, int OW, long ld_out,
+                       int method, const float* addend, int prec, hipStream_t s) {
+  if (C % 8 != 0 || OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_UNSUPPORTED, "resize_nhwc: C=%d must be a multiple of 8", C);
+  const long total = (long)B * OH * OW * (C / 8);
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(resize_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, B, H, W, C, ld_in,
+                       (float*)out, OH, OW, ld_out, method, addend);
+  else
+    hipLaunchKernelGGL(resize_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, B, H, W, C,
+                       ld_in, (bf16_t*)out, OH, OW, ld_out, method, addend);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a3 split / a6 merge on fp32 NCHW (stand-alone ops and debug taps)
 // ------------------------------------------------------------------------------------------------
 __global__ void split_kernel(const float* __restrict__ x, int B, int C, int S, int win, int stride, int steps,

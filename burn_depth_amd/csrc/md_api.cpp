@@ -169,6 +169,7 @@ int md_model_destroy(md_model_t m) { return model_destroy(m); }
 int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                        float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream) {
   if (!nchw) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");
+  if (m && m->kind != 0) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth Pro model");
   return model_infer(m, nchw, B, H, W, in_kind, depth, focallength_px, fovx_deg, fovy_rad, out_kind, (hipStream_t)stream,
                      nullptr, 0);
 }
@@ -180,6 +181,7 @@ int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, i
   // inference.rs:85-95: length check comes first and is an Err, not a panic
   const size_t expected = (size_t)w * (size_t)h * 3;
   if (rgb_len != expected) MD_FAIL(MD_ERR_SHAPE, "expected %zu RGB bytes for %dx%d, got %zu", expected, w, h, rgb_len);
+  if (m && m->kind != 0) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth Pro model");
   return model_infer(m, nullptr, 1, h, w, in_kind, depth, focallength_px, nullptr, fovy_rad, out_kind, (hipStream_t)stream,
                      rgb, rgb_len);
 }
@@ -588,6 +590,100 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
   (void)hipEventDestroy(e1);
   *avg_ms = ms / iters;
   return MD_OK;
+}
+
+namespace {
+int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
+  if (!c || !c->variant) MD_FAIL(MD_ERR_INVALID_ARG, "config is null");
+  Da3Cfg d;
+  d.variant = c->variant;
+  ViTDims v;
+  v.in_chans = 3; v.mlp_ratio = 4; v.ps = 14;
+  if (d.variant == "metric_large") {  // depth_anything3/mod.rs:153-156, dpt.rs:41-58
+    v.preset = "da3_vitl14"; v.D = 1024; v.depth = 24; v.heads = 16; v.img = 518;
+    d.image_size = 518; d.features = 256;
+    const int oc[4] = {256, 512, 1024, 1024}, hk[4] = {4, 11, 17, 23};
+    for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
+  } else if (d.variant == "tiny") {
+    v.preset = "da3_tiny14"; v.D = 256; v.depth = 4; v.heads = 4; v.img = 70;
+    d.image_size = 70; d.features = 64;
+    const int oc[4] = {64, 128, 256, 256}, hk[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
+  } else if (d.variant == "small") {
+    MD_FAIL(MD_ERR_UNSUPPORTED, "Depth-Anything-v3 `small` (dual head, camera decoder, RoPE/QK-norm backbone) is not built yet");
+  } else {
+    MD_FAIL(MD_ERR_INVALID_ARG, "unknown Depth-Anything-v3 variant `%s`", c->variant);
+  }
+  for (int i = 0; i < 4; ++i) { v.hook_ids[i] = d.hook_ids[i]; v.feat_dims[i] = d.out_channels[i]; }
+  d.vit = v;
+  d.precision = c->precision;
+  d.max_batch = c->max_batch > 0 ? c->max_batch : 1;
+  d.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
+  if (d.precision != MD_PREC_BF16 && d.precision != MD_PREC_F32) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", d.precision);
+  *out = d;
+  return MD_OK;
+}
+}  // namespace
+
+void md_da3_cfg_default(md_da3_cfg* cfg) {
+  if (!cfg) return;
+  cfg->variant = "metric_large";
+  cfg->precision = MD_PREC_BF16;
+  cfg->max_batch = 1;
+  cfg->ln_eps = 1e-6f;
+}
+
+int md_da3_create(md_device_t dev, const md_da3_cfg* cfg, uint64_t seed, int init_scheme, md_model_t* out) {
+  if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/out is null");
+  Da3Cfg dc;
+  MD_TRY(parse_da3_cfg(cfg, &dc));
+  md_model_t m = nullptr;
+  MD_TRY(da3_create(dev, dc, &m));
+  int s = da3_init_seeded(m, seed, init_scheme);
+  if (s != MD_OK) {
+    model_destroy(m);
+    return s;
+  }
+  *out = m;
+  return MD_OK;
+}
+
+int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_model_t* out) {
+  if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/out is null");
+  Da3Cfg dc;
+  MD_TRY(parse_da3_cfg(cfg, &dc));
+  {
+    Container probe;
+    MD_TRY(read_container(path, &probe));
+  }
+  md_model_t m = nullptr;
+  MD_TRY(da3_create(dev, dc, &m));
+  int s = da3_load_container(m, path);
+  if (s != MD_OK) {
+    model_destroy(m);
+    return s;
+  }
+  *out = m;
+  return MD_OK;
+}
+
+int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind, void* stream) {
+  return da3_infer(m, nchw, B, H, W, in_kind, depth, out_kind, (hipStream_t)stream);
+}
+
+int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count, float* lo,
+                           float* hi) {
+  Da3Cfg dc;
+  MD_TRY(parse_da3_cfg(cfg, &dc));
+  static thread_local std::vector<ParamSpec> specs;
+  specs = da3_param_specs(dc, init_scheme);
+  if (index >= 0 && index < (int)specs.size()) {
+    if (name) *name = specs[index].name.c_str();
+    if (count) *count = specs[index].count();
+    if (lo) *lo = specs[index].lo;
+    if (hi) *hi = specs[index].hi;
+  }
+  return (int)specs.size();
 }
 
 int md_param_inventory(const md_depth_pro_cfg* cfg, int init_scheme, int index, const char** name, size_t* count, float* lo,

@@ -1,0 +1,573 @@
+// Depth-Anything-v3 `metric_large` (ViT-L/14 backbone + mono DPT head) on the same kernel set.
+//
+// reference: src/model/depth_anything3/mod.rs:288-291,495-624 (infer), dpt.rs:515-731 (mono head),
+// dpt.rs:784-932 (UV position embedding), dpt.rs:1194-1301 (fusion blocks), interpolate.rs:7-47.
+// The backbone is burn_dino's plain DINOv2 ViT (un-vendored; restated, parity unpinned): hooks are the
+// final-LayerNorm'ed outputs of the hook blocks with the cls token dropped.
+//
+// Layout: tokens [b*SS + token, D] (fp32 residual, T operands), head feature maps NHWC. The mono head is
+// 1x1 conv (GEMM over gathered token rows, + UV position table as an epilogue addend) -> k4s4 / k2s2
+// ConvTranspose (GEMM + pixel shuffle) or 3x3 stride-2 conv (implicit GEMM with stride) -> 3x3 convs,
+// residual units and align-corners-true bilinear resizes in NHWC -> fused tail
+// exp(w_out . relu(conv1) + b) written straight to the depth output.
+#include <cmath>
+#include <cstring>
+
+#include "md_engine.h"
+#include "md_engine_util.h"
+
+using namespace md;
+
+struct md_model_s::Da3State {
+  Da3Cfg cfg;
+  int ph = 0, pw = 0, P = 0, NT = 0, SS = 0, kpad = 0, Kp = 0, h3 = 0;
+  VitW vit;
+  // workspace
+  void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vT = nullptr, *ao = nullptr, *hbuf = nullptr;
+  float *xres = nullptr, *lnf = nullptr, *scores = nullptr, *xin = nullptr;
+  void* hookn[4] = {0, 0, 0, 0};
+  void *sp[4] = {0, 0, 0, 0}, *sr[4] = {0, 0, 0, 0}, *rn[4] = {0, 0, 0, 0}, *rnr[4] = {0, 0, 0, 0};
+  void *t = nullptr, *x = nullptr, *xr = nullptr, *y = nullptr, *up = nullptr, *o = nullptr, *c1 = nullptr, *c1r = nullptr;
+  float* depth_stage = nullptr;
+  size_t depth_stage_elems = 0;
+  // tables
+  void* pos_stage[4] = {0, 0, 0, 0};  // T [P, cp(oc)] = 0.1 * UV embedding
+  float* pos_final = nullptr;         // f32 [H*W, F/2]
+  std::map<int, int*> tok_index;      // per B: [B*P] -> row b*SS + 1 + p
+};
+
+namespace md {
+
+// dpt.rs:835-932 -- the reference's table, including its transposed pixel index (dpt.rs:879)
+static void sincos(int dim, float position, float* out) {
+  const int half = dim / 2;
+  for (int i = 0; i < half; ++i) {
+    const float exponent = half > 0 ? (float)i / (float)half : 0.f;
+    const float omega = powf(100.0f, -exponent);
+    out[i] = sinf(position * omega);
+  }
+  const int remaining = dim - half;
+  for (int i = 0; i < remaining; ++i) {
+    const float exponent = remaining > 0 ? (float)i / (float)remaining : 0.f;
+    const float omega = powf(100.0f, -exponent);
+    out[half + i] = cosf(position * omega);
+  }
+}
+
+// returns NHWC [h*w][C] scaled by `ratio`
+static std::vector<float> build_pos_table_nhwc(int C, int h, int w, int image_w, int image_h, float ratio) {
+  const float aspect = (float)image_w / (float)image_h;
+  const float diag = sqrtf(aspect * aspect + 1.0f);
+  const float span_x = aspect / diag, span_y = 1.0f / diag;
+  const float left_x = -span_x * ((float)w - 1.0f) / (float)w, right_x = span_x * ((float)w - 1.0f) / (float)w;
+  const float top_y = -span_y * ((float)h - 1.0f) / (float)h, bottom_y = span_y * ((float)h - 1.0f) / (float)h;
+  auto lin = [](float a, float b, int n, int i) { return n <= 1 ? a : a + ((b - a) / ((float)n - 1.0f)) * (float)i; };
+  const int xc = C / 2, yc = C - xc;
+  std::vector<float> ex((size_t)w * xc), ey((size_t)h * yc);
+  for (int i = 0; i < w; ++i) sincos(xc, lin(left_x, right_x, w, i), ex.data() + (size_t)i * xc);
+  for (int i = 0; i < h; ++i) sincos(yc, lin(top_y, bottom_y, h, i), ey.data() + (size_t)i * yc);
+  std::vector<float> t((size_t)h * w * C);
+  // reference: chw[c*h*w + (x_idx*height + y_idx)], then viewed as [C, h, w]
+  for (int xi = 0; xi < w; ++xi)
+    for (int yi = 0; yi < h; ++yi) {
+      const size_t pix = (size_t)xi * h + yi;  // flat pixel index inside the [h, w] view
+      float* dst = t.data() + pix * C;
+      for (int c = 0; c < xc; ++c) dst[c] = ex[(size_t)xi * xc + c] * ratio;
+      for (int c = 0; c < yc; ++c) dst[xc + c] = ey[(size_t)yi * yc + c] * ratio;
+    }
+  return t;
+}
+
+static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
+  md_model_s::Da3State* d = m->da3;
+  const Da3Cfg& c = d->cfg;
+  const int B = c.max_batch, D = c.vit.D, F = c.features, esz = m->esz, S = c.image_size;
+  const int* oc = c.out_channels;
+  size_t total = 0;
+  auto take = [&](size_t bytes) -> void* {
+    bytes = align_up(bytes + 256, 256);
+    total += bytes;
+    return dry ? nullptr : m->ws.take(bytes);
+  };
+#define DA3_TAKE(field, type, bytes)                                          \
+  do {                                                                        \
+    void* _p = take(bytes);                                                   \
+    if (!dry) {                                                               \
+      if (!_p) MD_FAIL(MD_ERR_OOM, "workspace arena exhausted at " #field);   \
+      d->field = (type)_p;                                                    \
+    }                                                                         \
+  } while (0)
+  const size_t rows = (size_t)B * d->SS + 64;
+  const int ph = d->ph, pw = d->pw, h3 = d->h3;
+  const size_t P = d->P;
+  auto cp = [&](int ch) { return (size_t)round_up(ch, m->ke); };
+  DA3_TAKE(xin, float*, (size_t)B * 3 * S * S * 4);
+  DA3_TAKE(patches, void*, (size_t)B * P * d->Kp * esz);
+  DA3_TAKE(xres, float*, rows * D * 4);
+  DA3_TAKE(lnf, float*, rows * D * 4);
+  DA3_TAKE(xn, void*, rows * D * esz);
+  DA3_TAKE(qk, void*, rows * 2 * D * esz);
+  DA3_TAKE(vT, void*, (size_t)B * c.vit.heads * 64 * d->kpad * esz);
+  DA3_TAKE(ao, void*, rows * D * esz);
+  DA3_TAKE(hbuf, void*, rows * 4 * D * esz);
+  if (m->prec == MD_PREC_F32) DA3_TAKE(scores, float*, (size_t)B * c.vit.heads * d->SS * d->kpad * 4);
+  for (int s = 0; s < 4; ++s) DA3_TAKE(hookn[s], void*, rows * D * esz);
+  const size_t px[4] = {(size_t)16 * ph * pw, (size_t)4 * ph * pw, (size_t)ph * pw, (size_t)h3 * h3};
+  for (int s = 0; s < 4; ++s) {
+    DA3_TAKE(sp[s], void*, (size_t)B * P * cp(oc[s]) * esz);
+    if (s != 2) DA3_TAKE(sr[s], void*, (size_t)B * px[s] * cp(oc[s]) * esz);
+    DA3_TAKE(rn[s], void*, (size_t)B * px[s] * cp(F) * esz);
+    DA3_TAKE(rnr[s], void*, (size_t)B * px[s] * cp(F) * esz);
+  }
+  const size_t big = (size_t)B * 64 * ph * pw * cp(F) * esz;  // 8ph x 8pw
+  DA3_TAKE(t, void*, big / 4);
+  DA3_TAKE(x, void*, big / 4);
+  DA3_TAKE(xr, void*, big / 4);
+  DA3_TAKE(y, void*, big / 4);
+  DA3_TAKE(up, void*, big);
+  DA3_TAKE(o, void*, big);
+  DA3_TAKE(c1, void*, (size_t)B * 64 * ph * pw * cp(F / 2) * esz);
+  DA3_TAKE(c1r, void*, (size_t)B * S * S * cp(F / 2) * esz);
+  for (int s = 0; s < 4; ++s) DA3_TAKE(pos_stage[s], void*, P * cp(oc[s]) * esz);
+  DA3_TAKE(pos_final, float*, (size_t)S * S * (F / 2) * 4);
+#undef DA3_TAKE
+  if (total_out) *total_out = total + 4096;
+  return MD_OK;
+}
+
+int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
+  if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/model pointer is null");
+  const ViTDims& v = cfg.vit;
+  if (v.D != v.heads * 64 || v.D % 64 != 0 || v.D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "ViT width %d / heads %d unsupported", v.D, v.heads);
+  if (cfg.image_size % v.ps != 0) MD_FAIL(MD_ERR_SHAPE, "image size %d must be divisible by patch size %d", cfg.image_size, v.ps);
+  if (cfg.features % 64 != 0 || cfg.output_dim != 1) MD_FAIL(MD_ERR_UNSUPPORTED, "head features %d / output_dim %d unsupported", cfg.features, cfg.output_dim);
+  for (int s = 0; s < 4; ++s)
+    if (cfg.out_channels[s] % 64 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "head out_channels must be multiples of 64");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  md_model_s* m = new md_model_s();
+  m->dev = dev;
+  m->kind = 1;
+  m->prec = cfg.precision;
+  m->esz = cfg.precision == MD_PREC_F32 ? 4 : 2;
+  m->ke = 128 / m->esz;
+  m->cfg.max_batch = cfg.max_batch;
+  m->cfg.precision = cfg.precision;
+  m->da3 = new md_model_s::Da3State();
+  md_model_s::Da3State* d = m->da3;
+  d->cfg = cfg;
+  d->ph = d->pw = cfg.image_size / v.ps;
+  d->P = d->ph * d->pw;
+  d->NT = d->P + 1;
+  d->SS = round_up(d->NT, 4);
+  d->kpad = round_up(d->NT, 64);
+  d->Kp = round_up(3 * v.ps * v.ps, m->ke);
+  d->h3 = (d->ph + 2 - 3) / 2 + 1;
+  m->S = cfg.image_size;
+  m->SS = d->SS;
+  auto fail = [&](int code) {
+    model_destroy(m);
+    return code;
+  };
+  m->params = da3_param_specs(cfg, MD_INIT_REFERENCE);
+  size_t off = 0;
+  std::vector<size_t> offs;
+  for (size_t i = 0; i < m->params.size(); ++i) {
+    m->pindex[m->params[i].name] = (int)i;
+    offs.push_back(off);
+    off += align_up(m->params[i].count() * 4, 256);
+  }
+  m->w32_bytes = off;
+  if (hipMalloc((void**)&m->w32_base, m->w32_bytes) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the fp32 weights failed", m->w32_bytes);
+    return fail(MD_ERR_OOM);
+  }
+  (void)hipMemset(m->w32_base, 0, m->w32_bytes);
+  for (size_t i = 0; i < m->params.size(); ++i) m->w32.push_back((float*)(m->w32_base + offs[i]));
+
+  const int D = v.D, F = cfg.features;
+  const int* oc = cfg.out_channels;
+  const std::string bp = "backbone.pretrained";
+  add_pack(m, bp + ".patch_embed.proj.weight", PACK_NK, D, 3 * v.ps * v.ps, 1);
+  for (int i = 0; i < v.depth; ++i) {
+    const std::string b = bp + ".blocks." + std::to_string(i);
+    add_pack(m, b + ".attn.qkv.weight", PACK_NK, 3 * D, D, 1);
+    add_pack(m, b + ".attn.proj.weight", PACK_NK, D, D, 1);
+    add_pack(m, b + ".mlp.fc1.weight", PACK_NK, 4 * D, D, 1);
+    add_pack(m, b + ".mlp.fc2.weight", PACK_NK, D, 4 * D, 1);
+  }
+  for (int s = 0; s < 4; ++s) add_pack(m, "head_mono.projects." + std::to_string(s) + ".weight", PACK_NK, oc[s], D, 1);
+  add_pack(m, "head_mono.resize_layers.0.conv_t.weight", PACK_DECONV, oc[0], oc[0], 4);
+  add_pack(m, "head_mono.resize_layers.1.conv_t.weight", PACK_DECONV, oc[1], oc[1], 2);
+  add_pack(m, "head_mono.resize_layers.3.conv.weight", PACK_CONV3, oc[3], oc[3], 3);
+  for (int s = 0; s < 4; ++s) add_pack(m, "head_mono.scratch.layer" + std::to_string(s + 1) + "_rn.weight", PACK_CONV3, F, oc[s], 3);
+  for (int i = 1; i <= 4; ++i) {
+    const std::string r = "head_mono.scratch.refinenet" + std::to_string(i);
+    for (const char* u : {"residual1", "residual2"}) {
+      add_pack(m, r + "." + u + ".conv1.weight", PACK_CONV3, F, F, 3);
+      add_pack(m, r + "." + u + ".conv2.weight", PACK_CONV3, F, F, 3);
+    }
+    add_pack(m, r + ".out_conv.weight", PACK_NK, F, F, 1);
+  }
+  add_pack(m, "head_mono.scratch.output_conv1.weight", PACK_CONV3, F / 2, F, 3);
+  add_pack(m, "head_mono.scratch.output_conv2.conv1.weight", PACK_CONV3, 32, F / 2, 3);
+  size_t poff = 0;
+  for (auto& e : m->packs) {
+    e.dst = (void*)poff;
+    poff += align_up(e.bytes + 256, 256);
+  }
+  m->wpk_bytes = poff;
+  if (hipMalloc((void**)&m->wpk_base, m->wpk_bytes) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the packed weights failed", m->wpk_bytes);
+    return fail(MD_ERR_OOM);
+  }
+  (void)hipMemset(m->wpk_base, 0, m->wpk_bytes);
+  for (auto& e : m->packs) e.dst = m->wpk_base + (size_t)e.dst;
+
+  VitW& w = d->vit;
+  w.pe_w = PK(m, bp + ".patch_embed.proj.weight");
+  w.pe_b = P32(m, bp + ".patch_embed.proj.bias");
+  w.cls = P32(m, bp + ".cls_token");
+  w.pos = P32(m, bp + ".pos_embed");
+  w.norm_g = P32(m, bp + ".norm.gamma");
+  w.norm_b = P32(m, bp + ".norm.beta");
+  for (int i = 0; i < v.depth; ++i) {
+    const std::string b = bp + ".blocks." + std::to_string(i);
+    VitBlockW k;
+    k.n1g = P32(m, b + ".norm1.gamma"); k.n1b = P32(m, b + ".norm1.beta");
+    k.n2g = P32(m, b + ".norm2.gamma"); k.n2b = P32(m, b + ".norm2.beta");
+    k.qkv_w = PK(m, b + ".attn.qkv.weight"); k.qkv_b = P32(m, b + ".attn.qkv.bias");
+    k.proj_w = PK(m, b + ".attn.proj.weight"); k.proj_b = P32(m, b + ".attn.proj.bias");
+    k.ls1 = P32(m, b + ".ls1.gamma"); k.ls2 = P32(m, b + ".ls2.gamma");
+    k.fc1_w = PK(m, b + ".mlp.fc1.weight"); k.fc1_b = P32(m, b + ".mlp.fc1.bias");
+    k.fc2_w = PK(m, b + ".mlp.fc2.weight"); k.fc2_b = P32(m, b + ".mlp.fc2.bias");
+    w.blk.push_back(k);
+  }
+
+  size_t need = 0;
+  da3_plan(m, true, &need);
+  if (hipMalloc((void**)&m->ws.base, need) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the workspace failed (max_batch=%d)", need, cfg.max_batch);
+    return fail(MD_ERR_OOM);
+  }
+  m->ws.cap = need;
+  if (hipMemset(m->ws.base, 0, need) != hipSuccess) return fail(MD_ERR_HIP);
+  int st = da3_plan(m, false, nullptr);
+  if (st != MD_OK) return fail(st);
+  if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
+  (void)hipMemset(m->zero_page, 0, 4096);
+
+  // UV position tables for this image size (PosEmbedCache, dpt.rs:784-833: built once per shape)
+  {
+    const int S = cfg.image_size;
+    float* tmp = nullptr;
+    size_t tmp_elems = (size_t)S * S * (F / 2);
+    for (int s = 0; s < 4; ++s) tmp_elems = std::max(tmp_elems, (size_t)d->P * round_up(oc[s], m->ke));
+    if (hipMalloc((void**)&tmp, tmp_elems * 4) != hipSuccess) return fail(MD_ERR_OOM);
+    for (int s = 0; s < 4; ++s) {
+      std::vector<float> t = build_pos_table_nhwc(oc[s], d->ph, d->pw, S, S, 0.1f);
+      const int ld = round_up(oc[s], m->ke);
+      std::vector<float> padded((size_t)d->P * ld, 0.f);
+      for (int p = 0; p < d->P; ++p) memcpy(&padded[(size_t)p * ld], &t[(size_t)p * oc[s]], (size_t)oc[s] * 4);
+      if (hipMemcpy(tmp, padded.data(), padded.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
+      if (launch_f32_to_rows(tmp, (long)padded.size(), d->pos_stage[s], m->prec, dev->stream) != MD_OK) return fail(MD_ERR_HIP);
+      (void)hipStreamSynchronize(dev->stream);
+    }
+    std::vector<float> t = build_pos_table_nhwc(F / 2, S, S, S, S, 0.1f);
+    if (hipMemcpy(d->pos_final, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
+    (void)hipFree(tmp);
+  }
+  (void)hipDeviceSynchronize();
+  *out = m;
+  return MD_OK;
+}
+
+void da3_destroy_state(md_model_t m) {
+  if (!m || !m->da3) return;
+  for (auto& kv : m->da3->tok_index) (void)hipFree(kv.second);
+  if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
+  delete m->da3;
+  m->da3 = nullptr;
+}
+
+int da3_init_seeded(md_model_t m, uint64_t seed, int scheme) {
+  if (scheme != MD_INIT_REFERENCE && scheme != MD_INIT_PARITY) MD_FAIL(MD_ERR_INVALID_ARG, "unknown init scheme %d", scheme);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  std::vector<ParamSpec> specs = da3_param_specs(m->da3->cfg, scheme);
+  if (specs.size() != m->params.size()) MD_FAIL(MD_ERR_FORMAT, "internal: inventory mismatch");
+  std::vector<float> tmp;
+  for (size_t i = 0; i < specs.size(); ++i) {
+    const size_t n = specs[i].count();
+    tmp.resize(n);
+    uniform_stream(specs[i].name, seed, n, specs[i].lo, specs[i].hi, tmp.data());
+    MD_HIP(hipMemcpy(m->w32[i], tmp.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  return model_commit(m);
+}
+
+int da3_load_container(md_model_t m, const char* path) {
+  MD_TRY(model_load_params_from_container(m, path));
+  return model_commit(m);
+}
+
+static int da3_tok_index(md_model_s* m, int B, int** out) {
+  md_model_s::Da3State* d = m->da3;
+  auto it = d->tok_index.find(B);
+  if (it != d->tok_index.end()) {
+    *out = it->second;
+    return MD_OK;
+  }
+  std::vector<int> h((size_t)B * d->P);
+  for (int b = 0; b < B; ++b)
+    for (int p = 0; p < d->P; ++p) h[(size_t)b * d->P + p] = b * d->SS + 1 + p;
+  int* dev = nullptr;
+  MD_HIP(hipMalloc((void**)&dev, h.size() * 4));
+  MD_HIP(hipMemcpy(dev, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  d->tok_index[B] = dev;
+  *out = dev;
+  return MD_OK;
+}
+
+int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
+              hipStream_t stream) {
+  if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
+  if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
+  if (!nchw || !depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
+  md_model_s::Da3State* d = m->da3;
+  const Da3Cfg& c = d->cfg;
+  const ViTDims& v = c.vit;
+  if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
+  if (H % v.ps != 0 || W % v.ps != 0)  // depth_anything3/mod.rs:509-520 (assert -> checked precondition)
+    MD_FAIL(MD_ERR_SHAPE, "Input %dx%d must be divisible by patch size %d", H, W, v.ps);
+  if (H != c.image_size || W != c.image_size)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "only %dx%d inputs are supported so far (no position-embedding interpolation)", c.image_size, c.image_size);
+  if (B > c.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, c.max_batch);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : m->dev->stream;
+  Run r{m, st, B};
+  const int D = v.D, heads = v.heads, SS = d->SS, NT = d->NT, P = d->P, ph = d->ph, pw = d->pw, F = c.features, S = c.image_size;
+  const int* oc = c.out_channels;
+  const int Fp = cpad(m, F), F2 = F / 2, F2p = cpad(m, F2);
+  const float* x_dev = nchw;
+  if (in_kind == MD_MEM_HOST) {
+    MD_HIP(hipMemcpyAsync(d->xin, nchw, (size_t)B * 3 * H * W * 4, hipMemcpyHostToDevice, st));
+    x_dev = d->xin;
+  }
+  // ---- backbone ----
+  r.begin("patchify");
+  MD_TRY(launch_patchify(x_dev, B, H, W, v.ps, d->Kp, d->patches, m->prec, st));
+  r.end();
+  SeqGroups sg;
+  memset(&sg, 0, sizeof(sg));
+  sg.ngroups = 1;
+  sg.nseq[0] = B;
+  sg.a[0] = d->vit.cls;
+  sg.b[0] = d->vit.pos;
+  r.begin("cls_init");
+  MD_TRY(launch_cls_init(d->xres, B, SS, NT, D, sg, st));
+  r.end();
+  {
+    GemmParams p;
+    p.N = D; p.K = d->Kp; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = d->vit.pe_w; p.bias[0] = d->vit.pe_b; p.pos[0] = d->vit.pos;
+    p.A = d->patches; p.lda = d->Kp;
+    p.epi = EPI_PATCH_EMBED; p.out = d->xres; p.ldo = D; p.seq_stride = SS; p.seq_patches = P; p.embed = D;
+    r.begin("patch_embed");
+    MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+    r.end();
+  }
+  const long rows = (long)B * SS;
+  auto dense = [&](GemmParams& p) { p.ngroups = 1; p.g_rows[0] = (int)rows; };
+  int hook_slot = 0;
+  for (int i = 0; i < v.depth; ++i) {
+    const VitBlockW& k = d->vit.blk[i];
+    sg.a[0] = k.n1g; sg.b[0] = k.n1b;
+    r.begin("layernorm");
+    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, st));
+    r.end();
+    {
+      GemmParams p;
+      p.N = 3 * D; p.K = D; dense(p); p.W[0] = k.qkv_w; p.bias[0] = k.qkv_b; p.A = d->xn; p.lda = D;
+      p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad;
+      r.begin("qkv_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      r.end();
+    }
+    if (m->prec == MD_PREC_BF16) {
+      r.begin("attention");
+      MD_TRY(launch_attention_bf16(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, st));
+      r.end();
+    } else {
+      GemmParams p;
+      p.N = SS; p.K = 64; p.ngroups = 1; p.g_rows[0] = NT; p.batch = B * heads; p.batch_inner = heads;
+      p.A = d->qk; p.lda = 2 * D; p.a_bs[0] = (long)SS * 2 * D; p.a_bs[1] = 64;
+      p.W[0] = (const float*)d->qk + D; p.ldw = 2 * D; p.w_bs[0] = (long)SS * 2 * D; p.w_bs[1] = 64;
+      p.epi = EPI_STORE; p.out_f32 = 1; p.out = d->scores; p.ldo = d->kpad;
+      p.o_bs[0] = (long)heads * SS * d->kpad; p.o_bs[1] = (long)SS * d->kpad;
+      r.begin("attn_scores_f32");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_128x128, st));
+      r.end();
+      r.begin("attn_softmax_f32");
+      MD_TRY(launch_softmax_rows(d->scores, (long)B * heads * SS, NT, d->kpad, 0.125f, st));
+      r.end();
+      GemmParams q;
+      q.N = 64; q.K = d->kpad; q.ngroups = 1; q.g_rows[0] = NT; q.batch = B * heads; q.batch_inner = heads;
+      q.A = d->scores; q.lda = d->kpad; q.a_bs[0] = (long)heads * SS * d->kpad; q.a_bs[1] = (long)SS * d->kpad;
+      q.W[0] = d->vT; q.ldw = d->kpad; q.w_bs[0] = (long)heads * 64 * d->kpad; q.w_bs[1] = 64L * d->kpad;
+      q.epi = EPI_STORE; q.out = d->ao; q.ldo = D; q.o_bs[0] = (long)SS * D; q.o_bs[1] = 64;
+      r.begin("attn_pv_f32");
+      MD_TRY(launch_gemm(q, A_DENSE, m->prec, TILE_128x128, st));
+      r.end();
+    }
+    {
+      GemmParams p;
+      p.N = D; p.K = D; dense(p); p.W[0] = k.proj_w; p.bias[0] = k.proj_b; p.scale[0] = k.ls1;
+      p.A = d->ao; p.lda = D; p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      r.begin("proj_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      r.end();
+    }
+    sg.a[0] = k.n2g; sg.b[0] = k.n2b;
+    r.begin("layernorm");
+    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, st));
+    r.end();
+    {
+      GemmParams p;
+      p.N = 4 * D; p.K = D; dense(p); p.W[0] = k.fc1_w; p.bias[0] = k.fc1_b; p.A = d->xn; p.lda = D;
+      p.epi = EPI_STORE; p.act = ACT_GELU; p.out = d->hbuf; p.ldo = 4 * D;
+      r.begin("fc1_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      r.end();
+    }
+    {
+      GemmParams p;
+      p.N = D; p.K = 4 * D; dense(p); p.W[0] = k.fc2_w; p.bias[0] = k.fc2_b; p.scale[0] = k.ls2;
+      p.A = d->hbuf; p.lda = 4 * D; p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      r.begin("fc2_gemm");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      r.end();
+    }
+    // hooks (mod.rs:202-215): final LayerNorm of the block output, then the head's non-affine token
+    // norm (apply_token_norm, dpt.rs:761-766: biased variance, eps 1e-5). A block may feed several hooks.
+    for (int hk = 0; hk < 4; ++hk)
+      if (c.hook_ids[hk] == i) {
+        sg.a[0] = d->vit.norm_g; sg.b[0] = d->vit.norm_b;
+        r.begin("layernorm");
+        MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
+        r.end();
+        sg.a[0] = nullptr; sg.b[0] = nullptr;
+        r.begin("layernorm");
+        MD_TRY(launch_layernorm(d->lnf, d->hookn[hk], rows, D, 1e-5f, SS, sg, m->prec, 0, st));
+        r.end();
+        ++hook_slot;
+      }
+  }
+  if (hook_slot < 4) MD_FAIL(MD_ERR_LEVELS, "Backbone returned fewer hooks (%d) than requested (4)", hook_slot);  // mod.rs:532-537
+
+  // ---- mono DPT head (dpt.rs:587-631) ----
+  int* tok_idx = nullptr;
+  MD_TRY(da3_tok_index(m, B, &tok_idx));
+  auto Wk = [&](const std::string& n) { return PK(m, n); };
+  auto Bi = [&](const std::string& n) { return P32(m, n); };
+  const int sh[4] = {4 * ph, 2 * ph, ph, d->h3};  // stage spatial sizes (square)
+  for (int s = 0; s < 4; ++s) {
+    const int ocp = cpad(m, oc[s]);
+    const std::string ps = "head_mono.projects." + std::to_string(s);
+    {  // 1x1 projection over gathered patch tokens + 0.1 * UV position table (prepare_stage, dpt.rs:649-689)
+      GemmParams p;
+      p.N = oc[s]; p.K = D; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(ps + ".weight"); p.bias[0] = Bi(ps + ".bias");
+      p.A = d->hookn[s]; p.lda = D; p.a_index = tok_idx;
+      p.epi = EPI_STORE; p.out = d->sp[s]; p.ldo = ocp; p.res1 = d->pos_stage[s]; p.ldr = ocp; p.res_mod = P;
+      r.begin("head_proj");
+      MD_TRY(launch_gemm(p, A_INDEXED, m->prec, TILE_AUTO, st));
+      r.end();
+    }
+    const void* feat = d->sp[s];
+    if (s == 0 || s == 1) {  // ConvTranspose k4s4 / k2s2 (+bias)
+      const int f = s == 0 ? 4 : 2;
+      const std::string rl = "head_mono.resize_layers." + std::to_string(s) + ".conv_t";
+      GemmParams p;
+      p.N = f * f * oc[s]; p.K = ocp; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(rl + ".weight"); p.bias[0] = Bi(rl + ".bias");
+      p.A = d->sp[s]; p.lda = ocp;
+      p.epi = EPI_PIXSHUF; p.out = d->sr[s]; p.ldo = ocp; p.psH = ph; p.psW = pw; p.psC = oc[s]; p.ps_f = f;
+      r.begin("head_deconv");
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      r.end();
+      feat = d->sr[s];
+    } else if (s == 3) {  // Conv2d 3x3 stride 2 pad 1 (+bias)
+      GemmParams p;
+      p.N = oc[3]; p.K = 9 * ocp; p.ngroups = 1; p.g_rows[0] = B * d->h3 * d->h3;
+      p.W[0] = Wk("head_mono.resize_layers.3.conv.weight"); p.bias[0] = Bi("head_mono.resize_layers.3.conv.bias");
+      p.A = d->sp[3]; p.cH = ph; p.cW = pw; p.cC = ocp; p.cOH = d->h3; p.cOW = d->h3; p.cstride = 2; p.zero_page = m->zero_page;
+      p.epi = EPI_STORE; p.out = d->sr[3]; p.ldo = ocp;
+      r.begin("head_conv_s2");
+      MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_AUTO, st));
+      r.end();
+      feat = d->sr[3];
+    }
+    // layerN_rn: 3x3, no bias -> features (+ relu copy for the residual units)
+    MD_TRY(conv3(r, "head_conv3x3", feat, sh[s], sh[s], ocp, Wk("head_mono.scratch.layer" + std::to_string(s + 1) + "_rn.weight"), nullptr,
+                 F, d->rn[s], Fp, ACT_NONE, nullptr, nullptr, d->rnr[s]));
+  }
+  // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
+  auto rcu = [&](const std::string& name, int hw, const void* x, const void* xr, const void* extra, void* out, void* out_relu) -> int {
+    MD_TRY(conv3(r, "head_conv3x3", xr, hw, hw, Fp, Wk(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, d->t, Fp, ACT_RELU,
+                 nullptr, nullptr, nullptr));
+    return conv3(r, "head_conv3x3", d->t, hw, hw, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
+                 extra, out_relu);
+  };
+  // FeatureFusionBlock (dpt.rs:1206-1222); `top` comes in with no relu copy (it is only added)
+  const void* top = nullptr;
+  const int target[4] = {8 * ph, 4 * ph, 2 * ph, ph};  // output size of refinenet1..4
+  for (int lvl = 3; lvl >= 0; --lvl) {
+    const std::string rf = "head_mono.scratch.refinenet" + std::to_string(lvl + 1);
+    const void *yx, *yxr;
+    if (lvl == 3) {
+      yx = d->rn[3];
+      yxr = d->rnr[3];
+    } else {
+      MD_TRY(rcu(rf + ".residual1", sh[lvl], d->rn[lvl], d->rnr[lvl], top, d->x, d->xr));
+      yx = d->x;
+      yxr = d->xr;
+    }
+    MD_TRY(rcu(rf + ".residual2", sh[lvl], yx, yxr, nullptr, d->y, nullptr));
+    r.begin("head_resize");
+    MD_TRY(launch_resize_nhwc(d->y, B, sh[lvl], sh[lvl], F, Fp, d->up, target[lvl], target[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, st));
+    r.end();
+    MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * target[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
+                     Bi(rf + ".out_conv.bias"), d->o, Fp));
+    top = d->o;
+  }
+  // output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + exp (fused tail)
+  MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk("head_mono.scratch.output_conv1.weight"),
+               Bi("head_mono.scratch.output_conv1.bias"), F2, d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
+  r.begin("head_resize");
+  MD_TRY(launch_resize_nhwc(d->c1, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, S, S, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
+  r.end();
+  const size_t out_elems = (size_t)B * S * S;
+  float* depth_dev = depth;
+  if (out_kind == MD_MEM_HOST) {
+    if (d->depth_stage_elems < out_elems) {
+      if (d->depth_stage) (void)hipFree(d->depth_stage);
+      MD_HIP(hipMalloc((void**)&d->depth_stage, out_elems * 4));
+      d->depth_stage_elems = out_elems;
+    }
+    depth_dev = d->depth_stage;
+  }
+  {
+    GemmParams p;
+    p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = B * S * S; p.W[0] = Wk("head_mono.scratch.output_conv2.conv1.weight");
+    p.A = d->c1r; p.cH = S; p.cW = S; p.cC = F2p; p.zero_page = m->zero_page;
+    p.epi = EPI_HEAD; p.bias[0] = Bi("head_mono.scratch.output_conv2.conv1.bias");
+    p.head_w = Bi("head_mono.scratch.output_conv2.conv2.weight"); p.head_b = m->head_b_host; p.head_act = 1;
+    p.out = depth_dev;
+    r.begin("head_tail_fused");
+    MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, st));
+    r.end();
+  }
+  if (out_kind == MD_MEM_HOST) {
+    MD_HIP(hipMemcpyAsync(depth, depth_dev, out_elems * 4, hipMemcpyDeviceToHost, st));
+    MD_HIP(hipStreamSynchronize(st));
+  }
+  return MD_OK;
+}
+
+}  // namespace md

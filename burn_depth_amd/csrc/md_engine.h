@@ -111,6 +111,10 @@ struct md_model_s {
   std::vector<md::TimingEntry> timing;
   std::vector<std::string> timing_names_out;
 
+  // ---- model kind: 0 = Depth Pro, 1 = Depth-Anything-v3 (state in md_da3.hip) ----
+  int kind = 0;
+  struct Da3State;
+  Da3State* da3 = nullptr;
   // geometry shared by create/infer
   int S = 0, win = 0, g = 0, P = 0, NT = 0, SS = 0, kpad = 0;
   int steps0 = 0, stride0 = 0, steps1 = 0, stride1 = 0, pad_hi = 0, pad_mid = 0;
@@ -128,5 +132,24 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s);
 void fov_scalar_host(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad);
+
+// ---- Depth-Anything-v3 (md_da3.hip) ----
+struct Da3Cfg {
+  std::string variant = "metric_large";
+  ViTDims vit;
+  int image_size = 518, features = 256, output_dim = 1;
+  int out_channels[4] = {256, 512, 1024, 1024};
+  int hook_ids[4] = {4, 11, 17, 23};
+  int precision = MD_PREC_BF16, max_batch = 1;
+  float ln_eps = 1e-6f;
+};
+std::vector<ParamSpec> da3_param_specs(const Da3Cfg& cfg, int scheme);
+int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out);
+int da3_init_seeded(md_model_t m, uint64_t seed, int scheme);
+int da3_load_container(md_model_t m, const char* path);
+int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
+              hipStream_t stream);
+void da3_destroy_state(md_model_t m);
+int model_load_params_from_container(md_model_t m, const char* path);
 
 }  // namespace md

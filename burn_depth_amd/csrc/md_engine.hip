@@ -11,6 +11,7 @@
 //     ConvTranspose a GEMM + pixel-shuffle epilogue, a 3x3 conv an implicit GEMM over taps, and
 //     the token->map reshape + overlap-trim merge (encoder.rs:234-319) a row-index table.
 #include "md_engine.h"
+#include "md_engine_util.h"
 
 #include <algorithm>
 #include <cmath>
@@ -72,12 +73,12 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
       const int tap = (int)(t % 9);
       const long co = t / 9;
       if (ci < d1) v = src[(co * d1 + ci) * 9 + tap];
-    } else if (kind == PACK_DECONV) {  // [Cin][Cout][2][2] -> [4*Cout][kp], row = tap*Cout + co
+    } else if (kind == PACK_DECONV) {  // [Cin][Cout][k][k] -> [k*k*Cout][kp], row = tap*Cout + co
       const int ci = (int)(e % kp);
       const long n = e / kp;
       const int tap = (int)(n / d1);
       const int co = (int)(n % d1);
-      if (ci < d0) v = src[((long)ci * d1 + co) * 4 + tap];
+      if (ci < d0) v = src[((long)ci * d1 + co) * (k * k) + tap];
     } else {  // PACK_DIRECT: [Cout][Cin][k][k] -> [Cout][k][k][Cin]
       const int ci = (int)(e % d1);
       long t = e / d1;
@@ -91,15 +92,6 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
       ((float*)dst)[e] = v;
     else
       *((__bf16*)dst + e) = (__bf16)v;
-  }
-}
-
-static size_t pack_elems(const PackEntry& e) {
-  switch (e.kind) {
-    case PACK_NK: return (size_t)e.d0 * e.kp;
-    case PACK_CONV3: return (size_t)e.d0 * 9 * e.kp;
-    case PACK_DECONV: return (size_t)4 * e.d1 * e.kp;
-    default: return (size_t)e.d0 * e.d1 * e.k * e.k;
   }
 }
 
@@ -160,7 +152,6 @@ struct md_model_s::Buffers {
 
 namespace md {
 
-static int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 static void level_sizes(const md_model_s* m, int lvl_hw[5]) {
   // spatial size of encoder feature l (encoder.rs:416-434): latent0 x8, latent1 x4, x0 x2, x1 x2(mid), fused x2
@@ -271,33 +262,6 @@ static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
 // ------------------------------------------------------------------------------------------------
 // model construction
 // ------------------------------------------------------------------------------------------------
-static const float* P32(md_model_s* m, const std::string& name) {
-  auto it = m->pindex.find(name);
-  return it == m->pindex.end() ? nullptr : m->w32[it->second];
-}
-static const void* PK(md_model_s* m, const std::string& name) {
-  auto it = m->pack_index.find(name);
-  return it == m->pack_index.end() ? nullptr : m->packs[it->second].dst;
-}
-
-static void add_pack(md_model_s* m, const std::string& name, int kind, int d0, int d1, int k, bool f32 = false) {
-  auto it = m->pindex.find(name);
-  if (it == m->pindex.end()) return;
-  PackEntry e;
-  e.param = it->second;
-  e.kind = kind;
-  e.d0 = d0;
-  e.d1 = d1;
-  e.k = k;
-  e.f32 = f32 ? 1 : 0;
-  const int contraction = kind == PACK_NK ? d1 : kind == PACK_CONV3 ? d1 : kind == PACK_DECONV ? d0 : d1;
-  e.kp = f32 ? contraction : round_up(contraction, m->ke);
-  const size_t esz = (f32 || m->prec == MD_PREC_F32) ? 4 : 2;
-  e.bytes = pack_elems(e) * esz;
-  m->pack_index[name] = (int)m->packs.size();
-  m->packs.push_back(e);
-}
-
 int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/model pointer is null");
   if (!cfg.iv.same_arch(cfg.pv) || (cfg.use_fov_head && cfg.has_fov_vit && !cfg.fv.same_arch(cfg.pv)))
@@ -487,6 +451,7 @@ int model_destroy(md_model_t m) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
   }
+  if (m->da3) da3_destroy_state(m);
   if (m->buf) {
     if (m->buf->xraw) (void)hipFree(m->buf->xraw);
     if (m->buf->rgb) (void)hipFree(m->buf->rgb);
@@ -512,7 +477,7 @@ int model_init_seeded(md_model_t m, uint64_t seed, int scheme) {
   return model_commit(m);
 }
 
-int model_load_container(md_model_t m, const char* path) {
+int model_load_params_from_container(md_model_t m, const char* path) {
   Container c;
   MD_TRY(read_container(path, &c));
   MD_HIP(hipSetDevice(m->dev->ordinal));
@@ -543,6 +508,11 @@ int model_load_container(md_model_t m, const char* path) {
     }
     MD_HIP(hipMemcpy(m->w32[i], tmp.data(), n * 4, hipMemcpyHostToDevice));
   }
+  return MD_OK;
+}
+
+int model_load_container(md_model_t m, const char* path) {
+  MD_TRY(model_load_params_from_container(m, path));
   return model_commit(m);
 }
 
@@ -550,7 +520,7 @@ int model_commit(md_model_t m) {
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t s = m->dev->stream;
   for (auto& e : m->packs) MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
-  auto it = m->pindex.find("head.conv_out.bias");
+  auto it = m->pindex.find(m->kind == 1 ? "head_mono.scratch.output_conv2.conv2.bias" : "head.conv_out.bias");
   if (it != m->pindex.end()) MD_HIP(hipMemcpyAsync(&m->head_b_host, m->w32[it->second], 4, hipMemcpyDeviceToHost, s));
   MD_HIP(hipStreamSynchronize(s));
   m->committed = true;
@@ -610,101 +580,6 @@ static int get_index_set(md_model_s* m, int B, md_model_s::IndexSet* out) {
 // ------------------------------------------------------------------------------------------------
 // forward schedule
 // ------------------------------------------------------------------------------------------------
-namespace {
-
-struct Run {
-  md_model_s* m;
-  hipStream_t st;
-  int B;
-  int pending = -1;
-  void begin(const char* name) {
-    if (!m->timing_enabled) return;
-    TimingEntry t;
-    t.name = name;
-    (void)hipEventCreate(&t.a);
-    (void)hipEventCreate(&t.b);
-    (void)hipEventRecord(t.a, st);
-    m->timing.push_back(t);
-    pending = (int)m->timing.size() - 1;
-  }
-  void end() {
-    if (!m->timing_enabled || pending < 0) return;
-    (void)hipEventRecord(m->timing[pending].b, st);
-    pending = -1;
-  }
-  // NHWC T tensor -> NCHW fp32 tap
-  int tap_nhwc(const char* name, const void* p, int C, int H, int W, long ld, int coff = 0) {
-    if (!m->taps_enabled) return MD_OK;
-    Tap& t = m->taps[name];
-    const size_t n = (size_t)B * C * H * W;
-    if (t.count != n) {
-      if (t.dev) (void)hipFree(t.dev);
-      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
-      t.count = n;
-    }
-    t.dims[0] = B; t.dims[1] = C; t.dims[2] = H; t.dims[3] = W;
-    return launch_nhwc_to_nchw(p, B, C, H, W, ld, coff, t.dev, m->prec, st);
-  }
-  int tap_f32(const char* name, const float* p, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
-    if (!m->taps_enabled) return MD_OK;
-    Tap& t = m->taps[name];
-    const size_t n = (size_t)d0 * std::max<int64_t>(d1, 1) * std::max<int64_t>(d2, 1) * std::max<int64_t>(d3, 1);
-    if (t.count != n) {
-      if (t.dev) (void)hipFree(t.dev);
-      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
-      t.count = n;
-    }
-    t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = d3;
-    MD_HIP(hipMemcpyAsync(t.dev, p, n * 4, hipMemcpyDeviceToDevice, st));
-    return MD_OK;
-  }
-};
-
-inline int cpad(const md_model_s* m, int ch) { return (ch + m->ke - 1) / m->ke * m->ke; }
-
-// 1x1 conv / linear over NHWC rows.  A may be gathered through `idx`.
-int gemm_rows(Run& r, const char* name, const void* A, long lda, const int* idx, long M, const void* W, int N, int K,
-              const float* bias, void* out, long ldo, int out_f32 = 0, int act = ACT_NONE) {
-  GemmParams p;
-  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = (int)M; p.W[0] = W;
-  p.A = A; p.lda = lda; p.a_index = idx;
-  p.epi = EPI_STORE; p.act = act; p.out_f32 = out_f32; p.bias[0] = bias; p.out = out; p.ldo = ldo;
-  r.begin(name);
-  int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
-  r.end();
-  return s;
-}
-
-// ConvTranspose2d k=2 s=2 as GEMM + pixel shuffle (encoder.rs:61-69, decoder.rs:100-105, mod.rs:81-84)
-int deconv2(Run& r, const char* name, const void* A, long lda, const int* idx, int h, int w, const void* W, int Cin_p,
-            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr) {
-  GemmParams p;
-  p.N = 4 * Cout; p.K = Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W;
-  p.A = A; p.lda = lda; p.a_index = idx;
-  p.epi = EPI_PIXSHUF; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
-  p.psH = h; p.psW = w; p.psC = Cout; p.ps_coff = coff;
-  r.begin(name);
-  int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
-  r.end();
-  return s;
-}
-
-// Conv2d 3x3 s1 p1 over NHWC as implicit GEMM (decoder.rs:55-72,167-175; mod.rs:78-87)
-int conv3(Run& r, const char* name, const void* in, int H, int W, int Cin_p, const void* Wp, const float* bias,
-          int Cout, void* out, long ldo, int act, const void* res1, const void* res2, void* out2) {
-  GemmParams p;
-  p.N = Cout; p.K = 9 * Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * H * W; p.W[0] = Wp;
-  p.A = in; p.cH = H; p.cW = W; p.cC = Cin_p; p.zero_page = r.m->zero_page;
-  p.epi = EPI_STORE; p.act = act; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
-  p.res1 = res1; p.res2 = res2; p.ldr = ldo;
-  r.begin(name);
-  int s = launch_gemm(p, A_CONV3, r.m->prec, TILE_AUTO, r.st);
-  r.end();
-  return s;
-}
-
-}  // namespace
-
 static int run_vit(Run& r, int nseq_p, int nseq) {
   md_model_s* m = r.m;
   md_model_s::Buffers* b = m->buf;

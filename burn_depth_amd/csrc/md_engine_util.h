@@ -1,0 +1,141 @@
+// Helpers shared by the model engines (Depth Pro: md_engine.hip, Depth-Anything-v3: md_da3.hip).
+#pragma once
+
+#include <algorithm>
+#include <string>
+
+#include "md_engine.h"
+
+namespace md {
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+inline size_t pack_elems(const PackEntry& e) {
+  switch (e.kind) {
+    case PACK_NK: return (size_t)e.d0 * e.kp;
+    case PACK_CONV3: return (size_t)e.d0 * 9 * e.kp;
+    case PACK_DECONV: return (size_t)e.k * e.k * e.d1 * e.kp;
+    default: return (size_t)e.d0 * e.d1 * e.k * e.k;
+  }
+}
+
+inline const float* P32(md_model_s* m, const std::string& name) {
+  auto it = m->pindex.find(name);
+  return it == m->pindex.end() ? nullptr : m->w32[it->second];
+}
+inline const void* PK(md_model_s* m, const std::string& name) {
+  auto it = m->pack_index.find(name);
+  return it == m->pack_index.end() ? nullptr : m->packs[it->second].dst;
+}
+
+inline void add_pack(md_model_s* m, const std::string& name, int kind, int d0, int d1, int k, bool f32 = false) {
+  auto it = m->pindex.find(name);
+  if (it == m->pindex.end()) return;
+  PackEntry e;
+  e.param = it->second;
+  e.kind = kind;
+  e.d0 = d0;
+  e.d1 = d1;
+  e.k = k;
+  e.f32 = f32 ? 1 : 0;
+  const int contraction = kind == PACK_NK ? d1 : kind == PACK_CONV3 ? d1 : kind == PACK_DECONV ? d0 : d1;
+  e.kp = f32 ? contraction : round_up(contraction, m->ke);
+  const size_t esz = (f32 || m->prec == MD_PREC_F32) ? 4 : 2;
+  e.bytes = pack_elems(e) * esz;
+  m->pack_index[name] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
+struct Run {
+  md_model_s* m;
+  hipStream_t st;
+  int B;
+  int pending = -1;
+  void begin(const char* name) {
+    if (!m->timing_enabled) return;
+    TimingEntry t;
+    t.name = name;
+    (void)hipEventCreate(&t.a);
+    (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, st);
+    m->timing.push_back(t);
+    pending = (int)m->timing.size() - 1;
+  }
+  void end() {
+    if (!m->timing_enabled || pending < 0) return;
+    (void)hipEventRecord(m->timing[pending].b, st);
+    pending = -1;
+  }
+  // NHWC T tensor -> NCHW fp32 tap
+  int tap_nhwc(const char* name, const void* p, int C, int H, int W, long ld, int coff = 0) {
+    if (!m->taps_enabled) return MD_OK;
+    Tap& t = m->taps[name];
+    const size_t n = (size_t)B * C * H * W;
+    if (t.count != n) {
+      if (t.dev) (void)hipFree(t.dev);
+      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
+      t.count = n;
+    }
+    t.dims[0] = B; t.dims[1] = C; t.dims[2] = H; t.dims[3] = W;
+    return launch_nhwc_to_nchw(p, B, C, H, W, ld, coff, t.dev, m->prec, st);
+  }
+  int tap_f32(const char* name, const float* p, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
+    if (!m->taps_enabled) return MD_OK;
+    Tap& t = m->taps[name];
+    const size_t n = (size_t)d0 * std::max<int64_t>(d1, 1) * std::max<int64_t>(d2, 1) * std::max<int64_t>(d3, 1);
+    if (t.count != n) {
+      if (t.dev) (void)hipFree(t.dev);
+      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
+      t.count = n;
+    }
+    t.dims[0] = d0; t.dims[1] = d1; t.dims[2] = d2; t.dims[3] = d3;
+    MD_HIP(hipMemcpyAsync(t.dev, p, n * 4, hipMemcpyDeviceToDevice, st));
+    return MD_OK;
+  }
+};
+
+inline int cpad(const md_model_s* m, int ch) { return (ch + m->ke - 1) / m->ke * m->ke; }
+
+// 1x1 conv / linear over NHWC rows.  A may be gathered through `idx`.
+inline int gemm_rows(Run& r, const char* name, const void* A, long lda, const int* idx, long M, const void* W, int N, int K,
+              const float* bias, void* out, long ldo, int out_f32 = 0, int act = ACT_NONE) {
+  GemmParams p;
+  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = (int)M; p.W[0] = W;
+  p.A = A; p.lda = lda; p.a_index = idx;
+  p.epi = EPI_STORE; p.act = act; p.out_f32 = out_f32; p.bias[0] = bias; p.out = out; p.ldo = ldo;
+  r.begin(name);
+  int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
+  r.end();
+  return s;
+}
+
+// ConvTranspose2d k=2 s=2 as GEMM + pixel shuffle (encoder.rs:61-69, decoder.rs:100-105, mod.rs:81-84)
+inline int deconv2(Run& r, const char* name, const void* A, long lda, const int* idx, int h, int w, const void* W, int Cin_p,
+            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr) {
+  GemmParams p;
+  p.N = 4 * Cout; p.K = Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W;
+  p.A = A; p.lda = lda; p.a_index = idx;
+  p.epi = EPI_PIXSHUF; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
+  p.psH = h; p.psW = w; p.psC = Cout; p.ps_coff = coff;
+  r.begin(name);
+  int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
+  r.end();
+  return s;
+}
+
+// Conv2d 3x3 s1 p1 over NHWC as implicit GEMM (decoder.rs:55-72,167-175; mod.rs:78-87)
+inline int conv3(Run& r, const char* name, const void* in, int H, int W, int Cin_p, const void* Wp, const float* bias,
+          int Cout, void* out, long ldo, int act, const void* res1, const void* res2, void* out2) {
+  GemmParams p;
+  p.N = Cout; p.K = 9 * Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * H * W; p.W[0] = Wp;
+  p.A = in; p.cH = H; p.cW = W; p.cC = Cin_p; p.zero_page = r.m->zero_page;
+  p.epi = EPI_STORE; p.act = act; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
+  p.res1 = res1; p.res2 = res2; p.ldr = ldo;
+  r.begin(name);
+  int s = launch_gemm(p, A_CONV3, r.m->prec, TILE_AUTO, r.st);
+  r.end();
+  return s;
+}
+
+
+}  // namespace md

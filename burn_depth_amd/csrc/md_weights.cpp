@@ -1,6 +1,7 @@
 // Host-side parameter inventory / seeded init / container reader. Compiled with
 // -ffp-contract=off so that the generator matches burn_depth_amd/weights.py bit for bit.
 #include "md_weights.h"
+#include "md_engine.h"
 
 #include <cmath>
 #include <cstring>
@@ -182,6 +183,40 @@ std::vector<ParamSpec> depth_pro_param_specs(const ModelCfg& cfg, int scheme) {
     sb.sym(last + ".weight", {1, last_cin, 6, 6}, b);
     if (par) sb.add(last + ".bias", {1}, 55.0, 55.0); else sb.sym(last + ".bias", {1}, b);
   }
+  return specs;
+}
+
+// keep in lock-step with weights.py::da3_param_specs
+std::vector<ParamSpec> da3_param_specs(const Da3Cfg& cfg, int scheme) {
+  std::vector<ParamSpec> specs;
+  SpecBuilder sb{specs, scheme == MD_INIT_PARITY};
+  const bool par = sb.par;
+  sb.vit("backbone.pretrained", cfg.vit);
+  const int* oc = cfg.out_channels;
+  const int Fh = cfg.features, D = cfg.vit.D;
+  auto deconv = [&](const std::string& name, int cin, int cout, int k) {
+    const double b = par ? std::sqrt(3.0 / cin) : std::sqrt(1.0 / (cout * k * k));
+    sb.sym(name + ".weight", {cin, cout, k, k}, b);
+    sb.sym(name + ".bias", {cout}, par ? 0.1 : b);
+  };
+  for (int i = 0; i < 4; ++i) sb.conv("head_mono.projects." + std::to_string(i), oc[i], D, 1, true);
+  deconv("head_mono.resize_layers.0.conv_t", oc[0], oc[0], 4);
+  deconv("head_mono.resize_layers.1.conv_t", oc[1], oc[1], 2);
+  sb.conv("head_mono.resize_layers.3.conv", oc[3], oc[3], 3, true);
+  for (int i = 0; i < 4; ++i) sb.conv("head_mono.scratch.layer" + std::to_string(i + 1) + "_rn", Fh, oc[i], 3, false);
+  for (int i = 1; i <= 4; ++i) {
+    const std::string r = "head_mono.scratch.refinenet" + std::to_string(i);
+    if (i != 4) {
+      sb.conv(r + ".residual1.conv1", Fh, Fh, 3, true, true);
+      sb.conv(r + ".residual1.conv2", Fh, Fh, 3, true, true, 0.5);
+    }
+    sb.conv(r + ".residual2.conv1", Fh, Fh, 3, true, true);
+    sb.conv(r + ".residual2.conv2", Fh, Fh, 3, true, true, 0.5);
+    sb.conv(r + ".out_conv", Fh, Fh, 1, true);
+  }
+  sb.conv("head_mono.scratch.output_conv1", Fh / 2, Fh, 3, true);
+  sb.conv("head_mono.scratch.output_conv2.conv1", 32, Fh / 2, 3, true, true);
+  sb.conv("head_mono.scratch.output_conv2.conv2", cfg.output_dim, 32, 1, true, false, 0.5);
   return specs;
 }
 

@@ -1,0 +1,77 @@
+"""Host-side mirror of the reference's Depth-Anything-v3 interface (metric_large / mono head).
+
+* ``DepthAnything3.new(device, config)``  -- depth_anything3/mod.rs:253-286
+* ``DepthAnything3.load_file``            -- example/correctness.rs:977-982 (record load)
+* ``DepthAnything3.infer(x)``             -- depth_anything3/mod.rs:288-291
+* ``img_size`` / ``patch_size``           -- depth_anything3/mod.rs:566-572
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .config import DepthAnything3Config
+from .depth_pro import DepthPro, Device, _stream_ptr
+
+
+@dataclass
+class DepthAnything3Inference:
+    """depth_anything3/mod.rs:231-239 (the mono head fills `depth` only)."""
+    depth: torch.Tensor
+    depth_confidence: Optional[torch.Tensor] = None
+    aux: Optional[torch.Tensor] = None
+    aux_confidence: Optional[torch.Tensor] = None
+    pose_encoding: Optional[torch.Tensor] = None
+    extrinsics: Optional[torch.Tensor] = None
+    intrinsics: Optional[torch.Tensor] = None
+
+
+def _c_cfg(cfg: DepthAnything3Config):
+    keep = cfg.variant.encode()
+    return _lib.MdDa3Cfg(keep, int(cfg.precision), int(cfg.max_batch), float(cfg.ln_eps)), keep
+
+
+class DepthAnything3(DepthPro):
+    """Shares the record / timing / query plumbing of the md_model_t handle with DepthPro."""
+
+    @staticmethod
+    def new(device: Device, config: Optional[DepthAnything3Config] = None, seed: int = 0, init_scheme: int = 0) -> "DepthAnything3":
+        config = config or DepthAnything3Config.metric_large()
+        c, keep = _c_cfg(config)
+        h = C.c_void_p()
+        _lib.check(_lib.load().md_da3_create(device.handle, C.byref(c), C.c_uint64(seed), int(init_scheme), C.byref(h)))
+        return DepthAnything3(device, h, config)
+
+    @staticmethod
+    def load_file(device: Device, config: DepthAnything3Config, path: str) -> "DepthAnything3":
+        c, keep = _c_cfg(config)
+        h = C.c_void_p()
+        _lib.check(_lib.load().md_da3_load(device.handle, C.byref(c), os.fspath(path).encode(), C.byref(h)))
+        return DepthAnything3(device, h, config)
+
+    def patch_size(self) -> int:
+        return self.config.patch_size
+
+    def infer(self, x: torch.Tensor) -> DepthAnything3Inference:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
+        x = x.contiguous().to(torch.float32)
+        B, _, H, W = x.shape
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=torch.device("cuda", self.device.ordinal))
+        self.infer_into(x, depth)
+        return DepthAnything3Inference(depth=depth)
+
+    def infer_into(self, x: torch.Tensor, depth: torch.Tensor, *unused) -> None:
+        B, _, H, W = x.shape
+        in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_da3_infer(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind, C.c_void_p(depth.data_ptr()),
+                                          _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
+
+    def infer_from_rgb(self, rgb: bytes, width: int, height: int):
+        from .inference import rgb_to_input_tensor
+        return self.infer(rgb_to_input_tensor(rgb, width, height, self.device))

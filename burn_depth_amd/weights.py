@@ -28,7 +28,7 @@ from typing import Dict, Iterable, List, NamedTuple, Optional, Tuple
 
 import numpy as np
 
-from .config import DepthProConfig, ViTConfig
+from .config import DepthAnything3Config, DepthProConfig, ViTConfig
 
 # --------------------------------------------------------------------------------------------
 # Parameter inventory
@@ -182,6 +182,60 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
         # parity scheme: field of view around 55 degrees so tan(fov/2) is well conditioned
         specs.append(ParamSpec(f"{name}.bias", (cout,), *((55.0, 55.0) if par else _sym(b))))
     return specs
+
+
+def da3_param_specs(cfg: DepthAnything3Config, scheme: int = INIT_REFERENCE) -> List[ParamSpec]:
+    """Parameters of `DepthAnything3::new(metric_large)` (depth_anything3/mod.rs:253-286, dpt.rs:515-568,
+    1002-1083), named as the importer maps them (tool/import_da3.rs:67-195): `backbone.pretrained.*`,
+    `head_mono.*`."""
+    v = cfg.vit()
+    par = scheme == INIT_PARITY
+    specs: List[ParamSpec] = list(_vit_specs("backbone.pretrained", v, scheme))
+    oc, Fh = cfg.out_channels, cfg.features
+
+    def conv(name, cout, cin, k, bias, relu_after=False, gain=None):
+        fan = cin * k * k
+        if par:
+            b = math.sqrt((6.0 if relu_after else 3.0) / fan)
+            if gain is not None:
+                b *= gain
+        else:
+            b = math.sqrt(1.0 / fan)
+        specs.append(ParamSpec(f"{name}.weight", (cout, cin, k, k), *_sym(b)))
+        if bias:
+            specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
+
+    def deconv(name, cin, cout, k):
+        b = math.sqrt(3.0 / cin) if par else math.sqrt(1.0 / (cout * k * k))
+        specs.append(ParamSpec(f"{name}.weight", (cin, cout, k, k), *_sym(b)))
+        specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
+
+    for i in range(4):
+        conv(f"head_mono.projects.{i}", oc[i], cfg.dim_in, 1, True)
+    deconv("head_mono.resize_layers.0.conv_t", oc[0], oc[0], 4)
+    deconv("head_mono.resize_layers.1.conv_t", oc[1], oc[1], 2)
+    conv("head_mono.resize_layers.3.conv", oc[3], oc[3], 3, True)
+    for i in range(4):
+        conv(f"head_mono.scratch.layer{i + 1}_rn", Fh, oc[i], 3, False)
+    for i in (1, 2, 3, 4):
+        r = f"head_mono.scratch.refinenet{i}"
+        units = ("residual1", "residual2") if i != 4 else ("residual2",)
+        for u in units:
+            conv(f"{r}.{u}.conv1", Fh, Fh, 3, True, relu_after=True)
+            conv(f"{r}.{u}.conv2", Fh, Fh, 3, True, relu_after=True, gain=0.5)
+        conv(f"{r}.out_conv", Fh, Fh, 1, True)
+    conv("head_mono.scratch.output_conv1", Fh // 2, Fh, 3, True)
+    conv("head_mono.scratch.output_conv2.conv1", 32, Fh // 2, 3, True, relu_after=True)
+    conv("head_mono.scratch.output_conv2.conv2", cfg.output_dim, 32, 1, True, gain=0.5)
+    return specs
+
+
+def generate_da3_weights(cfg: DepthAnything3Config, seed: int = 0, scheme: int = INIT_REFERENCE) -> Dict[str, np.ndarray]:
+    out: Dict[str, np.ndarray] = {}
+    for spec in da3_param_specs(cfg, scheme):
+        n = int(np.prod(spec.shape))
+        out[spec.name] = uniform_stream(spec.name, seed, n, spec.lo, spec.hi).reshape(spec.shape)
+    return out
 
 
 # --------------------------------------------------------------------------------------------

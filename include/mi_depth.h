@@ -109,6 +109,31 @@ int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int
 int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, int h, int in_kind,
                       float* depth, float* focallength_px, float* fovy_rad, int out_kind, void* stream);
 
+/* ---- Depth-Anything-v3, `metric_large` variant (mono DPT head) -------------------------------------
+ * `DepthAnything3Config::metric_large()` (depth_anything3/mod.rs:153-156): ViT-L/14, 518x518, hooks
+ * [4,11,17,23], head `DepthAnything3HeadConfig::metric_large` (dpt.rs:41-58). variant "tiny" is a
+ * test-only reduction (ViT width 256, 4 blocks, 70x70). The `small` variant (dual head + camera
+ * decoder + RoPE/QK-norm backbone) is not built yet. The model handle is an md_model_t: set/get_tensor,
+ * commit, query, timing and destroy work on it unchanged. */
+typedef struct md_da3_cfg {
+  const char* variant; /* "metric_large" | "tiny" */
+  int precision;       /* md_precision */
+  int max_batch;
+  float ln_eps;        /* backbone LayerNorm eps (burn_dino's is not visible; default 1e-6) */
+} md_da3_cfg;
+void md_da3_cfg_default(md_da3_cfg* cfg);
+/* `DepthAnything3::new(&device, cfg)` (depth_anything3/mod.rs:253-286): seeded synthetic weights. */
+int md_da3_create(md_device_t dev, const md_da3_cfg* cfg, uint64_t seed, int init_scheme, md_model_t* out);
+/* `DepthAnything3::new(cfg).load_file(path, ..)` (example/correctness.rs:977-982), safetensors container. */
+int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_model_t* out);
+/* `DepthAnything3::infer(&self, x)` (depth_anything3/mod.rs:288-291): NCHW fp32 in, depth [B*H*W] out.
+ * H and W must be multiples of the patch size (mod.rs:509-520 assert -> MD_ERR_SHAPE); sizes other than
+ * the configured image size need position-embedding interpolation and return MD_ERR_UNSUPPORTED. */
+int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
+                 void* stream);
+int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,
+                           float* lo, float* hi);
+
 /* `img_size()` (mod.rs:296), `interpolation_method()` (mod.rs:308) and friends.
  * keys: "img_size", "patch_window", "interpolation", "precision", "max_batch", "num_params",
  *       "workspace_bytes", "weight_bytes", "tiles_per_image". */

@@ -1,0 +1,57 @@
+"""Oracle checks for the Depth-Anything-v3 mono head: the reference's shape smoke test
+(depth_anything3/mod.rs:634-642) on the reduced variant, and properties of the UV position table
+(dpt.rs:835-932) that the engine's C++ twin must reproduce."""
+import numpy as np
+import torch
+
+from burn_depth_amd import weights as Wt
+from burn_depth_amd.config import DepthAnything3Config
+from oracle import da3_ref as D
+from oracle import depth_pro_ref as R
+
+
+def test_depth_anything3_emits_depth_tensor():
+    # reference: depth_anything3/mod.rs:634-642 ([1,3,518,518] zeros -> depth [1,518,518]); tiny variant here
+    cfg = DepthAnything3Config.tiny_test()
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0))
+    out = D.infer(torch.zeros(1, 3, cfg.image_size, cfg.image_size), W, cfg)
+    assert tuple(out["depth"].shape) == (1, cfg.image_size, cfg.image_size)
+    assert torch.isfinite(out["depth"]).all() and (out["depth"] > 0).all()  # exp activation
+
+
+def test_rejects_sizes_not_divisible_by_patch():
+    # reference: depth_anything3/mod.rs:509-520 (assert)
+    cfg = DepthAnything3Config.tiny_test()
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0))
+    try:
+        D.infer(torch.zeros(1, 3, 71, 70), W, cfg)
+    except ValueError:
+        return
+    raise AssertionError("expected an error")
+
+
+def test_positional_embedding_layout():
+    # dpt.rs:835-890: first C/2 channels depend on the x coordinate, the rest on y; index x_idx*height + y_idx
+    C, h, w = 8, 3, 5
+    t = D.build_positional_embedding(C, h, w, 70, 42).reshape(C, h * w)
+    aspect = np.float32(70) / np.float32(42)
+    diag = np.sqrt(aspect * aspect + 1)
+    xs = np.linspace(-aspect / diag * (w - 1) / w, aspect / diag * (w - 1) / w, w)
+    ys = np.linspace(-1 / diag * (h - 1) / h, 1 / diag * (h - 1) / h, h)
+    for xi in range(w):
+        for yi in range(h):
+            pix = xi * h + yi
+            assert abs(t[0, pix] - np.sin(xs[xi])) < 1e-6          # omega = 100^0 = 1
+            assert abs(t[C // 2, pix] - np.sin(ys[yi])) < 1e-6
+            assert abs(t[C // 4, pix] - np.cos(xs[xi])) < 1e-6     # second half of the x block: cos
+    # square map: the reference's flat index makes the table the transpose of the natural (y, x) layout
+    s = D.build_positional_embedding(4, 4, 4, 64, 64).reshape(4, 4, 4)
+    assert np.allclose(s[0], s[0][:, :1])        # rows = x index: constant along the width axis
+    assert not np.allclose(s[0], s[0][:1, :])
+
+
+def test_align_corners_true_resize_identity():
+    x = torch.rand(1, 2, 5, 7)
+    assert D.resize_bilinear(x, (5, 7)) is x
+    y = D.resize_bilinear(x, (9, 13))
+    assert torch.allclose(y[..., 0, 0], x[..., 0, 0]) and torch.allclose(y[..., -1, -1], x[..., -1, -1])

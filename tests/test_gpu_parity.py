@@ -202,3 +202,38 @@ def test_full_size_properties(dev):
     o1 = model.infer(x[1:2].contiguous())                             # images never interact (B is a pure batch dim)
     assert torch.equal(o1.depth[0], d2[1]) and torch.equal(o1.fovx_deg[0], o2.fovx_deg[1])
     model.destroy()
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_depth_anything3_tiny_end_to_end(diag, dev, precision):
+    # reference: DepthAnything3::infer (depth_anything3/mod.rs:288-291) on the reduced variant
+    from burn_depth_amd.config import DepthAnything3Config
+    start = len(diag.RESULTS)
+    diag.guarded("da3-tiny")(diag.run_da3)(dev, DepthAnything3Config.tiny_test(), f"da3-tiny/p{precision}", 2, precision)
+    _assert_new_results_ok(diag, start)
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_depth_anything3_metric_large_end_to_end(diag, dev, precision):
+    # BASELINE config shape for DA3: ViT-L/14, one 518x518 image (depth_anything3/mod.rs:634-642)
+    from burn_depth_amd.config import DepthAnything3Config
+    start = len(diag.RESULTS)
+    diag.guarded("da3-large")(diag.run_da3)(dev, DepthAnything3Config.metric_large(), f"da3-large/p{precision}", 1, precision)
+    _assert_new_results_ok(diag, start)
+
+
+def test_depth_anything3_error_paths(dev):
+    from burn_depth_amd import _lib
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    m = DepthAnything3.new(dev, DepthAnything3Config.tiny_test(), seed=0)
+    assert m.img_size() == 70
+    with pytest.raises(_lib.MdError) as e:  # mod.rs:509-520: not divisible by the patch size
+        m.infer(torch.zeros(1, 3, 71, 70, device="cuda"))
+    assert e.value.code == _lib.MD_ERR_SHAPE
+    with pytest.raises(_lib.MdError) as e:  # other sizes need pos-embed interpolation: reported, not silently wrong
+        m.infer(torch.zeros(1, 3, 84, 84, device="cuda"))
+    assert e.value.code == _lib.MD_ERR_UNSUPPORTED
+    out = m.infer(torch.zeros(1, 3, 70, 70, device="cuda"))
+    assert tuple(out.depth.shape) == (1, 70, 70) and torch.isfinite(out.depth).all()
+    m.destroy()

@@ -55,6 +55,28 @@ def test_inventory_matches_python(lib, cfg, scheme):
         assert lo.value == np.float32(s.lo) and hi.value == np.float32(s.hi), s.name
 
 
+@pytest.mark.parametrize("scheme", [Wt.INIT_REFERENCE, Wt.INIT_PARITY])
+@pytest.mark.parametrize("variant", ["metric_large", "tiny"])
+def test_da3_inventory_matches_python(lib, variant, scheme):
+    from burn_depth_amd.config import DepthAnything3Config
+    cfg = DepthAnything3Config.metric_large() if variant == "metric_large" else DepthAnything3Config.tiny_test()
+    specs = Wt.da3_param_specs(cfg, scheme)
+    c = _lib.MdDa3Cfg(cfg.variant.encode(), 0, 1, 1e-6)
+    n = lib.md_da3_param_inventory(C.byref(c), scheme, -1, None, None, None, None)
+    assert n == len(specs)
+    for i, s in enumerate(specs):
+        name, cnt, lo, hi = C.c_char_p(), C.c_size_t(), C.c_float(), C.c_float()
+        lib.md_da3_param_inventory(C.byref(c), scheme, i, C.byref(name), C.byref(cnt), C.byref(lo), C.byref(hi))
+        assert name.value.decode() == s.name
+        assert cnt.value == int(np.prod(s.shape))
+        assert lo.value == np.float32(s.lo) and hi.value == np.float32(s.hi), s.name
+
+
+def test_da3_small_variant_is_reported_unsupported(lib):
+    c = _lib.MdDa3Cfg(b"small", 0, 1, 1e-6)
+    assert lib.md_da3_param_inventory(C.byref(c), 0, -1, None, None, None, None) == _lib.MD_ERR_UNSUPPORTED
+
+
 def test_unknown_preset_is_an_error_not_a_panic(lib):
     # layers/vit.rs:49-50 panics on an unknown preset; the ABI returns MD_ERR_INVALID_ARG
     cfg = DepthProConfig()

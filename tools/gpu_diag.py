@@ -275,6 +275,40 @@ def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY,
     model.destroy()
 
 
+def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY):
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from oracle import da3_ref as D3
+    cfg.precision = precision
+    cfg.max_batch = B
+    t0 = time.time()
+    model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=scheme)
+    print(f"      da3 model created in {time.time() - t0:.1f}s  workspace={model.query('workspace_bytes') / 1e9:.2f} GB", flush=True)
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, scheme))
+    for n in ("backbone.pretrained.blocks.0.attn.qkv.weight", "head_mono.resize_layers.0.conv_t.weight", "head_mono.scratch.output_conv2.conv2.weight"):
+        got = model.get_tensor(n, W[n].numel())
+        record(f"{label} seeded weight {n.split('.')[-3]}.{n.split('.')[-1]}", float(np.abs(got - W[n].numpy().reshape(-1)).max()), 0.0)
+    torch.manual_seed(1)
+    S = cfg.image_size
+    x = torch.randn(B, 3, S, S)
+    out = model.infer(x.cuda())
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ref = D3.infer(x, W, cfg)
+    print(f"      da3 oracle fp32 {time.time() - t0:.1f}s", flush=True)
+    d, rd = out.depth.cpu(), ref["depth"]
+    rel = (d - rd).abs() / rd.abs()
+    tol = (8e-2, 1e-2) if precision == Precision.BF16 else (1e-3, 1e-4)
+    record(f"{label} depth max-rel vs fp32 oracle", rel.max().item(), tol[0], f"mean-rel={rel.mean().item():.2e} depth in [{rd.min():.3f},{rd.max():.3f}]")
+    record(f"{label} depth mean-rel vs fp32 oracle", rel.mean().item(), tol[1])
+    model.enable_timing(True)
+    model.infer(x.cuda())
+    tm = model.read_timing()
+    tot = sum(v[0] for v in tm.values())
+    print(f"      da3 kernel time {tot:.2f} ms/batch: " + ", ".join(f"{k}={v[0]:.2f}ms/{v[1]}" for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0])[:12]), flush=True)
+    model.enable_timing(False)
+    model.destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-small", action="store_true")
@@ -303,6 +337,13 @@ def main():
     if want("small") and not args.skip_small:
         guarded("small bf16")(run_e2e)(dev, DepthProConfig.small_test(), "small/bf16", 1, (512, 512), Precision.BF16)
         guarded("small f32")(run_e2e)(dev, DepthProConfig.small_test(), "small/f32", 1, (512, 512), Precision.F32)
+    if want("da3"):
+        from burn_depth_amd.config import DepthAnything3Config
+        guarded("da3 tiny f32")(run_da3)(dev, DepthAnything3Config.tiny_test(), "da3-tiny/f32", 2, Precision.F32)
+        guarded("da3 tiny bf16")(run_da3)(dev, DepthAnything3Config.tiny_test(), "da3-tiny/bf16", 2, Precision.BF16)
+        if not args.skip_small:
+            guarded("da3 large f32")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/f32", 1, Precision.F32)
+            guarded("da3 large bf16")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/bf16", 1, Precision.BF16)
     if args.full or want("full") and only is not None:
         guarded("full bf16")(run_e2e)(dev, DepthProConfig(), "full/bf16", 1, (1536, 1536), Precision.BF16, taps=False)
     bad = [r for r in RESULTS if not r[3]]
