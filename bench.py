@@ -92,6 +92,9 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=2, help="images per GPU per step (B of DepthPro::infer([B,3,S,S]))")
     ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
+    ap.add_argument("--model", choices=["depth_pro", "da3_large"], default="depth_pro",
+                    help="depth_pro = the BASELINE headline; da3_large = Depth-Anything-v3 metric_large (configs 2/5 family)")
+    ap.add_argument("--image-size", type=int, default=0, help="da3_large only: square input side (multiple of 14), default 518")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--dump-launch-order", default="", help="write the per-launch kernel-family list of one infer (json)")
@@ -109,12 +112,14 @@ def main() -> int:
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
+    dev = Device(local_rank)
+    tdev = torch.device("cuda", local_rank)
+    if args.model == "da3_large":
+        return bench_da3(args, dev, tdev, world, rank)
     cfg = {"full": DepthProConfig(), "small": DepthProConfig.small_test(), "tiny": DepthProConfig.tiny_test()}[args.preset]
     cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
     cfg.max_batch = args.batch
     S, B = cfg.img_size(), args.batch
-    dev = Device(local_rank)
-    tdev = torch.device("cuda", local_rank)
     # weights: random init (DepthPro::new, bench/inference.rs:25). Rank 0 generates, the others receive
     # the fp32 weight arena over RCCL (one-time, outside the timed region).
     from burn_depth_amd.parallel import broadcast_weights, gather_depth
@@ -231,6 +236,65 @@ def main() -> int:
     return 0
 
 
+def bench_da3(args, dev, tdev, world, rank) -> int:
+    """frames/s of DepthAnything3::infer (metric_large, mono head) on synthetic [B,3,S,S]; same timing
+    contract as the Depth Pro path (barrier + synchronize, max over ranks, weak scaling)."""
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    cfg = DepthAnything3Config.metric_large()
+    if args.image_size:
+        cfg.image_size = args.image_size
+    cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
+    cfg.max_batch = args.batch
+    S, B = cfg.image_size, args.batch
+    model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    g = torch.Generator(device="cpu").manual_seed(99 + rank)
+    x = torch.randn(B, 3, S, S, generator=g).to(tdev)
+    depth = torch.empty((B, S, S), dtype=torch.float32, device=tdev)
+    for _ in range(args.warmup):
+        model.infer_into(x, depth)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    model.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.infer_into(x, depth)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = model.read_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        v = cfg.vit()
+        ph = S // 14
+        NT, D, depth_n = ph * ph + 1, v.embed_dim, v.depth
+        vit_flops = B * (2.0 * NT * D * 3 * D + 4.0 * NT * NT * D + 2.0 * NT * D * D + 4.0 * NT * D * 4 * D) * depth_n
+        fps = args.steps * B * world / elapsed
+        kernels = {k: {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": c // args.steps} for k, (ms, c) in timing.items()}
+        attn_ms = kernels.get("attention", {}).get("ms_per_step")
+        out = {"metric": f"frames/sec Depth-Anything-v3 metric_large @{S}^2 {args.precision}", "value": round(fps, 3), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+               "data": "synthetic (seeded normal images; random-init weights)",
+               "config": {"workload": f"DepthAnything3::infer [{B},3,{S},{S}] per GPU, metric_large (mono head)", "batch_per_gpu": B,
+                          "global_batch": B * world, "parallelism": f"dp{world}"},
+               "backbone_tflops_algorithmic": round(vit_flops / B / 1e12, 3),
+               "attention_tflops": round(4.0 * B * v.num_heads * NT * NT * 64 * depth_n / (attn_ms * 1e-3) / 1e12, 1) if attn_ms else None,
+               "kernels": kernels}
+        print(json.dumps(out))
+    model.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def pmc_traffic(kernel: str, B: int, args):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
@@ -249,7 +313,7 @@ def pmc_traffic(kernel: str, B: int, args):
 
 def cpu_baseline(cfg: DepthProConfig):
     """Times the CPU oracle (a port: the Rust reference cannot be built here) on a bounded sample:
-    the ViT-L patch encoder over 6 of the 35 tiles of one frame, scaled by algorithmic FLOPs.
+    the ViT-L patch encoder over 16 of the 37 tiles of one frame, scaled by algorithmic FLOPs.
     ViT work is 73 % of a frame and the oracle runs every part through the same oneDNN/MKL GEMMs."""
     from oracle import depth_pro_ref as R
     import numpy as np
@@ -262,7 +326,7 @@ def cpu_baseline(cfg: DepthProConfig):
     torch.set_num_threads(threads)
     v = cfg.patch_vit()
     torch.manual_seed(0)
-    tiles = 6
+    tiles = 16
     specs = [s for s in Wt.depth_pro_param_specs(cfg, Wt.INIT_PARITY) if s.name.startswith("encoder.patch_encoder.")]
     W = {s.name: torch.from_numpy(Wt.uniform_stream(s.name, 0, int(np.prod(s.shape)), s.lo, s.hi).reshape(s.shape)) for s in specs}
     x = torch.randn(tiles, 3, v.img_size, v.img_size)

@@ -28,7 +28,8 @@ class MdError(RuntimeError):
 
 
 class MdDa3Cfg(C.Structure):
-    _fields_ = [("variant", C.c_char_p), ("precision", C.c_int), ("max_batch", C.c_int), ("ln_eps", C.c_float)]
+    _fields_ = [("variant", C.c_char_p), ("image_size", C.c_int), ("precision", C.c_int), ("max_batch", C.c_int),
+                ("ln_eps", C.c_float)]
 
 
 class MdDepthProCfg(C.Structure):

@@ -616,6 +616,10 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
   }
   for (int i = 0; i < 4; ++i) { v.hook_ids[i] = d.hook_ids[i]; v.feat_dims[i] = d.out_channels[i]; }
   d.vit = v;
+  if (c->image_size > 0) {
+    if (c->image_size % v.ps != 0) MD_FAIL(MD_ERR_SHAPE, "image size %d must be divisible by patch size %d", c->image_size, v.ps);
+    d.image_size = c->image_size;
+  }
   d.precision = c->precision;
   d.max_batch = c->max_batch > 0 ? c->max_batch : 1;
   d.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
@@ -628,6 +632,7 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
 void md_da3_cfg_default(md_da3_cfg* cfg) {
   if (!cfg) return;
   cfg->variant = "metric_large";
+  cfg->image_size = 0;
   cfg->precision = MD_PREC_BF16;
   cfg->max_batch = 1;
   cfg->ln_eps = 1e-6f;

@@ -34,6 +34,8 @@ struct md_model_s::Da3State {
   void* pos_stage[4] = {0, 0, 0, 0};  // T [P, cp(oc)] = 0.1 * UV embedding
   float* pos_final = nullptr;         // f32 [H*W, F/2]
   std::map<int, int*> tok_index;      // per B: [B*P] -> row b*SS + 1 + p
+  float* pos_used = nullptr;          // [NT, D] position embedding for this grid (interpolated when ph != native)
+  int native_grid = 0;
 };
 
 namespace md {
@@ -76,6 +78,65 @@ static std::vector<float> build_pos_table_nhwc(int C, int h, int w, int image_w,
       for (int c = 0; c < yc; ++c) dst[xc + c] = ey[(size_t)yi * yc + c] * ratio;
     }
   return t;
+}
+
+// DINOv2 `interpolate_pos_encoding`: bicubic (A = -0.75, align_corners = False), scale factor
+// (grid + 0.1) / native_grid per axis, source index = (dst + 0.5) / scale - 0.5, border-clamped taps.
+// burn_dino's version is not visible (parity unpinned); this restates the public DINOv2 code path
+// (torch.nn.functional.interpolate with scale_factor, which the oracle calls directly).
+static void cubic_coeffs(float t, float w[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+static std::vector<float> interpolate_pos_embed(const std::vector<float>& pos, int M, int D, int ph, int pw) {
+  std::vector<float> out((size_t)(1 + ph * pw) * D);
+  memcpy(out.data(), pos.data(), (size_t)D * 4);  // class token position is kept
+  const float sy = 1.0f / (((float)ph + 0.1f) / (float)M), sx = 1.0f / (((float)pw + 0.1f) / (float)M);
+  for (int oy = 0; oy < ph; ++oy) {
+    const float fy = sy * ((float)oy + 0.5f) - 0.5f;
+    const int iy = (int)floorf(fy);
+    float wy[4];
+    cubic_coeffs(fy - (float)iy, wy);
+    for (int ox = 0; ox < pw; ++ox) {
+      const float fx = sx * ((float)ox + 0.5f) - 0.5f;
+      const int ix = (int)floorf(fx);
+      float wx[4];
+      cubic_coeffs(fx - (float)ix, wx);
+      float* dst = out.data() + (size_t)(1 + oy * pw + ox) * D;
+      for (int c = 0; c < D; ++c) dst[c] = 0.f;
+      for (int a = 0; a < 4; ++a) {
+        const int yy = std::min(std::max(iy - 1 + a, 0), M - 1);
+        for (int b = 0; b < 4; ++b) {
+          const int xx = std::min(std::max(ix - 1 + b, 0), M - 1);
+          const float wgt = wy[a] * wx[b];
+          const float* src = pos.data() + (size_t)(1 + yy * M + xx) * D;
+          for (int c = 0; c < D; ++c) dst[c] += wgt * src[c];
+        }
+      }
+    }
+  }
+  return out;
+}
+
+int da3_on_commit(md_model_t m) {
+  md_model_s::Da3State* d = m->da3;
+  const int D = d->cfg.vit.D, M = d->native_grid;
+  const float* pos_param = P32(m, "backbone.pretrained.pos_embed");
+  if (d->ph == M && d->pw == M) {
+    d->vit.pos = pos_param;
+    return MD_OK;
+  }
+  std::vector<float> pos((size_t)(1 + M * M) * D);
+  MD_HIP(hipMemcpy(pos.data(), pos_param, pos.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<float> ip = interpolate_pos_embed(pos, M, D, d->ph, d->pw);
+  MD_HIP(hipMemcpy(d->pos_used, ip.data(), ip.size() * 4, hipMemcpyHostToDevice));
+  d->vit.pos = d->pos_used;
+  return MD_OK;
 }
 
 static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
@@ -130,6 +191,7 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   DA3_TAKE(c1r, void*, (size_t)B * S * S * cp(F / 2) * esz);
   for (int s = 0; s < 4; ++s) DA3_TAKE(pos_stage[s], void*, P * cp(oc[s]) * esz);
   DA3_TAKE(pos_final, float*, (size_t)S * S * (F / 2) * 4);
+  DA3_TAKE(pos_used, float*, (size_t)d->NT * D * 4);
 #undef DA3_TAKE
   if (total_out) *total_out = total + 4096;
   return MD_OK;
@@ -155,6 +217,7 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   m->da3 = new md_model_s::Da3State();
   md_model_s::Da3State* d = m->da3;
   d->cfg = cfg;
+  d->native_grid = v.img / v.ps;  // the pos_embed parameter's grid (37 for ViT-L/14 @ 518)
   d->ph = d->pw = cfg.image_size / v.ps;
   d->P = d->ph * d->pw;
   d->NT = d->P + 1;

@@ -150,6 +150,7 @@ int da3_load_container(md_model_t m, const char* path);
 int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
               hipStream_t stream);
 void da3_destroy_state(md_model_t m);
+int da3_on_commit(md_model_t m);  // re-derives the (interpolated) position table from the weights
 int model_load_params_from_container(md_model_t m, const char* path);
 
 }  // namespace md

@@ -523,6 +523,7 @@ int model_commit(md_model_t m) {
   auto it = m->pindex.find(m->kind == 1 ? "head_mono.scratch.output_conv2.conv2.bias" : "head.conv_out.bias");
   if (it != m->pindex.end()) MD_HIP(hipMemcpyAsync(&m->head_b_host, m->w32[it->second], 4, hipMemcpyDeviceToHost, s));
   MD_HIP(hipStreamSynchronize(s));
+  if (m->kind == 1) MD_TRY(da3_on_commit(m));
   m->committed = true;
   return MD_OK;
 }

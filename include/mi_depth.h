@@ -117,6 +117,9 @@ int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, i
  * commit, query, timing and destroy work on it unchanged. */
 typedef struct md_da3_cfg {
   const char* variant; /* "metric_large" | "tiny" */
+  int image_size;      /* square input side, a multiple of 14; 0 = the variant's native size (518 / 70). Other
+                        * sizes interpolate the position embedding bicubically (DINOv2 interpolate_pos_encoding,
+                        * offset 0.1) once, when the weights are committed. */
   int precision;       /* md_precision */
   int max_batch;
   float ln_eps;        /* backbone LayerNorm eps (burn_dino's is not visible; default 1e-6) */
@@ -127,8 +130,8 @@ int md_da3_create(md_device_t dev, const md_da3_cfg* cfg, uint64_t seed, int ini
 /* `DepthAnything3::new(cfg).load_file(path, ..)` (example/correctness.rs:977-982), safetensors container. */
 int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_model_t* out);
 /* `DepthAnything3::infer(&self, x)` (depth_anything3/mod.rs:288-291): NCHW fp32 in, depth [B*H*W] out.
- * H and W must be multiples of the patch size (mod.rs:509-520 assert -> MD_ERR_SHAPE); sizes other than
- * the configured image size need position-embedding interpolation and return MD_ERR_UNSUPPORTED. */
+ * H and W must be multiples of the patch size (mod.rs:509-520 assert -> MD_ERR_SHAPE) and equal to the
+ * configured (square) image size, for which the position tables were built (else MD_ERR_UNSUPPORTED). */
 int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
                  void* stream);
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,

@@ -228,13 +228,29 @@ def vit_forward(x: Tensor, W: Dict[str, Tensor], prefix: str, v: ViTConfig, hook
     return torch.cat(outs, 0), [torch.cat(a, 0) for a in (hooks_acc or [])]
 
 
+def interpolate_pos_encoding(pos: Tensor, gh: int, gw: int) -> Tensor:
+    """Public DINOv2 `interpolate_pos_encoding` (offset 0.1, bicubic, no antialias): used when the input
+    grid differs from the pos_embed grid (Depth-Anything-v3 at sizes other than 518). burn_dino's own
+    version is not visible -> parity unpinned."""
+    n = pos.shape[1] - 1
+    M = int(round(math.sqrt(n)))
+    if gh == M and gw == M:
+        return pos
+    D = pos.shape[2]
+    patch = pos[:, 1:].reshape(1, M, M, D).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, scale_factor=((gh + 0.1) / M, (gw + 0.1) / M), mode="bicubic", align_corners=False)
+    assert patch.shape[-2:] == (gh, gw)
+    return torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], 1)
+
+
 def _vit_forward_chunk(x, W, prefix, v, hook_ids, q):
     B = x.shape[0]
     D, Hn, hd = v.embed_dim, v.num_heads, v.head_dim
     p = lambda n: W[f"{prefix}.{n}"]
     tok = F.conv2d(q(x), q(p("patch_embed.proj.weight")), p("patch_embed.proj.bias"), stride=v.patch_size)
     tok = tok.flatten(2).transpose(1, 2)                      # [B, g*g, D], row-major (h, w)
-    xs = torch.cat([p("cls_token").expand(B, 1, D), tok], 1) + p("pos_embed")
+    pos = interpolate_pos_encoding(p("pos_embed"), x.shape[2] // v.patch_size, x.shape[3] // v.patch_size)
+    xs = torch.cat([p("cls_token").expand(B, 1, D), tok], 1) + pos
     N = xs.shape[1]
     scale = hd ** -0.5
     hooks: List[Tensor] = []

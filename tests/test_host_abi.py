@@ -61,7 +61,7 @@ def test_da3_inventory_matches_python(lib, variant, scheme):
     from burn_depth_amd.config import DepthAnything3Config
     cfg = DepthAnything3Config.metric_large() if variant == "metric_large" else DepthAnything3Config.tiny_test()
     specs = Wt.da3_param_specs(cfg, scheme)
-    c = _lib.MdDa3Cfg(cfg.variant.encode(), 0, 1, 1e-6)
+    c = _lib.MdDa3Cfg(cfg.variant.encode(), 0, 0, 1, 1e-6)
     n = lib.md_da3_param_inventory(C.byref(c), scheme, -1, None, None, None, None)
     assert n == len(specs)
     for i, s in enumerate(specs):
@@ -73,7 +73,7 @@ def test_da3_inventory_matches_python(lib, variant, scheme):
 
 
 def test_da3_small_variant_is_reported_unsupported(lib):
-    c = _lib.MdDa3Cfg(b"small", 0, 1, 1e-6)
+    c = _lib.MdDa3Cfg(b"small", 0, 0, 1, 1e-6)
     assert lib.md_da3_param_inventory(C.byref(c), 0, -1, None, None, None, None) == _lib.MD_ERR_UNSUPPORTED
 
 

@@ -341,6 +341,9 @@ def main():
         from burn_depth_amd.config import DepthAnything3Config
         guarded("da3 tiny f32")(run_da3)(dev, DepthAnything3Config.tiny_test(), "da3-tiny/f32", 2, Precision.F32)
         guarded("da3 tiny bf16")(run_da3)(dev, DepthAnything3Config.tiny_test(), "da3-tiny/bf16", 2, Precision.BF16)
+        c98 = DepthAnything3Config.tiny_test()
+        c98.image_size = 98  # 7x7 grid from a 5x5 pos_embed: exercises the bicubic pos-embed interpolation
+        guarded("da3 tiny98 f32")(run_da3)(dev, c98, "da3-tiny98/f32", 1, Precision.F32)
         if not args.skip_small:
             guarded("da3 large f32")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/f32", 1, Precision.F32)
             guarded("da3 large bf16")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/bf16", 1, Precision.BF16)
