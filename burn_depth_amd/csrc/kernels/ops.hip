@@ -592,9 +592,23 @@ int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small direct convolution (FOV head): one wave per output element, lanes stride over k*k*Cin.
+// Small direct convolution (FOV head), fp32 arithmetic.  One wave per (output pixel, CO output
+// channels): lanes stride over the k*k*Cin window in 4-channel vectors, the input window is read
+// once and reused for the CO weight rows.
 // ------------------------------------------------------------------------------------------------
 template <typename TI>
+__device__ inline void load4(const TI* in, long src, float v[4]) {
+  if constexpr (sizeof(TI) == 4) {
+    const float4 t = *(const float4*)((const float*)in + src);
+    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+  } else {
+    const uint2 t = *(const uint2*)((const uint16_t*)in + src);
+    v[0] = __uint_as_float(t.x << 16), v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16), v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+
+template <typename TI, int CO, int VEC>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__ in, const float* __restrict__ add,
                                                           int B, int H, int W, int Cin, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int Cout, int k, int stride,
@@ -602,53 +616,96 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__
   const int lane = threadIdx.x & 63;
   const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-  const long total = (long)B * OH * OW * Cout;
+  const int cgroups = (Cout + CO - 1) / CO;
+  const long total = (long)B * OH * OW * cgroups;
   const int KK = k * k * Cin;
   for (long e = wave_id; e < total; e += nwaves) {
-    const int co = (int)(e % Cout);
-    long t = e / Cout;
+    const int co0 = (int)(e % cgroups) * CO;
+    long t = e / cgroups;
     const int ox = (int)(t % OW);
     t /= OW;
     const int oy = (int)(t % OH);
     const int b = (int)(t / OH);
-    float acc = 0.f;
-    for (int idx = lane; idx < KK; idx += 64) {
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int idx = lane * VEC; idx < KK; idx += 64 * VEC) {
       const int ci = idx % Cin;
       const int tap = idx / Cin;
       const int ky = tap / k, kx = tap % k;
       const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        const long src = (((long)b * H + iy) * W + ix) * Cin + ci;
-        float v;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const long src = (((long)b * H + iy) * W + ix) * Cin + ci;
+      float v[4];
+      if constexpr (VEC == 4) {
+        load4<TI>(in, src, v);
+        if (add) {
+          const float4 a4 = *(const float4*)(add + src);
+          v[0] += a4.x, v[1] += a4.y, v[2] += a4.z, v[3] += a4.w;
+        }
+      } else {
         if constexpr (sizeof(TI) == 4)
-          v = ((const float*)in)[src];
+          v[0] = ((const float*)in)[src];
         else
-          v = (float)*((const __bf16*)in + src);
-        if (add) v += add[src];
-        acc += v * w[(long)co * KK + idx];
+          v[0] = (float)*((const __bf16*)in + src);
+        if (add) v[0] += add[src];
+      }
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        if (co0 + c < Cout) {
+          const float* wr = w + (long)(co0 + c) * KK + idx;
+          if constexpr (VEC == 4) {
+            const float4 w4 = *(const float4*)wr;
+            acc[c] += v[0] * w4.x + v[1] * w4.y + v[2] * w4.z + v[3] * w4.w;
+          } else {
+            acc[c] += v[0] * wr[0];
+          }
+        }
       }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      acc += bias ? bias[co] : 0.f;
-      if (relu) acc = fmaxf(acc, 0.f);
-      out[e] = acc;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float sum = wave_sum(acc[c]);
+      if (lane == 0 && co0 + c < Cout) {
+        float r = sum + (bias ? bias[co0 + c] : 0.f);
+        if (relu) r = fmaxf(r, 0.f);
+        out[(((long)b * OH + oy) * OW + ox) * Cout + co0 + c] = r;
+      }
     }
   }
+}
+
+template <typename TI>
+static void conv_direct_dispatch(const TI* in, const float* add, int B, int H, int W, int Cin, const float* w,
+                                 const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, int OH,
+                                 int OW, hipStream_t s) {
+  const bool vec = Cin % 4 == 0;
+  const int co = Cout >= 8 ? 8 : 1;
+  const long total = (long)B * OH * OW * ((Cout + co - 1) / co);
+  const int grid = grid_for(total * 64);
+#define MD_CD(CO, VEC)                                                                                               \
+  hipLaunchKernelGGL((conv_direct_kernel<TI, CO, VEC>), dim3(grid), dim3(256), 0, s, in, add, B, H, W, Cin, w, bias, \
+                     Cout, k, stride, pad, relu, out, OH, OW)
+  if (co == 8 && vec)
+    MD_CD(8, 4);
+  else if (co == 8)
+    MD_CD(8, 1);
+  else if (vec)
+    MD_CD(1, 4);
+  else
+    MD_CD(1, 1);
+#undef MD_CD
 }
 
 int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
                        const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s) {
   const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
   if (OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_SHAPE, "conv_direct: input %dx%d smaller than kernel %d", H, W, k);
-  const long total = (long)B * OH * OW * Cout;
-  const int grid = grid_for(total * 64);
   if (in_prec == MD_PREC_F32)
-    hipLaunchKernelGGL(conv_direct_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, add, B, H, W, Cin, w,
-                       bias, Cout, k, stride, pad, relu, out, OH, OW);
+    conv_direct_dispatch<float>((const float*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW, s);
   else
-    hipLaunchKernelGGL(conv_direct_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, add, B, H, W, Cin,
-                       w, bias, Cout, k, stride, pad, relu, out, OH, OW);
+    conv_direct_dispatch<bf16_t>((const bf16_t*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW,
+                                 s);
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

@@ -40,6 +40,7 @@ enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT 
 
 struct PackEntry {
   int param = -1;   // index into params
+  int param2 = -1;  // PACK_DECONV only: 1x1 conv weight [Cout,Cout] composed behind the deconv at commit
   int kind = PACK_NK;
   int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k
   int kp = 0;       // padded contraction length per tap (elements)

@@ -95,6 +95,28 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
   }
 }
 
+// W'[ci][co][q] = sum_m Wd[ci][m][q] * Wo[co][m]; Wd is [Cin, Cmid, 2, 2], Wo is [Cout, Cmid] (1x1 conv)
+__global__ void compose_deconv_conv_kernel(const float* __restrict__ wd, const float* __restrict__ wo, int cin, int cmid,
+                                           int cout, float* __restrict__ out) {
+  const long total = (long)cin * cout * 4;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(e & 3);
+    const int co = (int)((e >> 2) % cout);
+    const int ci = (int)((e >> 2) / cout);
+    float acc = 0.f;
+    for (int mth = 0; mth < cmid; ++mth) acc += wd[((long)ci * cmid + mth) * 4 + q] * wo[(long)co * cmid + mth];
+    out[e] = acc;
+  }
+}
+
+int compose_deconv_conv(const float* wd, const float* wo, int cin, int cmid, int cout, float* out, hipStream_t s) {
+  const long total = (long)cin * cout * 4;
+  hipLaunchKernelGGL(compose_deconv_conv_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, wd,
+                     wo, cin, cmid, cout, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s) {
   const long total = (long)pack_elems(e);
   const int grid = (int)std::min<long>((total + 255) / 256, 4096);
@@ -358,8 +380,10 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
       add_pack(m, f + "." + r + ".conv1.weight", PACK_CONV3, F, F, 3);
       add_pack(m, f + "." + r + ".conv2.weight", PACK_CONV3, F, F, 3);
     }
-    if (l != 0) add_pack(m, f + ".deconv.weight", PACK_DECONV, F, F, 2);
-    add_pack(m, f + ".out_conv.weight", PACK_NK, F, F, 1);
+    if (l != 0)
+      add_pack_composed(m, f + ".deconv_out_conv", f + ".deconv.weight", f + ".out_conv.weight", F, F);
+    else
+      add_pack(m, f + ".out_conv.weight", PACK_NK, F, F, 1);
   }
   add_pack(m, "head.conv0.weight", PACK_CONV3, F / 2, F, 3);
   add_pack(m, "head.deconv.weight", PACK_DECONV, F / 2, F / 2, 2);
@@ -519,10 +543,21 @@ int model_load_container(md_model_t m, const char* path) {
 int model_commit(md_model_t m) {
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t s = m->dev->stream;
-  for (auto& e : m->packs) MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
+  float* composed = nullptr;
+  for (auto& e : m->packs) {
+    if (e.param2 < 0) {
+      MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
+      continue;
+    }
+    if (!composed) MD_HIP(hipMalloc((void**)&composed, (size_t)m->cfg.F * m->cfg.F * 4 * sizeof(float)));
+    if ((size_t)e.d0 * e.d1 > (size_t)m->cfg.F * m->cfg.F) MD_FAIL(MD_ERR_UNSUPPORTED, "composed deconv larger than the staging buffer");
+    MD_TRY(compose_deconv_conv(m->w32[e.param], m->w32[e.param2], e.d0, e.d1, e.d1, composed, s));
+    MD_TRY(pack_weight(composed, e, m->prec, s));
+  }
   auto it = m->pindex.find(m->kind == 1 ? "head_mono.scratch.output_conv2.conv2.bias" : "head.conv_out.bias");
   if (it != m->pindex.end()) MD_HIP(hipMemcpyAsync(&m->head_b_host, m->w32[it->second], 4, hipMemcpyDeviceToHost, s));
   MD_HIP(hipStreamSynchronize(s));
+  if (composed) MD_HIP(hipFree(composed));
   if (m->kind == 1) MD_TRY(da3_on_commit(m));
   m->committed = true;
   return MD_OK;
@@ -823,16 +858,16 @@ static int run_decoder_head(Run& r) {
       xr = b->dxr[l];
     }
     MD_TRY(resblock(f + ".resnet2", l, x, xr, nullptr, b->dt[l], b->dy[l], nullptr));
-    const void* pre = b->dy[l];
     int ohw = hw[l];
     if (l != 0) {
-      MD_TRY(deconv2(r, "dec_deconv", b->dy[l], Fp, nullptr, hw[l], hw[l], W(f + ".deconv.weight"), Fp, F, nullptr,
-                     b->dup[l], Fp, 0));
-      pre = b->dup[l];
+      // deconv (no bias) then 1x1 out_conv (decoder.rs:124-141): one GEMM on the weight product packed at commit
+      MD_TRY(deconv2(r, "dec_deconv_out", b->dy[l], Fp, nullptr, hw[l], hw[l], W(f + ".deconv_out_conv"), Fp, F,
+                     Bi(f + ".out_conv.bias"), b->df[l], Fp, 0));
       ohw = 2 * hw[l];
+    } else {
+      MD_TRY(gemm_rows(r, "dec_out_conv", b->dy[l], Fp, nullptr, (long)r.B * ohw * ohw, W(f + ".out_conv.weight"), F, Fp,
+                       Bi(f + ".out_conv.bias"), b->df[l], Fp));
     }
-    MD_TRY(gemm_rows(r, "dec_out_conv", pre, Fp, nullptr, (long)r.B * ohw * ohw, W(f + ".out_conv.weight"), F, Fp,
-                     Bi(f + ".out_conv.bias"), b->df[l], Fp));
     feats = b->df[l];
     if (m->taps_enabled) {
       const std::string tn = "decoder_fusion_" + std::to_string(l);

@@ -46,6 +46,25 @@ inline void add_pack(md_model_s* m, const std::string& name, int kind, int d0, i
   m->packs.push_back(e);
 }
 
+// deconv k2s2 (no bias) followed by a 1x1 conv: packed as ONE deconv whose weight is their product
+// W'[ci][co][q] = sum_m Wd[ci][m][q] * Wo[co][m]  (decoder.rs:124-141 applies out_conv right after deconv)
+inline void add_pack_composed(md_model_s* m, const std::string& name, const std::string& deconv, const std::string& conv1x1,
+                              int cin, int cout) {
+  auto a = m->pindex.find(deconv), b = m->pindex.find(conv1x1);
+  if (a == m->pindex.end() || b == m->pindex.end()) return;
+  PackEntry e;
+  e.param = a->second;
+  e.param2 = b->second;
+  e.kind = PACK_DECONV;
+  e.d0 = cin;
+  e.d1 = cout;
+  e.k = 2;
+  e.kp = round_up(cin, m->ke);
+  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  m->pack_index[name] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
 struct Run {
   md_model_s* m;
   hipStream_t st;
