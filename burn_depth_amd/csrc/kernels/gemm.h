@@ -23,6 +23,23 @@ enum EpiMode : int {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
+// Exact n / d for 0 <= n < 2^31 by a multiply-high and a shift (round-up method: mul = floor(2^(31+L)/d) + 1,
+// L = ceil(log2 d)); the epilogues decompose row indices per output vector, where a hardware-less integer
+// division (~40 VALU instructions on the 16-lane SIMDs) would dominate short-K GEMMs.
+struct FastDiv {
+  unsigned mul = 0, sh = 0, d = 1;
+};
+inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = d > 0 ? (unsigned)d : 1u;
+  if (f.d == 1) return f;
+  unsigned L = 0;
+  while ((1ull << L) < f.d) ++L;
+  f.mul = (unsigned)((1ull << (31 + L)) / f.d + 1);
+  f.sh = L - 1;
+  return f;
+}
+
 struct GemmParams {
   // ---- problem ----
   int N = 0, K = 0;  // K in elements of T
@@ -67,6 +84,8 @@ struct GemmParams {
   void* vT = nullptr;
   // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = f*f*psC (f = ps_f, 2 or 4); out NHWC [B, f*psH, f*psW, ldo] at +ps_coff
   int psH = 0, psW = 0, psC = 0, ps_coff = 0, ps_f = 2;
+  // divisors of the epilogue index math (filled by the launcher from the fields above)
+  FastDiv fd_res_mod, fd_seq_patches, fd_seq_stride, fd_psC, fd_psW, fd_psH, fd_ow, fd_oh, fd_cblocks;
   int raster_gn = 0;  // n-tiles per raster group (0 = all: plain n-fastest order); set by the launcher
   // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
   int debug_flags = 0;

@@ -45,6 +45,20 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     if (p.g_rows[g] <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has %d rows", g, p.g_rows[g]);
     if (!p.W[g]) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has no weights", g);
   }
+  p.fd_res_mod = make_fastdiv(p.res_mod);
+  p.fd_seq_patches = make_fastdiv(p.seq_patches);
+  p.fd_seq_stride = make_fastdiv(p.seq_stride);
+  p.fd_psC = make_fastdiv(p.psC);
+  p.fd_psW = make_fastdiv(p.psW);
+  p.fd_psH = make_fastdiv(p.psH);
+  p.fd_ow = make_fastdiv(p.cOW > 0 ? p.cOW : p.cW);
+  p.fd_oh = make_fastdiv(p.cOH > 0 ? p.cOH : p.cH);
+  p.fd_cblocks = make_fastdiv(p.cC / (prec == MD_PREC_F32 ? 32 : 64));
+  {
+    long rows = 0;
+    for (int g = 0; g < p.ngroups; ++g) rows = std::max<long>(rows, (long)p.g_arow0[g] + p.g_rows[g]);
+    if (rows >= (1L << 31)) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: more than 2^31 rows");
+  }
   if (tile == TILE_AUTO) tile = pick_tile(p);
   {
     const int bn = (tile == TILE_128x128) ? 128 : (tile == TILE_256x32 ? 32 : 256);

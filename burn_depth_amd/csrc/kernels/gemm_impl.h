@@ -22,6 +22,8 @@
 //  * XCD-aware block order: logical tile ids are dealt so that each XCD (private L2) works on a
 //    contiguous range of tiles that share the same A row-panel.
 #pragma once
+
+#include <type_traits>
 #include "gemm.h"
 
 namespace md {
@@ -120,25 +122,53 @@ __device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
   *(__bf16*)p = (__bf16)v;
 }
 
-// exact-erf GELU (burn/DINOv2 `Gelu`). fp32 mode: libm erff. bf16 mode: Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below the bf16 output rounding of 2^-9) -- about 3x fewer VALU ops in
-// the fc1 epilogue, which evaluates 87 M GELUs per launch.
+// exact-erf GELU (burn/DINOv2 `Gelu`). fp32 mode: libm erff. bf16 mode: erf(x/sqrt2) ~ x*P(x^2), a degree-8
+// minimax polynomial on |x| <= 4.4 (clamped to +-1 outside), evaluated two elements per instruction with
+// the packed fp32 VALU ops (v_pk_fma_f32): no transcendental, ~8 issue slots per element instead of ~26.
+// |GELU abs err| <= 8.5e-5 over the whole real line -- below half a bf16 ulp of any |output| >= 0.05 --
+// which matters because the 16-lane SIMDs make the fc1 epilogue (87 M GELUs per launch) VALU-bound.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <typename T>
 __device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ f32x2_t gelu2_poly(f32x2_t x) {
+  const float lim = 4.4f;
+  f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -lim, lim), __builtin_amdgcn_fmed3f(x[1], -lim, lim)};
+  const f32x2_t t = xc * xc;
+  f32x2_t p = {8.829475345306648e-11f, 8.829475345306648e-11f};
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-8.98145824379526e-09f, -8.98145824379526e-09f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){4.0165326709029614e-07f, 4.0165326709029614e-07f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-1.0493913578102365e-05f, -1.0493913578102365e-05f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.00018038309644907713f, 0.00018038309644907713f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.002187085337936878f, -0.002187085337936878f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.01956046372652054f, 0.01956046372652054f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.13261185586452484f, -0.13261185586452484f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.7977733016014099f, 0.7977733016014099f});
+  f32x2_t e = xc * p;
+  e[0] = __builtin_amdgcn_fmed3f(e[0], -1.0f, 1.0f);
+  e[1] = __builtin_amdgcn_fmed3f(e[1], -1.0f, 1.0f);
+  const f32x2_t hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, e, hx);
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
   if constexpr (sizeof(T) == 4) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    f32x4_t r = {gelu_erf<T>(v[0]), gelu_erf<T>(v[1]), gelu_erf<T>(v[2]), gelu_erf<T>(v[3])};
+    return r;
   } else {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = 1.0f - poly * t * e;
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const f32x2_t a = gelu2_poly((f32x2_t){v[0], v[1]}), b = gelu2_poly((f32x2_t){v[2], v[3]});
+    f32x4_t r = {a[0], a[1], b[0], b[1]};
+    return r;
   }
+}
+
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  const unsigned q = __umulhi((unsigned)n, f.mul) >> f.sh;
+  return f.d == 1 ? n : (int)q;
 }
 
 __device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
@@ -155,16 +185,13 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
   switch (p.epi) {
     case EPI_STORE: {
       if (bias) v += *(const f32x4_t*)(bias + n);
-      const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+      const long rm = p.res_mod > 0 ? (long)(m - fdiv(m, p.fd_res_mod) * p.res_mod) : (long)m;
       if (p.res1) v += load4<T>((const T*)p.res1 + rm * p.ldr + n);
       if (p.res2) v += load4<T>((const T*)p.res2 + rm * p.ldr + n);
       if (p.act == ACT_RELU) {
         v = relu4(v);
       } else if (p.act == ACT_GELU) {
-        v[0] = gelu_erf<T>(v[0]);
-        v[1] = gelu_erf<T>(v[1]);
-        v[2] = gelu_erf<T>(v[2]);
-        v[3] = gelu_erf<T>(v[3]);
+        v = gelu4<T>(v);
       }
       if (p.out_f32)
         store4<float>((float*)p.out + boff + (long)m * p.ldo + n, v);
@@ -185,7 +212,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
     }
     case EPI_PATCH_EMBED: {
       const float* pos = MD_SEL_G(p.pos, g);
-      int t = m / p.seq_patches;
+      int t = fdiv(m, p.fd_seq_patches);
       int pi = m - t * p.seq_patches;
       long row = (long)t * p.seq_stride + 1 + pi;
       v += *(const f32x4_t*)(bias + n);
@@ -201,7 +228,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       } else {
         int c = n - two_d;
         int hd = c >> 6, d = c & 63;
-        int seq = m / p.seq_stride;
+        int seq = fdiv(m, p.fd_seq_stride);
         int i = m - seq * p.seq_stride;
         long base = (((long)seq * p.heads + hd) * 64 + d) * p.kpad + i;
         T* vt = (T*)p.vT;
@@ -213,14 +240,14 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       break;
     }
     case EPI_PIXSHUF: {
-      int tap = n / p.psC;
+      int tap = fdiv(n, p.fd_psC);
       int co = n - tap * p.psC;
       const int f = p.ps_f;
-      int dy = tap / f, dx = tap - dy * f;
-      int x = m % p.psW;
-      int t = m / p.psW;
-      int y = t % p.psH;
-      int b = t / p.psH;
+      int dy = f == 4 ? tap >> 2 : tap >> 1, dx = tap - dy * f;
+      int t = fdiv(m, p.fd_psW);
+      int x = m - t * p.psW;
+      int b = fdiv(t, p.fd_psH);
+      int y = t - b * p.psH;
       long orow = ((long)b * f * p.psH + f * y + dy) * ((long)f * p.psW) + f * x + dx;
       if (bias) v += *(const f32x4_t*)(bias + co);
       long o = orow * p.ldo + p.ps_coff + co;
@@ -325,10 +352,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
       maskA[i] = 0;
     } else {
       const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
-      const int ox = (int)(am % ow);
-      const long t2 = am / ow;
-      const int oy = (int)(t2 % oh);
-      const long bimg = t2 / oh;
+      const int t2 = fdiv((int)am, p.fd_ow);
+      const int ox = (int)am - t2 * ow;
+      const long bimg = fdiv(t2, p.fd_oh);
+      const int oy = t2 - (int)bimg * oh;
       const int x = ox * p.cstride, y = oy * p.cstride;  // centre tap in the input grid
       unsigned mk = 0;
 #pragma unroll
@@ -363,9 +390,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     long a_delta;
     int tap = 0;
     if constexpr (AMODE == A_CONV3) {
-      tap = kt / cblocks;
+      tap = fdiv(kt, p.fd_cblocks);
       const int cb = kt - tap * cblocks;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 9
       a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * ESZ + (long)cb * 128;
     } else {
       a_delta = (long)kt * 128;
@@ -469,7 +496,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 // through LDS (wave-private 64x64 fp32 sub-tiles, rows padded to 272 B) so that every global
 // load/store instruction of the epilogue covers 4 full 256-byte row segments.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int AMODE, int PP>
+// EK selects the staged-epilogue specialisation at compile time (a runtime three-way branch around the
+// fully unrolled row loops cost 40 VGPRs and scratch spills): 0 generic (epilogue4 per vector),
+// 1 read-modify-write residual (EPI_RESID_LS), 2 bf16 store with optional residual inputs (EPI_STORE).
+template <typename T, int AMODE, int PP, int EK>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
   constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
@@ -551,10 +581,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       maskA[i] = 0;
     } else {
       const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
-      const int ox = (int)(am % ow);
-      const long t2 = am / ow;
-      const int oy = (int)(t2 % oh);
-      const long bimg = t2 / oh;
+      const int t2 = fdiv((int)am, p.fd_ow);
+      const int ox = (int)am - t2 * ow;
+      const long bimg = fdiv(t2, p.fd_oh);
+      const int oy = t2 - (int)bimg * oh;
       const int x = ox * p.cstride, y = oy * p.cstride;  // centre tap in the input grid
       unsigned mk = 0;
 #pragma unroll
@@ -596,9 +626,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     long a_delta;
     int tap = 0;
     if constexpr (AMODE == A_CONV3) {
-      tap = kt / cblocks;
+      tap = fdiv(kt, p.fd_cblocks);
       const int cb = kt - tap * cblocks;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 9
       a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * ESZ + (long)cb * 128;
     } else {
       a_delta = (long)kt * 128;
@@ -874,13 +904,64 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       }
     return;
   }
-  // staged: wave-private region of 64 rows x 272 bytes (68 floats)
+  // staged: wave-private region of 64 rows x 272 bytes (68 floats).  Only the first barrier is a block
+  // barrier (every wave is done reading the ring); the staging itself is wave-private and DS operations of
+  // one wave execute in order.
   constexpr int SROW = 272;
   char* st = smem + wave * (64 * SROW);
-  __builtin_amdgcn_s_barrier();  // every wave is done reading the ring (its MFMAs consumed the fragments)
+  __builtin_amdgcn_s_barrier();
+  const int col = (lane & 15) * 4;
+  const int n = n0 + wn * WTN + col;
+  const bool nvalid = n < p.N;
+  // The residual / read-modify-write epilogues prefetch all 16 row vectors of a half BEFORE the
+  // staging pass, so 16 loads per lane are in flight at once instead of a dependent load->store chain
+  // (that chain, not bandwidth, set the cost of the proj / fc2 / residual-conv epilogues).
+  constexpr bool rmw = EK == 1;
+  constexpr bool fast_store = EK == 2 && sizeof(T) == 2;
+  const float* biasp = MD_SEL_G(p.bias, g);
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {0.f, 0.f, 0.f, 0.f};
+  if ((rmw || fast_store) && nvalid) {
+    if (biasp) bias4 = *(const f32x4_t*)(biasp + n);
+    if (rmw) scale4 = *(const f32x4_t*)(MD_SEL_G(p.scale, g) + n);
+  }
+  // wave-uniform tile bases + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
+  const long tile_o = (long)m_base * p.ldo + n0, tile_r = (long)m_base * p.ldr + n0;
+  char* out_b = (char*)p.out + (out_boff + tile_o) * (p.out_f32 || rmw ? 4 : (long)sizeof(T));
+  char* out2_b = (char*)p.out2 + (out_boff + tile_o) * (long)sizeof(T);
+  const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(T);
+  const char* res2_b = (const char*)p.res2 + tile_r * (long)sizeof(T);
+  const bool has_res = fast_store && (p.res1 || p.res2);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    if (half) __builtin_amdgcn_s_barrier();
+    const int lrow0 = wm * WTM + half * 64 + (lane >> 4);  // tile-local row of iteration 0
+    const int m0 = m_base + lrow0;
+    const unsigned lcol = (unsigned)(wn * WTN + col);
+    // one register array serves both prefetches: RMW -> the fp32 x vector; residual store -> the raw
+    // bf16x4 of res1 in lanes .xy and of res2 in .zw
+    f32x4_t pre[16];
+    auto prefetch = [&](int it) {
+      const int m = m0 + it * 4;
+      const unsigned lr = (unsigned)(lrow0 + it * 4);
+      if constexpr (rmw) {
+        if (m < m_end && nvalid) pre[it] = *(const f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u);
+      } else if constexpr (fast_store) {
+        if (!has_res) return;
+        f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+        if (m < m_end && nvalid) {
+          const unsigned ro = (lr * (unsigned)p.ldr + lcol) * (unsigned)sizeof(T);
+          if (p.res1) a1 = *(const f32x2_t*)(res1_b + ro);
+          if (p.res2) a2 = *(const f32x2_t*)(res2_b + ro);
+        }
+        pre[it] = (f32x4_t){a1[0], a1[1], a2[0], a2[1]};
+      }
+    };
+    // half 0 still holds all 128 accumulator registers: prefetch 8 rows before the staging pass and the
+    // other 8 right after it (64 accumulators are dead by then); half 1 prefetches all 16 up front.
+    const int pre_first = half == 0 ? 8 : 16;
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+      if (it < pre_first) prefetch(it);
+    asm volatile("" ::: "memory");
     if constexpr (PP == 2) {
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb)
@@ -902,16 +983,59 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           }
       }
     }
-    __builtin_amdgcn_s_barrier();
-    const int col = (lane & 15) * 4;
-    const int n = n0 + wn * WTN + col;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+      if (it >= pre_first) prefetch(it);
+    asm volatile("" ::: "memory");
+    if constexpr (rmw) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = m0 + it * 4;
+        const unsigned lr = (unsigned)(lrow0 + it * 4);
+        const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
+        if (m < m_end && nvalid) *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
+      }
+    } else if constexpr (fast_store) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = m0 + it * 4;
+        const unsigned lr = (unsigned)(lrow0 + it * 4);
+        f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
+        if (m < m_end && nvalid) {
+          v += bias4;
+          if (has_res) {  // raw bf16 pairs: low half = even element, high half = odd element
+            const unsigned u0 = __float_as_uint(pre[it][0]), u1 = __float_as_uint(pre[it][1]);
+            const unsigned u2 = __float_as_uint(pre[it][2]), u3 = __float_as_uint(pre[it][3]);
+            v += (f32x4_t){__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
+                           __uint_as_float(u1 & 0xffff0000u)};
+            v += (f32x4_t){__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 << 16),
+                           __uint_as_float(u3 & 0xffff0000u)};
+          }
+          if (p.act == ACT_RELU)
+            v = relu4(v);
+          else if (p.act == ACT_GELU)
+            v = gelu4<T>(v);
+          const unsigned eo = lr * (unsigned)p.ldo + lcol;
+          if (p.out_f32)
+            store4<float>((float*)(out_b + eo * 4u), v);
+          else
+            store4<T>((T*)(out_b + eo * (unsigned)sizeof(T)), v);
+          if (p.out2) store4<T>((T*)(out2_b + eo * (unsigned)sizeof(T)), relu4(v));
+        }
+      }
+    } else {
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + (lane >> 4);
-      const int m = m_base + wm * WTM + half * 64 + row;
-      const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-      if (m < m_end && n < p.N) epilogue4<T>(p, g, m, n, v, out_boff);
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = m0 + it * 4;
+        const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
+        if (m < m_end && nvalid) epilogue4<T>(p, g, m, n, v, out_boff);
+      }
     }
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -929,15 +1053,26 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   if (blocks <= 0) return MD_OK;
   if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
   constexpr int smem = 5 * 256 * 128;  // 160 KB: the whole LDS of a CU
-  auto kern = gemm256_kernel<T, AMODE, PP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+  const dim3 grid((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1));
+  auto go = [&](auto kern, bool* attr_set) -> int {
+    if (!*attr_set) {
+      MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      *attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+    MD_HIP(hipGetLastError());
+    return MD_OK;
+  };
+  static bool set0 = false, set1 = false, set2 = false;
+  if constexpr (PP == 2) {  // the production schedule carries the specialised epilogues
+    if (p.epi == EPI_RESID_LS) return go(gemm256_kernel<T, AMODE, PP, 1>, &set1);
+    if constexpr (sizeof(T) == 2) {
+      if (p.epi == EPI_STORE && p.res_mod == 0) return go(gemm256_kernel<T, AMODE, PP, 2>, &set2);
+    }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(512), smem, stream, p);
-  MD_HIP(hipGetLastError());
-  return MD_OK;
+  (void)set1;
+  (void)set2;
+  return go(gemm256_kernel<T, AMODE, PP, 0>, &set0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -541,7 +541,13 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   MD_TRY(fill_random(w.p, (size_t)N * kw, precision, 2, 0.05f, st));
   GemmParams p;
   p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
-  p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = dbg;
+  p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = dbg & 3;
+  DevBuf bias;
+  if (dbg & 4) {  // fc1-style epilogue: bias + GELU
+    MD_TRY(bias.alloc((size_t)N * 4));
+    MD_TRY(fill_random(bias.p, (size_t)N, MD_PREC_F32, 5, 0.1f, st));
+    p.bias[0] = (const float*)bias.p; p.act = ACT_GELU;
+  }
   int amode = A_DENSE;
   if (mode == 1) {
     if ((long)aux0 * aux1 != M) MD_FAIL(MD_ERR_SHAPE, "conv bench: H*W must equal M");
