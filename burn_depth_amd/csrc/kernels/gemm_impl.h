@@ -918,14 +918,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // (that chain, not bandwidth, set the cost of the proj / fc2 / residual-conv epilogues).
   constexpr bool rmw = EK == 1;
   constexpr bool fast_store = EK == 2 && sizeof(T) == 2;
+  constexpr bool pixshuf = EK == 3;
+  // pixel shuffle: the lane's 4 columns fix (tap, channel) once; rows only move the output pixel
+  int ps_co = 0, ps_dy = 0, ps_dx = 0;
+  if constexpr (pixshuf) {
+    const int tap = fdiv(n, p.fd_psC);
+    ps_co = n - tap * p.psC;
+    ps_dy = p.ps_f == 4 ? tap >> 2 : tap >> 1;
+    ps_dx = tap - ps_dy * p.ps_f;
+  }
   const float* biasp = MD_SEL_G(p.bias, g);
   f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {0.f, 0.f, 0.f, 0.f};
+  if (pixshuf && nvalid && biasp) bias4 = *(const f32x4_t*)(biasp + ps_co);
   if ((rmw || fast_store) && nvalid) {
     if (biasp) bias4 = *(const f32x4_t*)(biasp + n);
     if (rmw) scale4 = *(const f32x4_t*)(MD_SEL_G(p.scale, g) + n);
   }
   // wave-uniform tile bases + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
-  const long tile_o = (long)m_base * p.ldo + n0, tile_r = (long)m_base * p.ldr + n0;
+  const long ldo = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;  // q,k rows are [M, 2D]
+  const long tile_o = (long)m_base * ldo + n0, tile_r = (long)m_base * p.ldr + n0;
   char* out_b = (char*)p.out + (out_boff + tile_o) * (p.out_f32 || rmw ? 4 : (long)sizeof(T));
   char* out2_b = (char*)p.out2 + (out_boff + tile_o) * (long)sizeof(T);
   const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(T);
@@ -943,7 +954,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       const int m = m0 + it * 4;
       const unsigned lr = (unsigned)(lrow0 + it * 4);
       if constexpr (rmw) {
-        if (m < m_end && nvalid) pre[it] = *(const f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u);
+        if (m < m_end && nvalid) pre[it] = *(const f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u);
       } else if constexpr (fast_store) {
         if (!has_res) return;
         f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
@@ -995,7 +1006,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int m = m0 + it * 4;
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (m < m_end && nvalid) *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
+        if (m < m_end && nvalid) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
       }
     } else if constexpr (fast_store) {
 #pragma unroll
@@ -1018,12 +1029,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             v = relu4(v);
           else if (p.act == ACT_GELU)
             v = gelu4<T>(v);
-          const unsigned eo = lr * (unsigned)p.ldo + lcol;
+          const unsigned eo = lr * (unsigned)ldo + lcol;
           if (p.out_f32)
             store4<float>((float*)(out_b + eo * 4u), v);
           else
             store4<T>((T*)(out_b + eo * (unsigned)sizeof(T)), v);
           if (p.out2) store4<T>((T*)(out2_b + eo * (unsigned)sizeof(T)), relu4(v));
+        }
+      }
+    } else if constexpr (pixshuf) {
+      const int f = p.ps_f;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = m0 + it * 4;
+        f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
+        if (m < m_end && nvalid) {
+          const int t = fdiv(m, p.fd_psW);
+          const int x = m - t * p.psW;
+          const int b = fdiv(t, p.fd_psH);
+          const int y = t - b * p.psH;
+          const long orow = ((long)b * f * p.psH + f * y + ps_dy) * ((long)f * p.psW) + f * x + ps_dx;
+          const long o = orow * p.ldo + p.ps_coff + ps_co;
+          v += bias4;
+          if (p.out_f32)
+            store4<float>((float*)p.out + o, v);
+          else
+            store4<T>((T*)p.out + o, v);
+          if (p.out2) store4<T>((T*)p.out2 + o, relu4(v));
         }
       }
     } else {
@@ -1063,15 +1096,17 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     MD_HIP(hipGetLastError());
     return MD_OK;
   };
-  static bool set0 = false, set1 = false, set2 = false;
+  static bool set0 = false, set1 = false, set2 = false, set3 = false;
   if constexpr (PP == 2) {  // the production schedule carries the specialised epilogues
     if (p.epi == EPI_RESID_LS) return go(gemm256_kernel<T, AMODE, PP, 1>, &set1);
+    if (p.epi == EPI_PIXSHUF) return go(gemm256_kernel<T, AMODE, PP, 3>, &set3);
     if constexpr (sizeof(T) == 2) {
-      if (p.epi == EPI_STORE && p.res_mod == 0) return go(gemm256_kernel<T, AMODE, PP, 2>, &set2);
+      if ((p.epi == EPI_STORE && p.res_mod == 0) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0)) return go(gemm256_kernel<T, AMODE, PP, 2>, &set2);
     }
   }
   (void)set1;
   (void)set2;
+  (void)set3;
   return go(gemm256_kernel<T, AMODE, PP, 0>, &set0);
 }
 
