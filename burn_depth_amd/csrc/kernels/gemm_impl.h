@@ -942,36 +942,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(T);
   const char* res2_b = (const char*)p.res2 + tile_r * (long)sizeof(T);
   const bool has_res = fast_store && (p.res1 || p.res2);
+  // one register array per half serves both prefetches: RMW -> the fp32 x vector; residual store -> the
+  // raw bf16x4 of res1 in lanes .xy and of res2 in .zw
+  f32x4_t pre2[2][16];
+  const unsigned lcol = (unsigned)(wn * WTN + col);
+  auto prefetch = [&](int half, int it) {
+    const int lrow = wm * WTM + half * 64 + (lane >> 4) + it * 4;
+    const int m = m_base + lrow;
+    const unsigned lr = (unsigned)lrow;
+    if constexpr (rmw) {
+      if (m < m_end && nvalid) pre2[half][it] = *(const f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u);
+    } else if constexpr (fast_store) {
+      if (!has_res) return;
+      f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+      if (m < m_end && nvalid) {
+        const unsigned ro = (lr * (unsigned)p.ldr + lcol) * (unsigned)sizeof(T);
+        if (p.res1) a1 = *(const f32x2_t*)(res1_b + ro);
+        if (p.res2) a2 = *(const f32x2_t*)(res2_b + ro);
+      }
+      pre2[half][it] = (f32x4_t){a1[0], a1[1], a2[0], a2[1]};
+    }
+  };
+  // Prefetch schedule (register budget: 128 accumulators are live until half 0 is staged): 8 rows of half 0
+  // before its staging pass and its other 8 rows right after it (64 accumulators are dead by then); the
+  // first 8 rows of half 1 once rows 0-7 of half 0 have been stored, the last 8 after rows 8-15.
+#pragma unroll
+  for (int it = 0; it < 8; ++it) prefetch(0, it);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int lrow0 = wm * WTM + half * 64 + (lane >> 4);  // tile-local row of iteration 0
     const int m0 = m_base + lrow0;
-    const unsigned lcol = (unsigned)(wn * WTN + col);
-    // one register array serves both prefetches: RMW -> the fp32 x vector; residual store -> the raw
-    // bf16x4 of res1 in lanes .xy and of res2 in .zw
-    f32x4_t pre[16];
-    auto prefetch = [&](int it) {
-      const int m = m0 + it * 4;
-      const unsigned lr = (unsigned)(lrow0 + it * 4);
-      if constexpr (rmw) {
-        if (m < m_end && nvalid) pre[it] = *(const f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u);
-      } else if constexpr (fast_store) {
-        if (!has_res) return;
-        f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
-        if (m < m_end && nvalid) {
-          const unsigned ro = (lr * (unsigned)p.ldr + lcol) * (unsigned)sizeof(T);
-          if (p.res1) a1 = *(const f32x2_t*)(res1_b + ro);
-          if (p.res2) a2 = *(const f32x2_t*)(res2_b + ro);
-        }
-        pre[it] = (f32x4_t){a1[0], a1[1], a2[0], a2[1]};
-      }
-    };
-    // half 0 still holds all 128 accumulator registers: prefetch 8 rows before the staging pass and the
-    // other 8 right after it (64 accumulators are dead by then); half 1 prefetches all 16 up front.
-    const int pre_first = half == 0 ? 8 : 16;
-#pragma unroll
-    for (int it = 0; it < 16; ++it)
-      if (it < pre_first) prefetch(it);
+    f32x4_t(&pre)[16] = pre2[half];
     asm volatile("" ::: "memory");
     if constexpr (PP == 2) {
 #pragma unroll
@@ -995,9 +996,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       }
     }
     asm volatile("" ::: "memory");
+    if (half == 0) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it)
-      if (it >= pre_first) prefetch(it);
+      for (int it = 8; it < 16; ++it) prefetch(0, it);
+    }
     asm volatile("" ::: "memory");
     if constexpr (rmw) {
 #pragma unroll
@@ -1007,6 +1009,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
         if (m < m_end && nvalid) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
+        if (half == 0 && it == 7) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) prefetch(1, j);
+        }
       }
     } else if constexpr (fast_store) {
 #pragma unroll
@@ -1035,6 +1041,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           else
             store4<T>((T*)(out_b + eo * (unsigned)sizeof(T)), v);
           if (p.out2) store4<T>((T*)(out2_b + eo * (unsigned)sizeof(T)), relu4(v));
+        }
+        if (half == 0 && it == 7) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) prefetch(1, j);
         }
       }
     } else if constexpr (pixshuf) {
@@ -1069,6 +1079,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       }
     }
     asm volatile("" ::: "memory");
+    if (half == 0) {
+#pragma unroll
+      for (int it = 8; it < 16; ++it) prefetch(1, it);
+    }
   }
 }
 
