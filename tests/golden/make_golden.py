@@ -1,0 +1,77 @@
+"""Generates the committed golden vectors under tests/golden/ from the CPU oracle.
+
+The reference (Rust/Burn) can be neither built nor imported in this image, so these
+vectors are outputs of `oracle/` -- itself pinned by the reference's known-answer tests
+(tests/test_oracle_kats.py) -- on seeded inputs and seeded weights.  They serve two purposes:
+  * `-m "not gpu"`: the oracle must keep reproducing them (guards the checker against drift);
+  * `-m gpu`: the HIP path is compared with them directly, no oracle in the loop.
+
+Inputs are not stored: they are `torch.manual_seed(seed); torch.rand(B,3,H,W)` normalised like
+`rgb_to_input_tensor` (inference.rs:96-117), and the weights come from the counter-based generator
+(`burn_depth_amd.weights`, seed 0, INIT_PARITY), both bit-reproducible.
+
+Usage:  python tests/golden/make_golden.py        (rewrites the .npz files next to this script)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from burn_depth_amd import weights as Wt  # noqa: E402
+from burn_depth_amd.config import DepthAnything3Config, DepthProConfig  # noqa: E402
+from oracle import da3_ref as D3  # noqa: E402
+from oracle import depth_pro_ref as R  # noqa: E402
+
+SUB = 4  # spatial subsampling of the stored depth maps (full-map checksums are stored beside them)
+
+
+def seeded_input(seed, B, H, W):
+    torch.manual_seed(seed)
+    img = torch.rand(B, 3, H, W)
+    return (img - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
+
+
+def depth_pro_case(B=2, seed=0):
+    cfg = DepthProConfig.tiny_test()
+    S = cfg.img_size()
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
+    x = seeded_input(seed, B, S, S)
+    with torch.no_grad():
+        ref = R.infer(x, W, cfg, q=R.identity, debug=True)
+    d = ref["depth"].numpy()
+    return dict(
+        batch=np.int32(B), seed=np.int32(seed), image_size=np.int32(S), sub=np.int32(SUB),
+        depth_sub=d[:, ::SUB, ::SUB].astype(np.float32),
+        depth_sum=np.float64(d.astype(np.float64).sum()), depth_sumsq=np.float64((d.astype(np.float64) ** 2).sum()),
+        fovx_deg=ref["fovx_deg"].numpy().astype(np.float32), fovy_rad=ref["fovy_rad"].numpy().astype(np.float32),
+        focallength_px=ref["focallength_px"].numpy().astype(np.float32),
+        canonical_sub=ref["debug"]["canonical"].numpy()[:, :, ::SUB, ::SUB].astype(np.float32),
+        enc4_sub=ref["debug"]["encoder"]["features"][4].numpy()[:, ::8].astype(np.float32),
+    )
+
+
+def da3_case(B=1, seed=0):
+    cfg = DepthAnything3Config.tiny_test()
+    S = cfg.image_size
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+    x = seeded_input(seed, B, S, S)
+    with torch.no_grad():
+        ref = D3.infer(x, W, cfg)
+    d = ref["depth"].numpy()
+    return dict(batch=np.int32(B), seed=np.int32(seed), image_size=np.int32(S), depth=d.astype(np.float32))
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "depth_pro_tiny_f32.npz"), **depth_pro_case())
+    np.savez_compressed(os.path.join(HERE, "da3_tiny_f32.npz"), **da3_case())
+    for f in ("depth_pro_tiny_f32.npz", "da3_tiny_f32.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
