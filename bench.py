@@ -220,7 +220,9 @@ def main() -> int:
         roofline = None
         if dom:
             e = kernels[dom]
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": e["tflops"], "peak": peak, "unit": "TFLOP/s",
+            symbols = {"fc1_gemm": "md::gemm256_kernel<md::bf16_t, 0, 2, 4> (dense A, 16x16x32 ping-pong, fused bias+GELU store)"}
+            roofline = {"kernel": dom, "kernel_symbol": symbols.get(dom) if args.precision == "bf16" else None,
+                        "bound": "mfma", "achieved": e["tflops"], "peak": peak, "unit": "TFLOP/s",
                         "frac": e["frac_mfma_peak"], "traffic": pmc_traffic(dom, B, args),
                         "avg_launch_ms": round(e["ms_per_step"] / max(e["launches_per_step"], 1), 4),
                         "flops_per_launch": fl[dom] / max(e["launches_per_step"], 1)}

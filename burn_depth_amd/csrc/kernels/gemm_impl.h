@@ -498,7 +498,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 // ------------------------------------------------------------------------------------------------
 // EK selects the staged-epilogue specialisation at compile time (a runtime three-way branch around the
 // fully unrolled row loops cost 40 VGPRs and scratch spills): 0 generic (epilogue4 per vector),
-// 1 read-modify-write residual (EPI_RESID_LS), 2 bf16 store with optional residual inputs (EPI_STORE).
+// 1 read-modify-write residual (EPI_RESID_LS), 2 bf16 store with optional residual inputs (EPI_STORE),
+// 3 pixel shuffle (EPI_PIXSHUF), 4 = 2 with the GELU fused at compile time (the fc1 GEMM: its own kernel
+// symbol, so profilers report it separately from the other store GEMMs).
 template <typename T, int AMODE, int PP, int EK>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // staging pass, so 16 loads per lane are in flight at once instead of a dependent load->store chain
   // (that chain, not bandwidth, set the cost of the proj / fc2 / residual-conv epilogues).
   constexpr bool rmw = EK == 1;
-  constexpr bool fast_store = EK == 2 && sizeof(T) == 2;
+  constexpr bool fast_store = (EK == 2 || EK == 4) && sizeof(T) == 2;  // EK 4: GELU fused at compile time (fc1)
   constexpr bool pixshuf = EK == 3;
   // pixel shuffle: the lane's 4 columns fix (tap, channel) once; rows only move the output pixel
   int ps_co = 0, ps_dy = 0, ps_dx = 0;
@@ -1031,10 +1033,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             v += (f32x4_t){__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 << 16),
                            __uint_as_float(u3 & 0xffff0000u)};
           }
-          if (p.act == ACT_RELU)
-            v = relu4(v);
-          else if (p.act == ACT_GELU)
+          if constexpr (EK == 4) {
             v = gelu4<T>(v);
+          } else {
+            if (p.act == ACT_RELU) v = relu4(v);
+          }
           const unsigned eo = lr * (unsigned)ldo + lcol;
           if (p.out_f32)
             store4<float>((float*)(out_b + eo * 4u), v);
@@ -1110,17 +1113,19 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     MD_HIP(hipGetLastError());
     return MD_OK;
   };
-  static bool set0 = false, set1 = false, set2 = false, set3 = false;
+  static bool set0 = false, set1 = false, set2 = false, set3 = false, set4 = false;
   if constexpr (PP == 2) {  // the production schedule carries the specialised epilogues
     if (p.epi == EPI_RESID_LS) return go(gemm256_kernel<T, AMODE, PP, 1>, &set1);
     if (p.epi == EPI_PIXSHUF) return go(gemm256_kernel<T, AMODE, PP, 3>, &set3);
     if constexpr (sizeof(T) == 2) {
+      if (p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) return go(gemm256_kernel<T, AMODE, PP, 4>, &set4);
       if ((p.epi == EPI_STORE && p.res_mod == 0) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0)) return go(gemm256_kernel<T, AMODE, PP, 2>, &set2);
     }
   }
   (void)set1;
   (void)set2;
   (void)set3;
+  (void)set4;
   return go(gemm256_kernel<T, AMODE, PP, 0>, &set0);
 }
 
