@@ -129,13 +129,15 @@ class DepthProConfig:
 # ---------------------------------------------------------------------------------------------
 DA3_VITL14 = ViTConfig("da3_vitl14", 3, 1024, 24, 16, 4, 518, 14, (4, 11, 17, 23), (256, 512, 1024, 1024))
 DA3_TINY14 = ViTConfig("da3_tiny14", 3, 256, 4, 4, 4, 70, 14, (0, 1, 2, 3), (64, 128, 256, 256))  # test-only
+DA3_VITS14 = ViTConfig("da3_vits14", 3, 384, 12, 6, 4, 518, 14, (5, 7, 9, 11), (48, 96, 192, 384))
+DA3_TINYDUAL14 = ViTConfig("da3_tinydual14", 3, 128, 6, 2, 4, 70, 14, (2, 3, 4, 5), (48, 96, 64, 128))  # test-only
 
 
 @dataclass
 class DepthAnything3Config:
     """`DepthAnything3Config::metric_large()` (depth_anything3/mod.rs:153-156) + head
-    (`DepthAnything3HeadConfig::metric_large`, dpt.rs:41-58). Only the mono-head ("metric_large")
-    variant is built so far; `small` (dual head, camera decoder, RoPE/QK-norm backbone) is a next row."""
+    (`DepthAnything3HeadConfig::metric_large`, dpt.rs:41-58). `metric_large` = plain ViT-L/14 + mono
+    head; `small` = ViT-S/14 with the burn_dino extras + dual head + camera decoder."""
 
     variant: str = "metric_large"
     image_size: int = 518
@@ -149,6 +151,16 @@ class DepthAnything3Config:
     precision: int = Precision.BF16
     max_batch: int = 1
     ln_eps: float = 1e-6
+    # `small` (mod.rs:158-171, 190-196; dpt.rs:60-79): dual head + camera decoder on a ViT whose blocks
+    # >= `ext_block_start` use QK-norm, 2-D RoPE and alternate local/global attention, with the cls slot
+    # replaced by a learned camera token at that block and hooks = cat(last local x, norm(x)) (dim 2*D)
+    dual_head: bool = False
+    ext_block_start: int = -1
+    rope_frequency: float = 100.0
+    qk_norm_eps: float = 1e-5
+    aux_out1_conv_num: int = 5
+    aux_output_dim: int = 7
+    aux_levels: int = 4
 
     @staticmethod
     def metric_large() -> "DepthAnything3Config":
@@ -158,8 +170,19 @@ class DepthAnything3Config:
     def tiny_test() -> "DepthAnything3Config":
         return DepthAnything3Config("tiny", 70, 14, (0, 1, 2, 3), 256, 64, (64, 128, 256, 256))
 
+    @staticmethod
+    def small() -> "DepthAnything3Config":
+        """`DepthAnything3Config::small()` (mod.rs:158-171) + `DepthAnything3HeadConfig::small()` (dpt.rs:60-79)."""
+        return DepthAnything3Config("small", 518, 14, (5, 7, 9, 11), 768, 64, (48, 96, 192, 384), 2,
+                                    dual_head=True, ext_block_start=4)
+
+    @staticmethod
+    def tiny_dual_test() -> "DepthAnything3Config":
+        return DepthAnything3Config("tiny_dual", 70, 14, (2, 3, 4, 5), 256, 64, (48, 96, 64, 128), 2,
+                                    dual_head=True, ext_block_start=2)
+
     def vit(self) -> ViTConfig:
-        base = DA3_VITL14 if self.variant == "metric_large" else DA3_TINY14
+        base = {"metric_large": DA3_VITL14, "small": DA3_VITS14, "tiny_dual": DA3_TINYDUAL14}.get(self.variant, DA3_TINY14)
         return dataclasses.replace(base, ln_eps=self.ln_eps, encoder_feature_layer_ids=tuple(self.hook_block_ids))
 
     def img_size(self) -> int:

@@ -615,8 +615,16 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
     d.image_size = 70; d.features = 64;
     const int oc[4] = {64, 128, 256, 256}, hk[4] = {0, 1, 2, 3};
     for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
-  } else if (d.variant == "small") {
-    MD_FAIL(MD_ERR_UNSUPPORTED, "Depth-Anything-v3 `small` (dual head, camera decoder, RoPE/QK-norm backbone) is not built yet");
+  } else if (d.variant == "small") {  // mod.rs:158-171,190-196; dpt.rs:60-79
+    v.preset = "da3_vits14"; v.D = 384; v.depth = 12; v.heads = 6; v.img = 518;
+    d.image_size = 518; d.features = 64; d.output_dim = 2; d.dual_head = true; d.ext_block_start = 4;
+    const int oc[4] = {48, 96, 192, 384}, hk[4] = {5, 7, 9, 11};
+    for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
+  } else if (d.variant == "tiny_dual") {  // test-only: same topology, 6 blocks of width 128
+    v.preset = "da3_tinydual14"; v.D = 128; v.depth = 6; v.heads = 2; v.img = 70;
+    d.image_size = 70; d.features = 64; d.output_dim = 2; d.dual_head = true; d.ext_block_start = 2;
+    const int oc[4] = {48, 96, 64, 128}, hk[4] = {2, 3, 4, 5};
+    for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
   } else {
     MD_FAIL(MD_ERR_INVALID_ARG, "unknown Depth-Anything-v3 variant `%s`", c->variant);
   }

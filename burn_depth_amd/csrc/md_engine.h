@@ -143,6 +143,10 @@ struct Da3Cfg {
   int hook_ids[4] = {4, 11, 17, 23};
   int precision = MD_PREC_BF16, max_batch = 1;
   float ln_eps = 1e-6f;
+  // `small`: dual head + camera decoder + burn_dino backbone extras from block `ext_block_start` on
+  bool dual_head = false;
+  int ext_block_start = -1, aux_levels = 4, aux_out1_conv_num = 5, aux_output_dim = 7;
+  float rope_frequency = 100.f, qk_norm_eps = 1e-5f;
 };
 std::vector<ParamSpec> da3_param_specs(const Da3Cfg& cfg, int scheme);
 int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out);

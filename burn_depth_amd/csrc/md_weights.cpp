@@ -191,32 +191,79 @@ std::vector<ParamSpec> da3_param_specs(const Da3Cfg& cfg, int scheme) {
   std::vector<ParamSpec> specs;
   SpecBuilder sb{specs, scheme == MD_INIT_PARITY};
   const bool par = sb.par;
-  sb.vit("backbone.pretrained", cfg.vit);
+  const std::string bp = "backbone.pretrained";
+  sb.vit(bp, cfg.vit);
   const int* oc = cfg.out_channels;
-  const int Fh = cfg.features, D = cfg.vit.D;
+  const int Fh = cfg.features, D = cfg.vit.D, din = cfg.dual_head ? 2 * D : D;
+  const std::string hp = cfg.dual_head ? "head_dual" : "head_mono";
   auto deconv = [&](const std::string& name, int cin, int cout, int k) {
     const double b = par ? std::sqrt(3.0 / cin) : std::sqrt(1.0 / (cout * k * k));
     sb.sym(name + ".weight", {cin, cout, k, k}, b);
     sb.sym(name + ".bias", {cout}, par ? 0.1 : b);
   };
-  for (int i = 0; i < 4; ++i) sb.conv("head_mono.projects." + std::to_string(i), oc[i], D, 1, true);
-  deconv("head_mono.resize_layers.0.conv_t", oc[0], oc[0], 4);
-  deconv("head_mono.resize_layers.1.conv_t", oc[1], oc[1], 2);
-  sb.conv("head_mono.resize_layers.3.conv", oc[3], oc[3], 3, true);
-  for (int i = 0; i < 4; ++i) sb.conv("head_mono.scratch.layer" + std::to_string(i + 1) + "_rn", Fh, oc[i], 3, false);
-  for (int i = 1; i <= 4; ++i) {
-    const std::string r = "head_mono.scratch.refinenet" + std::to_string(i);
-    if (i != 4) {
-      sb.conv(r + ".residual1.conv1", Fh, Fh, 3, true, true);
-      sb.conv(r + ".residual1.conv2", Fh, Fh, 3, true, true, 0.5);
+  auto norm = [&](const std::string& name, int dim) {
+    if (par) sb.add(name + ".gamma", {dim}, 0.5, 1.5); else sb.add(name + ".gamma", {dim}, 1.0, 1.0);
+    if (par) sb.sym(name + ".beta", {dim}, 0.1); else sb.add(name + ".beta", {dim}, 0.0, 0.0);
+  };
+  auto lin = [&](const std::string& name, int fan_out, int fan_in, double gain, bool fov_bias) {
+    const double b = (par ? std::sqrt(3.0 / fan_in) : std::sqrt(1.0 / fan_in)) * gain;
+    sb.sym(name + ".weight", {fan_out, fan_in}, b);
+    if (par && fov_bias)
+      sb.add(name + ".bias", {fan_out}, 0.6, 1.2);
+    else
+      sb.sym(name + ".bias", {fan_out}, par ? 0.1 : std::sqrt(1.0 / fan_in));
+  };
+  if (cfg.dual_head) {  // burn_dino extras (mod.rs:190-196)
+    for (int i = cfg.ext_block_start; i < cfg.vit.depth; ++i) {
+      norm(bp + ".blocks." + std::to_string(i) + ".attn.q_norm", 64);
+      norm(bp + ".blocks." + std::to_string(i) + ".attn.k_norm", 64);
     }
-    sb.conv(r + ".residual2.conv1", Fh, Fh, 3, true, true);
-    sb.conv(r + ".residual2.conv2", Fh, Fh, 3, true, true, 0.5);
-    sb.conv(r + ".out_conv", Fh, Fh, 1, true);
+    sb.sym(bp + ".camera_token", {1, 2, D}, par ? 0.5 : 1e-6);
+    norm(hp + ".norm", din);
   }
-  sb.conv("head_mono.scratch.output_conv1", Fh / 2, Fh, 3, true);
-  sb.conv("head_mono.scratch.output_conv2.conv1", 32, Fh / 2, 3, true, true);
-  sb.conv("head_mono.scratch.output_conv2.conv2", cfg.output_dim, 32, 1, true, false, 0.5);
+  for (int i = 0; i < 4; ++i) sb.conv(hp + ".projects." + std::to_string(i), oc[i], din, 1, true);
+  deconv(hp + ".resize_layers.0.conv_t", oc[0], oc[0], 4);
+  deconv(hp + ".resize_layers.1.conv_t", oc[1], oc[1], 2);
+  sb.conv(hp + ".resize_layers.3.conv", oc[3], oc[3], 3, true);
+  for (int i = 0; i < 4; ++i) sb.conv(hp + ".scratch.layer" + std::to_string(i + 1) + "_rn", Fh, oc[i], 3, false);
+  auto refinenets = [&](const std::string& suffix) {
+    for (int i = 1; i <= 4; ++i) {
+      const std::string r = hp + ".scratch.refinenet" + std::to_string(i) + suffix;
+      if (i != 4) {
+        sb.conv(r + ".residual1.conv1", Fh, Fh, 3, true, true);
+        sb.conv(r + ".residual1.conv2", Fh, Fh, 3, true, true, 0.5);
+      }
+      sb.conv(r + ".residual2.conv1", Fh, Fh, 3, true, true);
+      sb.conv(r + ".residual2.conv2", Fh, Fh, 3, true, true, 0.5);
+      sb.conv(r + ".out_conv", Fh, Fh, 1, true);
+    }
+  };
+  refinenets("");
+  sb.conv(hp + ".scratch.output_conv1", Fh / 2, Fh, 3, true);
+  sb.conv(hp + ".scratch.output_conv2.conv1", 32, Fh / 2, 3, true, true);
+  sb.conv(hp + ".scratch.output_conv2.conv2", cfg.output_dim, 32, 1, true, false, 0.5);
+  if (cfg.dual_head) {
+    refinenets("_aux");
+    for (int lvl = 0; lvl < cfg.aux_levels; ++lvl) {  // AuxPreHead (dpt.rs:1085-1113)
+      int cin = Fh;
+      for (int j = 0; j < cfg.aux_out1_conv_num; ++j) {
+        const int cout = j % 2 == 0 ? Fh / 2 : Fh;
+        sb.conv(hp + ".scratch.output_conv1_aux." + std::to_string(lvl) + ".layers." + std::to_string(j), cout, cin, 3, true);
+        cin = cout;
+      }
+    }
+    for (int lvl = 0; lvl < cfg.aux_levels; ++lvl) {  // AuxOutputHead (dpt.rs:1146-1192)
+      const std::string o = hp + ".scratch.output_conv2_aux." + std::to_string(lvl);
+      sb.conv(o + ".reduce", 32, Fh / 2, 3, true, true);
+      if (lvl == 0) norm(o + ".norm.layer_norm", 32);
+      sb.conv(o + ".project", cfg.aux_output_dim, 32, 1, true, false, 0.5);
+    }
+    lin("camera_decoder.backbone_1", din, din, par ? std::sqrt(2.0) : 1.0, false);  // camera.rs:113-141
+    lin("camera_decoder.backbone_2", din, din, par ? std::sqrt(2.0) : 1.0, false);
+    lin("camera_decoder.fc_t", 3, din, 1.0, false);
+    lin("camera_decoder.fc_qvec", 4, din, 1.0, false);
+    lin("camera_decoder.fc_fov", 2, din, 0.25, true);
+  }
   return specs;
 }
 

@@ -185,13 +185,16 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
 
 
 def da3_param_specs(cfg: DepthAnything3Config, scheme: int = INIT_REFERENCE) -> List[ParamSpec]:
-    """Parameters of `DepthAnything3::new(metric_large)` (depth_anything3/mod.rs:253-286, dpt.rs:515-568,
-    1002-1083), named as the importer maps them (tool/import_da3.rs:67-195): `backbone.pretrained.*`,
-    `head_mono.*`."""
+    """Parameters of `DepthAnything3::new` (depth_anything3/mod.rs:253-286, dpt.rs:153-226,515-568,1002-1083,
+    camera.rs:113-141), named as the importer maps them (tool/import_da3.rs:67-195): `backbone.pretrained.*`,
+    `head_mono.*` | `head_dual.*`, `camera_decoder.*`. The camera *encoder* (mod.rs:165-168) only runs when
+    extrinsics/intrinsics are passed in, which `infer` never does (mod.rs:288-291): not part of the inventory."""
     v = cfg.vit()
     par = scheme == INIT_PARITY
-    specs: List[ParamSpec] = list(_vit_specs("backbone.pretrained", v, scheme))
+    bp = "backbone.pretrained"
+    specs: List[ParamSpec] = list(_vit_specs(bp, v, scheme))
     oc, Fh = cfg.out_channels, cfg.features
+    hp = "head_dual" if cfg.dual_head else "head_mono"
 
     def conv(name, cout, cin, k, bias, relu_after=False, gain=None):
         fan = cin * k * k
@@ -210,23 +213,66 @@ def da3_param_specs(cfg: DepthAnything3Config, scheme: int = INIT_REFERENCE) -> 
         specs.append(ParamSpec(f"{name}.weight", (cin, cout, k, k), *_sym(b)))
         specs.append(ParamSpec(f"{name}.bias", (cout,), *_sym(0.1 if par else b)))
 
+    def lin(name, fan_out, fan_in, gain=1.0, bias_range=None):
+        b = (math.sqrt(3.0 / fan_in) if par else math.sqrt(1.0 / fan_in)) * gain
+        specs.append(ParamSpec(f"{name}.weight", (fan_out, fan_in), *_sym(b)))
+        if par and bias_range is not None:
+            specs.append(ParamSpec(f"{name}.bias", (fan_out,), *bias_range))
+        else:
+            specs.append(ParamSpec(f"{name}.bias", (fan_out,), *_sym(0.1 if par else math.sqrt(1.0 / fan_in))))
+
+    def norm(name, dim):
+        specs.append(ParamSpec(f"{name}.gamma", (dim,), *((0.5, 1.5) if par else (1.0, 1.0))))
+        specs.append(ParamSpec(f"{name}.beta", (dim,), *(_sym(0.1) if par else (0.0, 0.0))))
+
+    if cfg.dual_head:
+        # burn_dino extras (mod.rs:190-196): per-head q/k LayerNorm from `ext_block_start` on, camera tokens
+        for i in range(cfg.ext_block_start, v.depth):
+            norm(f"{bp}.blocks.{i}.attn.q_norm", v.head_dim)
+            norm(f"{bp}.blocks.{i}.attn.k_norm", v.head_dim)
+        specs.append(ParamSpec(f"{bp}.camera_token", (1, 2, v.embed_dim), *_sym(0.5 if par else 1e-6)))
+        norm(f"{hp}.norm", cfg.dim_in)
     for i in range(4):
-        conv(f"head_mono.projects.{i}", oc[i], cfg.dim_in, 1, True)
-    deconv("head_mono.resize_layers.0.conv_t", oc[0], oc[0], 4)
-    deconv("head_mono.resize_layers.1.conv_t", oc[1], oc[1], 2)
-    conv("head_mono.resize_layers.3.conv", oc[3], oc[3], 3, True)
+        conv(f"{hp}.projects.{i}", oc[i], cfg.dim_in, 1, True)
+    deconv(f"{hp}.resize_layers.0.conv_t", oc[0], oc[0], 4)
+    deconv(f"{hp}.resize_layers.1.conv_t", oc[1], oc[1], 2)
+    conv(f"{hp}.resize_layers.3.conv", oc[3], oc[3], 3, True)
     for i in range(4):
-        conv(f"head_mono.scratch.layer{i + 1}_rn", Fh, oc[i], 3, False)
-    for i in (1, 2, 3, 4):
-        r = f"head_mono.scratch.refinenet{i}"
-        units = ("residual1", "residual2") if i != 4 else ("residual2",)
-        for u in units:
-            conv(f"{r}.{u}.conv1", Fh, Fh, 3, True, relu_after=True)
-            conv(f"{r}.{u}.conv2", Fh, Fh, 3, True, relu_after=True, gain=0.5)
-        conv(f"{r}.out_conv", Fh, Fh, 1, True)
-    conv("head_mono.scratch.output_conv1", Fh // 2, Fh, 3, True)
-    conv("head_mono.scratch.output_conv2.conv1", 32, Fh // 2, 3, True, relu_after=True)
-    conv("head_mono.scratch.output_conv2.conv2", cfg.output_dim, 32, 1, True, gain=0.5)
+        conv(f"{hp}.scratch.layer{i + 1}_rn", Fh, oc[i], 3, False)
+
+    def refinenets(suffix):
+        for i in (1, 2, 3, 4):
+            r = f"{hp}.scratch.refinenet{i}{suffix}"
+            units = ("residual1", "residual2") if i != 4 else ("residual2",)
+            for u in units:
+                conv(f"{r}.{u}.conv1", Fh, Fh, 3, True, relu_after=True)
+                conv(f"{r}.{u}.conv2", Fh, Fh, 3, True, relu_after=True, gain=0.5)
+            conv(f"{r}.out_conv", Fh, Fh, 1, True)
+
+    refinenets("")
+    conv(f"{hp}.scratch.output_conv1", Fh // 2, Fh, 3, True)
+    conv(f"{hp}.scratch.output_conv2.conv1", 32, Fh // 2, 3, True, relu_after=True)
+    conv(f"{hp}.scratch.output_conv2.conv2", cfg.output_dim, 32, 1, True, gain=0.5)
+    if cfg.dual_head:
+        refinenets("_aux")
+        for lvl in range(cfg.aux_levels):  # AuxPreHead (dpt.rs:1085-1113): C -> C/2 -> C -> ... 3x3 convs, no activation
+            cin = Fh
+            for j in range(cfg.aux_out1_conv_num):
+                cout = Fh // 2 if j % 2 == 0 else Fh
+                conv(f"{hp}.scratch.output_conv1_aux.{lvl}.layers.{j}", cout, cin, 3, True)
+                cin = cout
+        for lvl in range(cfg.aux_levels):  # AuxOutputHead (dpt.rs:1146-1192); LayerNorm2d only on level 0 (dpt.rs:76)
+            o = f"{hp}.scratch.output_conv2_aux.{lvl}"
+            conv(f"{o}.reduce", 32, Fh // 2, 3, True, relu_after=True)
+            if lvl == 0:
+                norm(f"{o}.norm.layer_norm", 32)
+            conv(f"{o}.project", cfg.aux_output_dim, 32, 1, True, gain=0.5)
+        d = cfg.dim_in  # CameraDecoder (camera.rs:113-141)
+        lin("camera_decoder.backbone_1", d, d, gain=math.sqrt(2.0) if par else 1.0)
+        lin("camera_decoder.backbone_2", d, d, gain=math.sqrt(2.0) if par else 1.0)
+        lin("camera_decoder.fc_t", 3, d)
+        lin("camera_decoder.fc_qvec", 4, d)
+        lin("camera_decoder.fc_fov", 2, d, gain=0.25, bias_range=(0.6, 1.2))  # parity init keeps relu(fov) > 0
     return specs
 
 

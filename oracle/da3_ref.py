@@ -1,4 +1,4 @@
-"""CPU oracle for Depth-Anything-v3 `metric_large` (mono DPT head) -- TEST INFRASTRUCTURE ONLY.
+"""CPU oracle for Depth-Anything-v3 (`metric_large` mono head; `small` dual head + camera decoder) -- TEST INFRASTRUCTURE ONLY.
 
 fp32 PyTorch-CPU restatement of `DepthAnything3::infer` for the mono-head variant
 (/root/reference/src/model/depth_anything3/mod.rs:288-291,495-624 and dpt.rs:515-731,784-932,
@@ -162,16 +162,188 @@ def backbone_hooks(x: Tensor, W, cfg: DepthAnything3Config, q=identity) -> List[
     return [F.layer_norm(h, (v.embed_dim,), g, b, v.ln_eps)[:, 1:] for h in raw]
 
 
+# ---------------------------------------------------------------------------------------------
+# `small` variant: burn_dino backbone extras + dual head + camera decoder
+#
+# PARITY STATUS of the backbone extras: **unpinned and under-specified** in the reference tree -- they live in
+# burn_dino 0.6.0 and the reference only sets the switches (mod.rs:190-196: alt_block_start = qk_norm_block_start =
+# rope_block_start = 4, cat_token, use_camera_tokens). Restated here from the public Depth-Anything-3 model
+# definition those switches are named after (single view, S = 1):
+#   * from block `ext_block_start` on, q and k get a per-head affine LayerNorm (head_dim) and then a 2-D rotary
+#     embedding: the first half of head_dim rotates with the token's row, the second half with its column;
+#     within a half, pairs (j, j + n/2) rotate by pos * base^(-2j/n), base = 100; patch positions are 1-based,
+#     the cls slot sits at (0, 0);
+#   * blocks alternate local / global attention (global = odd block index >= start). With one view the two
+#     attend over the same tokens; global blocks use "no-diff" positions (every patch at (1, 1));
+#   * entering block `ext_block_start` the cls slot is overwritten with the learned reference camera token;
+#   * a hook is cat(x after the last LOCAL block, x after the hook block) (dim 2D) and only its second half
+#     goes through the final LayerNorm; the camera feature is token 0 of the raw (un-normalised) concat.
+# ---------------------------------------------------------------------------------------------
+def _rope_half(t: Tensor, pos: Tensor, base: float) -> Tensor:
+    """t [B, heads, N, n], pos [N] -> rotated t (pairs (j, j + n/2))."""
+    n = t.shape[-1]
+    inv = 1.0 / (base ** (torch.arange(0, n, 2, dtype=torch.float32) / n))   # [n/2]
+    ang = pos.to(torch.float32)[:, None] * inv[None, :]                         # [N, n/2]
+    ang = torch.cat([ang, ang], -1)                                             # [N, n]
+    rot = torch.cat([-t[..., n // 2:], t[..., :n // 2]], -1)
+    return t * ang.cos() + rot * ang.sin()
+
+
+def rope2d(t: Tensor, pos: Tensor, base: float) -> Tensor:
+    """t [B, heads, N, head_dim], pos [N, 2] = (row, col)."""
+    n = t.shape[-1] // 2
+    return torch.cat([_rope_half(t[..., :n], pos[:, 0], base), _rope_half(t[..., n:], pos[:, 1], base)], -1)
+
+
+def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity):
+    """Returns (hooks: 4 x [B, P, 2D] with the second half final-norm'ed, camera feature [B, 2D] of the last hook)."""
+    from oracle.depth_pro_ref import interpolate_pos_encoding
+    v = cfg.vit()
+    bp = "backbone.pretrained"
+    p = lambda n: W[f"{bp}.{n}"]
+    B = x.shape[0]
+    D, Hn, hd = v.embed_dim, v.num_heads, v.head_dim
+    gh, gw = x.shape[2] // v.patch_size, x.shape[3] // v.patch_size
+    tok = F.conv2d(q(x), q(p("patch_embed.proj.weight")), p("patch_embed.proj.bias"), stride=v.patch_size).flatten(2).transpose(1, 2)
+    xs = torch.cat([p("cls_token").expand(B, 1, D), tok], 1) + interpolate_pos_encoding(p("pos_embed"), gh, gw)
+    N = xs.shape[1]
+    yy, xx = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+    pos_l = torch.cat([torch.zeros(1, 2, dtype=torch.long), torch.stack([yy.reshape(-1), xx.reshape(-1)], 1) + 1], 0)
+    pos_g = torch.cat([torch.zeros(1, 2, dtype=torch.long), torch.ones(gh * gw, 2, dtype=torch.long)], 0)
+    start = cfg.ext_block_start
+    local_x = xs
+    raw = {}
+    for i in range(v.depth):
+        b = f"blocks.{i}"
+        ext = start >= 0 and i >= start
+        if ext and i == start:
+            xs = torch.cat([p("camera_token")[:, :1].expand(B, 1, D), xs[:, 1:]], 1)
+        is_global = ext and i % 2 == 1
+        xn = q(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
+        qkv = q(F.linear(xn, q(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
+        qkv = qkv.reshape(B, N, 3, Hn, hd).permute(2, 0, 3, 1, 4)
+        qq, kk, vv = qkv[0], qkv[1], qkv[2]
+        if ext:
+            pos = pos_g if is_global else pos_l
+            qq = F.layer_norm(qq, (hd,), p(f"{b}.attn.q_norm.gamma"), p(f"{b}.attn.q_norm.beta"), cfg.qk_norm_eps)
+            kk = F.layer_norm(kk, (hd,), p(f"{b}.attn.k_norm.gamma"), p(f"{b}.attn.k_norm.beta"), cfg.qk_norm_eps)
+            qq, kk = q(rope2d(qq, pos, cfg.rope_frequency)), q(rope2d(kk, pos, cfg.rope_frequency))
+        sc = (qq @ kk.transpose(-2, -1)) * hd ** -0.5
+        pu = torch.exp(sc - sc.amax(-1, keepdim=True))
+        o = (q(pu) @ vv) / pu.sum(-1, keepdim=True)
+        o = q(o.transpose(1, 2).reshape(B, N, D))
+        xs = xs + p(f"{b}.ls1.gamma") * F.linear(o, q(p(f"{b}.attn.proj.weight")), p(f"{b}.attn.proj.bias"))
+        xn = q(F.layer_norm(xs, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))
+        h = q(F.gelu(F.linear(xn, q(p(f"{b}.mlp.fc1.weight")), p(f"{b}.mlp.fc1.bias"))))
+        xs = xs + p(f"{b}.ls2.gamma") * F.linear(h, q(p(f"{b}.mlp.fc2.weight")), p(f"{b}.mlp.fc2.bias"))
+        if not is_global:
+            local_x = xs
+        if i in cfg.hook_block_ids:
+            raw[i] = torch.cat([local_x, xs], -1)
+    hooks, cam = [], None
+    for i in cfg.hook_block_ids:
+        r = raw[i]
+        hooks.append(torch.cat([r[..., :D], F.layer_norm(r[..., D:], (D,), p("norm.gamma"), p("norm.beta"), v.ln_eps)], -1)[:, 1:])
+        cam = r[:, 0]
+    return hooks, cam
+
+
+def dual_head_forward(hooks: List[Tensor], height: int, width: int, W, cfg: DepthAnything3Config, q=identity, debug=None):
+    """DualDepthAnything3Head::forward_dual (dpt.rs:227-280): returns depth, depth_confidence, aux, aux_confidence."""
+    hp, sc = "head_dual", "head_dual.scratch"
+    ps = cfg.patch_size
+    ph, pw = height // ps, width // ps
+    feats = []
+    for s in range(4):  # prepare_stage (dpt.rs:282-317): affine LayerNorm (Burn default eps 1e-5), 1x1, + UV, resize layer
+        x = q(F.layer_norm(hooks[s][:, :ph * pw], (cfg.dim_in,), W[f"{hp}.norm.gamma"], W[f"{hp}.norm.beta"], 1e-5))
+        x = x.permute(0, 2, 1).reshape(x.shape[0], -1, ph, pw)
+        x = F.conv2d(x, q(W[f"{hp}.projects.{s}.weight"]), W[f"{hp}.projects.{s}.bias"])
+        if cfg.pos_embed:
+            x = pos_embed_add(x, width, height)
+        x = q(x)
+        if s == 0:
+            x = q(F.conv_transpose2d(x, q(W[f"{hp}.resize_layers.0.conv_t.weight"]), W[f"{hp}.resize_layers.0.conv_t.bias"], stride=4))
+        elif s == 1:
+            x = q(F.conv_transpose2d(x, q(W[f"{hp}.resize_layers.1.conv_t.weight"]), W[f"{hp}.resize_layers.1.conv_t.bias"], stride=2))
+        elif s == 3:
+            x = q(F.conv2d(x, q(W[f"{hp}.resize_layers.3.conv.weight"]), W[f"{hp}.resize_layers.3.conv.bias"], stride=2, padding=1))
+        feats.append(x)
+    rn = [q(F.conv2d(feats[i], q(W[f"{sc}.layer{i + 1}_rn.weight"]), padding=1)) for i in range(4)]
+
+    def pyramid(suffix):
+        out = _ffb(rn[3], None, rn[2].shape[2:], W, f"{sc}.refinenet4{suffix}", q)
+        out = _ffb(out, rn[2], rn[1].shape[2:], W, f"{sc}.refinenet3{suffix}", q)
+        out = _ffb(out, rn[1], rn[0].shape[2:], W, f"{sc}.refinenet2{suffix}", q)
+        return _ffb(out, rn[0], None, W, f"{sc}.refinenet1{suffix}", q)
+
+    # main branch (fuse_main + build_main_logits, dpt.rs:319-353)
+    fused = q(F.conv2d(pyramid(""), q(W[f"{sc}.output_conv1.weight"]), W[f"{sc}.output_conv1.bias"], padding=1))
+    fused = resize_bilinear(fused, (height, width))
+    if cfg.pos_embed:
+        fused = pos_embed_add(fused, width, height)
+    fused = q(fused)
+    t = F.relu(F.conv2d(fused, q(W[f"{sc}.output_conv2.conv1.weight"]), W[f"{sc}.output_conv2.conv1.bias"], padding=1))
+    main = F.conv2d(t, W[f"{sc}.output_conv2.conv2.weight"], W[f"{sc}.output_conv2.conv2.bias"])
+    # aux branch (build_aux_logits, dpt.rs:356-441): only the last level's neck and output head reach the result
+    lvl = cfg.aux_levels - 1
+    y = pyramid("_aux")
+    for j in range(cfg.aux_out1_conv_num):
+        n = f"{sc}.output_conv1_aux.{lvl}.layers.{j}"
+        y = q(F.conv2d(y, q(W[f"{n}.weight"]), W[f"{n}.bias"], padding=1))
+    neck = y
+    if cfg.pos_embed:  # added twice (dpt.rs:428-435)
+        y = pos_embed_add(pos_embed_add(y, width, height), width, height)
+    y = q(y)
+    o = f"{sc}.output_conv2_aux.{lvl}"
+    t = F.conv2d(y, q(W[f"{o}.reduce.weight"]), W[f"{o}.reduce.bias"], padding=1)
+    if f"{o}.norm.layer_norm.gamma" in W:
+        t = F.layer_norm(t.permute(0, 2, 3, 1), (t.shape[1],), W[f"{o}.norm.layer_norm.gamma"], W[f"{o}.norm.layer_norm.beta"], 1e-5).permute(0, 3, 1, 2)
+    aux_logits = F.conv2d(F.relu(t), W[f"{o}.project.weight"], W[f"{o}.project.bias"])
+    if debug is not None:
+        debug.update(stage_feats=feats, rn=rn, fused=fused, main_logits=main, aux_neck=neck, aux_head_input=y, aux_logits=aux_logits)
+    k = cfg.aux_output_dim
+    return dict(depth=torch.exp(main[:, 0]), depth_confidence=torch.exp(main[:, -1]) + 1.0,
+                aux=aux_logits[:, :k - 1], aux_confidence=torch.exp(aux_logits[:, k - 1]) + 1.0)
+
+
+def camera_decode(cam: Tensor, W, height: int, width: int):
+    """CameraDecoder::forward + pose_encoding_to_extri_intri (camera.rs:143-199, 281-416), one view."""
+    lin = lambda n, t: F.linear(t, W[f"camera_decoder.{n}.weight"], W[f"camera_decoder.{n}.bias"])
+    h = F.relu(lin("backbone_2", F.relu(lin("backbone_1", cam))))
+    pose = torch.cat([lin("fc_t", h), lin("fc_qvec", h), F.relu(lin("fc_fov", h))], 1)  # [B, 9]
+    t, (qx, qy, qz, qw), fov = pose[:, :3], pose[:, 3:7].unbind(1), pose[:, 7:9]
+    R = torch.stack([torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)], 1),
+                     torch.stack([2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)], 1),
+                     torch.stack([2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)], 1)], 1)
+    Rt = R.transpose(1, 2)
+    extr = torch.cat([Rt, -(Rt @ t[:, :, None])], 2)                                       # [B, 3, 4] world-to-camera
+    tan_h = torch.sin(fov[:, 0] * 0.5) / torch.cos(fov[:, 0] * 0.5)
+    tan_w = torch.sin(fov[:, 1] * 0.5) / torch.cos(fov[:, 1] * 0.5)
+    intr = torch.zeros(cam.shape[0], 3, 3)
+    intr[:, 0, 0], intr[:, 0, 2] = (width / 2.0) / tan_w, width / 2.0
+    intr[:, 1, 1], intr[:, 1, 2] = (height / 2.0) / tan_h, height / 2.0
+    intr[:, 2, 2] = 1.0
+    return dict(pose_encoding=pose[:, None], extrinsics=extr[:, None], intrinsics=intr[:, None])
+
+
 def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False):
-    """DepthAnything3::infer (mod.rs:288-291 -> 495-564 -> 587-609): depth [B,H,W]."""
+    """DepthAnything3::infer (mod.rs:288-291 -> 495-564 -> 587-624): depth [B,H,W] (+ confidence, aux rays,
+    aux confidence, pose encoding, extrinsics, intrinsics for the dual-head variant)."""
     B, _, H, Wd = x.shape
     ps = cfg.patch_size
     if H % ps or Wd % ps:  # mod.rs:509-520 (panic)
         raise ValueError(f"Input {H}x{Wd} must be divisible by patch size {ps}")
-    hooks = backbone_hooks(x, W, cfg, q)
     dbg = {} if debug else None
-    act = head_forward_raw(hooks, H, Wd, W, cfg, q, dbg)
-    out = dict(depth=act[:, 0])  # select_depth_channel (dpt.rs:633-647)
+    if cfg.dual_head:
+        hooks, cam = backbone_hooks_ext(x, W, cfg, q)
+        out = dual_head_forward(hooks, H, Wd, W, cfg, q, dbg)
+        out.update(camera_decode(cam, W, H, Wd))
+        if debug:
+            dbg["camera_feature"] = cam
+    else:
+        hooks = backbone_hooks(x, W, cfg, q)
+        act = head_forward_raw(hooks, H, Wd, W, cfg, q, dbg)
+        out = dict(depth=act[:, 0])  # select_depth_channel (dpt.rs:633-647)
     if debug:
         dbg["hooks"] = hooks
         out["debug"] = dbg

@@ -56,10 +56,11 @@ def test_inventory_matches_python(lib, cfg, scheme):
 
 
 @pytest.mark.parametrize("scheme", [Wt.INIT_REFERENCE, Wt.INIT_PARITY])
-@pytest.mark.parametrize("variant", ["metric_large", "tiny"])
+@pytest.mark.parametrize("variant", ["metric_large", "tiny", "small", "tiny_dual"])
 def test_da3_inventory_matches_python(lib, variant, scheme):
     from burn_depth_amd.config import DepthAnything3Config
-    cfg = DepthAnything3Config.metric_large() if variant == "metric_large" else DepthAnything3Config.tiny_test()
+    cfg = {"metric_large": DepthAnything3Config.metric_large, "tiny": DepthAnything3Config.tiny_test,
+           "small": DepthAnything3Config.small, "tiny_dual": DepthAnything3Config.tiny_dual_test}[variant]()
     specs = Wt.da3_param_specs(cfg, scheme)
     c = _lib.MdDa3Cfg(cfg.variant.encode(), 0, 0, 1, 1e-6)
     n = lib.md_da3_param_inventory(C.byref(c), scheme, -1, None, None, None, None)
@@ -72,9 +73,9 @@ def test_da3_inventory_matches_python(lib, variant, scheme):
         assert lo.value == np.float32(s.lo) and hi.value == np.float32(s.hi), s.name
 
 
-def test_da3_small_variant_is_reported_unsupported(lib):
-    c = _lib.MdDa3Cfg(b"small", 0, 0, 1, 1e-6)
-    assert lib.md_da3_param_inventory(C.byref(c), 0, -1, None, None, None, None) == _lib.MD_ERR_UNSUPPORTED
+def test_da3_unknown_variant_is_an_error(lib):
+    c = _lib.MdDa3Cfg(b"giant", 0, 0, 1, 1e-6)
+    assert lib.md_da3_param_inventory(C.byref(c), 0, -1, None, None, None, None) == _lib.MD_ERR_INVALID_ARG
 
 
 def test_unknown_preset_is_an_error_not_a_panic(lib):
