@@ -27,6 +27,12 @@ class MdError(RuntimeError):
         self.message = message
 
 
+class MdDa3Outputs(C.Structure):
+    """md_da3_outputs (include/mi_depth.h)."""
+    _fields_ = [("depth", C.c_void_p), ("depth_confidence", C.c_void_p), ("aux", C.c_void_p), ("aux_confidence", C.c_void_p),
+                ("pose_encoding", C.c_void_p), ("extrinsics", C.c_void_p), ("intrinsics", C.c_void_p)]
+
+
 class MdDa3Cfg(C.Structure):
     _fields_ = [("variant", C.c_char_p), ("image_size", C.c_int), ("precision", C.c_int), ("max_batch", C.c_int),
                 ("ln_eps", C.c_float)]
@@ -73,6 +79,7 @@ SYMBOLS = {
     "md_da3_create": (_I, [_P, C.POINTER(MdDa3Cfg), C.c_uint64, _I, C.POINTER(_P)]),
     "md_da3_load": (_I, [_P, C.POINTER(MdDa3Cfg), C.c_char_p, C.POINTER(_P)]),
     "md_da3_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "md_da3_infer_ex": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "md_da3_param_inventory": (_I, [C.POINTER(MdDa3Cfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_model_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "md_model_enable_taps": (_I, [_P, _I]),

@@ -92,7 +92,7 @@ struct GemmParams {
   // EPI_HEAD
   const float* head_w = nullptr;  // [32]
   float head_b = 0.f;
-  int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear
+  int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear, 3 exp + 1 (DA3 confidence, dpt.rs:497)
 };
 
 enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_256x256_V2 = 4, TILE_256x256_PP32 = 5, TILE_AUTO = 99 };

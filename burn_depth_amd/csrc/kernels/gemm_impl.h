@@ -464,7 +464,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
         const int m = m_base + wm * WTM + b * 32 + (lane & 31);
         if (h == 0 && m < m_end) {
           const float z = part + p.head_b;
-          ((float*)p.out)[m] = p.head_act == 1 ? expf(z) : (p.head_act == 2 ? z : fmaxf(z, 0.f));
+          ((float*)p.out)[m] = p.head_act == 1 ? expf(z) : (p.head_act == 2 ? z : (p.head_act == 3 ? expf(z) + 1.0f : fmaxf(z, 0.f)));
         }
       }
     }

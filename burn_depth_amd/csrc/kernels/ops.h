@@ -72,6 +72,23 @@ int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStre
 int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
                        const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s);
 
+// ---- Depth-Anything-v3 `small` backbone extras (burn_dino, restated -- see oracle/da3_ref.py) ----
+// Per-head affine LayerNorm(64) of q and k followed by the 2-D rotary embedding, in place on qk [rows, 2D] T.
+// rope_cos/rope_sin: [max_pos + 1][16] tables (angle = pos * base^(-f/16)). global_pos: every patch at (1,1).
+int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int heads, int pw, const float* q_gamma,
+                        const float* q_beta, const float* k_gamma, const float* k_beta, float eps, const float* rope_cos,
+                        const float* rope_sin, int global_pos, int prec, hipStream_t s);
+// x[b*S + 0, :] = src[0:D] for every sequence (the learned camera token replaces the cls slot)
+int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s);
+// hook = LayerNorm_head( cat( x_local, LayerNorm_final(x) ) ) -> T rows [rows, 2D]; optional raw token-0 concat
+// [nseq, 2D] f32 (the camera feature).
+int launch_hook_cat_ln(const float* x_local, const float* x, long rows, int S, int n_tokens, int D, const float* norm_g,
+                       const float* norm_b, float eps_final, const float* head_g, const float* head_b, float eps_head,
+                       void* out, float* cam_out, int prec, hipStream_t s);
+// pose encoding [B,9] = (t3, quat xyzw, fov_h, fov_w) -> world-to-camera extrinsics [B,3,4], intrinsics [B,3,3]
+// (camera.rs:281-416)
+int launch_pose_to_camera(const float* pose, int B, int H, int W, float* extrinsics, float* intrinsics, hipStream_t s);
+
 // fov degrees -> focal length / fovy / ratio (mod.rs:330-346, 370-414). All [B] f32.
 int launch_fov_post(const float* fov_deg, int B, int H, int W, float* focal_px, float* fovy_rad, float* ratio,
                     hipStream_t s);

@@ -711,6 +711,204 @@ int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depth-Anything-v3 `small` backbone extras (restated from the public DA3 definition; oracle/da3_ref.py)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, long rows, int S, int NT, int D, int heads,
+                                                           int pw, const float* __restrict__ qg,
+                                                           const float* __restrict__ qb, const float* __restrict__ kg,
+                                                           const float* __restrict__ kb, float eps,
+                                                           const float* __restrict__ rope_cos,
+                                                           const float* __restrict__ rope_sin, int global_pos) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long total = rows * heads * 2;
+  for (long e = wave_id; e < total; e += nwaves) {
+    const int which = (int)(e & 1);
+    const int hd = (int)((e >> 1) % heads);
+    const long row = (e >> 1) / heads;
+    const int t = (int)(row % S);
+    if (t >= NT) continue;  // wave-uniform
+    T* p = qk + row * 2L * D + (long)which * D + hd * 64 + lane;
+    float v;
+    if constexpr (sizeof(T) == 4)
+      v = *(const float*)p;
+    else
+      v = (float)*(const __bf16*)p;
+    const float mean = wave_sum(v) * (1.0f / 64.0f);
+    const float c = v - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum(c * c) * (1.0f / 64.0f) + eps);
+    const float y = c * rstd * (which ? kg[lane] : qg[lane]) + (which ? kb[lane] : qb[lane]);
+    int py = 0, px = 0;
+    if (t > 0) {
+      if (global_pos) {
+        py = px = 1;
+      } else {
+        const int pi = t - 1;
+        py = pi / pw;
+        px = pi - py * pw + 1;
+        py += 1;
+      }
+    }
+    const int pos = (lane >> 5) ? px : py;  // first half of head_dim rotates with the row, second with the column
+    const int jj = lane & 31, f = jj & 15;
+    const float cs = rope_cos[pos * 16 + f], sn = rope_sin[pos * 16 + f];
+    const float partner = __shfl_xor(y, 16);
+    const float o = jj < 16 ? y * cs - partner * sn : y * cs + partner * sn;
+    if constexpr (sizeof(T) == 4)
+      *(float*)p = o;
+    else
+      *(__bf16*)p = (__bf16)o;
+  }
+}
+
+int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int heads, int pw, const float* q_gamma,
+                        const float* q_beta, const float* k_gamma, const float* k_beta, float eps, const float* rope_cos,
+                        const float* rope_sin, int global_pos, int prec, hipStream_t s) {
+  if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "qk_norm_rope: head_dim must be 64");
+  const int grid = grid_for(rows * heads * 2 * 64);
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(qk_norm_rope_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)qk, rows, S, n_tokens, D, heads, pw,
+                       q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos);
+  else
+    hipLaunchKernelGGL(qk_norm_rope_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)qk, rows, S, n_tokens, D, heads,
+                       pw, q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+__global__ void set_token0_kernel(float* __restrict__ x, int nseq, int S, int D, const float* __restrict__ src) {
+  const long total = (long)nseq * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / D), d = (int)(i - (long)b * D);
+    x[(long)b * S * D + d] = src[d];
+  }
+}
+
+int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s) {
+  hipLaunchKernelGGL(set_token0_kernel, dim3(grid_for((long)nseq * D)), dim3(256), 0, s, x, nseq, S, D, src);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void hook_cat_ln_kernel(const float* __restrict__ xl, const float* __restrict__ x,
+                                                          long rows, int S, int NT, int D, const float* __restrict__ ng,
+                                                          const float* __restrict__ nb, float eps_final,
+                                                          const float* __restrict__ hg, const float* __restrict__ hb,
+                                                          float eps_head, TO* __restrict__ out,
+                                                          float* __restrict__ cam_out) {
+  constexpr int MAXV = 16;  // D <= 1024
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int nv = D >> 6;
+  for (long row = wave_id; row < rows; row += nwaves) {
+    const int t = (int)(row % S);
+    if (t >= NT) continue;
+    float a[MAXV], b[MAXV];
+    float sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+      if (k < nv) {
+        a[k] = xl[row * D + lane + 64 * k];
+        b[k] = x[row * D + lane + 64 * k];
+        sb += b[k];
+      }
+    if (cam_out && t == 0) {
+      const long sq = row / S;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k)
+        if (k < nv) {
+          cam_out[sq * 2 * D + lane + 64 * k] = a[k];
+          cam_out[sq * 2 * D + D + lane + 64 * k] = b[k];
+        }
+    }
+    const float mb = wave_sum(sb) / (float)D;
+    float qb = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+      if (k < nv) qb += (b[k] - mb) * (b[k] - mb);
+    const float rb = 1.0f / sqrtf(wave_sum(qb) / (float)D + eps_final);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+      if (k < nv) {
+        b[k] = (b[k] - mb) * rb * ng[lane + 64 * k] + nb[lane + 64 * k];
+        sum += a[k] + b[k];
+      }
+    const float mean = wave_sum(sum) / (float)(2 * D);
+    float sq2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+      if (k < nv) sq2 += (a[k] - mean) * (a[k] - mean) + (b[k] - mean) * (b[k] - mean);
+    const float rstd = 1.0f / sqrtf(wave_sum(sq2) / (float)(2 * D) + eps_head);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+      if (k < nv) {
+        const int i = lane + 64 * k;
+        const float y1 = (a[k] - mean) * rstd * hg[i] + hb[i];
+        const float y2 = (b[k] - mean) * rstd * hg[D + i] + hb[D + i];
+        if constexpr (sizeof(TO) == 4) {
+          ((float*)out)[row * 2 * D + i] = y1;
+          ((float*)out)[row * 2 * D + D + i] = y2;
+        } else {
+          *((__bf16*)out + row * 2 * D + i) = (__bf16)y1;
+          *((__bf16*)out + row * 2 * D + D + i) = (__bf16)y2;
+        }
+      }
+  }
+}
+
+int launch_hook_cat_ln(const float* x_local, const float* x, long rows, int S, int n_tokens, int D, const float* norm_g,
+                       const float* norm_b, float eps_final, const float* head_g, const float* head_b, float eps_head,
+                       void* out, float* cam_out, int prec, hipStream_t s) {
+  if (D % 64 != 0 || D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "hook_cat_ln: D=%d must be a multiple of 64 and <= 1024", D);
+  const int grid = grid_for(rows * 64);
+  if (prec == MD_PREC_F32)
+    hipLaunchKernelGGL(hook_cat_ln_kernel<float>, dim3(grid), dim3(256), 0, s, x_local, x, rows, S, n_tokens, D, norm_g,
+                       norm_b, eps_final, head_g, head_b, eps_head, (float*)out, cam_out);
+  else
+    hipLaunchKernelGGL(hook_cat_ln_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x_local, x, rows, S, n_tokens, D, norm_g,
+                       norm_b, eps_final, head_g, head_b, eps_head, (bf16_t*)out, cam_out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+__global__ void pose_to_camera_kernel(const float* __restrict__ pose, int B, int H, int W, float* __restrict__ extr,
+                                      float* __restrict__ intr) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* p = pose + b * 9;
+  const float tx = p[0], ty = p[1], tz = p[2], x = p[3], y = p[4], z = p[5], w = p[6], fh = p[7], fw = p[8];
+  // quaternion_to_matrix (camera.rs:360-416), no normalisation, as in the reference
+  float R[3][3];
+  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - w * z); R[0][2] = 2.f * (x * z + w * y);
+  R[1][0] = 2.f * (x * y + w * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - w * x);
+  R[2][0] = 2.f * (x * z - w * y); R[2][1] = 2.f * (y * z + w * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+  float* e = extr + b * 12;
+  for (int i = 0; i < 3; ++i) {  // [R^T | -R^T t]
+    const float r0 = R[0][i], r1 = R[1][i], r2 = R[2][i];
+    e[i * 4 + 0] = r0; e[i * 4 + 1] = r1; e[i * 4 + 2] = r2;
+    e[i * 4 + 3] = -(r0 * tx + r1 * ty + r2 * tz);
+  }
+  const float th = sinf(fh * 0.5f) / cosf(fh * 0.5f), tw = sinf(fw * 0.5f) / cosf(fw * 0.5f);
+  const float hh = (float)H / 2.0f, wh = (float)W / 2.0f;
+  float* k = intr + b * 9;
+  k[0] = wh / tw; k[1] = 0.f; k[2] = wh;
+  k[3] = 0.f; k[4] = hh / th; k[5] = hh;
+  k[6] = 0.f; k[7] = 0.f; k[8] = 1.f;
+}
+
+int launch_pose_to_camera(const float* pose, int B, int H, int W, float* extrinsics, float* intrinsics, hipStream_t s) {
+  hipLaunchKernelGGL(pose_to_camera_kernel, dim3((B + 63) / 64), dim3(64), 0, s, pose, B, H, W, extrinsics, intrinsics);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a12/a13 scalar tail (depth_pro/mod.rs:330-346, 370-414)
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline void fov_scalar_math(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad,

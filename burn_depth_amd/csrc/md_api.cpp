@@ -690,6 +690,15 @@ int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_ki
   return da3_infer(m, nchw, B, H, W, in_kind, depth, out_kind, (hipStream_t)stream);
 }
 
+int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const md_da3_outputs* out, int out_kind,
+                    void* stream) {
+  if (!out) MD_FAIL(MD_ERR_INVALID_ARG, "outputs struct is null");
+  Da3Outputs o;
+  o.depth = out->depth; o.depth_confidence = out->depth_confidence; o.aux = out->aux; o.aux_confidence = out->aux_confidence;
+  o.pose_encoding = out->pose_encoding; o.extrinsics = out->extrinsics; o.intrinsics = out->intrinsics;
+  return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
+}
+
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count, float* lo,
                            float* hi) {
   Da3Cfg dc;

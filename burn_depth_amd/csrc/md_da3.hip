@@ -1,4 +1,7 @@
-// Depth-Anything-v3 `metric_large` (ViT-L/14 backbone + mono DPT head) on the same kernel set.
+// Depth-Anything-v3 on the same kernel set: `metric_large` (ViT-L/14 + mono DPT head) and `small` (ViT-S/14 with
+// the burn_dino extras -- QK-norm, 2-D RoPE, local/global alternation, camera token, concatenated hooks -- + dual
+// DPT head with the aux/ray branch + camera decoder; reference: mod.rs:158-216, dpt.rs:153-513, camera.rs:113-199,
+// 281-416; the backbone extras are restated from the public model, see oracle/da3_ref.py).
 //
 // reference: src/model/depth_anything3/mod.rs:288-291,495-624 (infer), dpt.rs:515-731 (mono head),
 // dpt.rs:784-932 (UV position embedding), dpt.rs:1194-1301 (fusion blocks), interpolate.rs:7-47.
@@ -36,6 +39,16 @@ struct md_model_s::Da3State {
   std::map<int, int*> tok_index;      // per B: [B*P] -> row b*SS + 1 + p
   float* pos_used = nullptr;          // [NT, D] position embedding for this grid (interpolated when ph != native)
   int native_grid = 0;
+  // ---- `small` (dual head) ----
+  std::string hp = "head_mono";       // head parameter prefix
+  int din = 0;                        // head input width: D (mono) or 2D (concatenated hooks)
+  float* xlocal = nullptr;            // [rows, D] fp32: residual stream after the last LOCAL block
+  float* rope_cos = nullptr;          // [max_pos + 1][16]
+  float* rope_sin = nullptr;
+  float *cam_raw = nullptr, *cam_h1 = nullptr, *cam_h2 = nullptr, *pose = nullptr, *extr = nullptr, *intr = nullptr;
+  float* pos_aux = nullptr;           // f32 [8ph*8pw, F/2] = 2 * 0.1 * UV table (added twice, dpt.rs:428-435)
+  float *conf_stage = nullptr, *aux_stage = nullptr;  // device staging when the caller wants host outputs
+  std::vector<float> main_bias, aux_bias;             // output_conv2.conv2.bias, output_conv2_aux.<last>.project.bias
 };
 
 namespace md {
@@ -126,6 +139,16 @@ static std::vector<float> interpolate_pos_embed(const std::vector<float>& pos, i
 int da3_on_commit(md_model_t m) {
   md_model_s::Da3State* d = m->da3;
   const int D = d->cfg.vit.D, M = d->native_grid;
+  {
+    const Da3Cfg& c = d->cfg;
+    d->main_bias.assign(c.output_dim, 0.f);
+    MD_HIP(hipMemcpy(d->main_bias.data(), P32(m, d->hp + ".scratch.output_conv2.conv2.bias"), c.output_dim * 4, hipMemcpyDeviceToHost));
+    if (c.dual_head) {
+      d->aux_bias.assign(c.aux_output_dim, 0.f);
+      MD_HIP(hipMemcpy(d->aux_bias.data(), P32(m, d->hp + ".scratch.output_conv2_aux." + std::to_string(c.aux_levels - 1) + ".project.bias"),
+                       c.aux_output_dim * 4, hipMemcpyDeviceToHost));
+    }
+  }
   const float* pos_param = P32(m, "backbone.pretrained.pos_embed");
   if (d->ph == M && d->pw == M) {
     d->vit.pos = pos_param;
@@ -162,6 +185,7 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   const int ph = d->ph, pw = d->pw, h3 = d->h3;
   const size_t P = d->P;
   auto cp = [&](int ch) { return (size_t)round_up(ch, m->ke); };
+  (void)S;
   DA3_TAKE(xin, float*, (size_t)B * 3 * S * S * 4);
   DA3_TAKE(patches, void*, (size_t)B * P * d->Kp * esz);
   DA3_TAKE(xres, float*, rows * D * 4);
@@ -172,7 +196,21 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   DA3_TAKE(ao, void*, rows * D * esz);
   DA3_TAKE(hbuf, void*, rows * 4 * D * esz);
   if (m->prec == MD_PREC_F32) DA3_TAKE(scores, float*, (size_t)B * c.vit.heads * d->SS * d->kpad * 4);
-  for (int s = 0; s < 4; ++s) DA3_TAKE(hookn[s], void*, rows * D * esz);
+  for (int s = 0; s < 4; ++s) DA3_TAKE(hookn[s], void*, rows * d->din * esz);
+  if (c.dual_head) {
+    DA3_TAKE(xlocal, float*, rows * D * 4);
+    DA3_TAKE(rope_cos, float*, (size_t)(std::max(ph, pw) + 2) * 16 * 4);
+    DA3_TAKE(rope_sin, float*, (size_t)(std::max(ph, pw) + 2) * 16 * 4);
+    DA3_TAKE(cam_raw, float*, (size_t)B * d->din * 4);
+    DA3_TAKE(cam_h1, float*, (size_t)B * d->din * 4);
+    DA3_TAKE(cam_h2, float*, (size_t)B * d->din * 4);
+    DA3_TAKE(pose, float*, (size_t)B * 9 * 4);
+    DA3_TAKE(extr, float*, (size_t)B * 12 * 4);
+    DA3_TAKE(intr, float*, (size_t)B * 9 * 4);
+    DA3_TAKE(pos_aux, float*, (size_t)64 * ph * pw * (F / 2) * 4);
+    DA3_TAKE(conf_stage, float*, (size_t)B * S * S * 4);
+    DA3_TAKE(aux_stage, float*, (size_t)B * c.aux_output_dim * 64 * ph * pw * 4);
+  }
   const size_t px[4] = {(size_t)16 * ph * pw, (size_t)4 * ph * pw, (size_t)ph * pw, (size_t)h3 * h3};
   for (int s = 0; s < 4; ++s) {
     DA3_TAKE(sp[s], void*, (size_t)B * P * cp(oc[s]) * esz);
@@ -202,9 +240,12 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   const ViTDims& v = cfg.vit;
   if (v.D != v.heads * 64 || v.D % 64 != 0 || v.D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "ViT width %d / heads %d unsupported", v.D, v.heads);
   if (cfg.image_size % v.ps != 0) MD_FAIL(MD_ERR_SHAPE, "image size %d must be divisible by patch size %d", cfg.image_size, v.ps);
-  if (cfg.features % 64 != 0 || cfg.output_dim != 1) MD_FAIL(MD_ERR_UNSUPPORTED, "head features %d / output_dim %d unsupported", cfg.features, cfg.output_dim);
+  if (cfg.features % 64 != 0 || cfg.output_dim != (cfg.dual_head ? 2 : 1))
+    MD_FAIL(MD_ERR_UNSUPPORTED, "head features %d / output_dim %d unsupported", cfg.features, cfg.output_dim);
   for (int s = 0; s < 4; ++s)
-    if (cfg.out_channels[s] % 64 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "head out_channels must be multiples of 64");
+    if (cfg.out_channels[s] % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "head out_channels must be multiples of 4");
+  if (cfg.dual_head && (cfg.ext_block_start < 0 || cfg.ext_block_start >= v.depth))
+    MD_FAIL(MD_ERR_INVALID_ARG, "dual head needs the extended backbone (ext_block_start %d)", cfg.ext_block_start);
   MD_HIP(hipSetDevice(dev->ordinal));
   md_model_s* m = new md_model_s();
   m->dev = dev;
@@ -217,6 +258,8 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   m->da3 = new md_model_s::Da3State();
   md_model_s::Da3State* d = m->da3;
   d->cfg = cfg;
+  d->hp = cfg.dual_head ? "head_dual" : "head_mono";
+  d->din = cfg.dual_head ? 2 * v.D : v.D;
   d->native_grid = v.img / v.ps;  // the pos_embed parameter's grid (37 for ViT-L/14 @ 518)
   d->ph = d->pw = cfg.image_size / v.ps;
   d->P = d->ph * d->pw;
@@ -258,21 +301,35 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
     add_pack(m, b + ".mlp.fc1.weight", PACK_NK, 4 * D, D, 1);
     add_pack(m, b + ".mlp.fc2.weight", PACK_NK, D, 4 * D, 1);
   }
-  for (int s = 0; s < 4; ++s) add_pack(m, "head_mono.projects." + std::to_string(s) + ".weight", PACK_NK, oc[s], D, 1);
-  add_pack(m, "head_mono.resize_layers.0.conv_t.weight", PACK_DECONV, oc[0], oc[0], 4);
-  add_pack(m, "head_mono.resize_layers.1.conv_t.weight", PACK_DECONV, oc[1], oc[1], 2);
-  add_pack(m, "head_mono.resize_layers.3.conv.weight", PACK_CONV3, oc[3], oc[3], 3);
-  for (int s = 0; s < 4; ++s) add_pack(m, "head_mono.scratch.layer" + std::to_string(s + 1) + "_rn.weight", PACK_CONV3, F, oc[s], 3);
-  for (int i = 1; i <= 4; ++i) {
-    const std::string r = "head_mono.scratch.refinenet" + std::to_string(i);
-    for (const char* u : {"residual1", "residual2"}) {
-      add_pack(m, r + "." + u + ".conv1.weight", PACK_CONV3, F, F, 3);
-      add_pack(m, r + "." + u + ".conv2.weight", PACK_CONV3, F, F, 3);
+  const std::string hp = d->hp;
+  for (int s = 0; s < 4; ++s) add_pack(m, hp + ".projects." + std::to_string(s) + ".weight", PACK_NK, oc[s], d->din, 1);
+  add_pack(m, hp + ".resize_layers.0.conv_t.weight", PACK_DECONV, oc[0], oc[0], 4);
+  add_pack(m, hp + ".resize_layers.1.conv_t.weight", PACK_DECONV, oc[1], oc[1], 2);
+  add_pack(m, hp + ".resize_layers.3.conv.weight", PACK_CONV3, oc[3], oc[3], 3);
+  for (int s = 0; s < 4; ++s) add_pack(m, hp + ".scratch.layer" + std::to_string(s + 1) + "_rn.weight", PACK_CONV3, F, oc[s], 3);
+  for (const char* suffix : {"", "_aux"}) {
+    if (suffix[0] && !cfg.dual_head) continue;
+    for (int i = 1; i <= 4; ++i) {
+      const std::string r = hp + ".scratch.refinenet" + std::to_string(i) + suffix;
+      for (const char* u : {"residual1", "residual2"}) {
+        add_pack(m, r + "." + u + ".conv1.weight", PACK_CONV3, F, F, 3);
+        add_pack(m, r + "." + u + ".conv2.weight", PACK_CONV3, F, F, 3);
+      }
+      add_pack(m, r + ".out_conv.weight", PACK_NK, F, F, 1);
     }
-    add_pack(m, r + ".out_conv.weight", PACK_NK, F, F, 1);
   }
-  add_pack(m, "head_mono.scratch.output_conv1.weight", PACK_CONV3, F / 2, F, 3);
-  add_pack(m, "head_mono.scratch.output_conv2.conv1.weight", PACK_CONV3, 32, F / 2, 3);
+  add_pack(m, hp + ".scratch.output_conv1.weight", PACK_CONV3, F / 2, F, 3);
+  add_pack(m, hp + ".scratch.output_conv2.conv1.weight", PACK_CONV3, 32, F / 2, 3);
+  if (cfg.dual_head) {  // only the last aux level reaches the outputs (build_aux_logits, dpt.rs:405-440)
+    const std::string lv = std::to_string(cfg.aux_levels - 1);
+    int cin = F;
+    for (int j = 0; j < cfg.aux_out1_conv_num; ++j) {
+      const int cout = j % 2 == 0 ? F / 2 : F;
+      add_pack(m, hp + ".scratch.output_conv1_aux." + lv + ".layers." + std::to_string(j) + ".weight", PACK_CONV3, cout, cin, 3);
+      cin = cout;
+    }
+    add_pack(m, hp + ".scratch.output_conv2_aux." + lv + ".reduce.weight", PACK_CONV3, 32, F / 2, 3);
+  }
   size_t poff = 0;
   for (auto& e : m->packs) {
     e.dst = (void*)poff;
@@ -338,6 +395,24 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
     std::vector<float> t = build_pos_table_nhwc(F / 2, S, S, S, S, 0.1f);
     if (hipMemcpy(d->pos_final, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
     (void)hipFree(tmp);
+    if (cfg.dual_head) {
+      // aux head input = neck + 0.1*UV + 0.1*UV (added twice, dpt.rs:428-435)
+      std::vector<float> ta = build_pos_table_nhwc(F / 2, 8 * d->ph, 8 * d->pw, S, S, 0.1f);
+      for (auto& x : ta) x = x + x;
+      if (hipMemcpy(d->pos_aux, ta.data(), ta.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
+      // 2-D RoPE tables: angle(pos, f) = pos * base^(-2f/32), f < 16 (fp32 like the oracle)
+      const int npos = std::max(d->ph, d->pw) + 2;
+      std::vector<float> rc((size_t)npos * 16), rs((size_t)npos * 16);
+      for (int pz = 0; pz < npos; ++pz)
+        for (int f = 0; f < 16; ++f) {
+          const float inv = 1.0f / powf(cfg.rope_frequency, (float)(2 * f) / 32.0f);
+          const float ang = (float)pz * inv;
+          rc[(size_t)pz * 16 + f] = cosf(ang);
+          rs[(size_t)pz * 16 + f] = sinf(ang);
+        }
+      if (hipMemcpy(d->rope_cos, rc.data(), rc.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
+      if (hipMemcpy(d->rope_sin, rs.data(), rs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
+    }
   }
   (void)hipDeviceSynchronize();
   *out = m;
@@ -390,31 +465,37 @@ static int da3_tok_index(md_model_s* m, int B, int** out) {
   return MD_OK;
 }
 
-int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
-              hipStream_t stream) {
+int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& outp, int out_kind,
+                 hipStream_t stream) {
   if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
   if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
-  if (!nchw || !depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
+  if (!nchw || !outp.depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
   md_model_s::Da3State* d = m->da3;
   const Da3Cfg& c = d->cfg;
   const ViTDims& v = c.vit;
+  if (!c.dual_head && (outp.depth_confidence || outp.aux || outp.aux_confidence || outp.pose_encoding || outp.extrinsics || outp.intrinsics))
+    MD_FAIL(MD_ERR_UNSUPPORTED, "the mono head produces depth only (finalize_inference, mod.rs:587-624)");
   if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
   if (H % v.ps != 0 || W % v.ps != 0)  // depth_anything3/mod.rs:509-520 (assert -> checked precondition)
     MD_FAIL(MD_ERR_SHAPE, "Input %dx%d must be divisible by patch size %d", H, W, v.ps);
   if (H != c.image_size || W != c.image_size)
-    MD_FAIL(MD_ERR_UNSUPPORTED, "only %dx%d inputs are supported so far (no position-embedding interpolation)", c.image_size, c.image_size);
+    MD_FAIL(MD_ERR_UNSUPPORTED, "only %dx%d inputs are supported (the model was created for that size)", c.image_size, c.image_size);
   if (B > c.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, c.max_batch);
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t st = stream ? stream : m->dev->stream;
   Run r{m, st, B};
   const int D = v.D, heads = v.heads, SS = d->SS, NT = d->NT, P = d->P, ph = d->ph, pw = d->pw, F = c.features, S = c.image_size;
+  const int din = d->din;
   const int* oc = c.out_channels;
   const int Fp = cpad(m, F), F2 = F / 2, F2p = cpad(m, F2);
+  const std::string hp = d->hp, bp = "backbone.pretrained";
   const float* x_dev = nchw;
   if (in_kind == MD_MEM_HOST) {
     MD_HIP(hipMemcpyAsync(d->xin, nchw, (size_t)B * 3 * H * W * 4, hipMemcpyHostToDevice, st));
     x_dev = d->xin;
   }
+  auto Wk = [&](const std::string& n) { return PK(m, n); };
+  auto Bi = [&](const std::string& n) { return P32(m, n); };
   // ---- backbone ----
   r.begin("patchify");
   MD_TRY(launch_patchify(x_dev, B, H, W, v.ps, d->Kp, d->patches, m->prec, st));
@@ -440,8 +521,15 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
   const long rows = (long)B * SS;
   auto dense = [&](GemmParams& p) { p.ngroups = 1; p.g_rows[0] = (int)rows; };
   int hook_slot = 0;
+  const int ext0 = c.dual_head ? c.ext_block_start : v.depth + 1;
   for (int i = 0; i < v.depth; ++i) {
     const VitBlockW& k = d->vit.blk[i];
+    const bool ext = i >= ext0, is_global = ext && (i % 2 == 1);
+    if (i == ext0) {  // the learned reference-view camera token takes the cls slot (single view)
+      r.begin("camera_token");
+      MD_TRY(launch_set_token0(d->xres, B, SS, D, Bi(bp + ".camera_token"), st));
+      r.end();
+    }
     sg.a[0] = k.n1g; sg.b[0] = k.n1b;
     r.begin("layernorm");
     MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, st));
@@ -452,6 +540,14 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
       p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad;
       r.begin("qkv_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      r.end();
+    }
+    if (ext) {  // per-head q/k LayerNorm + 2-D RoPE (global blocks: every patch at position (1,1))
+      const std::string a = bp + ".blocks." + std::to_string(i) + ".attn.";
+      r.begin("qk_norm_rope");
+      MD_TRY(launch_qk_norm_rope(d->qk, rows, SS, NT, D, heads, pw, Bi(a + "q_norm.gamma"), Bi(a + "q_norm.beta"),
+                                 Bi(a + "k_norm.gamma"), Bi(a + "k_norm.beta"), c.qk_norm_eps, d->rope_cos, d->rope_sin,
+                                 is_global ? 1 : 0, m->prec, st));
       r.end();
     }
     if (m->prec == MD_PREC_BF16) {
@@ -508,36 +604,57 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
       r.end();
     }
-    // hooks (mod.rs:202-215): final LayerNorm of the block output, then the head's non-affine token
-    // norm (apply_token_norm, dpt.rs:761-766: biased variance, eps 1e-5). A block may feed several hooks.
-    for (int hk = 0; hk < 4; ++hk)
-      if (c.hook_ids[hk] == i) {
-        sg.a[0] = d->vit.norm_g; sg.b[0] = d->vit.norm_b;
-        r.begin("layernorm");
-        MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
+    if (c.dual_head) {
+      // hooks = LayerNorm_head(cat(x after the last local block, LayerNorm_final(x))); the camera feature is
+      // token 0 of the raw concat at the last hook
+      bool hooked = false;
+      for (int hk = 0; hk < 4; ++hk) hooked |= c.hook_ids[hk] == i;
+      const bool next_needs_local = !is_global && i + 1 < v.depth;
+      const float* xl = is_global ? d->xlocal : d->xres;  // a local block is its own "last local" state
+      for (int hk = 0; hk < 4; ++hk)
+        if (c.hook_ids[hk] == i) {
+          r.begin("hook_cat_ln");
+          MD_TRY(launch_hook_cat_ln(xl, d->xres, rows, SS, NT, D, d->vit.norm_g, d->vit.norm_b, c.ln_eps, Bi(hp + ".norm.gamma"),
+                                    Bi(hp + ".norm.beta"), 1e-5f, d->hookn[hk], hk == 3 ? d->cam_raw : nullptr, m->prec, st));
+          r.end();
+          ++hook_slot;
+        }
+      (void)hooked;
+      if (next_needs_local && i + 1 >= ext0 && ((i + 1) % 2 == 1)) {  // the next block is global: keep this x
+        r.begin("keep_local");
+        MD_HIP(hipMemcpyAsync(d->xlocal, d->xres, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st));
         r.end();
-        sg.a[0] = nullptr; sg.b[0] = nullptr;
-        r.begin("layernorm");
-        MD_TRY(launch_layernorm(d->lnf, d->hookn[hk], rows, D, 1e-5f, SS, sg, m->prec, 0, st));
-        r.end();
-        ++hook_slot;
       }
+    } else {
+      // hooks (mod.rs:202-215): final LayerNorm of the block output, then the head's non-affine token
+      // norm (apply_token_norm, dpt.rs:761-766: biased variance, eps 1e-5). A block may feed several hooks.
+      for (int hk = 0; hk < 4; ++hk)
+        if (c.hook_ids[hk] == i) {
+          sg.a[0] = d->vit.norm_g; sg.b[0] = d->vit.norm_b;
+          r.begin("layernorm");
+          MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
+          r.end();
+          sg.a[0] = nullptr; sg.b[0] = nullptr;
+          r.begin("layernorm");
+          MD_TRY(launch_layernorm(d->lnf, d->hookn[hk], rows, D, 1e-5f, SS, sg, m->prec, 0, st));
+          r.end();
+          ++hook_slot;
+        }
+    }
   }
   if (hook_slot < 4) MD_FAIL(MD_ERR_LEVELS, "Backbone returned fewer hooks (%d) than requested (4)", hook_slot);  // mod.rs:532-537
 
-  // ---- mono DPT head (dpt.rs:587-631) ----
+  // ---- DPT head: prepare_stage (dpt.rs:282-317 / 649-689) ----
   int* tok_idx = nullptr;
   MD_TRY(da3_tok_index(m, B, &tok_idx));
-  auto Wk = [&](const std::string& n) { return PK(m, n); };
-  auto Bi = [&](const std::string& n) { return P32(m, n); };
   const int sh[4] = {4 * ph, 2 * ph, ph, d->h3};  // stage spatial sizes (square)
   for (int s = 0; s < 4; ++s) {
     const int ocp = cpad(m, oc[s]);
-    const std::string ps = "head_mono.projects." + std::to_string(s);
-    {  // 1x1 projection over gathered patch tokens + 0.1 * UV position table (prepare_stage, dpt.rs:649-689)
+    const std::string ps = hp + ".projects." + std::to_string(s);
+    {  // 1x1 projection over gathered patch tokens + 0.1 * UV position table
       GemmParams p;
-      p.N = oc[s]; p.K = D; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(ps + ".weight"); p.bias[0] = Bi(ps + ".bias");
-      p.A = d->hookn[s]; p.lda = D; p.a_index = tok_idx;
+      p.N = oc[s]; p.K = din; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(ps + ".weight"); p.bias[0] = Bi(ps + ".bias");
+      p.A = d->hookn[s]; p.lda = din; p.a_index = tok_idx;
       p.epi = EPI_STORE; p.out = d->sp[s]; p.ldo = ocp; p.res1 = d->pos_stage[s]; p.ldr = ocp; p.res_mod = P;
       r.begin("head_proj");
       MD_TRY(launch_gemm(p, A_INDEXED, m->prec, TILE_AUTO, st));
@@ -546,7 +663,7 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
     const void* feat = d->sp[s];
     if (s == 0 || s == 1) {  // ConvTranspose k4s4 / k2s2 (+bias)
       const int f = s == 0 ? 4 : 2;
-      const std::string rl = "head_mono.resize_layers." + std::to_string(s) + ".conv_t";
+      const std::string rl = hp + ".resize_layers." + std::to_string(s) + ".conv_t";
       GemmParams p;
       p.N = f * f * oc[s]; p.K = ocp; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(rl + ".weight"); p.bias[0] = Bi(rl + ".bias");
       p.A = d->sp[s]; p.lda = ocp;
@@ -558,7 +675,7 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
     } else if (s == 3) {  // Conv2d 3x3 stride 2 pad 1 (+bias)
       GemmParams p;
       p.N = oc[3]; p.K = 9 * ocp; p.ngroups = 1; p.g_rows[0] = B * d->h3 * d->h3;
-      p.W[0] = Wk("head_mono.resize_layers.3.conv.weight"); p.bias[0] = Bi("head_mono.resize_layers.3.conv.bias");
+      p.W[0] = Wk(hp + ".resize_layers.3.conv.weight"); p.bias[0] = Bi(hp + ".resize_layers.3.conv.bias");
       p.A = d->sp[3]; p.cH = ph; p.cW = pw; p.cC = ocp; p.cOH = d->h3; p.cOW = d->h3; p.cstride = 2; p.zero_page = m->zero_page;
       p.epi = EPI_STORE; p.out = d->sr[3]; p.ldo = ocp;
       r.begin("head_conv_s2");
@@ -567,7 +684,7 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
       feat = d->sr[3];
     }
     // layerN_rn: 3x3, no bias -> features (+ relu copy for the residual units)
-    MD_TRY(conv3(r, "head_conv3x3", feat, sh[s], sh[s], ocp, Wk("head_mono.scratch.layer" + std::to_string(s + 1) + "_rn.weight"), nullptr,
+    MD_TRY(conv3(r, "head_conv3x3", feat, sh[s], sh[s], ocp, Wk(hp + ".scratch.layer" + std::to_string(s + 1) + "_rn.weight"), nullptr,
                  F, d->rn[s], Fp, ACT_NONE, nullptr, nullptr, d->rnr[s]));
   }
   // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
@@ -577,36 +694,56 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
     return conv3(r, "head_conv3x3", d->t, hw, hw, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
                  extra, out_relu);
   };
-  // FeatureFusionBlock (dpt.rs:1206-1222); `top` comes in with no relu copy (it is only added)
-  const void* top = nullptr;
+  // the four FeatureFusionBlocks (dpt.rs:1206-1222) from the coarsest stage up; result in d->o at 8ph x 8pw
   const int target[4] = {8 * ph, 4 * ph, 2 * ph, ph};  // output size of refinenet1..4
-  for (int lvl = 3; lvl >= 0; --lvl) {
-    const std::string rf = "head_mono.scratch.refinenet" + std::to_string(lvl + 1);
-    const void *yx, *yxr;
-    if (lvl == 3) {
-      yx = d->rn[3];
-      yxr = d->rnr[3];
-    } else {
-      MD_TRY(rcu(rf + ".residual1", sh[lvl], d->rn[lvl], d->rnr[lvl], top, d->x, d->xr));
-      yx = d->x;
-      yxr = d->xr;
+  auto pyramid = [&](const std::string& suffix) -> int {
+    const void* top = nullptr;
+    for (int lvl = 3; lvl >= 0; --lvl) {
+      const std::string rf = hp + ".scratch.refinenet" + std::to_string(lvl + 1) + suffix;
+      const void *yx, *yxr;
+      if (lvl == 3) {
+        yx = d->rn[3];
+        yxr = d->rnr[3];
+      } else {
+        MD_TRY(rcu(rf + ".residual1", sh[lvl], d->rn[lvl], d->rnr[lvl], top, d->x, d->xr));
+        yx = d->x;
+        yxr = d->xr;
+      }
+      MD_TRY(rcu(rf + ".residual2", sh[lvl], yx, yxr, nullptr, d->y, nullptr));
+      r.begin("head_resize");
+      MD_TRY(launch_resize_nhwc(d->y, B, sh[lvl], sh[lvl], F, Fp, d->up, target[lvl], target[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, st));
+      r.end();
+      MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * target[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
+                       Bi(rf + ".out_conv.bias"), d->o, Fp));
+      top = d->o;
     }
-    MD_TRY(rcu(rf + ".residual2", sh[lvl], yx, yxr, nullptr, d->y, nullptr));
-    r.begin("head_resize");
-    MD_TRY(launch_resize_nhwc(d->y, B, sh[lvl], sh[lvl], F, Fp, d->up, target[lvl], target[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, st));
+    return MD_OK;
+  };
+  // fused tail: out[m] = act(w . relu(conv3x3(in) + b1) + b2) over a [B, hh, ww, 64-padded] map (ConvStack, dpt.rs:1287-1290)
+  auto tail = [&](const char* name, const void* in, int hh, int ww, const void* w1, const float* b1, const float* w2, float b2, int act,
+                  float* out) -> int {
+    GemmParams p;
+    p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = B * hh * ww; p.W[0] = w1;
+    p.A = in; p.cH = hh; p.cW = ww; p.cC = F2p; p.zero_page = m->zero_page;
+    p.epi = EPI_HEAD; p.bias[0] = b1; p.head_w = w2; p.head_b = b2; p.head_act = act; p.out = out;
+    r.begin(name);
+    int s2 = launch_gemm(p, A_CONV3, m->prec, TILE_256x32, st);
     r.end();
-    MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * target[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
-                     Bi(rf + ".out_conv.bias"), d->o, Fp));
-    top = d->o;
-  }
-  // output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + exp (fused tail)
-  MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk("head_mono.scratch.output_conv1.weight"),
-               Bi("head_mono.scratch.output_conv1.bias"), F2, d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
+    return s2;
+  };
+  auto host_out = [&](float* dst, const float* src, size_t n) -> int {
+    if (out_kind == MD_MEM_HOST && dst) MD_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToHost, st));
+    return MD_OK;
+  };
+  // ---- main branch: output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + activation ----
+  MD_TRY(pyramid(""));
+  MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk(hp + ".scratch.output_conv1.weight"),
+               Bi(hp + ".scratch.output_conv1.bias"), F2, d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
   r.begin("head_resize");
   MD_TRY(launch_resize_nhwc(d->c1, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, S, S, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
   r.end();
   const size_t out_elems = (size_t)B * S * S;
-  float* depth_dev = depth;
+  float* depth_dev = outp.depth;
   if (out_kind == MD_MEM_HOST) {
     if (d->depth_stage_elems < out_elems) {
       if (d->depth_stage) (void)hipFree(d->depth_stage);
@@ -615,22 +752,97 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
     }
     depth_dev = d->depth_stage;
   }
-  {
-    GemmParams p;
-    p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = B * S * S; p.W[0] = Wk("head_mono.scratch.output_conv2.conv1.weight");
-    p.A = d->c1r; p.cH = S; p.cW = S; p.cC = F2p; p.zero_page = m->zero_page;
-    p.epi = EPI_HEAD; p.bias[0] = Bi("head_mono.scratch.output_conv2.conv1.bias");
-    p.head_w = Bi("head_mono.scratch.output_conv2.conv2.weight"); p.head_b = m->head_b_host; p.head_act = 1;
-    p.out = depth_dev;
-    r.begin("head_tail_fused");
-    MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, st));
-    r.end();
+  const void* w1 = Wk(hp + ".scratch.output_conv2.conv1.weight");
+  const float* b1 = Bi(hp + ".scratch.output_conv2.conv1.bias");
+  const float* w2 = Bi(hp + ".scratch.output_conv2.conv2.weight");
+  MD_TRY(tail("head_tail_fused", d->c1r, S, S, w1, b1, w2, d->main_bias[0], 1, depth_dev));  // depth = exp(ch 0)
+  MD_TRY(host_out(outp.depth, depth_dev, out_elems));
+  if (c.dual_head) {
+    if (outp.depth_confidence) {  // confidence = exp(last channel) + 1 (select_conf_channel, ExpP1)
+      float* cd = out_kind == MD_MEM_HOST ? d->conf_stage : outp.depth_confidence;
+      MD_TRY(tail("head_tail_fused", d->c1r, S, S, w1, b1, w2 + 32 * (c.output_dim - 1), d->main_bias[c.output_dim - 1], 3, cd));
+      MD_TRY(host_out(outp.depth_confidence, cd, out_elems));
+    }
+    if (outp.aux || outp.aux_confidence) {
+      // aux branch (build_aux_logits, dpt.rs:356-441): aux fusion pyramid on the same layerN_rn maps -> last
+      // level's 5-conv neck -> + 2 x 0.1 x UV -> reduce 3x3 -> ReLU -> project 1x1 (7 ch: 6 ray values + conf)
+      MD_TRY(pyramid("_aux"));
+      const int ah = 8 * ph, aw = 8 * pw;
+      const std::string lv = std::to_string(c.aux_levels - 1);
+      const void* cur = d->o;
+      void* pp[2] = {d->up, d->o};
+      int cin = F;
+      for (int j = 0; j < c.aux_out1_conv_num; ++j) {
+        const int cout = j % 2 == 0 ? F / 2 : F;
+        const std::string n = hp + ".scratch.output_conv1_aux." + lv + ".layers." + std::to_string(j);
+        MD_TRY(conv3(r, "aux_conv3x3", cur, ah, aw, cpad(m, cin), Wk(n + ".weight"), Bi(n + ".bias"), cout, pp[j & 1], cpad(m, cout), ACT_NONE,
+                     nullptr, nullptr, nullptr));
+        cur = pp[j & 1];
+        cin = cout;
+      }
+      void* hin = cur == d->up ? d->o : d->up;
+      r.begin("head_resize");
+      MD_TRY(launch_resize_nhwc(cur, B, ah, aw, F2, F2p, hin, ah, aw, F2p, MD_INTERP_BURN, d->pos_aux, m->prec, st));
+      r.end();
+      const std::string oh = hp + ".scratch.output_conv2_aux." + lv;
+      const size_t plane = (size_t)ah * aw;
+      const int K7 = c.aux_output_dim;
+      for (int ch = 0; ch < K7; ++ch) {
+        const bool conf = ch == K7 - 1;
+        float* user = conf ? outp.aux_confidence : outp.aux;
+        if (!user) continue;
+        for (int b = 0; b < B; ++b) {
+          // planes are written per image so that aux lands as [B, 6, h, w] and the confidence as [B, h, w]
+          float* dst_user = conf ? user + (size_t)b * plane : user + ((size_t)b * (K7 - 1) + ch) * plane;
+          float* dst = out_kind == MD_MEM_HOST ? d->aux_stage + ((size_t)b * K7 + ch) * plane : dst_user;
+          GemmParams p;
+          p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = ah * aw; p.W[0] = Wk(oh + ".reduce.weight");
+          p.A = (const char*)hin + (size_t)b * plane * F2p * m->esz; p.cH = ah; p.cW = aw; p.cC = F2p; p.zero_page = m->zero_page;
+          p.epi = EPI_HEAD; p.bias[0] = Bi(oh + ".reduce.bias"); p.head_w = Bi(oh + ".project.weight") + 32 * ch;
+          p.head_b = d->aux_bias[ch]; p.head_act = conf ? 3 : 2; p.out = dst;
+          r.begin("aux_tail_fused");
+          MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, st));
+          r.end();
+          MD_TRY(host_out(dst_user, dst, plane));
+        }
+      }
+    }
+    if (outp.pose_encoding || outp.extrinsics || outp.intrinsics) {
+      // CameraDecoder (camera.rs:143-199) on the raw camera feature of the last hook, fp32
+      auto lin = [&](const char* n, const float* in, int cout, int relu, float* out) -> int {
+        const std::string q = std::string("camera_decoder.") + n;
+        r.begin("camera_decoder");
+        int s2 = launch_conv_direct(in, MD_PREC_F32, nullptr, B, 1, 1, din, Bi(q + ".weight"), Bi(q + ".bias"), cout, 1, 1, 0, relu, out, st);
+        r.end();
+        return s2;
+      };
+      MD_TRY(lin("backbone_1", d->cam_raw, din, 1, d->cam_h1));
+      MD_TRY(lin("backbone_2", d->cam_h1, din, 1, d->cam_h2));
+      // pose = (t3 | quat4 | relu(fov2)), assembled through a [B,9] buffer with strided outputs
+      MD_TRY(lin("fc_t", d->cam_h2, 3, 0, d->cam_h1));
+      MD_TRY(lin("fc_qvec", d->cam_h2, 4, 0, d->cam_h1 + (size_t)B * 3));
+      MD_TRY(lin("fc_fov", d->cam_h2, 2, 1, d->cam_h1 + (size_t)B * 7));
+      for (int b = 0; b < B; ++b) {
+        MD_HIP(hipMemcpyAsync(d->pose + b * 9, d->cam_h1 + b * 3, 12, hipMemcpyDeviceToDevice, st));
+        MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 3, d->cam_h1 + (size_t)B * 3 + b * 4, 16, hipMemcpyDeviceToDevice, st));
+        MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 7, d->cam_h1 + (size_t)B * 7 + b * 2, 8, hipMemcpyDeviceToDevice, st));
+      }
+      MD_TRY(launch_pose_to_camera(d->pose, B, H, W, d->extr, d->intr, st));
+      const hipMemcpyKind kk = out_kind == MD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+      if (outp.pose_encoding) MD_HIP(hipMemcpyAsync(outp.pose_encoding, d->pose, (size_t)B * 9 * 4, kk, st));
+      if (outp.extrinsics) MD_HIP(hipMemcpyAsync(outp.extrinsics, d->extr, (size_t)B * 12 * 4, kk, st));
+      if (outp.intrinsics) MD_HIP(hipMemcpyAsync(outp.intrinsics, d->intr, (size_t)B * 9 * 4, kk, st));
+    }
   }
-  if (out_kind == MD_MEM_HOST) {
-    MD_HIP(hipMemcpyAsync(depth, depth_dev, out_elems * 4, hipMemcpyDeviceToHost, st));
-    MD_HIP(hipStreamSynchronize(st));
-  }
+  if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
+}
+
+int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
+              hipStream_t stream) {
+  Da3Outputs o;
+  o.depth = depth;
+  return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, stream);
 }
 
 }  // namespace md

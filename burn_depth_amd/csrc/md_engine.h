@@ -154,6 +154,13 @@ int da3_init_seeded(md_model_t m, uint64_t seed, int scheme);
 int da3_load_container(md_model_t m, const char* path);
 int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
               hipStream_t stream);
+// DepthAnything3Inference (mod.rs:231-239); null = not wanted. aux is [B, aux_output_dim-1, 8ph, 8pw].
+struct Da3Outputs {
+  float *depth = nullptr, *depth_confidence = nullptr, *aux = nullptr, *aux_confidence = nullptr;
+  float *pose_encoding = nullptr, *extrinsics = nullptr, *intrinsics = nullptr;
+};
+int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& out, int out_kind,
+                 hipStream_t stream);
 void da3_destroy_state(md_model_t m);
 int da3_on_commit(md_model_t m);  // re-derives the (interpolated) position table from the weights
 int model_load_params_from_container(md_model_t m, const char* path);

@@ -21,7 +21,7 @@ from .depth_pro import DepthPro, Device, _stream_ptr
 
 @dataclass
 class DepthAnything3Inference:
-    """depth_anything3/mod.rs:231-239 (the mono head fills `depth` only)."""
+    """depth_anything3/mod.rs:231-239 (the mono head fills `depth` only; the dual head every field)."""
     depth: torch.Tensor
     depth_confidence: Optional[torch.Tensor] = None
     aux: Optional[torch.Tensor] = None
@@ -62,9 +62,24 @@ class DepthAnything3(DepthPro):
             raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
         x = x.contiguous().to(torch.float32)
         B, _, H, W = x.shape
-        depth = torch.empty((B, H, W), dtype=torch.float32, device=torch.device("cuda", self.device.ordinal))
-        self.infer_into(x, depth)
-        return DepthAnything3Inference(depth=depth)
+        dev = torch.device("cuda", self.device.ordinal)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        if not self.config.dual_head:
+            self.infer_into(x, depth)
+            return DepthAnything3Inference(depth=depth)
+        # dual head (`small`): every field of DepthAnything3Inference (mod.rs:231-239, 605-621)
+        ps = self.config.patch_size
+        ah, aw = 8 * (H // ps), 8 * (W // ps)
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        out = DepthAnything3Inference(depth=depth, depth_confidence=f(B, H, W), aux=f(B, self.config.aux_output_dim - 1, ah, aw),
+                                      aux_confidence=f(B, ah, aw), pose_encoding=f(B, 1, 9), extrinsics=f(B, 1, 3, 4),
+                                      intrinsics=f(B, 1, 3, 3))
+        o = _lib.MdDa3Outputs(*(t.data_ptr() for t in (out.depth, out.depth_confidence, out.aux, out.aux_confidence,
+                                                       out.pose_encoding, out.extrinsics, out.intrinsics)))
+        in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_da3_infer_ex(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind, C.byref(o), _lib.MD_MEM_DEVICE,
+                                             _stream_ptr(self.device.ordinal)))
+        return out
 
     def infer_into(self, x: torch.Tensor, depth: torch.Tensor, *unused) -> None:
         B, _, H, W = x.shape

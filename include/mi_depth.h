@@ -134,6 +134,22 @@ int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_mod
  * configured (square) image size, for which the position tables were built (else MD_ERR_UNSUPPORTED). */
 int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
                  void* stream);
+/* `DepthAnything3Inference` (depth_anything3/mod.rs:231-239) for the dual-head `small` variant. Every pointer
+ * except `depth` may be NULL (that output is then not computed). Shapes, fp32, batch-major:
+ *   depth, depth_confidence [B,H,W]; aux [B,6,8*H/14,8*W/14] (ray values); aux_confidence [B,8*H/14,8*W/14];
+ *   pose_encoding [B,1,9] = (t3 | quat xyzw | fov_h fov_w); extrinsics [B,1,3,4] (world-to-camera);
+ *   intrinsics [B,1,3,3] (camera.rs:281-358). The mono variant accepts `depth` only (else MD_ERR_UNSUPPORTED). */
+typedef struct md_da3_outputs {
+  float* depth;
+  float* depth_confidence;
+  float* aux;
+  float* aux_confidence;
+  float* pose_encoding;
+  float* extrinsics;
+  float* intrinsics;
+} md_da3_outputs;
+int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const md_da3_outputs* out,
+                    int out_kind, void* stream);
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,
                            float* lo, float* hi);
 

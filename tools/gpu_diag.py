@@ -284,7 +284,8 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY):
     model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=scheme)
     print(f"      da3 model created in {time.time() - t0:.1f}s  workspace={model.query('workspace_bytes') / 1e9:.2f} GB", flush=True)
     W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, scheme))
-    for n in ("backbone.pretrained.blocks.0.attn.qkv.weight", "head_mono.resize_layers.0.conv_t.weight", "head_mono.scratch.output_conv2.conv2.weight"):
+    hp = "head_dual" if cfg.dual_head else "head_mono"
+    for n in ("backbone.pretrained.blocks.0.attn.qkv.weight", f"{hp}.resize_layers.0.conv_t.weight", f"{hp}.scratch.output_conv2.conv2.weight"):
         got = model.get_tensor(n, W[n].numel())
         record(f"{label} seeded weight {n.split('.')[-3]}.{n.split('.')[-1]}", float(np.abs(got - W[n].numpy().reshape(-1)).max()), 0.0)
     torch.manual_seed(1)
@@ -300,6 +301,21 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY):
     tol = (8e-2, 1e-2) if precision == Precision.BF16 else (1e-3, 1e-4)
     record(f"{label} depth max-rel vs fp32 oracle", rel.max().item(), tol[0], f"mean-rel={rel.mean().item():.2e} depth in [{rd.min():.3f},{rd.max():.3f}]")
     record(f"{label} depth mean-rel vs fp32 oracle", rel.mean().item(), tol[1])
+    if cfg.dual_head:  # every other field of DepthAnything3Inference (mod.rs:231-239)
+        bf = precision == Precision.BF16
+        for name, rt, at in (("depth_confidence", 8e-2 if bf else 1e-3, 0.0), ("aux_confidence", 8e-2 if bf else 1e-3, 0.0),
+                             ("aux", 0.0, 8e-2 if bf else 1e-3), ("pose_encoding", 0.0, 3e-2 if bf else 2e-4),
+                             ("extrinsics", 0.0, 3e-2 if bf else 2e-4)):
+            g, w = getattr(out, name).cpu(), ref[name]
+            assert g.shape == w.shape, (name, g.shape, w.shape)
+            if rt:
+                record(f"{label} {name} max-rel", ((g - w).abs() / w.abs()).max().item(), rt, f"range [{w.min():.3f},{w.max():.3f}]")
+            else:
+                record(f"{label} {name} max-abs", (g - w).abs().max().item(), at, f"range [{w.min():.3f},{w.max():.3f}]")
+        g, w = out.intrinsics.cpu(), ref["intrinsics"]
+        fin = torch.isfinite(w)
+        record(f"{label} intrinsics rel (finite entries)", rel_err(g[fin], w[fin]), 3e-2 if bf else 2e-4, f"fx={w[0, 0, 0, 0]:.2f} fy={w[0, 0, 1, 1]:.2f}")
+        record(f"{label} intrinsics non-finite pattern", float((torch.isfinite(g) != fin).sum().item()), 0.0)
     model.enable_timing(True)
     model.infer(x.cuda())
     tm = model.read_timing()
@@ -344,9 +360,13 @@ def main():
         c98 = DepthAnything3Config.tiny_test()
         c98.image_size = 98  # 7x7 grid from a 5x5 pos_embed: exercises the bicubic pos-embed interpolation
         guarded("da3 tiny98 f32")(run_da3)(dev, c98, "da3-tiny98/f32", 1, Precision.F32)
+        guarded("da3 tiny-dual f32")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/f32", 2, Precision.F32)
+        guarded("da3 tiny-dual bf16")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/bf16", 2, Precision.BF16)
         if not args.skip_small:
             guarded("da3 large f32")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/f32", 1, Precision.F32)
             guarded("da3 large bf16")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/bf16", 1, Precision.BF16)
+            guarded("da3 small f32")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/f32", 1, Precision.F32)
+            guarded("da3 small bf16")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/bf16", 2, Precision.BF16)
     if args.full or want("full") and only is not None:
         guarded("full bf16")(run_e2e)(dev, DepthProConfig(), "full/bf16", 1, (1536, 1536), Precision.BF16, taps=False)
     bad = [r for r in RESULTS if not r[3]]
