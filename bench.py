@@ -93,9 +93,9 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (B of DepthPro::infer([B,3,S,S]))")
     ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
-    ap.add_argument("--model", choices=["depth_pro", "da3_large"], default="depth_pro",
-                    help="depth_pro = the BASELINE headline; da3_large = Depth-Anything-v3 metric_large (configs 2/5 family)")
-    ap.add_argument("--image-size", type=int, default=0, help="da3_large only: square input side (multiple of 14), default 518")
+    ap.add_argument("--model", choices=["depth_pro", "da3_large", "da3_small"], default="depth_pro",
+                    help="depth_pro = the BASELINE headline; da3_large / da3_small = Depth-Anything-v3 (BASELINE configs 5 / 2)")
+    ap.add_argument("--image-size", type=int, default=0, help="da3_* only: square input side (multiple of 14), default 518")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent in-flight batches per GPU, each on its own HIP stream with its own workspace")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,7 +117,7 @@ def main() -> int:
 
     dev = Device(local_rank)
     tdev = torch.device("cuda", local_rank)
-    if args.model == "da3_large":
+    if args.model in ("da3_large", "da3_small"):
         return bench_da3(args, dev, tdev, world, rank)
     cfg = {"full": DepthProConfig(), "small": DepthProConfig.small_test(), "tiny": DepthProConfig.tiny_test()}[args.preset]
     cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
@@ -261,7 +261,8 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
     contract as the Depth Pro path (barrier + synchronize, max over ranks, weak scaling)."""
     from burn_depth_amd.config import DepthAnything3Config
     from burn_depth_amd.depth_anything3 import DepthAnything3
-    cfg = DepthAnything3Config.metric_large()
+    small = args.model == "da3_small"
+    cfg = DepthAnything3Config.small() if small else DepthAnything3Config.metric_large()
     if args.image_size:
         cfg.image_size = args.image_size
     cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
@@ -271,8 +272,10 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
     g = torch.Generator(device="cpu").manual_seed(99 + rank)
     x = torch.randn(B, 3, S, S, generator=g).to(tdev)
     depth = torch.empty((B, S, S), dtype=torch.float32, device=tdev)
+    # the dual-head variant is timed with EVERY output of DepthAnything3Inference (confidence, aux rays, camera)
+    step = (lambda: model.infer(x)) if small else (lambda: model.infer_into(x, depth))
     for _ in range(args.warmup):
-        model.infer_into(x, depth)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -280,7 +283,7 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
     model.enable_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.infer_into(x, depth)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -299,11 +302,11 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
         fps = args.steps * B * world / elapsed
         kernels = {k: {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": c // args.steps} for k, (ms, c) in timing.items()}
         attn_ms = kernels.get("attention", {}).get("ms_per_step")
-        out = {"metric": f"frames/sec Depth-Anything-v3 metric_large @{S}^2 {args.precision}", "value": round(fps, 3), "unit": "frames/s",
+        out = {"metric": f"frames/sec Depth-Anything-v3 {cfg.variant} @{S}^2 {args.precision}", "value": round(fps, 3), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                "data": "synthetic (seeded normal images; random-init weights)",
-               "config": {"workload": f"DepthAnything3::infer [{B},3,{S},{S}] per GPU, metric_large (mono head)", "batch_per_gpu": B,
+               "config": {"workload": f"DepthAnything3::infer [{B},3,{S},{S}] per GPU, " + ("small (dual head, all outputs)" if small else "metric_large (mono head)"), "batch_per_gpu": B,
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "backbone_tflops_algorithmic": round(vit_flops / B / 1e12, 3),
                "attention_tflops": round(4.0 * B * v.num_heads * NT * NT * 64 * depth_n / (attn_ms * 1e-3) / 1e12, 1) if attn_ms else None,

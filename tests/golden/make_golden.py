@@ -66,10 +66,24 @@ def da3_case(B=1, seed=0):
     return dict(batch=np.int32(B), seed=np.int32(seed), image_size=np.int32(S), depth=d.astype(np.float32))
 
 
+def da3_dual_case(B=1, seed=0):
+    cfg = DepthAnything3Config.tiny_dual_test()
+    S = cfg.image_size
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+    x = seeded_input(seed, B, S, S)
+    with torch.no_grad():
+        ref = D3.infer(x, W, cfg)
+    out = dict(batch=np.int32(B), seed=np.int32(seed), image_size=np.int32(S))
+    for k in ("depth", "depth_confidence", "aux", "aux_confidence", "pose_encoding", "extrinsics", "intrinsics"):
+        out[k] = ref[k].numpy().astype(np.float32)
+    return out
+
+
 def main():
     np.savez_compressed(os.path.join(HERE, "depth_pro_tiny_f32.npz"), **depth_pro_case())
     np.savez_compressed(os.path.join(HERE, "da3_tiny_f32.npz"), **da3_case())
-    for f in ("depth_pro_tiny_f32.npz", "da3_tiny_f32.npz"):
+    np.savez_compressed(os.path.join(HERE, "da3_tiny_dual_f32.npz"), **da3_dual_case())
+    for f in ("depth_pro_tiny_f32.npz", "da3_tiny_f32.npz", "da3_tiny_dual_f32.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

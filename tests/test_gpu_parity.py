@@ -222,6 +222,56 @@ def test_depth_anything3_metric_large_end_to_end(diag, dev, precision):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("precision", [1, 0])
+def test_depth_anything3_tiny_dual_end_to_end(diag, dev, precision):
+    # the `small` topology (QK-norm + RoPE + camera token + concatenated hooks, dual head, camera decoder;
+    # mod.rs:158-216, dpt.rs:153-513, camera.rs:113-199) on the reduced variant: every output field
+    from burn_depth_amd.config import DepthAnything3Config
+    start = len(diag.RESULTS)
+    diag.guarded("da3-tinydual")(diag.run_da3)(dev, DepthAnything3Config.tiny_dual_test(), f"da3-tinydual/p{precision}", 2, precision)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 12
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_depth_anything3_small_end_to_end(diag, dev, precision):
+    # BASELINE config 2: DA3-small, one 518x518 image
+    from burn_depth_amd.config import DepthAnything3Config
+    start = len(diag.RESULTS)
+    diag.guarded("da3-small")(diag.run_da3)(dev, DepthAnything3Config.small(), f"da3-small/p{precision}", 1, precision)
+    _assert_new_results_ok(diag, start)
+
+
+def test_depth_anything3_small_batch_independence_and_partial_outputs(dev):
+    import ctypes as C
+    from burn_depth_amd import _lib, weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    cfg = DepthAnything3Config.tiny_dual_test()
+    cfg.precision = Precision.F32
+    cfg.max_batch = 2
+    m = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 70, 70, device="cuda")
+    o2 = m.infer(x)
+    o1 = m.infer(x[1:2].contiguous())
+    for f in ("depth", "depth_confidence", "aux", "aux_confidence", "pose_encoding", "extrinsics"):
+        assert torch.equal(getattr(o1, f)[0], getattr(o2, f)[1]), f          # views of a batch never interact
+    assert (o2.depth_confidence >= 1).all() and (o2.aux_confidence >= 1).all()  # exp(.) + 1 (dpt.rs:497)
+    # NULL outputs are skipped, depth alone through the plain entry point gives the same map
+    d = torch.empty(2, 70, 70, device="cuda")
+    m.infer_into(x, d)
+    assert torch.equal(d, o2.depth)
+    # the mono variant rejects the extra outputs instead of leaving them unwritten
+    mono = DepthAnything3.new(dev, DepthAnything3Config.tiny_test(), seed=0)
+    buf = torch.empty(1, 70, 70, device="cuda")
+    o = _lib.MdDa3Outputs(buf.data_ptr(), buf.data_ptr(), None, None, None, None, None)
+    rc = _lib.load().md_da3_infer_ex(mono._h, C.c_void_p(x.data_ptr()), 1, 70, 70, _lib.MD_MEM_DEVICE, C.byref(o), _lib.MD_MEM_DEVICE, None)
+    assert rc == _lib.MD_ERR_UNSUPPORTED
+    mono.destroy()
+    m.destroy()
+
+
 def test_depth_anything3_error_paths(dev):
     from burn_depth_amd import _lib
     from burn_depth_amd.config import DepthAnything3Config
