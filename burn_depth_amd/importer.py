@@ -65,9 +65,14 @@ DEPTH_PRO_IGNORED = (r"\.mask_token$", r"\.num_batches_tracked$")
 
 
 def da3_rules(head_prefix: str = "head_mono") -> List[Rule]:
-    """import_da3.rs:67-195 for the `metric_large` (mono head) checkpoint layout."""
+    """import_da3.rs:67-195: `head_mono` for metric_large, `head_dual` (+ camera decoder, aux heads) for small."""
     hp = re.escape(head_prefix)
     r: List[Rule] = [(r"^model\.", ""), (r"^head\.", f"{head_prefix}.")]
+    # camera decoder Sequentials (import_da3.rs:70-88)
+    r += [(r"^cam_dec\.backbone\.0\.(weight|bias)$", r"camera_decoder.backbone_1.\1"),
+          (r"^cam_dec\.backbone\.2\.(weight|bias)$", r"camera_decoder.backbone_2.\1"),
+          (r"^cam_dec\.fc_fov\.0\.(weight|bias)$", r"camera_decoder.fc_fov.\1"),
+          (r"^cam_dec\.", "camera_decoder."), (r"^cam_enc\.", "camera_encoder.")]
     r += _norm_rules(r"backbone\.pretrained\..*\.norm\d+")
     r += _norm_rules(r"backbone\.pretrained\.norm")
     r += _norm_rules(r"backbone\.pretrained\..*\.attn\.[qk]_norm")
@@ -76,11 +81,19 @@ def da3_rules(head_prefix: str = "head_mono") -> List[Rule]:
           (rf"^({hp}\.resize_layers\.3)\.(weight|bias)$", r"\1.conv.\2"),
           (rf"^({hp}\.scratch\.output_conv2)\.0\.(weight|bias)$", r"\1.conv1.\2"),
           (rf"^({hp}\.scratch\.output_conv2)\.2\.(weight|bias)$", r"\1.conv2.\2"),
-          (rf"^({hp}\.scratch\.refinenet\d+(?:_aux)?)\.resConfUnit([12])\.", r"\1.residual\2.")]
+          (rf"^({hp}\.scratch\.refinenet\d+(?:_aux)?)\.resConfUnit([12])\.", r"\1.residual\2."),
+          # aux heads (import_da3.rs:146-178): pre-head Sequential of convs; output head Sequential
+          # (0 reduce conv, 2 LayerNorm2d when present, 5 project conv)
+          (rf"^({hp}\.scratch\.output_conv1_aux\.\d+)\.(\d+)\.(weight|bias)$", r"\1.layers.\2.\3"),
+          (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.0\.(weight|bias)$", r"\1.reduce.\2"),
+          (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.2\.weight$", r"\1.norm.layer_norm.gamma"),
+          (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.2\.bias$", r"\1.norm.layer_norm.beta"),
+          (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.5\.(weight|bias)$", r"\1.project.\2")]
     return r
 
 
-DA3_IGNORED = (r"\.mask_token$", r"^camera_token$", r"^backbone\.pretrained\.camera_token$")
+# the camera ENCODER only runs when extrinsics/intrinsics are passed in, which `infer` never does (mod.rs:288-291)
+DA3_IGNORED = (r"\.mask_token$", r"^camera_encoder\.")
 
 
 class ImportError_(ValueError):
@@ -174,10 +187,11 @@ def import_depth_pro(src: str, dst: str, cfg: DepthProConfig | None = None, dtyp
 
 
 def import_da3(src: str, dst: str, cfg: DepthAnything3Config | None = None, dtype: str = "F16") -> Dict[str, np.ndarray]:
-    """DA3 `model.safetensors` (metric_large, mono head) -> container readable by `DepthAnything3.load`."""
+    """DA3 `model.safetensors` (metric_large: mono head; small: dual head + camera decoder) -> container readable
+    by `DepthAnything3.load_file`."""
     cfg = cfg or DepthAnything3Config()
     specs = Wt.da3_param_specs(cfg, Wt.INIT_REFERENCE)
-    tensors = convert_state_dict(load_upstream(src), specs, da3_rules("head_mono"), DA3_IGNORED)
+    tensors = convert_state_dict(load_upstream(src), specs, da3_rules("head_dual" if cfg.dual_head else "head_mono"), DA3_IGNORED)
     Wt.save_container(dst, tensors, metadata={"model": "depth_anything3", "variant": cfg.variant,
                                               "image_size": str(cfg.image_size)}, dtype=dtype)
     return tensors

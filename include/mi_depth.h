@@ -109,14 +109,15 @@ int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int
 int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, int h, int in_kind,
                       float* depth, float* focallength_px, float* fovy_rad, int out_kind, void* stream);
 
-/* ---- Depth-Anything-v3, `metric_large` variant (mono DPT head) -------------------------------------
- * `DepthAnything3Config::metric_large()` (depth_anything3/mod.rs:153-156): ViT-L/14, 518x518, hooks
- * [4,11,17,23], head `DepthAnything3HeadConfig::metric_large` (dpt.rs:41-58). variant "tiny" is a
- * test-only reduction (ViT width 256, 4 blocks, 70x70). The `small` variant (dual head + camera
- * decoder + RoPE/QK-norm backbone) is not built yet. The model handle is an md_model_t: set/get_tensor,
- * commit, query, timing and destroy work on it unchanged. */
+/* ---- Depth-Anything-v3 ---------------------------------------------------------------------------------
+ * "metric_large" = `DepthAnything3Config::metric_large()` (depth_anything3/mod.rs:153-156): ViT-L/14, 518x518,
+ * hooks [4,11,17,23], mono head `DepthAnything3HeadConfig::metric_large` (dpt.rs:41-58).
+ * "small" = `DepthAnything3Config::small()` (mod.rs:158-171): ViT-S/14 with QK-norm / 2-D RoPE / camera token /
+ * concatenated hooks from block 4 (mod.rs:190-196), hooks [5,7,9,11], dual head (dpt.rs:60-79) and the camera
+ * decoder (camera.rs:113-199). "tiny" / "tiny_dual" are test-only reductions of the two (70x70).
+ * The model handle is an md_model_t: set/get_tensor, commit, query, timing and destroy work on it unchanged. */
 typedef struct md_da3_cfg {
-  const char* variant; /* "metric_large" | "tiny" */
+  const char* variant; /* "metric_large" | "small" | "tiny" | "tiny_dual" */
   int image_size;      /* square input side, a multiple of 14; 0 = the variant's native size (518 / 70). Other
                         * sizes interpolate the position embedding bicubically (DINOv2 interpolate_pos_encoding,
                         * offset 0.1) once, when the weights are committed. */

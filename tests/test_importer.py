@@ -147,3 +147,37 @@ def test_da3_round_trip(tmp_path):
     assert meta["model"] == "depth_anything3" and set(got) == set(W)
     for k in W:
         assert np.array_equal(got[k], W[k]), k
+
+
+def test_da3_small_round_trip(tmp_path):
+    """Dual head + camera decoder + backbone extras: upstream spellings written out by hand (Sequential indices of
+    the aux heads and of the camera decoder, `cam_dec.` / `cam_enc.` prefixes, q_norm/k_norm weight/bias)."""
+    cfg = DepthAnything3Config.tiny_dual_test()
+    W = Wt.generate_da3_weights(cfg, 7, Wt.INIT_REFERENCE)
+
+    def up(n: str) -> str:
+        if (n.endswith(".gamma") or n.endswith(".beta")) and ("norm" in n):
+            n = n[:n.rfind(".")] + (".weight" if n.endswith(".gamma") else ".bias")
+        if n.startswith("head_dual."):
+            n = "head." + n[len("head_dual."):]
+            n = n.replace(".conv_t.", ".").replace("resize_layers.3.conv.", "resize_layers.3.")
+            n = n.replace("output_conv2.conv1.", "output_conv2.0.").replace("output_conv2.conv2.", "output_conv2.2.")
+            n = n.replace(".residual1.", ".resConfUnit1.").replace(".residual2.", ".resConfUnit2.")
+            n = n.replace(".layers.", ".").replace(".reduce.", ".0.").replace(".project.", ".5.")
+            n = n.replace(".norm.layer_norm.", ".2.")
+        if n.startswith("camera_decoder."):
+            n = "cam_dec." + n[len("camera_decoder."):]
+            n = n.replace("backbone_1.", "backbone.0.").replace("backbone_2.", "backbone.2.").replace("fc_fov.", "fc_fov.0.")
+        return "model." + n
+
+    upstream = {up(k): v for k, v in W.items()}
+    assert "model.cam_dec.backbone.2.weight" in upstream and "model.head.scratch.output_conv2_aux.0.2.weight" in upstream
+    assert "model.backbone.pretrained.blocks.3.attn.q_norm.weight" in upstream and "model.head.norm.bias" in upstream
+    upstream["model.cam_enc.trunk.0.norm1.weight"] = np.zeros(4, np.float32)   # camera encoder: dropped
+    src, dst = str(tmp_path / "model.safetensors"), str(tmp_path / "da3s.safetensors")
+    Wt.save_container(src, upstream, dtype="F32")
+    importer.import_da3(src, dst, cfg, dtype="F32")
+    got, _ = Wt.load_container(dst)
+    assert set(got) == set(W)
+    for k in W:
+        assert np.array_equal(got[k], W[k]), k
