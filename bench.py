@@ -90,7 +90,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step (B of DepthPro::infer([B,3,S,S]))")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (B of DepthPro::infer([B,3,S,S])); default 8 for depth_pro (BASELINE config 4's 8 images/GPU), 1 for da3_* (single-image configs 2 / 5)")
     ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
     ap.add_argument("--model", choices=["depth_pro", "da3_large", "da3_small"], default="depth_pro",
@@ -98,10 +98,15 @@ def main() -> int:
     ap.add_argument("--image-size", type=int, default=0, help="da3_* only: square input side (multiple of 14), default 518")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent in-flight batches per GPU, each on its own HIP stream with its own workspace")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the launch schedule from a hipGraph and drop the per-kernel HIP events from the timed region "
+                         "(no `kernels` / `roofline` in the line: latency mode for the single-image configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--dump-launch-order", default="", help="write the per-launch kernel-family list of one infer (json)")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 8 if args.model == "depth_pro" else 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,13 +181,15 @@ def main() -> int:
             json.dump({"families": model.read_launch_order(), "infers": args.steps}, f)
         model.read_timing()
         model.enable_timing(False)
-    for _ in range(args.warmup):
+    if args.graph:
+        model.enable_graph(True)
+    for _ in range(max(args.warmup, 3 if args.graph else 0)):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    model.enable_timing(True)
+    model.enable_timing(not args.graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -274,13 +281,26 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
     depth = torch.empty((B, S, S), dtype=torch.float32, device=tdev)
     # the dual-head variant is timed with EVERY output of DepthAnything3Inference (confidence, aux rays, camera)
     step = (lambda: model.infer(x)) if small else (lambda: model.infer_into(x, depth))
-    for _ in range(args.warmup):
+    if args.graph:
+        if small:  # fixed output buffers so that the graph key repeats
+            from burn_depth_amd import _lib as L
+            import ctypes as C
+            ps = cfg.patch_size
+            ah = 8 * (S // ps)
+            bufs = [depth] + [torch.empty(sh, dtype=torch.float32, device=tdev) for sh in
+                              ((B, S, S), (B, cfg.aux_output_dim - 1, ah, ah), (B, ah, ah), (B, 1, 9), (B, 1, 3, 4), (B, 1, 3, 3))]
+            o = L.MdDa3Outputs(*(t.data_ptr() for t in bufs))
+            from burn_depth_amd.depth_pro import _stream_ptr
+            step = lambda: L.check(L.load().md_da3_infer_ex(model._h, C.c_void_p(x.data_ptr()), B, S, S, L.MD_MEM_DEVICE, C.byref(o),
+                                                            L.MD_MEM_DEVICE, _stream_ptr(dev.ordinal)))
+        model.enable_graph(True)
+    for _ in range(max(args.warmup, 3 if args.graph else 0)):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    model.enable_timing(True)
+    model.enable_timing(not args.graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

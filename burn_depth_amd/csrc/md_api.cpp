@@ -186,6 +186,12 @@ int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, i
                      rgb, rgb_len);
 }
 
+int md_model_enable_graph(md_model_t m, int enable) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  m->graph_enabled = enable != 0;
+  return MD_OK;
+}
+
 int md_model_query(md_model_t m, const char* key, int64_t* out) {
   if (!m || !key || !out) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   const std::string k = key;

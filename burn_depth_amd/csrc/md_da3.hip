@@ -465,8 +465,26 @@ static int da3_tok_index(md_model_s* m, int B, int** out) {
   return MD_OK;
 }
 
+static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& outp, int out_kind,
+                           hipStream_t stream);
+
 int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& outp, int out_kind,
                  hipStream_t stream) {
+  if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
+  auto body = [&]() { return da3_infer_eager(m, nchw, B, H, W, in_kind, outp, out_kind, stream); };
+  if (!m->graph_enabled) return body();
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : m->dev->stream;
+  const bool eligible = nchw && outp.depth && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
+                        B <= m->da3->cfg.max_batch && H == m->da3->cfg.image_size && W == H;
+  const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)outp.depth,
+                                      (uintptr_t)outp.depth_confidence, (uintptr_t)outp.aux, (uintptr_t)outp.aux_confidence,
+                                      (uintptr_t)outp.pose_encoding, (uintptr_t)outp.extrinsics, (uintptr_t)outp.intrinsics};
+  return run_with_graph(m, st, key, eligible, body);
+}
+
+static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& outp, int out_kind,
+                           hipStream_t stream) {
   if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
   if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
   if (!nchw || !outp.depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");

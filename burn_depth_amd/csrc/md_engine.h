@@ -1,6 +1,7 @@
 // Depth Pro engine: device-resident weights, static workspace plan, forward schedule.
 #pragma once
 
+#include <cstdint>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -111,6 +112,14 @@ struct md_model_s {
   bool timing_enabled = false;
   std::vector<md::TimingEntry> timing;
   std::vector<std::string> timing_names_out;
+
+  // ---- hipGraph replay of the launch schedule (md_model_enable_graph) ----
+  bool graph_enabled = false;
+  struct GraphEntry {
+    int seen = 0;
+    hipGraphExec_t exec = nullptr;
+  };
+  std::map<std::vector<uintptr_t>, GraphEntry> graphs;  // key: stream, shapes and every in/out pointer
 
   // ---- model kind: 0 = Depth Pro, 1 = Depth-Anything-v3 (state in md_da3.hip) ----
   int kind = 0;

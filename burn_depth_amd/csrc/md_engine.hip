@@ -470,6 +470,8 @@ int model_destroy(md_model_t m) {
   if (m->ws.base) (void)hipFree(m->ws.base);
   if (m->zero_page) (void)hipFree(m->zero_page);
   for (auto& kv : m->index_tables) (void)hipFree(kv.second);
+  for (auto& kv : m->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   for (auto& kv : m->taps) (void)hipFree(kv.second.dev);
   for (auto& t : m->timing) {
     (void)hipEventDestroy(t.a);
@@ -999,8 +1001,25 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
   return MD_OK;
 }
 
+static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
+                             float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
+
 int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  auto body = [&]() { return model_infer_eager(m, nchw, B, H, W, in_kind, depth, focal, fovx, fovy, out_kind, stream, rgb, rgb_len); };
+  if (!m->graph_enabled) return body();
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : m->dev->stream;
+  const bool eligible = nchw && !rgb && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
+                        B <= m->cfg.max_batch && H == m->S && W == m->S;
+  const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)depth,
+                                      (uintptr_t)focal, (uintptr_t)fovx, (uintptr_t)fovy};
+  return run_with_graph(m, st, key, eligible, body);
+}
+
+static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
+                             float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len) {
   if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
   if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
   if (!nchw && !rgb) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");

@@ -65,6 +65,40 @@ inline void add_pack_composed(md_model_s* m, const std::string& name, const std:
   m->packs.push_back(e);
 }
 
+// Runs `body` (the launch schedule of one infer) eagerly the first time a (stream, shapes, pointers) key is
+// seen -- that call allocates index tables and sets function attributes --, captures it into a hipGraph the second
+// time and replays the instantiated graph from then on. Timing / tap modes and host-side buffers always run eagerly.
+template <typename F>
+inline int run_with_graph(md_model_s* m, hipStream_t st, const std::vector<uintptr_t>& key, bool eligible, F&& body) {
+  if (!m->graph_enabled || !eligible || m->timing_enabled || m->taps_enabled) return body();
+  md_model_s::GraphEntry& e = m->graphs[key];
+  if (e.exec) {
+    MD_HIP(hipGraphLaunch(e.exec, st));
+    return MD_OK;
+  }
+  if (e.seen++ == 0) return body();
+  MD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  const int s = body();
+  hipGraph_t g = nullptr;
+  const hipError_t ce = hipStreamEndCapture(st, &g);
+  if (s != MD_OK || ce != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    m->graphs.erase(key);
+    if (s != MD_OK) return s;
+    MD_FAIL(MD_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ce));
+  }
+  hipGraphExec_t ex = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (ie != hipSuccess || !ex) {
+    m->graphs.erase(key);
+    MD_FAIL(MD_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+  }
+  e.exec = ex;
+  MD_HIP(hipGraphLaunch(ex, st));
+  return MD_OK;
+}
+
 struct Run {
   md_model_s* m;
   hipStream_t st;

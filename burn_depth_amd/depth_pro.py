@@ -215,6 +215,10 @@ class DepthPro:
     def enable_timing(self, enable: bool = True) -> None:
         _lib.check(self._lib.md_model_enable_timing(self._h, int(enable)))
 
+    def enable_graph(self, enable: bool = True) -> None:
+        """Replay the launch schedule from a hipGraph for repeated calls with the same buffers (md_model_enable_graph)."""
+        _lib.check(self._lib.md_model_enable_graph(self._h, int(enable)))
+
     def read_launch_order(self) -> List[str]:
         n = C.c_int()
         _lib.check(self._lib.md_model_read_launch_order(self._h, None, 0, C.byref(n)))

@@ -154,6 +154,11 @@ int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,
                            float* lo, float* hi);
 
+/* hipGraph replay: with it enabled, an infer call whose (stream, B, H, W, input pointer, output pointers) were seen
+ * before is replayed from an instantiated graph of the launch schedule (first call eager, second call captured).
+ * Only all-device-memory calls at the configured image size are eligible; timing / tap modes run eagerly. */
+int md_model_enable_graph(md_model_t m, int enable);
+
 /* `img_size()` (mod.rs:296), `interpolation_method()` (mod.rs:308) and friends.
  * keys: "img_size", "patch_window", "interpolation", "precision", "max_batch", "num_params",
  *       "workspace_bytes", "weight_bytes", "tiles_per_image". */

@@ -272,6 +272,49 @@ def test_depth_anything3_small_batch_independence_and_partial_outputs(dev):
     m.destroy()
 
 
+def test_graph_replay_matches_eager(dev):
+    """md_model_enable_graph: first call eager, second captured, later calls replayed -- all bit-identical, and a
+    change of buffers or a timing/tap request falls back to eager launches."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, DepthProConfig
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.tiny_test()
+    cfg.max_batch = 2
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    torch.manual_seed(5)
+    x = torch.randn(2, 3, 512, 512, device="cuda")
+    want = m.infer(x)
+    bufs = [torch.empty(2, 512, 512, device="cuda")] + [torch.empty(2, device="cuda") for _ in range(3)]
+    m.enable_graph(True)
+    for it in range(4):  # eager, capture, replay, replay
+        for b in bufs:
+            b.fill_(-1.0)
+        m.infer_into(x, *bufs)
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[0], want.depth) and torch.equal(bufs[1], want.focallength_px), it
+    x2 = x.flip(0).contiguous()  # new input pointer -> new key, still correct
+    m.infer_into(x2, *bufs)
+    assert torch.equal(bufs[0], want.depth.flip(0))
+    m.enable_timing(True)  # timing mode runs eagerly and still reports every launch
+    m.infer_into(x, *bufs)
+    assert sum(c for _, c in m.read_timing().values()) > 50
+    m.enable_timing(False)
+    m.destroy()
+    c3 = DepthAnything3Config.tiny_dual_test()
+    d = DepthAnything3.new(dev, c3, seed=0, init_scheme=Wt.INIT_PARITY)
+    y = torch.randn(1, 3, 70, 70, device="cuda")
+    w3 = d.infer(y).depth
+    out = torch.empty(1, 70, 70, device="cuda")
+    d.enable_graph(True)
+    for it in range(3):
+        out.zero_()
+        d.infer_into(y, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, w3), it
+    d.destroy()
+
+
 def test_depth_anything3_error_paths(dev):
     from burn_depth_amd import _lib
     from burn_depth_amd.config import DepthAnything3Config

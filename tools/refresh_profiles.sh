@@ -8,7 +8,7 @@
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-BATCH=${BATCH:-4}
+BATCH=${BATCH:-8}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 "$ROOT/bench.py" --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
