@@ -272,6 +272,42 @@ def test_depth_anything3_small_batch_independence_and_partial_outputs(dev):
     m.destroy()
 
 
+def test_check_parity_cli_against_an_oracle_made_reference_dump(dev, tmp_path):
+    """tools/check_parity.py = the reference's example/correctness.rs flow: image -> infer_from_rgb -> compare with a
+    PyTorch-side dump by the harness's names and thresholds. The dump here is produced by the CPU oracle."""
+    import importlib.util
+    import math
+    import numpy as np
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from oracle import depth_pro_ref as R
+    cfg = DepthProConfig.tiny_test()
+    Wn = Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY)
+    wpath = str(tmp_path / "w.safetensors")
+    Wt.save_container(wpath, Wn, metadata=Wt.config_metadata(cfg), dtype="F32")
+    rng = np.random.default_rng(4)
+    h, w = 360, 540
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    np.save(str(tmp_path / "img.npy"), rgb)
+    x = R.rgb_to_input_tensor(rgb.tobytes(), w, h)
+    with torch.no_grad():
+        ref = R.infer(x, R.weights_to_torch(Wn), cfg, debug=True)
+    dump = {"metric_depth": ref["depth"][0].numpy()[:, :, None], "fovx": ref["fovx_deg"].numpy().reshape(1),
+            "fovy": np.array([math.degrees(float(ref["fovy_rad"][0]))], np.float32),
+            "canonical_inverse_depth": ref["debug"]["canonical"].numpy()}
+    for i, t in enumerate(ref["debug"]["encoder"]["features"]):
+        dump[f"encoder_feature_{i}"] = t.numpy()
+    for i, t in enumerate(ref["debug"]["fusions"]):
+        dump[f"decoder_fusion_{i}"] = t.numpy()
+    Wt.save_container(str(tmp_path / "ref.safetensors"), dump, dtype="F32")
+    spec = importlib.util.spec_from_file_location("check_parity", os.path.join(ROOT, "tools", "check_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    args = ["--weights", wpath, "--image", str(tmp_path / "img.npy"), "--reference", str(tmp_path / "ref.safetensors"), "--preset", "tiny"]
+    assert mod.main(args) == 0                      # fp32 parity mode passes the reference's own thresholds
+    assert mod.main(args + ["--precision", "bf16"]) in (0, 1)  # throughput mode: reported, may exceed 5e-3
+
+
 def test_graph_replay_matches_eager(dev):
     """md_model_enable_graph: first call eager, second captured, later calls replayed -- all bit-identical, and a
     change of buffers or a timing/tap request falls back to eager launches."""
