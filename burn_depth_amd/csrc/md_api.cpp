@@ -1,6 +1,7 @@
 // extern "C" surface of libmi_depth.so (include/mi_depth.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -547,7 +548,7 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   MD_TRY(fill_random(w.p, (size_t)N * kw, precision, 2, 0.05f, st));
   GemmParams p;
   p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
-  p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = dbg & 3;
+  p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = (dbg & 3) | ((dbg & 64) ? 4 : 0) | ((dbg & 128) ? 8 : 0);
   DevBuf bias;
   if (dbg & 4) {  // fc1-style epilogue: bias + GELU
     MD_TRY(bias.alloc((size_t)N * 4));
@@ -562,6 +563,29 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
     p.K = K; p.lda = K;
   }
   for (int i = 0; i < 2; ++i) MD_TRY(launch_gemm(p, amode, precision, tile, st));
+  if (dbg & 32) {  // per-block phase stamps of ONE launch (100 MHz s_memrealtime), printed to stderr
+    const long blocks = (long)((M + 255) / 256) * ((N + 255) / 256);
+    DevBuf sb;
+    MD_TRY(sb.alloc((size_t)blocks * 64));
+    p.stamps = (unsigned long long*)sb.p;
+    MD_TRY(launch_gemm(p, amode, precision, tile, st));
+    MD_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)blocks * 8);
+    MD_HIP(hipMemcpy(h.data(), sb.p, h.size() * 8, hipMemcpyDeviceToHost));
+    p.stamps = nullptr;
+    double d[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (long b = 0; b < blocks; ++b) {
+      const unsigned long long* q = &h[(size_t)b * 8];
+      for (int k = 0; k < 7; ++k) d[k] += (double)(q[k + 1] - q[k]);
+      tmin = std::min(tmin, q[0]);
+      tmax = std::max(tmax, q[7]);
+    }
+    fprintf(stderr, "[stamps] blocks=%ld  setup %.2f  issue %.2f  first-wait %.2f  mainloop %.2f  epi-barrier %.2f  epi-body %.2f  store-drain %.2f us "
+                    "(wave 0, mean per block); kernel span %.1f us\n",
+            blocks, d[0] / blocks / 100.0, d[1] / blocks / 100.0, d[2] / blocks / 100.0, d[3] / blocks / 100.0, d[4] / blocks / 100.0,
+            d[5] / blocks / 100.0, d[6] / blocks / 100.0, (double)(tmax - tmin) / 100.0);
+  }
   hipEvent_t e0, e1;
   MD_HIP(hipEventCreate(&e0));
   MD_HIP(hipEventCreate(&e1));
