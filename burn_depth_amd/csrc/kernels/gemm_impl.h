@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(T);
   const char* res2_b = (const char*)p.res2 + tile_r * (long)sizeof(T);
   const bool has_res = fast_store && (p.res1 || p.res2);
+  const bool interior_t = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform: no per-row predicates needed
   // one register array per half serves both prefetches: RMW -> the fp32 x vector; residual store -> the
   // raw bf16x4 of res1 in lanes .xy and of res2 in .zw
   f32x4_t pre2[2][16];
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const int m = m_base + lrow;
     const unsigned lr = (unsigned)lrow;
     if constexpr (rmw) {
-      if (m < m_end && nvalid) pre2[half][it] = *(const f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u);
+      if (interior_t || (m < m_end && nvalid)) pre2[half][it] = *(const f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u);
     } else if constexpr (fast_store) {
       if (!has_res) return;
       f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
@@ -1147,7 +1148,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int m = m0 + it * 4;
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (m < m_end && nvalid) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
+        if (interior_t || (m < m_end && nvalid)) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
         if (half == 0 && it == 7) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) prefetch(1, j);
