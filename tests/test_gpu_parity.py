@@ -308,6 +308,41 @@ def test_check_parity_cli_against_an_oracle_made_reference_dump(dev, tmp_path):
     assert mod.main(args + ["--precision", "bf16"]) in (0, 1)  # throughput mode: reported, may exceed 5e-3
 
 
+def test_infer_cli_writes_a_depth_png_for_both_model_kinds(dev, tmp_path):
+    """tools/infer.py = example/inference.rs: AnyDepthModel::load -> prepare_input_image -> infer_from_rgb ->
+    save_depth_map. Depth Pro keeps the image size; Depth-Anything-v3 resizes + centre-crops to the model size and
+    the PNG is restored to the original size. AnyDepthModel tries metric_large before small unless the file name
+    says "small" (src/model/mod.rs:62-100)."""
+    import importlib.util
+    import numpy as np
+    from burn_depth_amd import pipeline as P, weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config
+    spec = importlib.util.spec_from_file_location("infer_cli", os.path.join(ROOT, "tools", "infer.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(0, 256, (120, 180, 3), dtype=np.uint8)
+    img = str(tmp_path / "img.npy")
+    np.save(img, rgb)
+    assert cli.main(["--checkpoint", str(tmp_path / "missing.safetensors"), "--image", img]) == 1
+    # DA3 `small` checkpoint (full ViT-S/14 inventory, seeded): loads through the "small" file-name hint
+    cfg = DepthAnything3Config.small()
+    ck = str(tmp_path / "da3_small.safetensors")
+    Wt.save_container(ck, Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY), dtype="F16")
+    out = str(tmp_path / "depth_da3.png")
+    assert cli.main(["--model", "depth-anything-3", "--checkpoint", ck, "--image", img, "--output", out]) == 0
+    px = P.read_gray_png(out)
+    assert px.shape == (120, 180) and px.min() == 0 and px.max() == 255
+    # the same file under a neutral name: metric_large is tried first and rejected (shape mismatch), then small loads
+    ck2 = str(tmp_path / "weights.safetensors")
+    os.replace(ck, ck2)
+    m = P.AnyDepthModel.load(P.DepthModelKind.DEPTH_ANYTHING3, dev, ck2)
+    assert m.model.config.variant == "small" and m.preferred_input_resolution() == 518
+    m.model.destroy()
+    with pytest.raises(RuntimeError, match="Failed to load DepthPro checkpoint"):
+        P.AnyDepthModel.load(P.DepthModelKind.DEPTH_PRO, dev, ck2)
+
+
 def test_graph_replay_matches_eager(dev):
     """md_model_enable_graph: first call eager, second captured, later calls replayed -- all bit-identical, and a
     change of buffers or a timing/tap request falls back to eager launches."""
