@@ -61,7 +61,7 @@ def _depth_pro_rules() -> List[Rule]:
 DEPTH_PRO_RULES: List[Rule] = _depth_pro_rules()
 # upstream buffers with no counterpart in the Burn module (import_depth_pro.rs:439-445 lists them as allowed
 # to be absent on the Burn side; when present upstream they are dropped)
-DEPTH_PRO_IGNORED = (r"\.mask_token$", r"\.num_batches_tracked$")
+DEPTH_PRO_IGNORED = (r"\.mask_token$", r"\.num_batches_tracked$", r"\.register_tokens$")
 
 
 def da3_rules(head_prefix: str = "head_mono") -> List[Rule]:
@@ -166,6 +166,9 @@ def load_upstream(path: str) -> Dict[str, object]:
     if path.endswith(".safetensors"):
         tensors, _ = Wt.load_container(path)
         return tensors
+    if path.endswith(".mpk"):  # a Burn record: names are already the Burn field paths (rules are no-ops on them)
+        from .mpk import read_mpk
+        return read_mpk(path)
     import torch
     obj = torch.load(path, map_location="cpu", weights_only=True)
     for k in ("state_dict", "model"):

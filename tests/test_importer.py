@@ -181,3 +181,28 @@ def test_da3_small_round_trip(tmp_path):
     assert set(got) == set(W)
     for k in W:
         assert np.array_equal(got[k], W[k]), k
+
+
+def test_burn_mpk_record_round_trip(tmp_path):
+    """`.mpk` (Burn NamedMpk, f16) -> container: the reader is validated against files written by burn_depth_amd.mpk
+    itself (no `.mpk` exists in the reference tree): nested maps, Vec<Module> as arrays, {id, param{bytes,shape,dtype}}."""
+    import msgpack
+    from burn_depth_amd import mpk
+    cfg = DepthProConfig.tiny_test()
+    W = Wt.generate_depth_pro_weights(cfg, 1, Wt.INIT_REFERENCE)
+    src, dst = str(tmp_path / "depth_pro.mpk"), str(tmp_path / "dp.safetensors")
+    mpk.write_mpk(src, W, dtype="F16")
+    doc = msgpack.unpackb(open(src, "rb").read(), raw=False)
+    assert set(doc) == {"metadata", "item"} and isinstance(doc["item"]["encoder"]["patch_encoder"]["blocks"], list)
+    leaf = doc["item"]["head"]["conv0"]["weight"]
+    assert set(leaf) == {"id", "param"} and leaf["param"]["dtype"] == "F16" and leaf["param"]["shape"] == [32, 64, 3, 3]
+    got = mpk.read_mpk(src)
+    assert set(got) == set(W)
+    k = "encoder.patch_encoder.blocks.1.mlp.fc1.weight"
+    assert np.array_equal(got[k], W[k].astype(np.float16).astype(np.float32))
+    importer.import_depth_pro(src, dst, cfg, dtype="F16")          # .mpk straight into the engine container
+    c, _ = Wt.load_container(dst)
+    assert np.array_equal(c[k], got[k])
+    with pytest.raises(ValueError, match="not a Burn record"):
+        open(str(tmp_path / "bad.mpk"), "wb").write(msgpack.packb({"x": 1}))
+        mpk.read_mpk(str(tmp_path / "bad.mpk"))
