@@ -674,17 +674,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   int issued = 2, slot_i = 2;
   issue_A(0, 0);
   issue_W(0, 1);
-  if (KT > 1) {
-    issue_A(1, 2);
-    issue_W(1, 3);
-    issued = 4;
-    slot_i = 4;
+  if constexpr (PP != 2) {
+    if (KT > 1) {
+      issue_A(1, 2);
+      issue_W(1, 3);
+      issued = 4;
+      slot_i = 4;
+    }
+    if (KT > 2) {
+      issue_A(2, 4);
+      issued = 5;
+      slot_i = 0;
+    }
   }
-  if (KT > 2) {
-    issue_A(2, 4);
-    issued = 5;
-    slot_i = 0;
-  }
+  // PP == 2 (production schedule): SHORT prologue. Only k-tile 0 is requested up front; A1, W1, A2 are issued
+  // from the load segments of k-tile 0 (every ring slot is free then). In-kernel stamps showed the five-half-tile
+  // prologue costing 1.9 us of issue + 1.8 us until k-tile 0 had landed behind the other 96 KB of the queue.
   int slot_c = 0;  // slot of the current tile's A half
 
   // counted wait for the two half-tiles of k-tile `t`: all but the `younger` most recent half-tiles
@@ -849,7 +854,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) af[b] = *(const i32x4_t*)(As + (mh * 4 + b) * 2048 + off);
-        if (g1) {
+        if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
+          if (!no_loads) {
+            if (s == 0 && KT > 1) { issue_A(1, 2); issued = 3; slot_i = 3; }
+            if (s == 1 && KT > 1) { issue_W(1, 3); issued = 4; slot_i = 4; }
+            if (s == 2 && KT > 2) issue_A_part(2, 4, 0, 2);
+            if (s == 3 && KT > 2) { issue_A_part(2, 4, 2, 4); issued = 5; slot_i = 0; }
+          }
+          if (g1 && s == 3 && KT > 1) wait_tile(1);
+        } else if (g1) {
           if (s == 0) issue_next_W(t);
           if (s == 1) issue_next_A_lo(t);
           if (s == 2) issue_next_A_hi(t);
