@@ -68,6 +68,12 @@ struct GemmParams {
   const float* bias[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
   const float* scale[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
   const float* pos[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+  // fp8 operands: acc is multiplied by ascale * wscale[n] (activation scale x per-output-channel weight scale)
+  // before the bias; out_fp8: the GELU store writes e4m3 (value * out_inv_scale), the next GEMM's A operand
+  const float* wscale[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};
+  float ascale = 1.f;
+  int out_fp8 = 0;
+  float out_inv_scale = 1.f;
   void* out = nullptr;
   long ldo = 0;
   void* out2 = nullptr;         // optional relu(out) copy, element type T, same ld

@@ -7,6 +7,7 @@ namespace md {
 
 int launch_gemm_bf16(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_f32(GemmParams& p, int amode, int tile, hipStream_t stream);
+int launch_gemm_fp8(GemmParams& p, int amode, int tile, hipStream_t stream);
 
 static int pick_tile(const GemmParams& p) {
   if (p.epi == EPI_HEAD || p.N <= 32) return TILE_256x32;
@@ -27,7 +28,7 @@ static int pick_tile(const GemmParams& p) {
 }
 
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream) {
-  const int ke = prec == MD_PREC_F32 ? 32 : 64;
+  const int ke = prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64);
   if (p.ngroups < 1 || p.ngroups > kMaxGroups) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: ngroups %d", p.ngroups);
   if (p.N <= 0 || p.N % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: N=%d must be a positive multiple of 4", p.N);
   if (p.K <= 0 || p.K % ke != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", p.K, ke);
@@ -53,7 +54,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   p.fd_psH = make_fastdiv(p.psH);
   p.fd_ow = make_fastdiv(p.cOW > 0 ? p.cOW : p.cW);
   p.fd_oh = make_fastdiv(p.cOH > 0 ? p.cOH : p.cH);
-  p.fd_cblocks = make_fastdiv(p.cC / (prec == MD_PREC_F32 ? 32 : 64));
+  p.fd_cblocks = make_fastdiv(p.cC / ke);
   {
     long rows = 0;
     for (int g = 0; g < p.ngroups; ++g) rows = std::max<long>(rows, (long)p.g_arow0[g] + p.g_rows[g]);
@@ -67,6 +68,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   }
   if (p.epi == EPI_HEAD) tile = TILE_256x32;
   if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);
+  if (prec == MD_PREC_FP8) {
+    if (p.out_fp8 && !(p.epi == EPI_STORE && p.act == ACT_GELU)) MD_FAIL(MD_ERR_UNSUPPORTED, "fp8 output is built for the GELU store only");
+    return launch_gemm_fp8(p, amode, tile, stream);
+  }
+  if (p.out_fp8) MD_FAIL(MD_ERR_UNSUPPORTED, "fp8 output needs fp8 operands");
   return launch_gemm_bf16(p, amode, tile, stream);
 }
 

@@ -83,6 +83,36 @@ struct Atom16<float> {
   }
 };
 
+// fp8 (OCP e4m3) operands: a 16-byte fragment holds 16 k-values per lane = two 8-byte MFMA operands. Which k
+// each lane holds does not matter as long as A and B agree (both are read with the same fragment address), so
+// the LDS image, swizzle and fragment reads are byte-identical to the bf16 / f32 forms; only KE doubles to 128.
+typedef long i64x2_t __attribute__((ext_vector_type(2)));
+template <>
+struct Atom<fp8_t> {
+  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+    const i64x2_t av = __builtin_bit_cast(i64x2_t, a), bv = __builtin_bit_cast(i64x2_t, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(av[0], bv[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
+  }
+};
+template <>
+struct Atom16<fp8_t> {
+  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x4acc_t& c) {
+    const i64x2_t av = __builtin_bit_cast(i64x2_t, a), bv = __builtin_bit_cast(i64x2_t, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[0], bv[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
+  }
+};
+// element type of everything the epilogue reads / writes as "T" (outputs, residuals): bf16 for fp8 operands
+template <typename T>
+struct OutT {
+  typedef T type;
+};
+template <>
+struct OutT<fp8_t> {
+  typedef bf16_t type;
+};
+
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -182,6 +212,7 @@ __device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int n, f32x4_t v, long boff) {
   const float* bias = MD_SEL_G(p.bias, g);
+  if (const float* ws = MD_SEL_G(p.wscale, g)) v *= *(const f32x4_t*)(ws + n) * p.ascale;  // fp8 operands: dequantise
   switch (p.epi) {
     case EPI_STORE: {
       if (bias) v += *(const f32x4_t*)(bias + n);
@@ -274,6 +305,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
   constexpr int A_ITERS = RG_A / NW;
   constexpr int W_ITERS = (RG_W + NW - 1) / NW;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
+  typedef typename OutT<T>::type TO;  // element type of outputs / residuals
   constexpr int ESZ = (int)sizeof(T);
   constexpr int KE = 128 / ESZ;  // K elements per 128-byte LDS row
 
@@ -480,7 +512,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
         const int n = n0 + wn * WTN + a * 32 + 8 * q4 + 4 * h;
         if (m < m_end && n < p.N) {
           f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
-          epilogue4<T>(p, g, m, n, v, out_boff);
+          epilogue4<TO>(p, g, m, n, v, out_boff);
         }
       }
     }
@@ -507,6 +539,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
   constexpr int HALF_BYTES = 256 * 128;  // one half-tile slot
   constexpr int NSLOT = 5;
+  typedef typename OutT<T>::type TO;  // element type of outputs / residuals
   constexpr int ESZ = (int)sizeof(T);
   constexpr int KE = 128 / ESZ;
   constexpr int LPH = 4;  // glds wave-instructions per wave per half-tile (32 row groups / 8 waves)
@@ -905,7 +938,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           const int n = n0 + wn * WTN + a * 16 + 4 * q16;
           if (m < m_end && n < p.N) {
             f32x4_t v = {acc16[a][b][0], acc16[a][b][1], acc16[a][b][2], acc16[a][b][3]};
-            epilogue4<T>(p, g, m, n, v, out_boff);
+            epilogue4<TO>(p, g, m, n, v, out_boff);
           }
         }
       return;
@@ -920,7 +953,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           const int n = n0 + wn * WTN + a * 32 + 8 * q4 + 4 * h;
           if (m < m_end && n < p.N) {
             f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
-            epilogue4<T>(p, g, m, n, v, out_boff);
+            epilogue4<TO>(p, g, m, n, v, out_boff);
           }
         }
       }
@@ -940,7 +973,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // staging pass, so 16 loads per lane are in flight at once instead of a dependent load->store chain
   // (that chain, not bandwidth, set the cost of the proj / fc2 / residual-conv epilogues).
   constexpr bool rmw = EK == 1;
-  constexpr bool fast_store = (EK == 2 || EK == 4) && sizeof(T) == 2;  // EK 4: GELU fused at compile time (fc1)
+  constexpr bool fast_store = (EK == 2 || EK == 4) && sizeof(TO) == 2;  // EK 4: GELU fused at compile time (fc1)
   constexpr bool pixshuf = EK == 3;
   // pixel shuffle: the lane's 4 columns fix (tap, channel) once; rows only move the output pixel
   int ps_co = 0, ps_dy = 0, ps_dx = 0;
@@ -957,6 +990,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (biasp) bias4 = *(const f32x4_t*)(biasp + n);
     if (rmw) scale4 = *(const f32x4_t*)(MD_SEL_G(p.scale, g) + n);
   }
+  f32x4_t ws4 = {1.f, 1.f, 1.f, 1.f};  // fp8 operands: dequantisation scale of the lane's 4 columns
+  if (rmw && nvalid && MD_SEL_G(p.wscale, g)) ws4 = *(const f32x4_t*)(MD_SEL_G(p.wscale, g) + n) * p.ascale;
   if constexpr (fast_store) {
     // ---- bf16 store epilogue (EPI_STORE / q,k tiles of EPI_QKV; launcher guarantees N, ldo, ldr % 8 == 0) ----
     // A lane owns 8 consecutive columns of a row: per 64-row half 8 iterations of {2 ds_read_b128, math,
@@ -975,8 +1010,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       bl = *(const f32x4_t*)(biasp + n8);
       bh = *(const f32x4_t*)(biasp + n8 + 4);
     }
+    const float* wsp = MD_SEL_G(p.wscale, g);  // fp8 operands: acc * (ascale * wscale[n]) before the bias
+    f32x4_t wl = {1.f, 1.f, 1.f, 1.f}, wh = wl;
+    if (wsp && nv8) {
+      wl = *(const f32x4_t*)(wsp + n8) * p.ascale;
+      wh = *(const f32x4_t*)(wsp + n8 + 4) * p.ascale;
+    }
+    const bool fp8o = p.out_fp8 != 0;
     const long tb = (long)m_base * ldo8 + n0 + out_boff;
-    char* ob = (char*)p.out + tb * (f32o ? 4 : 2);
+    char* ob = (char*)p.out + tb * (fp8o ? 1 : (f32o ? 4 : 2));
     char* o2b = (char*)p.out2 + tb * 2;
     const long trb = (long)m_base * p.ldr + n0;
     const char* q1b = (const char*)p.res1 + trb * 2;
@@ -1037,21 +1079,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         f32x4_t lo = *(const f32x4_t*)(st + row * SROW + c8 * 4);
         f32x4_t hi = *(const f32x4_t*)(st + row * SROW + c8 * 4 + 16);
         if (interior || (m_base + lrow < m_end && nv8)) {
-          lo += bl;
-          hi += bh;
+          lo = lo * wl + bl;
+          hi = hi * wh + bh;
           if (any_res) {
             add_raw(lo, hi, pr1[half][it]);
             add_raw(lo, hi, pr2[half][it]);
           }
           if constexpr (EK == 4) {
-            lo = gelu4<T>(lo);
-            hi = gelu4<T>(hi);
+            lo = gelu4<TO>(lo);
+            hi = gelu4<TO>(hi);
           } else if (relu) {
             lo = relu4(lo);
             hi = relu4(hi);
           }
           const unsigned eo = (unsigned)lrow * (unsigned)ldo8 + lc8;
-          if (f32o) {
+          if (fp8o) {  // e4m3 (saturating) for the next GEMM's A operand
+            const float is = p.out_inv_scale;
+            auto cl = [&](float a) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f(a * is, -448.f, 448.f); };
+            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(lo[0]), cl(lo[1]), 0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(lo[2]), cl(lo[3]), w0, true);
+            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(hi[0]), cl(hi[1]), 0, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cl(hi[2]), cl(hi[3]), w1, true);
+            *(long*)(ob + eo) = (long)(unsigned)w0 | ((long)(unsigned)w1 << 32);
+          } else if (f32o) {
             *(f32x4_t*)(ob + eo * 4u) = lo;
             *(f32x4_t*)(ob + eo * 4u + 16) = hi;
           } else {
@@ -1087,10 +1137,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // wave-uniform tile bases + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
   const long ldo = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;  // q,k rows are [M, 2D]
   const long tile_o = (long)m_base * ldo + n0, tile_r = (long)m_base * p.ldr + n0;
-  char* out_b = (char*)p.out + (out_boff + tile_o) * (p.out_f32 || rmw ? 4 : (long)sizeof(T));
-  char* out2_b = (char*)p.out2 + (out_boff + tile_o) * (long)sizeof(T);
-  const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(T);
-  const char* res2_b = (const char*)p.res2 + tile_r * (long)sizeof(T);
+  char* out_b = (char*)p.out + (out_boff + tile_o) * (p.out_f32 || rmw ? 4 : (long)sizeof(TO));
+  char* out2_b = (char*)p.out2 + (out_boff + tile_o) * (long)sizeof(TO);
+  const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(TO);
+  const char* res2_b = (const char*)p.res2 + tile_r * (long)sizeof(TO);
   const bool has_res = fast_store && (p.res1 || p.res2);
   const bool interior_t = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform: no per-row predicates needed
   // one register array per half serves both prefetches: RMW -> the fp32 x vector; residual store -> the
@@ -1107,7 +1157,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       if (!has_res) return;
       f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
       if (m < m_end && nvalid) {
-        const unsigned ro = (lr * (unsigned)p.ldr + lcol) * (unsigned)sizeof(T);
+        const unsigned ro = (lr * (unsigned)p.ldr + lcol) * (unsigned)sizeof(TO);
         if (p.res1) a1 = *(const f32x2_t*)(res1_b + ro);
         if (p.res2) a2 = *(const f32x2_t*)(res2_b + ro);
       }
@@ -1161,7 +1211,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int m = m0 + it * 4;
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (interior_t || (m < m_end && nvalid)) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v + bias4);
+        if (interior_t || (m < m_end && nvalid)) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v * ws4 + bias4);
         if (half == 0 && it == 7) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) prefetch(1, j);
@@ -1185,18 +1235,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                            __uint_as_float(u3 & 0xffff0000u)};
           }
           if constexpr (EK == 4) {
-            v = gelu4<T>(v);
+            v = gelu4<TO>(v);
           } else {
             if (p.act == ACT_RELU) v = relu4(v);
           }
           const unsigned eo = lr * (unsigned)ldo + lcol;
           if (p.debug_flags & 4) {  // timing-only ablation: no global stores (keep the value alive)
-            if (v[0] == 123.456f) store4<T>((T*)(out_b + eo * (unsigned)sizeof(T)), v);
+            if (v[0] == 123.456f) store4<TO>((TO*)(out_b + eo * (unsigned)sizeof(TO)), v);
           } else if (p.out_f32)
             store4<float>((float*)(out_b + eo * 4u), v);
           else
-            store4<T>((T*)(out_b + eo * (unsigned)sizeof(T)), v);
-          if (p.out2) store4<T>((T*)(out2_b + eo * (unsigned)sizeof(T)), relu4(v));
+            store4<TO>((TO*)(out_b + eo * (unsigned)sizeof(TO)), v);
+          if (p.out2) store4<TO>((TO*)(out2_b + eo * (unsigned)sizeof(TO)), relu4(v));
         }
         if (half == 0 && it == 7) {
 #pragma unroll
@@ -1221,8 +1271,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           if (p.out_f32)
             store4<float>((float*)p.out + o, v);
           else
-            store4<T>((T*)p.out + o, v);
-          if (p.out2) store4<T>((T*)p.out2 + o, relu4(v));
+            store4<TO>((TO*)p.out + o, v);
+          if (p.out2) store4<TO>((TO*)p.out2 + o, relu4(v));
         }
       }
     } else {
@@ -1231,7 +1281,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int row = it * 4 + (lane >> 4);
         const int m = m0 + it * 4;
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (m < m_end && nvalid) epilogue4<T>(p, g, m, n, v, out_boff);
+        if (m < m_end && nvalid) epilogue4<TO>(p, g, m, n, v, out_boff);
       }
     }
     asm volatile("" ::: "memory");
@@ -1275,7 +1325,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   if constexpr (PP == 2) {  // the production schedule carries the specialised epilogues
     if (p.epi == EPI_RESID_LS) return go(gemm256_kernel<T, AMODE, PP, 1>, &set1);
     if (p.epi == EPI_PIXSHUF) return go(gemm256_kernel<T, AMODE, PP, 3>, &set3);
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(typename OutT<T>::type) == 2) {
       const long ldo_e = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
       const bool vec8 = p.N % 8 == 0 && ldo_e % 8 == 0 && (!(p.res1 || p.res2) || p.ldr % 8 == 0);
       if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) return go(gemm256_kernel<T, AMODE, PP, 4>, &set4);

@@ -72,6 +72,13 @@ int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStre
 int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
                        const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s);
 
+// ---- fp8 (OCP e4m3) MFMA operands (MD_PREC_FP8) ----
+// out[i] = e4m3(clamp(in[i] * inv_scale, +-448)); n a multiple of 4.
+int launch_f32_to_fp8(const float* in, long n, float inv_scale, void* out, hipStream_t s);
+// W [N][K] f32 -> e4m3 [N][Kp] (K zero-padded to Kp) with one scale per output row: scale[n] = amax_n / 448 (1 for an
+// all-zero row); the GEMM epilogue multiplies the accumulator by activation_scale * scale[n].
+int launch_pack_fp8_rows(const float* w, int N, int K, int Kp, void* out, float* scale, hipStream_t s);
+
 // ---- Depth-Anything-v3 `small` backbone extras (burn_dino, restated -- see oracle/da3_ref.py) ----
 // Per-head affine LayerNorm(64) of q and k followed by the 2-D rotary embedding, in place on qk [rows, 2D] T.
 // rope_cos/rope_sin: [max_pos + 1][16] tables (angle = pos * base^(-f/16)). global_pos: every patch at (1,1).

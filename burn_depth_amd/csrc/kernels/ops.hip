@@ -711,6 +711,58 @@ int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) operand preparation
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), w, true);
+}
+
+__global__ void f32_to_fp8_kernel(const float* __restrict__ in, long n4, float inv_scale, int* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4_t v = *(const f32x4_t*)(in + 4 * i) * inv_scale;
+    out[i] = pack4_fp8(v[0], v[1], v[2], v[3]);
+  }
+}
+
+int launch_f32_to_fp8(const float* in, long n, float inv_scale, void* out, hipStream_t s) {
+  if (n % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "f32_to_fp8: count must be a multiple of 4");
+  hipLaunchKernelGGL(f32_to_fp8_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, in, n / 4, inv_scale, (int*)out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+__global__ __launch_bounds__(256) void pack_fp8_rows_kernel(const float* __restrict__ w, int N, int K, int Kp,
+                                                            int* __restrict__ out, float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long n = wave_id; n < N; n += nwaves) {
+    const float* row = w + n * K;
+    float amax = 0.f;
+    for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(row[k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[n] = sc;
+    for (int k4 = lane; k4 < Kp / 4; k4 += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (4 * k4 + j) < K ? row[4 * k4 + j] * inv : 0.f;
+      out[n * (Kp / 4) + k4] = pack4_fp8(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+int launch_pack_fp8_rows(const float* w, int N, int K, int Kp, void* out, float* scale, hipStream_t s) {
+  if (Kp % 4 != 0 || Kp < K) MD_FAIL(MD_ERR_INVALID_ARG, "pack_fp8_rows: bad padded K");
+  hipLaunchKernelGGL(pack_fp8_rows_kernel, dim3(grid_for((long)N * 64)), dim3(256), 0, s, w, N, K, Kp, (int*)out, scale);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Depth-Anything-v3 `small` backbone extras (restated from the public DA3 definition; oracle/da3_ref.py)
 // ------------------------------------------------------------------------------------------------
 template <typename T>

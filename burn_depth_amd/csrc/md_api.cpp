@@ -24,8 +24,8 @@ struct DevBuf {  // scoped device allocation for the stand-alone test operators
   }
 };
 hipStream_t pick_stream(md_device_t dev, void* stream) { return stream ? (hipStream_t)stream : dev->stream; }
-int ke_of(int prec) { return prec == MD_PREC_F32 ? 32 : 64; }
-size_t esz_of(int prec) { return prec == MD_PREC_F32 ? 4 : 2; }
+int ke_of(int prec) { return prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64); }
+size_t esz_of(int prec) { return prec == MD_PREC_F32 ? 4 : (prec == MD_PREC_FP8 ? 1 : 2); }
 }  // namespace
 
 extern "C" {
@@ -354,36 +354,34 @@ int md_op_layernorm(md_device_t dev, const float* x_dev, const float* gamma_dev,
 
 int md_op_linear(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int M, int N, int K, int act,
                  int precision, float* out_dev, void* stream) {
-  if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
-  if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
-  if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
-  MD_HIP(hipSetDevice(dev->ordinal));
-  hipStream_t st = pick_stream(dev, stream);
-  DevBuf xa, wa;
-  MD_TRY(xa.alloc((size_t)M * K * esz_of(precision)));
-  MD_TRY(wa.alloc((size_t)N * K * esz_of(precision)));
-  MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st));
-  MD_TRY(launch_f32_to_rows(w_dev, (long)N * K, wa.p, precision, st));
-  GemmParams p;
-  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = K;
-  p.epi = EPI_STORE; p.act = act; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = out_dev; p.ldo = N;
-  MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_AUTO, st));
-  MD_HIP(hipStreamSynchronize(st));
-  return MD_OK;
+  return md_op_linear_tile(dev, x_dev, w_dev, bias_dev, M, N, K, act, precision, TILE_AUTO, out_dev, stream);
 }
 
 int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, const float* bias_dev, int M, int N, int K,
                       int act, int precision, int tile, float* out_dev, void* stream) {
   if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
   if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = pick_stream(dev, stream);
-  DevBuf xa, wa;
+  DevBuf xa, wa, ws;
   MD_TRY(xa.alloc((size_t)M * K * esz_of(precision)));
   MD_TRY(wa.alloc((size_t)N * K * esz_of(precision)));
-  MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st));
-  MD_TRY(launch_f32_to_rows(w_dev, (long)N * K, wa.p, precision, st));
   GemmParams p;
+  if (precision == MD_PREC_FP8) {
+    // stand-alone fp8 check: activations on the static scale 8/448 (the engine's LayerNorm-output scale), weights
+    // per output row
+    const float xs = 8.0f / 448.0f;
+    MD_TRY(ws.alloc((size_t)N * 4));
+    MD_TRY(launch_f32_to_fp8(x_dev, (long)M * K, 1.0f / xs, xa.p, st));
+    MD_TRY(launch_pack_fp8_rows(w_dev, N, K, K, wa.p, (float*)ws.p, st));
+    p.wscale[0] = (const float*)ws.p;
+    p.ascale = xs;
+  } else {
+    MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st));
+    MD_TRY(launch_f32_to_rows(w_dev, (long)N * K, wa.p, precision, st));
+  }
   p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = K;
   p.epi = EPI_STORE; p.act = act; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = out_dev; p.ldo = N;
   MD_TRY(launch_gemm(p, A_DENSE, precision, tile, st));
@@ -520,10 +518,13 @@ __attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, 
   DevBuf tmp;
   MD_TRY(tmp.alloc(h.size() * 4));
   MD_HIP(hipMemcpy(tmp.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-  const size_t es = precision == MD_PREC_F32 ? 4 : 2;
+  const size_t es = esz_of(precision);
   for (size_t off = 0; off < elems; off += h.size()) {
     const size_t n = std::min(h.size(), elems - off);
-    MD_TRY(launch_f32_to_rows((const float*)tmp.p, (long)n, (char*)dst + off * es, precision, st));
+    if (precision == MD_PREC_FP8)
+      MD_TRY(launch_f32_to_fp8((const float*)tmp.p, (long)(n & ~(size_t)3), 448.0f / scale * 0.25f, (char*)dst + off, st));
+    else
+      MD_TRY(launch_f32_to_rows((const float*)tmp.p, (long)n, (char*)dst + off * es, precision, st));
   }
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
@@ -542,7 +543,7 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   const size_t kw = mode == 1 ? (size_t)9 * K : (size_t)K;
   MD_TRY(a.alloc((size_t)M * K * es));
   MD_TRY(w.alloc((size_t)N * kw * es));
-  MD_TRY(o.alloc((size_t)M * N * es));
+  MD_TRY(o.alloc((size_t)M * N * (es < 2 ? 2 : es)));
   MD_TRY(zp.alloc(4096));
   MD_TRY(fill_random(a.p, (size_t)M * K, precision, 1, 1.0f, st));
   MD_TRY(fill_random(w.p, (size_t)N * kw, precision, 2, 0.05f, st));

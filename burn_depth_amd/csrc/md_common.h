@@ -41,6 +41,11 @@ struct Error {
     if (_s != MD_OK) return _s; \
   } while (0)
 
+// ---- fp8 (OCP e4m3fn) storage type: MFMA operands only ---------------------------------------
+struct fp8_t {
+  uint8_t bits;
+};
+
 // ---- bf16 storage type ------------------------------------------------------------------------
 struct bf16_t {
   uint16_t bits;

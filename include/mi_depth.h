@@ -40,7 +40,10 @@ typedef enum md_status {
 typedef enum md_mem_kind { MD_MEM_HOST = 0, MD_MEM_DEVICE = 1 } md_mem_kind;
 /* Arithmetic type of the MFMA operands; accumulation, LayerNorm, softmax and the final
  * focal/clamp/reciprocal are fp32 in both modes. */
-typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1 } md_precision;
+/* MD_PREC_FP8 (Depth-Anything-v3 only, BASELINE config 5): bf16 everywhere except the four ViT linear layers
+ * (qkv, proj, fc1, fc2), which run on OCP e4m3 MFMA operands -- weights quantised per output channel at commit,
+ * activations with static per-tensor scales -- with fp32 accumulation. */
+typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1, MD_PREC_FP8 = 2 } md_precision;
 /* depth_pro/interpolate.rs:11-22 */
 typedef enum md_interp { MD_INTERP_CUSTOM = 0, MD_INTERP_BURN = 1 } md_interp;
 /* synthetic initialisation (no trained weights exist in the reference tree) */

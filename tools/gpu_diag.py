@@ -145,6 +145,46 @@ def check_linear(dev):
         record(f"linear {pname} relu nobias", rel_err(ops.linear(dev, x.cuda(), w.cuda(), None, 1, prec), F.relu(F.linear(x, w))), 2e-5)
 
 
+def q8_mul(x, inv_scale):
+    """e4m3 operand emulation with the device's arithmetic: fp32 multiply by the reciprocal scale, saturate at
+    +-448 (the engine clamps before converting), torch's e4m3fn cast (bit-identical to v_cvt_pk_fp8_f32 incl.
+    subnormals -- checked elementwise on the GPU)."""
+    return (x.float() * inv_scale).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+def q8_rows(w):
+    """per-output-row weight quantisation as pack_fp8_rows_kernel does it: scale = amax * (1/448), inv = 1/scale (fp32)"""
+    amax = w.abs().amax(1, keepdim=True).float()
+    sc = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones_like(amax))
+    return q8_mul(w, 1.0 / sc), sc
+
+
+FP8_ACT_SCALE = float(np.float32(8.0) / np.float32(448.0))  # static scale of LayerNorm / attention outputs
+
+
+def check_linear_fp8(dev):
+    """MD_PREC_FP8 GEMM: e4m3 operands (activations on the static scale 8/448, weights scaled per output row),
+    fp32 accumulation. Compared with the same quantisation done in torch: only accumulation order differs."""
+    g = torch.Generator().manual_seed(5)
+    xs = torch.tensor(FP8_ACT_SCALE, dtype=torch.float32)
+    for (M, N, K, tile, act) in [(300, 256, 128, _lib.TILE_128x128, 0), (300, 256, 256, _lib.TILE_256x256, 0), (1370, 3072, 1024, _lib.TILE_AUTO, 0),
+                                 (2740, 4096, 1024, _lib.TILE_256x256, 2), (2740, 1024, 4096, _lib.TILE_256x256, 0), (513, 260, 384, _lib.TILE_AUTO, 0)]:
+        x = torch.randn(M, K, generator=g) * 1.5
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        xq = q8_mul(x, 1.0 / xs)
+        wq, wsc = q8_rows(w)
+        want = (xq.double() @ wq.double().t()).float() * (xs * wsc.t()) + b
+        if act == 2:
+            want = F.gelu(want)
+        got = ops.linear(dev, x.cuda(), w.cuda(), b.cuda(), act, 2, tile)
+        record(f"linear fp8 M{M} N{N} K{K} tile{tile} act{act}", rel_err(got, want), 2e-4 if act == 2 else 5e-5)
+        full = F.linear(x, w, b)
+        if act == 2:
+            full = F.gelu(full)
+        record(f"linear fp8 M{M} N{N} K{K} quantisation error vs fp32 (informative)", rel_err(got, full), 8e-2)
+
+
 def attn_ref(qkv, heads, quant):
     T, N, _ = qkv.shape
     q, k, v = qkv.reshape(T, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
@@ -343,6 +383,7 @@ def main():
         check_split_merge(dev)
         check_layernorm(dev)
         check_linear(dev)
+        check_linear_fp8(dev)
         check_attention(dev)
         check_convs(dev)
     if want("tiny"):
