@@ -91,7 +91,8 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (B of DepthPro::infer([B,3,S,S])); default 8 for depth_pro (BASELINE config 4's 8 images/GPU), 1 for da3_* (single-image configs 2 / 5)")
-    ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "f32", "fp8"], default="bf16",
+                    help="fp8 (da3_* only, BASELINE config 5): e4m3 operands for the four ViT linear layers, bf16 elsewhere")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
     ap.add_argument("--model", choices=["depth_pro", "da3_large", "da3_small"], default="depth_pro",
                     help="depth_pro = the BASELINE headline; da3_large / da3_small = Depth-Anything-v3 (BASELINE configs 5 / 2)")
@@ -124,6 +125,10 @@ def main() -> int:
     tdev = torch.device("cuda", local_rank)
     if args.model in ("da3_large", "da3_small"):
         return bench_da3(args, dev, tdev, world, rank)
+    if args.precision == "fp8":
+        print("fp8 operands are built for the Depth-Anything-v3 models only (BASELINE config 5); the Depth Pro headline is bf16",
+              file=sys.stderr)
+        return 2
     cfg = {"full": DepthProConfig(), "small": DepthProConfig.small_test(), "tiny": DepthProConfig.tiny_test()}[args.preset]
     cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
     cfg.max_batch = args.batch
@@ -272,7 +277,7 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
     cfg = DepthAnything3Config.small() if small else DepthAnything3Config.metric_large()
     if args.image_size:
         cfg.image_size = args.image_size
-    cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
+    cfg.precision = {"bf16": Precision.BF16, "f32": Precision.F32, "fp8": Precision.FP8}[args.precision]
     cfg.max_batch = args.batch
     S, B = cfg.image_size, args.batch
     model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)

@@ -34,6 +34,7 @@ class Precision:
 
     BF16 = 0
     F32 = 1
+    FP8 = 2  # Depth-Anything-v3 only: e4m3 operands for the four ViT linear layers, bf16 elsewhere (BASELINE config 5)
 
 
 @dataclass(frozen=True)

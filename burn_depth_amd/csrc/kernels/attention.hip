@@ -42,10 +42,11 @@ __device__ __forceinline__ int pack_bf16x2(float a, float b) {
 // the q blocks of one (sequence, head) run on ONE XCD -- its K and V^T (148 KB) are fetched into that
 // L2 once instead of once per q block (measured before the remap: 1.0 GB fetched per launch against
 // 0.27 GB of q/k/v).
+template <bool FP8OUT>
 __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ qk,
                                                              const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
                                                              int S, int n_tokens, int heads, int D, int kpad,
-                                                             int qblocks) {
+                                                             int qblocks, float out_fp8_inv) {
   constexpr int STAGE = 16384;  // K tile 64x128B + V^T tile 64x128B
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -218,7 +219,22 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv_l = 1.0f / l_tot;
   const int q = q0 + c;
-  if (q < n_tokens) {
+  if constexpr (FP8OUT) {  // e4m3 rows for an fp8-operand output projection
+    if (q < n_tokens) {
+    char* orow8 = (char*)out + (seq_row0 + q) * (long)D + head * 64;
+    const float sc = inv_l * out_fp8_inv;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = dt * 32 + 8 * q4 + 4 * h;
+        auto cl = [&](float a) { return __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f); };
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(o[dt][4 * q4]), cl(o[dt][4 * q4 + 1]), 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(o[dt][4 * q4 + 2]), cl(o[dt][4 * q4 + 3]), w, true);
+        *(int*)(orow8 + d) = w;
+      }
+    }
+  } else if (q < n_tokens) {
     bf16_t* orow = out + (seq_row0 + q) * (long)D + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -233,15 +249,19 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 }
 
 int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                          int kpad, hipStream_t s) {
+                          int kpad, hipStream_t s, float out_fp8_inv) {
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
     MD_FAIL(MD_ERR_INVALID_ARG, "attention: kpad=%d must be a multiple of 64 covering %d keys", kpad, n_tokens);
   const int qblocks = (n_tokens + 127) / 128;
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
-  hipLaunchKernelGGL(attention_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
-                     (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks);
+  if (out_fp8_inv > 0.f)
+    hipLaunchKernelGGL(attention_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+                       (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+  else
+    hipLaunchKernelGGL(attention_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+                       (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

@@ -54,8 +54,9 @@ int launch_cls_init(float* x, int nseq_total, int S, int n_tokens, int D, const 
 
 // K3 LayerNorm over D (biased variance), fp32 rows -> T rows (bf16/f32) or fp32 (out_f32).
 // gamma/beta per group (a = gamma, b = beta); NULL gamma = non-affine. Rows grouped by sequence.
+// prec == MD_PREC_FP8 (and !out_f32): rows of OCP e4m3 bytes, value * fp8_inv_scale, saturating.
 int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
-                     int out_f32, hipStream_t s);
+                     int out_f32, hipStream_t s, float fp8_inv_scale = 1.f);
 // fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s);
 
@@ -112,7 +113,8 @@ int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad
 int launch_unpad_rows(const void* in, int T, int N, int SS, int D, float* out, int prec, hipStream_t s);
 
 // fused multi-head attention, bf16 (K5): qk [rows, 2D] (q | k), vT [seq][heads][64][kpad], out [rows, D].
+// out_fp8_inv > 0: the output rows are OCP e4m3 bytes (value * out_fp8_inv, saturating) instead of bf16.
 int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                          int kpad, hipStream_t s);
+                          int kpad, hipStream_t s, float out_fp8_inv = 0.f);
 
 }  // namespace md

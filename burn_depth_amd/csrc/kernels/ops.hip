@@ -413,9 +413,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// four values -> four saturating OCP e4m3 bytes
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), w, true);
+}
+
 template <typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, TO* __restrict__ out, long rows,
-                                                        int D, float eps, int S, SeqGroups g) {
+                                                        int D, float eps, int S, SeqGroups g, float fp8_inv_scale) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -455,6 +461,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (gamma) y = y * *(const f32x4_t*)(gamma + i) + *(const f32x4_t*)(beta + i);
         if constexpr (sizeof(TO) == 4) {
           *(f32x4_t*)((float*)out + row * D + i) = y;
+        } else if constexpr (sizeof(TO) == 1) {  // e4m3 MFMA operand on a static scale
+          y = y * fp8_inv_scale;
+          *(int*)((char*)out + row * D + i) = pack4_fp8(y[0], y[1], y[2], y[3]);
         } else {
           bf16x4_t b = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
           *(bf16x4_t*)((bf16_t*)out + row * D + i) = b;
@@ -465,16 +474,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
-                     int out_f32, hipStream_t s) {
+                     int out_f32, hipStream_t s, float fp8_inv_scale) {
   if (D % 4 != 0 || D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
   const int nv = (D + 255) / 256;
   const int grid = grid_for(rows * 64);
   const bool f32o = out_f32 || prec == MD_PREC_F32;
+  const bool fp8o = !out_f32 && prec == MD_PREC_FP8;
 #define MD_LN(NV)                                                                                                   \
   if (f32o)                                                                                                         \
-    hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3(grid), dim3(256), 0, s, x, (float*)out, rows, D, eps, S, g); \
+    hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3(grid), dim3(256), 0, s, x, (float*)out, rows, D, eps, S, g, 1.f); \
+  else if (fp8o)                                                                                                    \
+    hipLaunchKernelGGL((layernorm_kernel<fp8_t, NV>), dim3(grid), dim3(256), 0, s, x, (fp8_t*)out, rows, D, eps, S, g, \
+                       fp8_inv_scale);                                                                              \
   else                                                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g);
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g, 1.f);
   switch (nv) {
     case 1: MD_LN(1) break;
     case 2: MD_LN(2) break;
@@ -713,11 +726,6 @@ int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int
 // ------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) operand preparation
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), 0, false);
-  return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), w, true);
-}
-
 __global__ void f32_to_fp8_kernel(const float* __restrict__ in, long n4, float inv_scale, int* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4_t v = *(const f32x4_t*)(in + 4 * i) * inv_scale;

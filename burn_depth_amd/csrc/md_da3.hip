@@ -49,6 +49,16 @@ struct md_model_s::Da3State {
   float* pos_aux = nullptr;           // f32 [8ph*8pw, F/2] = 2 * 0.1 * UV table (added twice, dpt.rs:428-435)
   float *conf_stage = nullptr, *aux_stage = nullptr;  // device staging when the caller wants host outputs
   std::vector<float> main_bias, aux_bias;             // output_conv2.conv2.bias, output_conv2_aux.<last>.project.bias
+  // ---- MD_PREC_FP8: the four ViT linear layers on e4m3 operands (weights per output channel, static activation scales) ----
+  bool fp8 = false;
+  char* w8_base = nullptr;                            // one allocation: per block qkv | proj | fc1 | fc2 (e4m3) + their scales
+  struct Fp8Block {
+    void* w[4] = {0, 0, 0, 0};
+    float* s[4] = {0, 0, 0, 0};
+  };
+  std::vector<Fp8Block> w8;
+  static constexpr float kActScale = 8.0f / 448.0f;   // LayerNorm output, attention output
+  static constexpr float kHidScale = 16.0f / 448.0f;  // GELU output
 };
 
 namespace md {
@@ -139,6 +149,17 @@ static std::vector<float> interpolate_pos_embed(const std::vector<float>& pos, i
 int da3_on_commit(md_model_t m) {
   md_model_s::Da3State* d = m->da3;
   const int D = d->cfg.vit.D, M = d->native_grid;
+  if (d->fp8) {  // e4m3 copies of the ViT linear weights, one scale per output channel
+    const char* names[4] = {".attn.qkv.weight", ".attn.proj.weight", ".mlp.fc1.weight", ".mlp.fc2.weight"};
+    const int nn[4] = {3 * D, D, 4 * D, D}, kk[4] = {D, D, D, 4 * D};
+    for (int i = 0; i < d->cfg.vit.depth; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const float* src = P32(m, "backbone.pretrained.blocks." + std::to_string(i) + names[j]);
+        if (!src) MD_FAIL(MD_ERR_FORMAT, "missing ViT weight for the fp8 pack");
+        MD_TRY(launch_pack_fp8_rows(src, nn[j], kk[j], kk[j], d->w8[i].w[j], d->w8[i].s[j], m->dev->stream));
+      }
+    MD_HIP(hipStreamSynchronize(m->dev->stream));
+  }
   {
     const Da3Cfg& c = d->cfg;
     d->main_bias.assign(c.output_dim, 0.f);
@@ -250,14 +271,19 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   md_model_s* m = new md_model_s();
   m->dev = dev;
   m->kind = 1;
-  m->prec = cfg.precision;
-  m->esz = cfg.precision == MD_PREC_F32 ? 4 : 2;
+  // MD_PREC_FP8 is bf16 everywhere except the four ViT linear layers (e4m3 operands)
+  const bool fp8 = cfg.precision == MD_PREC_FP8;
+  if (fp8 && v.D % 128 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "fp8 operands need a ViT width that is a multiple of 128 (got %d)", v.D);
+  m->prec = fp8 ? MD_PREC_BF16 : cfg.precision;
+  m->esz = m->prec == MD_PREC_F32 ? 4 : 2;
   m->ke = 128 / m->esz;
   m->cfg.max_batch = cfg.max_batch;
-  m->cfg.precision = cfg.precision;
+  m->cfg.precision = m->prec;
   m->da3 = new md_model_s::Da3State();
   md_model_s::Da3State* d = m->da3;
   d->cfg = cfg;
+  d->cfg.precision = m->prec;
+  d->fp8 = fp8;
   d->hp = cfg.dual_head ? "head_dual" : "head_mono";
   d->din = cfg.dual_head ? 2 * v.D : v.D;
   d->native_grid = v.img / v.ps;  // the pos_embed parameter's grid (37 for ViT-L/14 @ 518)
@@ -343,6 +369,26 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   (void)hipMemset(m->wpk_base, 0, m->wpk_bytes);
   for (auto& e : m->packs) e.dst = m->wpk_base + (size_t)e.dst;
 
+  if (fp8) {
+    const size_t per_block = (size_t)12 * D * D + (size_t)(3 * D + D + 4 * D + D) * 4 + 8 * 256;
+    if (hipMalloc((void**)&d->w8_base, per_block * v.depth) != hipSuccess) {
+      set_error("hipMalloc of %zu bytes for the fp8 weights failed", per_block * v.depth);
+      return fail(MD_ERR_OOM);
+    }
+    (void)hipMemset(d->w8_base, 0, per_block * v.depth);
+    char* q = d->w8_base;
+    const int nn[4] = {3 * D, D, 4 * D, D}, kk[4] = {D, D, D, 4 * D};
+    for (int i = 0; i < v.depth; ++i) {
+      md_model_s::Da3State::Fp8Block b8;
+      for (int j = 0; j < 4; ++j) {
+        b8.w[j] = q;
+        q += align_up((size_t)nn[j] * kk[j], 256);
+        b8.s[j] = (float*)q;
+        q += align_up((size_t)nn[j] * 4, 256);
+      }
+      d->w8.push_back(b8);
+    }
+  }
   VitW& w = d->vit;
   w.pe_w = PK(m, bp + ".patch_embed.proj.weight");
   w.pe_b = P32(m, bp + ".patch_embed.proj.bias");
@@ -420,6 +466,7 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
 }
 
 void da3_destroy_state(md_model_t m) {
+  if (m && m->da3 && m->da3->w8_base) (void)hipFree(m->da3->w8_base);
   if (!m || !m->da3) return;
   for (auto& kv : m->da3->tok_index) (void)hipFree(kv.second);
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
@@ -548,16 +595,22 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       MD_TRY(launch_set_token0(d->xres, B, SS, D, Bi(bp + ".camera_token"), st));
       r.end();
     }
+    // MD_PREC_FP8: the operands of the four linear layers are e4m3 (LayerNorm / attention / GELU outputs are
+    // written as e4m3 on static scales; weights were quantised per output channel at commit)
+    const bool f8 = d->fp8;
+    const int lin_prec = f8 ? MD_PREC_FP8 : m->prec;
+    const float a_inv = 1.0f / md_model_s::Da3State::kActScale, h_inv = 1.0f / md_model_s::Da3State::kHidScale;
     sg.a[0] = k.n1g; sg.b[0] = k.n1b;
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, st));
+    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
     r.end();
     {
       GemmParams p;
       p.N = 3 * D; p.K = D; dense(p); p.W[0] = k.qkv_w; p.bias[0] = k.qkv_b; p.A = d->xn; p.lda = D;
       p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad;
+      if (f8) { p.W[0] = d->w8[i].w[0]; p.wscale[0] = d->w8[i].s[0]; p.ascale = md_model_s::Da3State::kActScale; }
       r.begin("qkv_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
       r.end();
     }
     if (ext) {  // per-head q/k LayerNorm + 2-D RoPE (global blocks: every patch at position (1,1))
@@ -570,7 +623,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
     if (m->prec == MD_PREC_BF16) {
       r.begin("attention");
-      MD_TRY(launch_attention_bf16(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, st));
+      MD_TRY(launch_attention_bf16(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, st, f8 ? a_inv : 0.f));
       r.end();
     } else {
       GemmParams p;
@@ -598,28 +651,34 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       GemmParams p;
       p.N = D; p.K = D; dense(p); p.W[0] = k.proj_w; p.bias[0] = k.proj_b; p.scale[0] = k.ls1;
       p.A = d->ao; p.lda = D; p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      if (f8) { p.W[0] = d->w8[i].w[1]; p.wscale[0] = d->w8[i].s[1]; p.ascale = md_model_s::Da3State::kActScale; }
       r.begin("proj_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
       r.end();
     }
     sg.a[0] = k.n2g; sg.b[0] = k.n2b;
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, st));
+    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
     r.end();
     {
       GemmParams p;
       p.N = 4 * D; p.K = D; dense(p); p.W[0] = k.fc1_w; p.bias[0] = k.fc1_b; p.A = d->xn; p.lda = D;
       p.epi = EPI_STORE; p.act = ACT_GELU; p.out = d->hbuf; p.ldo = 4 * D;
+      if (f8) {
+        p.W[0] = d->w8[i].w[2]; p.wscale[0] = d->w8[i].s[2]; p.ascale = md_model_s::Da3State::kActScale;
+        p.out_fp8 = 1; p.out_inv_scale = h_inv;
+      }
       r.begin("fc1_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      MD_TRY(launch_gemm(p, A_DENSE, lin_prec, f8 ? TILE_256x256 : TILE_AUTO, st));
       r.end();
     }
     {
       GemmParams p;
       p.N = D; p.K = 4 * D; dense(p); p.W[0] = k.fc2_w; p.bias[0] = k.fc2_b; p.scale[0] = k.ls2;
       p.A = d->hbuf; p.lda = 4 * D; p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      if (f8) { p.W[0] = d->w8[i].w[3]; p.wscale[0] = d->w8[i].s[3]; p.ascale = md_model_s::Da3State::kHidScale; }
       r.begin("fc2_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
+      MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
       r.end();
     }
     if (c.dual_head) {

@@ -154,10 +154,10 @@ def head_forward_raw(hooks: List[Tensor], height: int, width: int, W, cfg: Depth
     return torch.exp(logits)  # HeadActivation::Exp (dpt.rs:700)
 
 
-def backbone_hooks(x: Tensor, W, cfg: DepthAnything3Config, q=identity) -> List[Tensor]:
+def backbone_hooks(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8: bool = False) -> List[Tensor]:
     """Backbone::forward_with_hooks (mod.rs:202-215): per hook block the final-norm'ed patch tokens."""
     v = cfg.vit()
-    _, raw = vit_forward(x, W, "backbone.pretrained", v, cfg.hook_block_ids, q)
+    _, raw = vit_forward(x, W, "backbone.pretrained", v, cfg.hook_block_ids, q, fp8=fp8)
     g, b = W["backbone.pretrained.norm.gamma"], W["backbone.pretrained.norm.beta"]
     return [F.layer_norm(h, (v.embed_dim,), g, b, v.ln_eps)[:, 1:] for h in raw]
 
@@ -195,9 +195,10 @@ def rope2d(t: Tensor, pos: Tensor, base: float) -> Tensor:
     return torch.cat([_rope_half(t[..., :n], pos[:, 0], base), _rope_half(t[..., n:], pos[:, 1], base)], -1)
 
 
-def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity):
+def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8: bool = False):
     """Returns (hooks: 4 x [B, P, 2D] with the second half final-norm'ed, camera feature [B, 2D] of the last hook)."""
-    from oracle.depth_pro_ref import interpolate_pos_encoding
+    from oracle.depth_pro_ref import interpolate_pos_encoding, linear_quantisers
+    qn, qo, qh, qw = linear_quantisers(q, fp8)
     v = cfg.vit()
     bp = "backbone.pretrained"
     p = lambda n: W[f"{bp}.{n}"]
@@ -219,8 +220,8 @@ def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity):
         if ext and i == start:
             xs = torch.cat([p("camera_token")[:, :1].expand(B, 1, D), xs[:, 1:]], 1)
         is_global = ext and i % 2 == 1
-        xn = q(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
-        qkv = q(F.linear(xn, q(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
+        xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
+        qkv = q(F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
         qkv = qkv.reshape(B, N, 3, Hn, hd).permute(2, 0, 3, 1, 4)
         qq, kk, vv = qkv[0], qkv[1], qkv[2]
         if ext:
@@ -231,11 +232,11 @@ def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity):
         sc = (qq @ kk.transpose(-2, -1)) * hd ** -0.5
         pu = torch.exp(sc - sc.amax(-1, keepdim=True))
         o = (q(pu) @ vv) / pu.sum(-1, keepdim=True)
-        o = q(o.transpose(1, 2).reshape(B, N, D))
-        xs = xs + p(f"{b}.ls1.gamma") * F.linear(o, q(p(f"{b}.attn.proj.weight")), p(f"{b}.attn.proj.bias"))
-        xn = q(F.layer_norm(xs, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))
-        h = q(F.gelu(F.linear(xn, q(p(f"{b}.mlp.fc1.weight")), p(f"{b}.mlp.fc1.bias"))))
-        xs = xs + p(f"{b}.ls2.gamma") * F.linear(h, q(p(f"{b}.mlp.fc2.weight")), p(f"{b}.mlp.fc2.bias"))
+        o = qo(o.transpose(1, 2).reshape(B, N, D))
+        xs = xs + p(f"{b}.ls1.gamma") * F.linear(o, qw(p(f"{b}.attn.proj.weight")), p(f"{b}.attn.proj.bias"))
+        xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))
+        h = qh(F.gelu(F.linear(xn, qw(p(f"{b}.mlp.fc1.weight")), p(f"{b}.mlp.fc1.bias"))))
+        xs = xs + p(f"{b}.ls2.gamma") * F.linear(h, qw(p(f"{b}.mlp.fc2.weight")), p(f"{b}.mlp.fc2.bias"))
         if not is_global:
             local_x = xs
         if i in cfg.hook_block_ids:
@@ -326,7 +327,7 @@ def camera_decode(cam: Tensor, W, height: int, width: int):
     return dict(pose_encoding=pose[:, None], extrinsics=extr[:, None], intrinsics=intr[:, None])
 
 
-def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False):
+def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False, fp8: bool = False):
     """DepthAnything3::infer (mod.rs:288-291 -> 495-564 -> 587-624): depth [B,H,W] (+ confidence, aux rays,
     aux confidence, pose encoding, extrinsics, intrinsics for the dual-head variant)."""
     B, _, H, Wd = x.shape
@@ -335,13 +336,13 @@ def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = Fal
         raise ValueError(f"Input {H}x{Wd} must be divisible by patch size {ps}")
     dbg = {} if debug else None
     if cfg.dual_head:
-        hooks, cam = backbone_hooks_ext(x, W, cfg, q)
+        hooks, cam = backbone_hooks_ext(x, W, cfg, q, fp8)
         out = dual_head_forward(hooks, H, Wd, W, cfg, q, dbg)
         out.update(camera_decode(cam, W, H, Wd))
         if debug:
             dbg["camera_feature"] = cam
     else:
-        hooks = backbone_hooks(x, W, cfg, q)
+        hooks = backbone_hooks(x, W, cfg, q, fp8)
         act = head_forward_raw(hooks, H, Wd, W, cfg, q, dbg)
         out = dict(depth=act[:, 0])  # select_depth_channel (dpt.rs:633-647)
     if debug:

@@ -213,8 +213,35 @@ def reshape_feature(emb: Tensor, width: int, height: int, cls_token_offset: int)
 # a4  DINOv2 ViT (burn_dino 0.6.0 -- un-vendored; public DINOv2 definition; PARITY UNPINNED)
 #     call sites: layers/vit.rs:45-68, encoder.rs:346-348,409, fov.rs:203
 # ---------------------------------------------------------------------------------------------
+FP8_ACT_SCALE = 8.0 / 448.0   # engine: Da3State::kActScale (LayerNorm / attention outputs)
+FP8_HID_SCALE = 16.0 / 448.0  # engine: Da3State::kHidScale (GELU output)
+
+
+def fp8_static(x: Tensor, scale: float) -> Tensor:
+    """e4m3 MFMA-operand emulation on a static scale, with the engine's arithmetic: fp32 multiply by the fp32
+    reciprocal, saturate at +-448, OCP e4m3fn cast (bit-identical to v_cvt_pk_fp8_f32, checked on the GPU)."""
+    s32 = torch.tensor(scale, dtype=torch.float32)
+    return (x.float() * (1.0 / s32)).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s32
+
+
+def fp8_rows(w: Tensor) -> Tensor:
+    """per-output-channel e4m3 weights as pack_fp8_rows_kernel makes them: scale = amax * (1/448), inv = 1/scale."""
+    amax = w.abs().amax(1, keepdim=True).float()
+    sc = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones_like(amax))
+    return (w.float() * (1.0 / sc)).clamp(-448, 448).to(torch.float8_e4m3fn).float() * sc
+
+
+def linear_quantisers(q: "Quant", fp8: bool):
+    """(LayerNorm-output, attention-output, GELU-output, weight) operand quantisers of the four ViT linear layers:
+    `q` everywhere (bf16 emulation or identity), or the MD_PREC_FP8 scheme."""
+    if not fp8:
+        return q, q, q, q
+    return (lambda t: fp8_static(t, FP8_ACT_SCALE), lambda t: fp8_static(t, FP8_ACT_SCALE),
+            lambda t: fp8_static(t, FP8_HID_SCALE), fp8_rows)
+
+
 def vit_forward(x: Tensor, W: Dict[str, Tensor], prefix: str, v: ViTConfig, hook_ids: Sequence[int],
-                q: Quant = identity, chunk: int = 8) -> Tuple[Tensor, List[Tensor]]:
+                q: Quant = identity, chunk: int = 8, fp8: bool = False) -> Tuple[Tensor, List[Tensor]]:
     """Returns (x_norm_patchtokens [B, g*g, D], hooks: un-normalised tokens incl. cls after the
     0-based block indices ``hook_ids``; vit.rs:63 ``normalize_intermediate_tokens=false``).
 
@@ -222,7 +249,7 @@ def vit_forward(x: Tensor, W: Dict[str, Tensor], prefix: str, v: ViTConfig, hook
     no mask token.  qkv bias, exact-erf GELU, LayerScale, LN eps = v.ln_eps."""
     outs, hooks_acc = [], None
     for s in range(0, x.shape[0], chunk):  # chunk only bounds peak memory
-        o, h = _vit_forward_chunk(x[s:s + chunk], W, prefix, v, hook_ids, q)
+        o, h = _vit_forward_chunk(x[s:s + chunk], W, prefix, v, hook_ids, q, fp8)
         outs.append(o)
         hooks_acc = [[t] for t in h] if hooks_acc is None else [a + [t] for a, t in zip(hooks_acc, h)]
     return torch.cat(outs, 0), [torch.cat(a, 0) for a in (hooks_acc or [])]
@@ -243,8 +270,9 @@ def interpolate_pos_encoding(pos: Tensor, gh: int, gw: int) -> Tensor:
     return torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], 1)
 
 
-def _vit_forward_chunk(x, W, prefix, v, hook_ids, q):
+def _vit_forward_chunk(x, W, prefix, v, hook_ids, q, fp8=False):
     B = x.shape[0]
+    qn, qo, qh, qw = linear_quantisers(q, fp8)
     D, Hn, hd = v.embed_dim, v.num_heads, v.head_dim
     p = lambda n: W[f"{prefix}.{n}"]
     tok = F.conv2d(q(x), q(p("patch_embed.proj.weight")), p("patch_embed.proj.bias"), stride=v.patch_size)
@@ -256,18 +284,18 @@ def _vit_forward_chunk(x, W, prefix, v, hook_ids, q):
     hooks: List[Tensor] = []
     for i in range(v.depth):
         b = f"blocks.{i}"
-        xn = q(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
-        qkv = q(F.linear(xn, q(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
+        xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
+        qkv = q(F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
         qkv = qkv.reshape(B, N, 3, Hn, hd).permute(2, 0, 3, 1, 4)
         qq, kk, vv = qkv[0], qkv[1], qkv[2]
         s = (qq @ kk.transpose(-2, -1)) * scale
         pu = torch.exp(s - s.amax(-1, keepdim=True))
         o = (q(pu) @ vv) / pu.sum(-1, keepdim=True)
-        o = q(o.transpose(1, 2).reshape(B, N, D))
-        xs = xs + p(f"{b}.ls1.gamma") * F.linear(o, q(p(f"{b}.attn.proj.weight")), p(f"{b}.attn.proj.bias"))
-        xn = q(F.layer_norm(xs, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))
-        h = q(F.gelu(F.linear(xn, q(p(f"{b}.mlp.fc1.weight")), p(f"{b}.mlp.fc1.bias"))))
-        xs = xs + p(f"{b}.ls2.gamma") * F.linear(h, q(p(f"{b}.mlp.fc2.weight")), p(f"{b}.mlp.fc2.bias"))
+        o = qo(o.transpose(1, 2).reshape(B, N, D))
+        xs = xs + p(f"{b}.ls1.gamma") * F.linear(o, qw(p(f"{b}.attn.proj.weight")), p(f"{b}.attn.proj.bias"))
+        xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))
+        h = qh(F.gelu(F.linear(xn, qw(p(f"{b}.mlp.fc1.weight")), p(f"{b}.mlp.fc1.bias"))))
+        xs = xs + p(f"{b}.ls2.gamma") * F.linear(h, qw(p(f"{b}.mlp.fc2.weight")), p(f"{b}.mlp.fc2.bias"))
         for hid in hook_ids:
             if hid == i:
                 hooks.append(xs.clone())

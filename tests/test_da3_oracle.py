@@ -55,3 +55,37 @@ def test_align_corners_true_resize_identity():
     assert D.resize_bilinear(x, (5, 7)) is x
     y = D.resize_bilinear(x, (9, 13))
     assert torch.allclose(y[..., 0, 0], x[..., 0, 0]) and torch.allclose(y[..., -1, -1], x[..., -1, -1])
+
+
+def test_fp8_operand_emulation_properties():
+    """The MD_PREC_FP8 emulation used to check the engine: static-scale / per-row e4m3 quantisers."""
+    import torch
+    from oracle import depth_pro_ref as R
+    x = torch.tensor([0.0, 1e-4, 0.5, 7.9, 8.1, 20.0, -9.0])
+    q = R.fp8_static(x, R.FP8_ACT_SCALE)
+    assert q[0] == 0 and abs(q[2] - 0.5) < 0.5 / 16 and q[4] == q[5] == 8.0 and q[6] == -8.0   # saturates at 448 * scale
+    assert abs(q[3] - 7.9) <= 8.0 / 16                                                              # 3 mantissa bits
+    w = torch.randn(5, 64)
+    w[3] = 0
+    wq = R.fp8_rows(w)
+    assert torch.equal(wq[3], torch.zeros(64))
+    assert torch.allclose(wq.abs().amax(1)[[0, 1, 2, 4]], w.abs().amax(1)[[0, 1, 2, 4]], rtol=1e-6)  # the row maximum is exact
+    assert ((wq - w).abs() <= w.abs().amax(1, keepdim=True) / 16 + 1e-9).all()
+    qn, qo, qh, qw = R.linear_quantisers(R.identity, False)
+    assert qn is R.identity and qw is R.identity
+
+
+def test_fp8_mode_stays_close_to_fp32_on_the_oracle():
+    import torch
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config
+    from oracle import da3_ref as D3, depth_pro_ref as R
+    cfg = DepthAnything3Config.tiny_dual_test()
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+    torch.manual_seed(1)
+    x = torch.randn(1, 3, 70, 70)
+    with torch.no_grad():
+        a = D3.infer(x, W, cfg)["depth"]
+        b = D3.infer(x, W, cfg, q=R.bf16_round, fp8=True)["depth"]
+    rel = ((a - b).abs() / a.abs())
+    assert rel.mean() < 3e-2 and rel.max() < 0.3

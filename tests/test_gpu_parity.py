@@ -242,6 +242,35 @@ def test_depth_anything3_small_end_to_end(diag, dev, precision):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("variant", ["tiny", "tiny_dual"])
+def test_depth_anything3_fp8_linear_layers(diag, dev, variant):
+    # BASELINE config 5 family: e4m3 operands for the four ViT linear layers (weights per output channel, static
+    # activation scales), bf16 elsewhere; compared with the oracle running the same quantisation and with fp32
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    cfg = DepthAnything3Config.tiny_test() if variant == "tiny" else DepthAnything3Config.tiny_dual_test()
+    start = len(diag.RESULTS)
+    diag.guarded("da3-fp8")(diag.run_da3)(dev, cfg, f"da3-{variant}/fp8", 2, Precision.FP8)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 7
+
+
+def test_fp8_gemm_matches_the_quantised_product(diag, dev):
+    start = len(diag.RESULTS)
+    diag.check_linear_fp8(dev)
+    _assert_new_results_ok(diag, start)
+
+
+def test_fp8_is_rejected_for_depth_pro(dev):
+    from burn_depth_amd import _lib
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = Precision.FP8
+    with pytest.raises(_lib.MdError) as e:
+        DepthPro.new(dev, cfg, seed=0)
+    assert e.value.code == _lib.MD_ERR_INVALID_ARG
+
+
 def test_depth_anything3_small_batch_independence_and_partial_outputs(dev):
     import ctypes as C
     from burn_depth_amd import _lib, weights as Wt

@@ -338,6 +338,23 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY):
     print(f"      da3 oracle fp32 {time.time() - t0:.1f}s", flush=True)
     d, rd = out.depth.cpu(), ref["depth"]
     rel = (d - rd).abs() / rd.abs()
+    if precision == Precision.FP8:
+        # e4m3 operands in the four ViT linear layers: compared with the oracle running the SAME quantisation
+        # (bf16 operand rounding elsewhere), and reported against the fp32 oracle
+        refq = D3.infer(x, W, cfg, q=R.bf16_round, fp8=True)
+        rq = refq["depth"]
+        relq = (d - rq).abs() / rq.abs()
+        record(f"{label} depth max-rel vs fp8-emulating oracle", relq.max().item(), 1.5e-1, f"mean-rel={relq.mean().item():.2e}")
+        record(f"{label} depth mean-rel vs fp8-emulating oracle", relq.mean().item(), 1.5e-2)
+        record(f"{label} depth mean-rel vs fp32 oracle (quantisation error)", rel.mean().item(), 6e-2, f"max-rel={rel.max().item():.2e}")
+        record(f"{label} oracle: fp8 emulation vs fp32 mean-rel (informative)", ((rq - rd).abs() / rd.abs()).mean().item(), 6e-2)
+        model.enable_timing(True)
+        model.infer(x.cuda())
+        tm = model.read_timing()
+        tot = sum(v[0] for v in tm.values())
+        print(f"      da3 kernel time {tot:.2f} ms/batch: " + ", ".join(f"{k}={v[0]:.2f}ms/{v[1]}" for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0])[:10]), flush=True)
+        model.destroy()
+        return
     tol = (8e-2, 1e-2) if precision == Precision.BF16 else (1e-3, 1e-4)
     record(f"{label} depth max-rel vs fp32 oracle", rel.max().item(), tol[0], f"mean-rel={rel.mean().item():.2e} depth in [{rd.min():.3f},{rd.max():.3f}]")
     record(f"{label} depth mean-rel vs fp32 oracle", rel.mean().item(), tol[1])
@@ -403,11 +420,15 @@ def main():
         guarded("da3 tiny98 f32")(run_da3)(dev, c98, "da3-tiny98/f32", 1, Precision.F32)
         guarded("da3 tiny-dual f32")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/f32", 2, Precision.F32)
         guarded("da3 tiny-dual bf16")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/bf16", 2, Precision.BF16)
+        guarded("da3 tiny fp8")(run_da3)(dev, DepthAnything3Config.tiny_test(), "da3-tiny/fp8", 2, Precision.FP8)
+        guarded("da3 tiny-dual fp8")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/fp8", 2, Precision.FP8)
         if not args.skip_small:
             guarded("da3 large f32")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/f32", 1, Precision.F32)
             guarded("da3 large bf16")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/bf16", 1, Precision.BF16)
             guarded("da3 small f32")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/f32", 1, Precision.F32)
             guarded("da3 small bf16")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/bf16", 2, Precision.BF16)
+            guarded("da3 large fp8")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/fp8", 1, Precision.FP8)
+            guarded("da3 small fp8")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/fp8", 1, Precision.FP8)
     if args.full or want("full") and only is not None:
         guarded("full bf16")(run_e2e)(dev, DepthProConfig(), "full/bf16", 1, (1536, 1536), Precision.BF16, taps=False)
     bad = [r for r in RESULTS if not r[3]]
