@@ -929,6 +929,57 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime();
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
+    if constexpr (PP == 2 && sizeof(TO) == 2) {
+      // V^T[seq][head][d][token] tiles: staged TRANSPOSED through the wave-private LDS area (64 n-rows x 64 tokens
+      // per half) so that a lane stores 4 consecutive tokens of one (head, d) row -- 8-byte stores, 4 full 128-byte
+      // row segments per instruction -- instead of 2-byte scatter stores (4x the store instructions). Needs whole
+      // 64-column head slices (embed % 64 == 0, always true: head_dim = 64) and 4-token groups inside one sequence
+      // (seq_stride % 4 == 0).
+      if ((p.seq_stride & 3) == 0 && n0 + BN <= p.N) {
+        constexpr int SRT = 272;  // 64 tokens x 4 B + 16 B pad: the 4 q16 groups of a write land 16 banks apart
+        char* stt = smem + wave * (64 * SRT);
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+        const int nl0 = lane >> 4;                       // n row of iteration 0
+        const int c0 = n0 - 2 * p.embed + wn * WTN;      // first V column of this wave: one whole head
+        const int hd = c0 >> 6;
+        const float* bp_ = MD_SEL_G(p.bias, g) + n0 + wn * WTN;
+        const float* wsp_ = MD_SEL_G(p.wscale, g);
+        float bia[16], wsc[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          bia[it] = bp_[it * 4 + nl0];
+          wsc[it] = wsp_ ? wsp_[n0 + wn * WTN + it * 4 + nl0] * p.ascale : 1.f;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const f32x4acc_t c = acc16[a][half * 4 + bb];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                *(float*)(stt + (a * 16 + 4 * q16 + j) * SRT + (bb * 16 + (lane & 15)) * 4) = c[j];
+            }
+          asm volatile("" ::: "memory");
+          const int m = m_base + wm * WTM + half * 64 + (lane & 15) * 4;  // first of this lane's 4 tokens
+          const int seq = fdiv(m, p.fd_seq_stride);
+          const int tok = m - seq * p.seq_stride;
+          TO* vrow = (TO*)p.vT + (((long)seq * p.heads + hd) * 64) * p.kpad + tok;
+          const bool ok = m < m_end;  // groups of 4 rows are all inside or all outside (g_rows % 4 == 0 for token buffers)
+#pragma unroll
+          for (int it = 0; it < 16; ++it) {
+            const int nl = it * 4 + nl0;
+            f32x4_t v = *(const f32x4_t*)(stt + nl * SRT + (lane & 15) * 16);
+            v = v * wsc[it] + bia[it];
+            if (ok) store4<TO>(vrow + (long)nl * p.kpad, v);
+          }
+          asm volatile("" ::: "memory");
+        }
+        return;
+      }
+    }
     if constexpr (PP == 2) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
