@@ -551,6 +551,13 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
   p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = (dbg & 3) | ((dbg & 64) ? 4 : 0) | ((dbg & 128) ? 8 : 0);
   DevBuf bias;
+  DevBuf xres, lsc;
+  if (dbg & 16) {  // proj / fc2-style epilogue: x(f32) += scale * (acc + bias)
+    MD_TRY(xres.alloc((size_t)M * N * 4));
+    MD_TRY(lsc.alloc((size_t)N * 8));
+    MD_TRY(fill_random(lsc.p, (size_t)N * 2, MD_PREC_F32, 6, 0.1f, st));
+    p.epi = EPI_RESID_LS; p.out = xres.p; p.ldo = N; p.scale[0] = (const float*)lsc.p; p.bias[0] = (const float*)lsc.p + N;
+  }
   if (dbg & 4) {  // fc1-style epilogue: bias + GELU
     MD_TRY(bias.alloc((size_t)N * 4));
     MD_TRY(fill_random(bias.p, (size_t)N, MD_PREC_F32, 5, 0.1f, st));
