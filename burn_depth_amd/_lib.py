@@ -35,7 +35,7 @@ class MdDa3Outputs(C.Structure):
 
 class MdDa3Cfg(C.Structure):
     _fields_ = [("variant", C.c_char_p), ("image_size", C.c_int), ("precision", C.c_int), ("max_batch", C.c_int),
-                ("ln_eps", C.c_float)]
+                ("ln_eps", C.c_float), ("image_width", C.c_int)]
 
 
 class MdDepthProCfg(C.Structure):

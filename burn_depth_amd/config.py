@@ -141,7 +141,7 @@ class DepthAnything3Config:
     head; `small` = ViT-S/14 with the burn_dino extras + dual head + camera decoder."""
 
     variant: str = "metric_large"
-    image_size: int = 518
+    image_size: int = 518   # input rows (and columns when image_width == 0)
     patch_size: int = 14
     hook_block_ids: tuple = (4, 11, 17, 23)
     dim_in: int = 1024
@@ -162,6 +162,7 @@ class DepthAnything3Config:
     aux_out1_conv_num: int = 5
     aux_output_dim: int = 7
     aux_levels: int = 4
+    image_width: int = 0    # 0 = square; else input columns (multiple of 14): `infer` only asserts divisibility (mod.rs:509-520)
 
     @staticmethod
     def metric_large() -> "DepthAnything3Config":

@@ -672,6 +672,10 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
     if (c->image_size % v.ps != 0) MD_FAIL(MD_ERR_SHAPE, "image size %d must be divisible by patch size %d", c->image_size, v.ps);
     d.image_size = c->image_size;
   }
+  if (c->image_width > 0) {
+    if (c->image_width % v.ps != 0) MD_FAIL(MD_ERR_SHAPE, "image width %d must be divisible by patch size %d", c->image_width, v.ps);
+    d.image_width = c->image_width;
+  }
   d.precision = c->precision;
   d.max_batch = c->max_batch > 0 ? c->max_batch : 1;
   d.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
@@ -686,6 +690,7 @@ void md_da3_cfg_default(md_da3_cfg* cfg) {
   if (!cfg) return;
   cfg->variant = "metric_large";
   cfg->image_size = 0;
+  cfg->image_width = 0;
   cfg->precision = MD_PREC_BF16;
   cfg->max_batch = 1;
   cfg->ln_eps = 1e-6f;

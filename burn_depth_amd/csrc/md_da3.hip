@@ -23,7 +23,8 @@ using namespace md;
 
 struct md_model_s::Da3State {
   Da3Cfg cfg;
-  int ph = 0, pw = 0, P = 0, NT = 0, SS = 0, kpad = 0, Kp = 0, h3 = 0;
+  int ih = 0, iw = 0;  // configured input size (rows x columns; any multiples of the patch size)
+  int ph = 0, pw = 0, P = 0, NT = 0, SS = 0, kpad = 0, Kp = 0, h3h = 0, h3w = 0;
   VitW vit;
   // workspace
   void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vT = nullptr, *ao = nullptr, *hbuf = nullptr;
@@ -186,7 +187,8 @@ int da3_on_commit(md_model_t m) {
 static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   md_model_s::Da3State* d = m->da3;
   const Da3Cfg& c = d->cfg;
-  const int B = c.max_batch, D = c.vit.D, F = c.features, esz = m->esz, S = c.image_size;
+  const int B = c.max_batch, D = c.vit.D, F = c.features, esz = m->esz;
+  const size_t SS2 = (size_t)d->ih * d->iw;  // pixels of one input image
   const int* oc = c.out_channels;
   size_t total = 0;
   auto take = [&](size_t bytes) -> void* {
@@ -203,11 +205,10 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
     }                                                                         \
   } while (0)
   const size_t rows = (size_t)B * d->SS + 64;
-  const int ph = d->ph, pw = d->pw, h3 = d->h3;
+  const int ph = d->ph, pw = d->pw;
   const size_t P = d->P;
   auto cp = [&](int ch) { return (size_t)round_up(ch, m->ke); };
-  (void)S;
-  DA3_TAKE(xin, float*, (size_t)B * 3 * S * S * 4);
+  DA3_TAKE(xin, float*, (size_t)B * 3 * SS2 * 4);
   DA3_TAKE(patches, void*, (size_t)B * P * d->Kp * esz);
   DA3_TAKE(xres, float*, rows * D * 4);
   DA3_TAKE(lnf, float*, rows * D * 4);
@@ -229,10 +230,10 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
     DA3_TAKE(extr, float*, (size_t)B * 12 * 4);
     DA3_TAKE(intr, float*, (size_t)B * 9 * 4);
     DA3_TAKE(pos_aux, float*, (size_t)64 * ph * pw * (F / 2) * 4);
-    DA3_TAKE(conf_stage, float*, (size_t)B * S * S * 4);
+    DA3_TAKE(conf_stage, float*, (size_t)B * SS2 * 4);
     DA3_TAKE(aux_stage, float*, (size_t)B * c.aux_output_dim * 64 * ph * pw * 4);
   }
-  const size_t px[4] = {(size_t)16 * ph * pw, (size_t)4 * ph * pw, (size_t)ph * pw, (size_t)h3 * h3};
+  const size_t px[4] = {(size_t)16 * ph * pw, (size_t)4 * ph * pw, (size_t)ph * pw, (size_t)d->h3h * d->h3w};
   for (int s = 0; s < 4; ++s) {
     DA3_TAKE(sp[s], void*, (size_t)B * P * cp(oc[s]) * esz);
     if (s != 2) DA3_TAKE(sr[s], void*, (size_t)B * px[s] * cp(oc[s]) * esz);
@@ -247,9 +248,9 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   DA3_TAKE(up, void*, big);
   DA3_TAKE(o, void*, big);
   DA3_TAKE(c1, void*, (size_t)B * 64 * ph * pw * cp(F / 2) * esz);
-  DA3_TAKE(c1r, void*, (size_t)B * S * S * cp(F / 2) * esz);
+  DA3_TAKE(c1r, void*, (size_t)B * SS2 * cp(F / 2) * esz);
   for (int s = 0; s < 4; ++s) DA3_TAKE(pos_stage[s], void*, P * cp(oc[s]) * esz);
-  DA3_TAKE(pos_final, float*, (size_t)S * S * (F / 2) * 4);
+  DA3_TAKE(pos_final, float*, SS2 * (F / 2) * 4);
   DA3_TAKE(pos_used, float*, (size_t)d->NT * D * 4);
 #undef DA3_TAKE
   if (total_out) *total_out = total + 4096;
@@ -260,7 +261,9 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   if (!dev || !out) MD_FAIL(MD_ERR_INVALID_ARG, "device/model pointer is null");
   const ViTDims& v = cfg.vit;
   if (v.D != v.heads * 64 || v.D % 64 != 0 || v.D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "ViT width %d / heads %d unsupported", v.D, v.heads);
-  if (cfg.image_size % v.ps != 0) MD_FAIL(MD_ERR_SHAPE, "image size %d must be divisible by patch size %d", cfg.image_size, v.ps);
+  const int img_h = cfg.image_size, img_w = cfg.image_width > 0 ? cfg.image_width : cfg.image_size;
+  if (img_h % v.ps != 0 || img_w % v.ps != 0 || img_h <= 0 || img_w <= 0)  // mod.rs:509-520
+    MD_FAIL(MD_ERR_SHAPE, "Input %dx%d must be divisible by patch size %d", img_h, img_w, v.ps);
   if (cfg.features % 64 != 0 || cfg.output_dim != (cfg.dual_head ? 2 : 1))
     MD_FAIL(MD_ERR_UNSUPPORTED, "head features %d / output_dim %d unsupported", cfg.features, cfg.output_dim);
   for (int s = 0; s < 4; ++s)
@@ -287,13 +290,17 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   d->hp = cfg.dual_head ? "head_dual" : "head_mono";
   d->din = cfg.dual_head ? 2 * v.D : v.D;
   d->native_grid = v.img / v.ps;  // the pos_embed parameter's grid (37 for ViT-L/14 @ 518)
-  d->ph = d->pw = cfg.image_size / v.ps;
+  d->ih = img_h;
+  d->iw = img_w;
+  d->ph = img_h / v.ps;
+  d->pw = img_w / v.ps;
   d->P = d->ph * d->pw;
   d->NT = d->P + 1;
   d->SS = round_up(d->NT, 4);
   d->kpad = round_up(d->NT, 64);
   d->Kp = round_up(3 * v.ps * v.ps, m->ke);
-  d->h3 = (d->ph + 2 - 3) / 2 + 1;
+  d->h3h = (d->ph + 2 - 3) / 2 + 1;
+  d->h3w = (d->pw + 2 - 3) / 2 + 1;
   m->S = cfg.image_size;
   m->SS = d->SS;
   auto fail = [&](int code) {
@@ -424,13 +431,13 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
 
   // UV position tables for this image size (PosEmbedCache, dpt.rs:784-833: built once per shape)
   {
-    const int S = cfg.image_size;
+    const int IH = d->ih, IW = d->iw;
     float* tmp = nullptr;
-    size_t tmp_elems = (size_t)S * S * (F / 2);
+    size_t tmp_elems = (size_t)IH * IW * (F / 2);
     for (int s = 0; s < 4; ++s) tmp_elems = std::max(tmp_elems, (size_t)d->P * round_up(oc[s], m->ke));
     if (hipMalloc((void**)&tmp, tmp_elems * 4) != hipSuccess) return fail(MD_ERR_OOM);
     for (int s = 0; s < 4; ++s) {
-      std::vector<float> t = build_pos_table_nhwc(oc[s], d->ph, d->pw, S, S, 0.1f);
+      std::vector<float> t = build_pos_table_nhwc(oc[s], d->ph, d->pw, IW, IH, 0.1f);
       const int ld = round_up(oc[s], m->ke);
       std::vector<float> padded((size_t)d->P * ld, 0.f);
       for (int p = 0; p < d->P; ++p) memcpy(&padded[(size_t)p * ld], &t[(size_t)p * oc[s]], (size_t)oc[s] * 4);
@@ -438,12 +445,12 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
       if (launch_f32_to_rows(tmp, (long)padded.size(), d->pos_stage[s], m->prec, dev->stream) != MD_OK) return fail(MD_ERR_HIP);
       (void)hipStreamSynchronize(dev->stream);
     }
-    std::vector<float> t = build_pos_table_nhwc(F / 2, S, S, S, S, 0.1f);
+    std::vector<float> t = build_pos_table_nhwc(F / 2, IH, IW, IW, IH, 0.1f);
     if (hipMemcpy(d->pos_final, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
     (void)hipFree(tmp);
     if (cfg.dual_head) {
       // aux head input = neck + 0.1*UV + 0.1*UV (added twice, dpt.rs:428-435)
-      std::vector<float> ta = build_pos_table_nhwc(F / 2, 8 * d->ph, 8 * d->pw, S, S, 0.1f);
+      std::vector<float> ta = build_pos_table_nhwc(F / 2, 8 * d->ph, 8 * d->pw, IW, IH, 0.1f);
       for (auto& x : ta) x = x + x;
       if (hipMemcpy(d->pos_aux, ta.data(), ta.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
       // 2-D RoPE tables: angle(pos, f) = pos * base^(-2f/32), f < 16 (fp32 like the oracle)
@@ -523,7 +530,7 @@ int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_ki
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t st = stream ? stream : m->dev->stream;
   const bool eligible = nchw && outp.depth && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
-                        B <= m->da3->cfg.max_batch && H == m->da3->cfg.image_size && W == H;
+                        B <= m->da3->cfg.max_batch && H == m->da3->ih && W == m->da3->iw;
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)outp.depth,
                                       (uintptr_t)outp.depth_confidence, (uintptr_t)outp.aux, (uintptr_t)outp.aux_confidence,
                                       (uintptr_t)outp.pose_encoding, (uintptr_t)outp.extrinsics, (uintptr_t)outp.intrinsics};
@@ -543,13 +550,14 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
   if (H % v.ps != 0 || W % v.ps != 0)  // depth_anything3/mod.rs:509-520 (assert -> checked precondition)
     MD_FAIL(MD_ERR_SHAPE, "Input %dx%d must be divisible by patch size %d", H, W, v.ps);
-  if (H != c.image_size || W != c.image_size)
-    MD_FAIL(MD_ERR_UNSUPPORTED, "only %dx%d inputs are supported (the model was created for that size)", c.image_size, c.image_size);
+  if (H != d->ih || W != d->iw)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "only %dx%d inputs are supported (the model was created for that size)", d->ih, d->iw);
   if (B > c.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, c.max_batch);
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t st = stream ? stream : m->dev->stream;
   Run r{m, st, B};
-  const int D = v.D, heads = v.heads, SS = d->SS, NT = d->NT, P = d->P, ph = d->ph, pw = d->pw, F = c.features, S = c.image_size;
+  const int D = v.D, heads = v.heads, SS = d->SS, NT = d->NT, P = d->P, ph = d->ph, pw = d->pw, F = c.features;
+  const int IH = d->ih, IW = d->iw;
   const int din = d->din;
   const int* oc = c.out_channels;
   const int Fp = cpad(m, F), F2 = F / 2, F2p = cpad(m, F2);
@@ -724,7 +732,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   // ---- DPT head: prepare_stage (dpt.rs:282-317 / 649-689) ----
   int* tok_idx = nullptr;
   MD_TRY(da3_tok_index(m, B, &tok_idx));
-  const int sh[4] = {4 * ph, 2 * ph, ph, d->h3};  // stage spatial sizes (square)
+  const int sh[4] = {4 * ph, 2 * ph, ph, d->h3h}, sw[4] = {4 * pw, 2 * pw, pw, d->h3w};  // stage sizes (rows, columns)
   for (int s = 0; s < 4; ++s) {
     const int ocp = cpad(m, oc[s]);
     const std::string ps = hp + ".projects." + std::to_string(s);
@@ -751,9 +759,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       feat = d->sr[s];
     } else if (s == 3) {  // Conv2d 3x3 stride 2 pad 1 (+bias)
       GemmParams p;
-      p.N = oc[3]; p.K = 9 * ocp; p.ngroups = 1; p.g_rows[0] = B * d->h3 * d->h3;
+      p.N = oc[3]; p.K = 9 * ocp; p.ngroups = 1; p.g_rows[0] = B * d->h3h * d->h3w;
       p.W[0] = Wk(hp + ".resize_layers.3.conv.weight"); p.bias[0] = Bi(hp + ".resize_layers.3.conv.bias");
-      p.A = d->sp[3]; p.cH = ph; p.cW = pw; p.cC = ocp; p.cOH = d->h3; p.cOW = d->h3; p.cstride = 2; p.zero_page = m->zero_page;
+      p.A = d->sp[3]; p.cH = ph; p.cW = pw; p.cC = ocp; p.cOH = d->h3h; p.cOW = d->h3w; p.cstride = 2; p.zero_page = m->zero_page;
       p.epi = EPI_STORE; p.out = d->sr[3]; p.ldo = ocp;
       r.begin("head_conv_s2");
       MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_AUTO, st));
@@ -761,18 +769,18 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       feat = d->sr[3];
     }
     // layerN_rn: 3x3, no bias -> features (+ relu copy for the residual units)
-    MD_TRY(conv3(r, "head_conv3x3", feat, sh[s], sh[s], ocp, Wk(hp + ".scratch.layer" + std::to_string(s + 1) + "_rn.weight"), nullptr,
+    MD_TRY(conv3(r, "head_conv3x3", feat, sh[s], sw[s], ocp, Wk(hp + ".scratch.layer" + std::to_string(s + 1) + "_rn.weight"), nullptr,
                  F, d->rn[s], Fp, ACT_NONE, nullptr, nullptr, d->rnr[s]));
   }
   // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
-  auto rcu = [&](const std::string& name, int hw, const void* x, const void* xr, const void* extra, void* out, void* out_relu) -> int {
-    MD_TRY(conv3(r, "head_conv3x3", xr, hw, hw, Fp, Wk(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, d->t, Fp, ACT_RELU,
+  auto rcu = [&](const std::string& name, int hh, int ww, const void* x, const void* xr, const void* extra, void* out, void* out_relu) -> int {
+    MD_TRY(conv3(r, "head_conv3x3", xr, hh, ww, Fp, Wk(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, d->t, Fp, ACT_RELU,
                  nullptr, nullptr, nullptr));
-    return conv3(r, "head_conv3x3", d->t, hw, hw, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
+    return conv3(r, "head_conv3x3", d->t, hh, ww, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
                  extra, out_relu);
   };
   // the four FeatureFusionBlocks (dpt.rs:1206-1222) from the coarsest stage up; result in d->o at 8ph x 8pw
-  const int target[4] = {8 * ph, 4 * ph, 2 * ph, ph};  // output size of refinenet1..4
+  const int target[4] = {8 * ph, 4 * ph, 2 * ph, ph}, targw[4] = {8 * pw, 4 * pw, 2 * pw, pw};  // output size of refinenet1..4
   auto pyramid = [&](const std::string& suffix) -> int {
     const void* top = nullptr;
     for (int lvl = 3; lvl >= 0; --lvl) {
@@ -782,15 +790,15 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
         yx = d->rn[3];
         yxr = d->rnr[3];
       } else {
-        MD_TRY(rcu(rf + ".residual1", sh[lvl], d->rn[lvl], d->rnr[lvl], top, d->x, d->xr));
+        MD_TRY(rcu(rf + ".residual1", sh[lvl], sw[lvl], d->rn[lvl], d->rnr[lvl], top, d->x, d->xr));
         yx = d->x;
         yxr = d->xr;
       }
-      MD_TRY(rcu(rf + ".residual2", sh[lvl], yx, yxr, nullptr, d->y, nullptr));
+      MD_TRY(rcu(rf + ".residual2", sh[lvl], sw[lvl], yx, yxr, nullptr, d->y, nullptr));
       r.begin("head_resize");
-      MD_TRY(launch_resize_nhwc(d->y, B, sh[lvl], sh[lvl], F, Fp, d->up, target[lvl], target[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, st));
+      MD_TRY(launch_resize_nhwc(d->y, B, sh[lvl], sw[lvl], F, Fp, d->up, target[lvl], targw[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, st));
       r.end();
-      MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * target[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
+      MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * targw[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
                        Bi(rf + ".out_conv.bias"), d->o, Fp));
       top = d->o;
     }
@@ -817,9 +825,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk(hp + ".scratch.output_conv1.weight"),
                Bi(hp + ".scratch.output_conv1.bias"), F2, d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
   r.begin("head_resize");
-  MD_TRY(launch_resize_nhwc(d->c1, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, S, S, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
+  MD_TRY(launch_resize_nhwc(d->c1, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, IH, IW, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
   r.end();
-  const size_t out_elems = (size_t)B * S * S;
+  const size_t out_elems = (size_t)B * IH * IW;
   float* depth_dev = outp.depth;
   if (out_kind == MD_MEM_HOST) {
     if (d->depth_stage_elems < out_elems) {
@@ -832,12 +840,12 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   const void* w1 = Wk(hp + ".scratch.output_conv2.conv1.weight");
   const float* b1 = Bi(hp + ".scratch.output_conv2.conv1.bias");
   const float* w2 = Bi(hp + ".scratch.output_conv2.conv2.weight");
-  MD_TRY(tail("head_tail_fused", d->c1r, S, S, w1, b1, w2, d->main_bias[0], 1, depth_dev));  // depth = exp(ch 0)
+  MD_TRY(tail("head_tail_fused", d->c1r, IH, IW, w1, b1, w2, d->main_bias[0], 1, depth_dev));  // depth = exp(ch 0)
   MD_TRY(host_out(outp.depth, depth_dev, out_elems));
   if (c.dual_head) {
     if (outp.depth_confidence) {  // confidence = exp(last channel) + 1 (select_conf_channel, ExpP1)
       float* cd = out_kind == MD_MEM_HOST ? d->conf_stage : outp.depth_confidence;
-      MD_TRY(tail("head_tail_fused", d->c1r, S, S, w1, b1, w2 + 32 * (c.output_dim - 1), d->main_bias[c.output_dim - 1], 3, cd));
+      MD_TRY(tail("head_tail_fused", d->c1r, IH, IW, w1, b1, w2 + 32 * (c.output_dim - 1), d->main_bias[c.output_dim - 1], 3, cd));
       MD_TRY(host_out(outp.depth_confidence, cd, out_elems));
     }
     if (outp.aux || outp.aux_confidence) {

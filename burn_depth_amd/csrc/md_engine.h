@@ -147,7 +147,7 @@ void fov_scalar_host(float fovx_deg, int H, int W, float* focal_px, float* fovy_
 struct Da3Cfg {
   std::string variant = "metric_large";
   ViTDims vit;
-  int image_size = 518, features = 256, output_dim = 1;
+  int image_size = 518, image_width = 0, features = 256, output_dim = 1;  // image_size = rows; image_width 0 = square
   int out_channels[4] = {256, 512, 1024, 1024};
   int hook_ids[4] = {4, 11, 17, 23};
   int precision = MD_PREC_BF16, max_batch = 1;

@@ -33,7 +33,8 @@ class DepthAnything3Inference:
 
 def _c_cfg(cfg: DepthAnything3Config):
     keep = cfg.variant.encode()
-    return _lib.MdDa3Cfg(keep, int(cfg.image_size), int(cfg.precision), int(cfg.max_batch), float(cfg.ln_eps)), keep
+    return _lib.MdDa3Cfg(keep, int(cfg.image_size), int(cfg.precision), int(cfg.max_batch), float(cfg.ln_eps),
+                         int(cfg.image_width)), keep
 
 
 class DepthAnything3(DepthPro):

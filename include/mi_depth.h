@@ -127,6 +127,8 @@ typedef struct md_da3_cfg {
   int precision;       /* md_precision */
   int max_batch;
   float ln_eps;        /* backbone LayerNorm eps (burn_dino's is not visible; default 1e-6) */
+  int image_width;     /* 0 = square (image_size x image_size); else the input is image_size rows x image_width columns,
+                        * both multiples of 14 -- `DepthAnything3::infer` only asserts divisibility (mod.rs:509-520) */
 } md_da3_cfg;
 void md_da3_cfg_default(md_da3_cfg* cfg);
 /* `DepthAnything3::new(&device, cfg)` (depth_anything3/mod.rs:253-286): seeded synthetic weights. */
@@ -135,7 +137,8 @@ int md_da3_create(md_device_t dev, const md_da3_cfg* cfg, uint64_t seed, int ini
 int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_model_t* out);
 /* `DepthAnything3::infer(&self, x)` (depth_anything3/mod.rs:288-291): NCHW fp32 in, depth [B*H*W] out.
  * H and W must be multiples of the patch size (mod.rs:509-520 assert -> MD_ERR_SHAPE) and equal to the
- * configured (square) image size, for which the position tables were built (else MD_ERR_UNSUPPORTED). */
+ * configured image size (image_size x image_width), for which the position tables were built (else
+ * MD_ERR_UNSUPPORTED). */
 int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
                  void* stream);
 /* `DepthAnything3Inference` (depth_anything3/mod.rs:231-239) for the dual-head `small` variant. Every pointer

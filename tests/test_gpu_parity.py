@@ -415,6 +415,20 @@ def test_graph_replay_matches_eager(dev):
     d.destroy()
 
 
+def test_depth_anything3_non_square_inputs(diag, dev):
+    # `DepthAnything3::infer` only asserts that H and W are multiples of the patch size (mod.rs:509-520)
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    start = len(diag.RESULTS)
+    c = DepthAnything3Config.tiny_test()
+    c.image_size, c.image_width = 70, 98
+    diag.guarded("da3-ns")(diag.run_da3)(dev, c, "da3-tiny70x98/f32", 2, Precision.F32)
+    cd = DepthAnything3Config.tiny_dual_test()
+    cd.image_size, cd.image_width = 112, 84
+    diag.guarded("da3-ns-dual")(diag.run_da3)(dev, cd, "da3-tinydual112x84/f32", 1, Precision.F32)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 15
+
+
 def test_depth_anything3_error_paths(dev):
     from burn_depth_amd import _lib
     from burn_depth_amd.config import DepthAnything3Config

@@ -330,7 +330,7 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY):
         record(f"{label} seeded weight {n.split('.')[-3]}.{n.split('.')[-1]}", float(np.abs(got - W[n].numpy().reshape(-1)).max()), 0.0)
     torch.manual_seed(1)
     S = cfg.image_size
-    x = torch.randn(B, 3, S, S)
+    x = torch.randn(B, 3, S, cfg.image_width or S)
     out = model.infer(x.cuda())
     torch.cuda.synchronize()
     t0 = time.time()
@@ -419,6 +419,14 @@ def main():
         c98.image_size = 98  # 7x7 grid from a 5x5 pos_embed: exercises the bicubic pos-embed interpolation
         guarded("da3 tiny98 f32")(run_da3)(dev, c98, "da3-tiny98/f32", 1, Precision.F32)
         guarded("da3 tiny-dual f32")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/f32", 2, Precision.F32)
+        # non-square inputs (any multiples of 14, mod.rs:509-520): 70 x 98 and 112 x 84 on the 5 x 5 position table
+        cns = DepthAnything3Config.tiny_test()
+        cns.image_size, cns.image_width = 70, 98
+        guarded("da3 tiny 70x98 f32")(run_da3)(dev, cns, "da3-tiny70x98/f32", 2, Precision.F32)
+        cnd = DepthAnything3Config.tiny_dual_test()
+        cnd.image_size, cnd.image_width = 112, 84
+        guarded("da3 tiny-dual 112x84 f32")(run_da3)(dev, cnd, "da3-tinydual112x84/f32", 1, Precision.F32)
+        guarded("da3 tiny-dual 112x84 bf16")(run_da3)(dev, cnd, "da3-tinydual112x84/bf16", 1, Precision.BF16)
         guarded("da3 tiny-dual bf16")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/bf16", 2, Precision.BF16)
         guarded("da3 tiny fp8")(run_da3)(dev, DepthAnything3Config.tiny_test(), "da3-tiny/fp8", 2, Precision.FP8)
         guarded("da3 tiny-dual fp8")(run_da3)(dev, DepthAnything3Config.tiny_dual_test(), "da3-tinydual/fp8", 2, Precision.FP8)
