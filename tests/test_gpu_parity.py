@@ -372,6 +372,37 @@ def test_infer_cli_writes_a_depth_png_for_both_model_kinds(dev, tmp_path):
         P.AnyDepthModel.load(P.DepthModelKind.DEPTH_PRO, dev, ck2)
 
 
+def test_rccl_weight_broadcast_and_depth_gather_on_the_gpu(dev):
+    """The multi-GPU plumbing of bench.py (burn_depth_amd/parallel.py) on a 1-rank RCCL group: the zero-copy view of
+    the device weight arena, the bucketed broadcast + re-commit, and the depth gather. (World sizes > 1 are
+    covered on CPU with gloo in tests/test_parallel_gloo.py; the driver runs the real 2/4/8-GPU case.)"""
+    import torch.distributed as dist
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    from burn_depth_amd.parallel import broadcast_weights, gather_depth
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29561", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        cfg = DepthProConfig.tiny_test()
+        m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+        torch.manual_seed(0)
+        x = torch.randn(1, 3, 512, 512, device="cuda")
+        before = m.infer(x).depth.clone()
+        ptr, nbytes = m.weight_arena()
+        assert ptr != 0 and nbytes > 1 << 20
+        broadcast_weights(m, src=0)                       # marks the weights dirty, broadcasts in place, re-commits
+        assert torch.equal(m.infer(x).depth, before)
+        out = [torch.empty_like(before)]
+        gather_depth(before, out, dst=0)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], before)
+        m.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_graph_replay_matches_eager(dev):
     """md_model_enable_graph: first call eager, second captured, later calls replayed -- all bit-identical, and a
     change of buffers or a timing/tap request falls back to eager launches."""
