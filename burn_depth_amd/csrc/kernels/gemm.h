@@ -95,7 +95,7 @@ struct GemmParams {
   int raster_gn = 0;  // n-tiles per raster group (0 = all: plain n-fastest order); set by the launcher
   // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
   int debug_flags = 0;
-  unsigned long long* stamps = nullptr;  // timing-only: [blocks][8] s_memrealtime stamps (md_bench_gemm)
+  unsigned long long* stamps = nullptr;  // timing-only: [blocks][16] stamps: 8 x s_memrealtime, then 2 x shader clock around the main loop (md_bench_gemm)
   // EPI_HEAD
   const float* head_w = nullptr;  // [32]
   float head_b = 0.f;

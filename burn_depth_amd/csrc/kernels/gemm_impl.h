@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // timing-only instrumentation (md_bench_gemm): wave 0 / lane 0 stamps s_memrealtime (100 MHz) at five points
-  unsigned long long* stamp = (p.stamps && threadIdx.x == 0) ? p.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  unsigned long long* stamp = (p.stamps && threadIdx.x == 0) ? p.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -860,51 +860,44 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (!g1) __builtin_amdgcn_s_barrier();
   }
   if constexpr (PP == 2) {
-    // ---- the same staggered schedule on 16x16x32 MFMAs ----
-    // phase s = 2*ks + mh: k-step ks (32 deep) x m-half mh (64 rows). R = 4 W + 4 A fragment reads when
-    // mh == 0, 4 A reads when mh == 1 (the W fragments of the k-step stay in registers); M = 16 MFMAs
-    // of 16 cycles = the same 256-cycle cluster as 8 MFMAs of the 32x32x16 form.
+    // ---- the staggered schedule on 16x16x32 MFMAs, with 512-cycle MFMA clusters ----
+    // The shader-clock stamps (md_bench_gemm, flag 32) showed a 256-cycle cluster costing 374 cycles per
+    // interval: the s_barrier round trip (~100 cycles) is paid per cluster, so the clusters are made
+    // twice as long instead (one phase per 32-deep k-step, both m-halves).
     const bool g1 = wm == 1;
     if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
     wait_tile(0);
     __builtin_amdgcn_s_barrier();
-    if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (stamp) { stamp[3] = __builtin_amdgcn_s_memrealtime(); stamp[8] = __builtin_readcyclecounter(); }
     if (g1) __builtin_amdgcn_s_barrier();
+    // Two phases per k-tile (one per 32-deep k-step): R = 4 W + 8 A fragment reads, M = 32 MFMAs = 512
+    // cycles, so the ~120-cycle barrier round trip is paid 4 times per k-tile instead of 8. Every R
+    // ends with lgkmcnt(0) BEFORE its barrier (R has 512 cycles of cover), so the slots of tile t are
+    // free one interval after its last R and the loads that reuse them go out in R(0) of tile t+1.
     for (int t = 0; t < KT; ++t) {
       const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
       const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
       const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
       slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
-      i32x4_t wf[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int ks = s >> 1, mh = s & 1;
+      for (int ks = 0; ks < 2; ++ks) {
         const int off = lane_off16 ^ (ks << 6);
-        i32x4_t af[4];
-        if (mh == 0) {
+        i32x4_t wf[4], af[8];
 #pragma unroll
-          for (int a = 0; a < 4; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 2048 + off);
-        }
+        for (int a = 0; a < 4; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 2048 + off);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) af[b] = *(const i32x4_t*)(As + (mh * 4 + b) * 2048 + off);
+        for (int b = 0; b < 8; ++b) af[b] = *(const i32x4_t*)(As + b * 2048 + off);
         if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
           if (!no_loads) {
-            if (s == 0 && KT > 1) { issue_A(1, 2); issued = 3; slot_i = 3; }
-            if (s == 1 && KT > 1) { issue_W(1, 3); issued = 4; slot_i = 4; }
-            if (s == 2 && KT > 2) issue_A_part(2, 4, 0, 2);
-            if (s == 3 && KT > 2) { issue_A_part(2, 4, 2, 4); issued = 5; slot_i = 0; }
+            if (ks == 0 && KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
+            if (ks == 1 && KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
           }
-          if (g1 && s == 3 && KT > 1) wait_tile(1);
-        } else if (g1) {
-          if (s == 0) issue_next_W(t);
-          if (s == 1) issue_next_A_lo(t);
-          if (s == 2) issue_next_A_hi(t);
-          if (s == 3 && t + 1 < KT) wait_tile(t + 1);
         } else {
-          if (s == 1) issue_next_W(t);
-          if (s == 2) issue_next_A_lo(t);
-          if (s == 3) issue_next_A_hi(t);
+          if (ks == 0) issue_next_W(t);
+          if (ks == 1) { issue_next_A_lo(t); issue_next_A_hi(t); }
         }
+        if (g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -912,11 +905,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) Atom16<T>::mma(wf[a], af[b], acc16[a][mh * 4 + b]);
+          for (int b = 0; b < 8; ++b) Atom16<T>::mma(wf[a], af[b], acc16[a][b]);
         __builtin_amdgcn_s_setprio(0);
-        if (!g1) {
-          if (s == 3 && t + 1 < KT) wait_tile(t + 1);
-        }
+        if (!g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -926,7 +917,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
 
   // ---------------- epilogue ----------------
-  if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime();
+  if (stamp) { stamp[4] = __builtin_amdgcn_s_memrealtime(); stamp[9] = __builtin_readcyclecounter(); }
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
     if constexpr (PP == 2 && sizeof(TO) == 2) {

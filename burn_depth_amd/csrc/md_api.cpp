@@ -574,25 +574,26 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   if (dbg & 32) {  // per-block phase stamps of ONE launch (100 MHz s_memrealtime), printed to stderr
     const long blocks = (long)((M + 255) / 256) * ((N + 255) / 256);
     DevBuf sb;
-    MD_TRY(sb.alloc((size_t)blocks * 64));
+    MD_TRY(sb.alloc((size_t)blocks * 128));
     p.stamps = (unsigned long long*)sb.p;
     MD_TRY(launch_gemm(p, amode, precision, tile, st));
     MD_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> h((size_t)blocks * 8);
+    std::vector<unsigned long long> h((size_t)blocks * 16);
     MD_HIP(hipMemcpy(h.data(), sb.p, h.size() * 8, hipMemcpyDeviceToHost));
     p.stamps = nullptr;
-    double d[7] = {0, 0, 0, 0, 0, 0, 0};
+    double d[7] = {0, 0, 0, 0, 0, 0, 0}, cyc = 0;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (long b = 0; b < blocks; ++b) {
-      const unsigned long long* q = &h[(size_t)b * 8];
+      const unsigned long long* q = &h[(size_t)b * 16];
       for (int k = 0; k < 7; ++k) d[k] += (double)(q[k + 1] - q[k]);
+      cyc += (double)(q[9] - q[8]);
       tmin = std::min(tmin, q[0]);
       tmax = std::max(tmax, q[7]);
     }
     fprintf(stderr, "[stamps] blocks=%ld  setup %.2f  issue %.2f  first-wait %.2f  mainloop %.2f  epi-barrier %.2f  epi-body %.2f  store-drain %.2f us "
-                    "(wave 0, mean per block); kernel span %.1f us\n",
+                    "(wave 0, mean per block); kernel span %.1f us; mainloop %.0f shader cycles = %.3f GHz\n",
             blocks, d[0] / blocks / 100.0, d[1] / blocks / 100.0, d[2] / blocks / 100.0, d[3] / blocks / 100.0, d[4] / blocks / 100.0,
-            d[5] / blocks / 100.0, d[6] / blocks / 100.0, (double)(tmax - tmin) / 100.0);
+            d[5] / blocks / 100.0, d[6] / blocks / 100.0, (double)(tmax - tmin) / 100.0, cyc / blocks, cyc / (d[3] * 10.0));
   }
   hipEvent_t e0, e1;
   MD_HIP(hipEventCreate(&e0));
