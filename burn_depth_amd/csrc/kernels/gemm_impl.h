@@ -328,22 +328,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
   // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
   // the XCD's 4-MB L2 while the A panels stream past it.
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile_n, tile_mg;
-  {
+  auto map_tile = [&](int tid_lin, int& tn, int& tmg) {
     const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
     const int tiles_m = p.g_tile0[kMaxGroups];  // total m-tiles over all groups
     const int gsz = tiles_m * gn;
     const int full = tiles_n / gn;
-    if (id < full * gsz) {
-      const int ng = id / gsz, r = id - ng * gsz;
-      tile_mg = r / gn;
-      tile_n = ng * gn + (r - tile_mg * gn);
+    if (tid_lin < full * gsz) {
+      const int ng = tid_lin / gsz, r = tid_lin - ng * gsz;
+      tmg = r / gn;
+      tn = ng * gn + (r - tmg * gn);
     } else {
-      const int rn = tiles_n - full * gn, r = id - full * gsz;
-      tile_mg = r / rn;
-      tile_n = full * gn + (r - tile_mg * rn);
+      const int rn = tiles_n - full * gn, r = tid_lin - full * gsz;
+      tmg = r / rn;
+      tn = full * gn + (r - tmg * rn);
     }
-  }
+  };
+  int tile_n, tile_mg;
+  map_tile(id, tile_n, tile_mg);
   int g = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroups; ++i)
@@ -565,22 +566,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
   // the XCD's 4-MB L2 while the A panels stream past it.
   const int tiles_n = (p.N + BN - 1) / BN;
-  int tile_n, tile_mg;
-  {
+  auto map_tile = [&](int tid_lin, int& tn, int& tmg) {
     const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
     const int tiles_m = p.g_tile0[kMaxGroups];  // total m-tiles over all groups
     const int gsz = tiles_m * gn;
     const int full = tiles_n / gn;
-    if (id < full * gsz) {
-      const int ng = id / gsz, r = id - ng * gsz;
-      tile_mg = r / gn;
-      tile_n = ng * gn + (r - tile_mg * gn);
+    if (tid_lin < full * gsz) {
+      const int ng = tid_lin / gsz, r = tid_lin - ng * gsz;
+      tmg = r / gn;
+      tn = ng * gn + (r - tmg * gn);
     } else {
-      const int rn = tiles_n - full * gn, r = id - full * gsz;
-      tile_mg = r / rn;
-      tile_n = full * gn + (r - tile_mg * rn);
+      const int rn = tiles_n - full * gn, r = tid_lin - full * gsz;
+      tmg = r / rn;
+      tn = full * gn + (r - tmg * rn);
     }
-  }
+  };
+  int tile_n, tile_mg;
+  map_tile(id, tile_n, tile_mg);
   int g = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroups; ++i)
@@ -1066,6 +1068,57 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const char* q1b = (const char*)p.res1 + trb * 2;
     const char* q2b = (const char*)p.res2 + trb * 2;
     const unsigned lc8 = (unsigned)(wn * WTN + c8);
+    if constexpr (PP == 2) {
+      // No residual inputs and a plain bf16 output (fc1, the q/k tiles of qkv, most convolutions): bias, scale and
+      // activation are applied in the ACCUMULATOR layout and the tile is staged as bf16 -- 8-byte writes, ONE
+      // 16-byte read per 8 columns -- which halves the LDS bytes of the epilogue (LDS bandwidth, 2 x 128 KB per
+      // half through a 128 B/clk port, was half of its 4.2 us). Rows are 128 B; 16-byte chunks are XOR-swizzled
+      // by (row & 7), conflict-free for both the b64 writes and the b128 reads.
+      if (!any_res && !f32o && !fp8o && !has_o2) {
+        f32x4_t bq[4], wq[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int na = n0 + wn * WTN + a * 16 + 4 * q16;
+          bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          wq[a] = (wsp && na < p.N) ? *(const f32x4_t*)(wsp + na) * p.ascale : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        }
+        const int r16 = lane & 15;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const f32x4acc_t c = acc16[a][half * 4 + bb];
+              f32x4_t v = (f32x4_t){c[0], c[1], c[2], c[3]} * wq[a] + bq[a];
+              if constexpr (EK == 4) {
+                v = gelu4<TO>(v);
+              } else if (relu) {
+                v = relu4(v);
+              }
+              const int row = bb * 16 + r16;
+              const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
+              *(bf16x4_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = (bf16x4_t){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + rsub;
+            const int lrow = wm * WTM + half * 64 + row;
+            const i32x4_t raw = *(const i32x4_t*)(st + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+            if (interior || (m_base + lrow < m_end && nv8)) *(i32x4_t*)(ob + ((unsigned)lrow * (unsigned)ldo8 + lc8) * 2u) = raw;
+          }
+          asm volatile("" ::: "memory");
+        }
+        if (stamp) {
+          stamp[6] = __builtin_amdgcn_s_memrealtime();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp[7] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+      }
+    }
     i32x4_t pr1[2][8], pr2[2][8];  // raw bf16x8 residual vectors
     auto pf8 = [&](int half, int it) {
       if (!any_res) return;
