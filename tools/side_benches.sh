@@ -13,3 +13,6 @@ run da3L_1036_fp8 --model da3_large --image-size 1036 --precision fp8
 run da3S --model da3_small
 run da3S_graph --model da3_small --graph
 run da3S_b8 --model da3_small --batch 8
+run da3L_graph_fp8 --model da3_large --graph --precision fp8
+run da3L_b8_fp8 --model da3_large --batch 8 --precision fp8
+run da3S_b8_fp8 --model da3_small --batch 8 --precision fp8
