@@ -90,6 +90,7 @@ struct GemmParams {
   void* vT = nullptr;
   // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = f*f*psC (f = ps_f, 2 or 4); out NHWC [B, f*psH, f*psW, ldo] at +ps_coff
   int psH = 0, psW = 0, psC = 0, ps_coff = 0, ps_f = 2;
+  int ps_fast = 0;  // set by launch_gemm: bf16 out, no second output, 8-column groups inside one tap, 32-bit element offsets
   // divisors of the epilogue index math (filled by the launcher from the fields above)
   FastDiv fd_res_mod, fd_seq_patches, fd_seq_stride, fd_psC, fd_psW, fd_psH, fd_ow, fd_oh, fd_cblocks;
   int raster_gn = 0;  // n-tiles per raster group (0 = all: plain n-fastest order); set by the launcher

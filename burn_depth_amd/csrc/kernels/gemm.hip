@@ -50,6 +50,15 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   p.fd_seq_patches = make_fastdiv(p.seq_patches);
   p.fd_seq_stride = make_fastdiv(p.seq_stride);
   p.fd_psC = make_fastdiv(p.psC);
+  if (p.epi == EPI_PIXSHUF) {
+    long px = 0;
+    for (int g = 0; g < p.ngroups; ++g) px = std::max<long>(px, (long)p.g_row0[g] + p.g_rows[g]);
+    const double out_elems = (double)px * p.ps_f * p.ps_f * (double)p.ldo;
+    bool no_scale = true;
+    for (int g = 0; g < p.ngroups; ++g) no_scale = no_scale && !p.wscale[g];
+    p.ps_fast = prec != MD_PREC_F32 && !p.out_f32 && !p.out2 && !p.out_fp8 && no_scale && p.psC % 8 == 0 && p.N % 8 == 0 &&
+                p.ldo % 8 == 0 && p.ps_coff % 8 == 0 && out_elems < 4.0e9;
+  }
   p.fd_psW = make_fastdiv(p.psW);
   p.fd_psH = make_fastdiv(p.psH);
   p.fd_ow = make_fastdiv(p.cOW > 0 ? p.cOW : p.cW);

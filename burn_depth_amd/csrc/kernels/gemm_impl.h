@@ -709,7 +709,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   int issued = 2, slot_i = 2;
   issue_A(0, 0);
   issue_W(0, 1);
-  if constexpr (PP != 2) {
+  // Short-K tiles (KT <= 4: the deconvolutions, K = 128 / 256) request everything up front instead: with two k-tiles
+  // the in-loop fill exposed a second full memory latency (stamps on K = 128: first wait 2.4 us + 4.2 us for two
+  // k-tiles that multiply in 1.4 us each).
+  const bool pro_full = PP != 2 || KT <= 4;
+  if (pro_full) {
     if (KT > 1) {
       issue_A(1, 2);
       issue_W(1, 3);
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) af[b] = *(const i32x4_t*)(As + b * 2048 + off);
         if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
-          if (!no_loads) {
+          if (!no_loads && !pro_full) {
             if (ks == 0 && KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
             if (ks == 1 && KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
           }
@@ -1026,6 +1030,69 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     ps_co = n - tap * p.psC;
     ps_dy = p.ps_f == 4 ? tap >> 2 : tap >> 1;
     ps_dx = tap - ps_dy * p.ps_f;
+  }
+  if constexpr (pixshuf && PP == 2 && sizeof(TO) == 2) {
+    // ---- pixel shuffle, fast form (launch_gemm sets ps_fast) ----
+    // out row of input pixel m = y'*psW + x (y' = b*psH + y) and tap (dy, dx): (f*y' + dy)*(f*psW) + f*x + dx
+    //   = f*m + f*(f-1)*psW*y' + (dy*f*psW + dx): ONE multiply-high division per row instead of two divisions and a
+    // chain of 64-bit products. Bias is added in the accumulator layout, the tile is staged as bf16 (XOR-swizzled
+    // 128-byte rows, as in the store epilogue) and a lane stores 8 channels = 16 bytes of one output pixel.
+    if (p.ps_fast) {
+      const int f = p.ps_f;
+      const int c8 = (lane & 7) * 8, rsub = lane >> 3;
+      const int n8 = n0 + wn * WTN + c8;
+      const bool nv8 = n8 < p.N;
+      const bool interior = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform
+      const int tap8 = fdiv(nv8 ? n8 : 0, p.fd_psC);
+      const int co8 = (nv8 ? n8 : 0) - tap8 * p.psC;
+      const int dy8 = f == 4 ? tap8 >> 2 : tap8 >> 1, dx8 = tap8 - dy8 * f;
+      const unsigned ldo_u = (unsigned)p.ldo;
+      const unsigned c_lane = (unsigned)(dy8 * f * p.psW + dx8) * ldo_u + (unsigned)(p.ps_coff + co8);
+      const unsigned k1 = (unsigned)f * ldo_u, k2 = (unsigned)(f * (f - 1) * p.psW) * ldo_u;
+      const float* biasq = MD_SEL_G(p.bias, g);
+      f32x4_t bq[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int na = n0 + wn * WTN + a * 16 + 4 * q16;
+        const int ca = na - fdiv(na, p.fd_psC) * p.psC;
+        bq[a] = (biasq && na < p.N) ? *(const f32x4_t*)(biasq + ca) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+      const int r16 = lane & 15;
+      char* ob = (char*)p.out;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const f32x4acc_t c = acc16[a][half * 4 + bb];
+            const f32x4_t v = (f32x4_t){c[0], c[1], c[2], c[3]} + bq[a];
+            const int row = bb * 16 + r16;
+            const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
+            *(bf16x4_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = (bf16x4_t){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + rsub;
+          const int m = m_base + wm * WTM + half * 64 + row;
+          const i32x4_t raw = *(const i32x4_t*)(st + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+          if (interior || (m < m_end && nv8)) {
+            const unsigned yq = (unsigned)fdiv(m, p.fd_psW);
+            const unsigned eo = (unsigned)m * k1 + yq * k2 + c_lane;
+            *(i32x4_t*)(ob + (size_t)eo * 2u) = raw;
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+      if (stamp) {
+        stamp[6] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[7] = __builtin_amdgcn_s_memrealtime();
+      }
+      return;
+    }
   }
   const float* biasp = MD_SEL_G(p.bias, g);
   f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {0.f, 0.f, 0.f, 0.f};

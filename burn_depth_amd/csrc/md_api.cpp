@@ -563,6 +563,12 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
     MD_TRY(fill_random(bias.p, (size_t)N, MD_PREC_F32, 5, 0.1f, st));
     p.bias[0] = (const float*)bias.p; p.act = ACT_GELU;
   }
+  if ((dbg & 8) && mode != 1) {  // deconv k2s2 epilogue: pixel shuffle of N = 4 * psC columns; aux0 x aux1 = input pixel grid (batch folded into H)
+    if ((long)aux0 * aux1 != M || N % 4 != 0) MD_FAIL(MD_ERR_SHAPE, "pixel-shuffle bench: aux0*aux1 must equal M, N = 4*C");
+    MD_TRY(bias.alloc((size_t)N * 4));
+    MD_TRY(fill_random(bias.p, (size_t)N, MD_PREC_F32, 5, 0.1f, st));
+    p.epi = EPI_PIXSHUF; p.bias[0] = (const float*)bias.p; p.psH = aux0; p.psW = aux1; p.psC = N / 4; p.ps_f = 2; p.ldo = N / 4; p.ps_coff = 0;
+  }
   int amode = A_DENSE;
   if (mode == 1) {
     if ((long)aux0 * aux1 != M) MD_FAIL(MD_ERR_SHAPE, "conv bench: H*W must equal M");
