@@ -390,16 +390,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
       const long bimg = fdiv(t2, p.fd_oh);
       const int oy = t2 - (int)bimg * oh;
       const int x = ox * p.cstride, y = oy * p.cstride;  // centre tap in the input grid
-      unsigned mk = 0;
+      // tap mask = outer product of 3 row bits and 3 column bits; pixel index in 32 bits, ONE 64-bit multiply-add
+      unsigned c3 = 0, mk = 0;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) c3 |= ((unsigned)(x + kx - 1) < (unsigned)p.cW ? 1u : 0u) << kx;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
-          if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) mk |= 1u << (ky * 3 + kx);
-        }
+      for (int ky = 0; ky < 3; ++ky) mk |= ((unsigned)(y + ky - 1) < (unsigned)p.cH ? c3 : 0u) << (3 * ky);
       maskA[i] = mk;
-      srcA[i] = Ab + ((bimg * p.cH + y) * p.cW + x) * p.cC * ESZ + lc * 16;
+      const int pix = ((int)bimg * p.cH + y) * p.cW + x;
+      srcA[i] = Ab + (long)pix * (long)(p.cC * ESZ) + lc * 16;
     }
   }
   const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
@@ -626,16 +625,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       const long bimg = fdiv(t2, p.fd_oh);
       const int oy = t2 - (int)bimg * oh;
       const int x = ox * p.cstride, y = oy * p.cstride;  // centre tap in the input grid
-      unsigned mk = 0;
+      // tap mask = outer product of 3 row bits and 3 column bits; pixel index in 32 bits, ONE 64-bit multiply-add
+      unsigned c3 = 0, mk = 0;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) c3 |= ((unsigned)(x + kx - 1) < (unsigned)p.cW ? 1u : 0u) << kx;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
-          if (yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW) mk |= 1u << (ky * 3 + kx);
-        }
+      for (int ky = 0; ky < 3; ++ky) mk |= ((unsigned)(y + ky - 1) < (unsigned)p.cH ? c3 : 0u) << (3 * ky);
       maskA[i] = mk;
-      srcA[i] = Ab + ((bimg * p.cH + y) * p.cW + x) * p.cC * ESZ + lc * 16;
+      const int pix = ((int)bimg * p.cH + y) * p.cW + x;
+      srcA[i] = Ab + (long)pix * (long)(p.cC * ESZ) + lc * 16;
     }
   }
   const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
