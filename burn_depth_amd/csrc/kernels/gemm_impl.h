@@ -378,10 +378,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     m = m < m_end ? m : m_end - 1;
     const long am = (long)g_arow0 + (m - g_row0);  // physical A row
     if constexpr (AMODE == A_DENSE) {
-      srcA[i] = Ab + am * p.lda * ESZ + lc * 16;
+      srcA[i] = Ab + (long)(int)am * (long)(int)(p.lda * ESZ) + lc * 16;  // 32 x 32 -> 64: one v_mad_i64_i32
       maskA[i] = 0;
     } else if constexpr (AMODE == A_INDEXED) {
-      srcA[i] = Ab + (long)p.a_index[am] * p.lda * ESZ + lc * 16;
+      srcA[i] = Ab + (long)p.a_index[am] * (long)(int)(p.lda * ESZ) + lc * 16;
       maskA[i] = 0;
     } else {
       const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     const int lc = pc ^ ((r >> 1) & 7);
     int n = n0 + r;
     n = n < p.N ? n : p.N - 1;
-    srcW[i] = Wg + (long)n * ldw * ESZ + lc * 16;
+    srcW[i] = Wg + (long)n * (long)(int)(ldw * ESZ) + lc * 16;
   }
   const char* zsrc = (const char*)p.zero_page + pc * 16;
 
@@ -613,10 +613,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     m = m < m_end ? m : m_end - 1;
     const long am = (long)g_arow0 + (m - g_row0);
     if constexpr (AMODE == A_DENSE) {
-      srcA[i] = Ab + am * p.lda * ESZ + lc * 16;
+      srcA[i] = Ab + (long)(int)am * (long)(int)(p.lda * ESZ) + lc * 16;  // 32 x 32 -> 64: one v_mad_i64_i32
       maskA[i] = 0;
     } else if constexpr (AMODE == A_INDEXED) {
-      srcA[i] = Ab + (long)p.a_index[am] * p.lda * ESZ + lc * 16;
+      srcA[i] = Ab + (long)p.a_index[am] * (long)(int)(p.lda * ESZ) + lc * 16;
       maskA[i] = 0;
     } else {
       const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const int lc = pc ^ ((r >> 1) & 7);
     int n = n0 + r;
     n = n < p.N ? n : p.N - 1;
-    srcW[i] = Wg + (long)n * ldw * ESZ + lc * 16;
+    srcW[i] = Wg + (long)n * (long)(int)(ldw * ESZ) + lc * 16;
   }
   const char* zsrc = (const char*)p.zero_page + pc * 16;
   const int KT = p.K / KE;
