@@ -361,6 +361,8 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
                       int act, int precision, int tile, float* out_dev, void* stream) {
   if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  const bool storage_out = (precision & MD_OP_STORAGE_OUT) && (precision & 0xff) != MD_PREC_F32;
+  precision &= 0xff;
   if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
   if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
   MD_HIP(hipSetDevice(dev->ordinal));
@@ -384,7 +386,13 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
   }
   p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = K;
   p.epi = EPI_STORE; p.act = act; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = out_dev; p.ldo = N;
+  DevBuf ob;
+  if (storage_out) {
+    MD_TRY(ob.alloc((size_t)M * N * 2));
+    p.out_f32 = 0; p.out = ob.p;
+  }
   MD_TRY(launch_gemm(p, A_DENSE, precision, tile, st));
+  if (storage_out) MD_TRY(launch_rows_to_f32(ob.p, (long)M * N, out_dev, MD_PREC_BF16, st));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
@@ -431,6 +439,8 @@ int md_op_conv3x3(md_device_t dev, const float* x_dev, const float* w_dev, const
                   int Cout, int pre_relu, int precision, float* out_dev, void* stream) {
   if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  const bool storage_out = (precision & MD_OP_STORAGE_OUT) && (precision & 0xff) != MD_PREC_F32;
+  precision &= 0xff;
   if (Cin % ke_of(precision) != 0 || Cout % 4 != 0)
     MD_FAIL(MD_ERR_UNSUPPORTED, "conv3x3: Cin=%d must be a multiple of %d and Cout=%d of 4", Cin, ke_of(precision), Cout);
   MD_HIP(hipSetDevice(dev->ordinal));
@@ -448,9 +458,9 @@ int md_op_conv3x3(md_device_t dev, const float* x_dev, const float* w_dev, const
   GemmParams p;
   p.N = Cout; p.K = 9 * Cin; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p;
   p.A = xa.p; p.cH = H; p.cW = W; p.cC = Cin; p.zero_page = zp.p;
-  p.epi = EPI_STORE; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
+  p.epi = EPI_STORE; p.out_f32 = storage_out ? 0 : 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
   MD_TRY(launch_gemm(p, A_CONV3, precision, TILE_AUTO, st));
-  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, H, W, Cout, 0, out_dev, MD_PREC_F32, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, H, W, Cout, 0, out_dev, storage_out ? MD_PREC_BF16 : MD_PREC_F32, st));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
@@ -459,6 +469,8 @@ int md_op_deconv2x2(md_device_t dev, const float* x_dev, const float* w_dev, con
                     int W, int Cout, int precision, float* out_dev, void* stream) {
   if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  const bool storage_out = (precision & MD_OP_STORAGE_OUT) && (precision & 0xff) != MD_PREC_F32;
+  precision &= 0xff;
   if (Cin % ke_of(precision) != 0 || Cout % 4 != 0)
     MD_FAIL(MD_ERR_UNSUPPORTED, "deconv: Cin=%d must be a multiple of %d and Cout=%d of 4", Cin, ke_of(precision), Cout);
   MD_HIP(hipSetDevice(dev->ordinal));
@@ -474,10 +486,10 @@ int md_op_deconv2x2(md_device_t dev, const float* x_dev, const float* w_dev, con
   MD_TRY(pack_weight(w_dev, e, precision, st));
   GemmParams p;
   p.N = 4 * Cout; p.K = Cin; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p; p.A = xa.p; p.lda = Cin;
-  p.epi = EPI_PIXSHUF; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
+  p.epi = EPI_PIXSHUF; p.out_f32 = storage_out ? 0 : 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
   p.psH = H; p.psW = W; p.psC = Cout; p.ps_coff = 0;
   MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_AUTO, st));
-  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, 2 * H, 2 * W, Cout, 0, out_dev, MD_PREC_F32, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, 2 * H, 2 * W, Cout, 0, out_dev, storage_out ? MD_PREC_BF16 : MD_PREC_F32, st));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }

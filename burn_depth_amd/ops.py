@@ -70,8 +70,12 @@ def layernorm(dev: Device, x: torch.Tensor, gamma: Optional[torch.Tensor], beta:
     return out
 
 
+STORAGE_OUT = 0x100  # MD_OP_STORAGE_OUT: result through the engine's storage type (bf16) instead of the fp32 store
+
+
 def linear(dev: Device, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0, precision: int = 0,
-           tile: int = _lib.TILE_AUTO) -> torch.Tensor:
+           tile: int = _lib.TILE_AUTO, storage_out: bool = False) -> torch.Tensor:
+    precision |= STORAGE_OUT if storage_out else 0
     x, w = _f32c(x), _f32c(w)
     M, K = x.shape
     N = w.shape[0]
@@ -90,7 +94,8 @@ def attention(dev: Device, qkv: torch.Tensor, heads: int, precision: int = 0) ->
 
 
 def conv3x3(dev: Device, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], pre_relu: bool = False,
-            precision: int = 0) -> torch.Tensor:
+            precision: int = 0, storage_out: bool = False) -> torch.Tensor:
+    precision |= STORAGE_OUT if storage_out else 0
     x, w = _f32c(x), _f32c(w)
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -100,7 +105,9 @@ def conv3x3(dev: Device, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.
     return out
 
 
-def deconv2x2(dev: Device, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], precision: int = 0) -> torch.Tensor:
+def deconv2x2(dev: Device, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], precision: int = 0,
+              storage_out: bool = False) -> torch.Tensor:
+    precision |= STORAGE_OUT if storage_out else 0
     x, w = _f32c(x), _f32c(w)
     B, Cin, H, W = x.shape
     Cout = w.shape[1]

@@ -45,6 +45,10 @@ typedef enum md_mem_kind { MD_MEM_HOST = 0, MD_MEM_DEVICE = 1 } md_mem_kind;
  * activations with static per-tensor scales -- with fp32 accumulation. */
 typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1, MD_PREC_FP8 = 2 } md_precision;
 /* depth_pro/interpolate.rs:11-22 */
+/* Stand-alone operator checks only (md_op_linear*, md_op_conv3x3, md_op_deconv2x2): OR into `precision` to route the
+ * result through the engine's storage type (bf16 in the BF16 / FP8 modes) before it is widened to the fp32 output --
+ * the store epilogues the engine itself uses -- instead of the fp32 store. Ignored for MD_PREC_F32. */
+#define MD_OP_STORAGE_OUT 0x100
 typedef enum md_interp { MD_INTERP_CUSTOM = 0, MD_INTERP_BURN = 1 } md_interp;
 /* synthetic initialisation (no trained weights exist in the reference tree) */
 typedef enum md_init_scheme { MD_INIT_REFERENCE = 0, MD_INIT_PARITY = 1 } md_init_scheme;

@@ -42,7 +42,7 @@ def _assert_new_results_ok(diag, start):
 
 
 @pytest.mark.parametrize("check", ["check_rgb", "check_resize", "check_split_merge", "check_layernorm", "check_linear",
-                                   "check_attention", "check_convs"])
+                                   "check_attention", "check_convs", "check_storage_epilogues"])
 def test_operator_parity(diag, dev, check):
     start = len(diag.RESULTS)
     getattr(diag, check)(dev)

@@ -145,6 +145,36 @@ def check_linear(dev):
         record(f"linear {pname} relu nobias", rel_err(ops.linear(dev, x.cuda(), w.cuda(), None, 1, prec), F.relu(F.linear(x, w))), 2e-5)
 
 
+def check_storage_epilogues(dev):
+    """The store epilogues the ENGINE uses (bf16 output through the bf16-staged / pixel-shuffle paths of the 256x256
+    kernel), at sizes that select that kernel and leave partial tiles. Tolerance = bf16 output rounding."""
+    g = torch.Generator().manual_seed(11)
+    tol = 6e-3
+    for (M, N, K, act, has_bias) in [(2000, 1024, 1024, 0, True), (513, 264, 320, 0, True), (700, 512, 128, 2, True),
+                                     (1300, 256, 192, 1, False), (513, 260, 320, 0, True), (21349, 1024, 1024, 2, True)]:
+        x = bf(torch.randn(M, K, generator=g))
+        w = bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+        b = torch.randn(N, generator=g) if has_bias else None
+        want = F.linear(x.double(), w.double(), b.double() if has_bias else None)
+        want = F.gelu(want) if act == 2 else (F.relu(want) if act == 1 else want)
+        got = ops.linear(dev, x.cuda(), w.cuda(), b.cuda() if has_bias else None, act, 0, _lib.TILE_256x256, storage_out=True)
+        record(f"linear bf16-out M{M} N{N} K{K} act{act}", rel_err(got, want.float()), tol)
+    for (B, Cin, H, W, Cout) in [(2, 128, 160, 120, 256), (1, 64, 33, 17, 32)]:
+        x = bf(torch.randn(B, Cin, H, W, generator=g))
+        w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin))
+        b = torch.randn(Cout, generator=g)
+        want = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+        got = ops.conv3x3(dev, x.cuda(), w.cuda(), b.cuda(), False, 0, storage_out=True)
+        record(f"conv3x3 bf16-out B{B} {Cin}->{Cout} {H}x{W}", rel_err(got, want), tol)
+    for (B, Cin, H, W, Cout) in [(2, 256, 97, 88, 128), (1, 128, 150, 130, 64), (2, 256, 12, 10, 128)]:
+        x = bf(torch.randn(B, Cin, H, W, generator=g))
+        w = bf(torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin))
+        b = torch.randn(Cout, generator=g)
+        want = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2).float()
+        got = ops.deconv2x2(dev, x.cuda(), w.cuda(), b.cuda(), 0, storage_out=True)
+        record(f"deconv2x2 bf16-out B{B} {Cin}->{Cout} {H}x{W}", rel_err(got, want), tol)
+
+
 def q8_mul(x, inv_scale):
     """e4m3 operand emulation with the device's arithmetic: fp32 multiply by the reciprocal scale, saturate at
     +-448 (the engine clamps before converting), torch's e4m3fn cast (bit-identical to v_cvt_pk_fp8_f32 incl.
@@ -229,7 +259,8 @@ def check_convs(dev):
         x = bf(torch.randn(1, 64, 12, 12, generator=g))
         w = bf(torch.randn(64, 64, 3, 3, generator=g) / 24)
         record(f"conv3x3 {pname} pre-relu nobias", rel_err(ops.conv3x3(dev, x.cuda(), w.cuda(), None, True, prec), F.conv2d(F.relu(x), w, None, padding=1)), tol)
-        for (B, Cin, H, W, Cout) in [(1, 64, 8, 8, 64), (2, 256, 12, 10, 128), (1, 1024, 24, 24, 256)]:
+        # the last shape is large enough for the 256x256 kernel (its one-division pixel-shuffle epilogue, partial last tile)
+        for (B, Cin, H, W, Cout) in [(1, 64, 8, 8, 64), (2, 256, 12, 10, 128), (1, 1024, 24, 24, 256), (2, 256, 97, 88, 128)]:
             x = torch.randn(B, Cin, H, W, generator=g)
             w = torch.randn(Cin, Cout, 2, 2, generator=g) / math.sqrt(Cin)
             b = torch.randn(Cout, generator=g)
@@ -403,6 +434,7 @@ def main():
         check_linear_fp8(dev)
         check_attention(dev)
         check_convs(dev)
+        check_storage_epilogues(dev)
     if want("tiny"):
         guarded("tiny f32")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f32", 1, (512, 512), Precision.F32)
         guarded("tiny bf16")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/bf16", 1, (512, 512), Precision.BF16)
