@@ -94,6 +94,10 @@ struct GemmParams {
   // divisors of the epilogue index math (filled by the launcher from the fields above)
   FastDiv fd_res_mod, fd_seq_patches, fd_seq_stride, fd_psC, fd_psW, fd_psH, fd_ow, fd_oh, fd_cblocks;
   int raster_gn = 0;  // n-tiles per raster group (0 = all: plain n-fastest order); set by the launcher
+  // block -> tile map, prepared by the launcher (prep_tile_map): the kernel prologue did three runtime integer
+  // divisions (float-reciprocal sequences, ~150 dependent cycles each) per workgroup for it
+  int map_gn = 1, map_gsz = 1, map_full = 0, map_full_gsz = 0, map_rn = 0;
+  FastDiv fd_map_gsz, fd_map_gn, fd_map_rn;
   // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
   int debug_flags = 0;
   unsigned long long* stamps = nullptr;  // timing-only: [blocks][16] stamps: 8 x s_memrealtime, then 2 x shader clock around the main loop (md_bench_gemm)

@@ -327,20 +327,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
   // L2-aware raster: n-tiles are walked in groups of `gn` (host-chosen, <= 4): the 32 blocks an XCD
   // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
   // the XCD's 4-MB L2 while the A panels stream past it.
-  const int tiles_n = (p.N + BN - 1) / BN;
+  // (divisors prepared on the host: prep_tile_map)
   auto map_tile = [&](int tid_lin, int& tn, int& tmg) {
-    const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
-    const int tiles_m = p.g_tile0[kMaxGroups];  // total m-tiles over all groups
-    const int gsz = tiles_m * gn;
-    const int full = tiles_n / gn;
-    if (tid_lin < full * gsz) {
-      const int ng = tid_lin / gsz, r = tid_lin - ng * gsz;
-      tmg = r / gn;
-      tn = ng * gn + (r - tmg * gn);
+    if (tid_lin < p.map_full_gsz) {
+      const int ng = fdiv(tid_lin, p.fd_map_gsz), r = tid_lin - ng * p.map_gsz;
+      tmg = fdiv(r, p.fd_map_gn);
+      tn = ng * p.map_gn + (r - tmg * p.map_gn);
     } else {
-      const int rn = tiles_n - full * gn, r = tid_lin - full * gsz;
-      tmg = r / rn;
-      tn = full * gn + (r - tmg * rn);
+      const int r = tid_lin - p.map_full_gsz;
+      tmg = fdiv(r, p.fd_map_rn);
+      tn = p.map_full * p.map_gn + (r - tmg * p.map_rn);
     }
   };
   int tile_n, tile_mg;
@@ -564,20 +560,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // L2-aware raster: n-tiles are walked in groups of `gn` (host-chosen, <= 4): the 32 blocks an XCD
   // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
   // the XCD's 4-MB L2 while the A panels stream past it.
-  const int tiles_n = (p.N + BN - 1) / BN;
+  // (divisors prepared on the host: prep_tile_map)
   auto map_tile = [&](int tid_lin, int& tn, int& tmg) {
-    const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
-    const int tiles_m = p.g_tile0[kMaxGroups];  // total m-tiles over all groups
-    const int gsz = tiles_m * gn;
-    const int full = tiles_n / gn;
-    if (tid_lin < full * gsz) {
-      const int ng = tid_lin / gsz, r = tid_lin - ng * gsz;
-      tmg = r / gn;
-      tn = ng * gn + (r - tmg * gn);
+    if (tid_lin < p.map_full_gsz) {
+      const int ng = fdiv(tid_lin, p.fd_map_gsz), r = tid_lin - ng * p.map_gsz;
+      tmg = fdiv(r, p.fd_map_gn);
+      tn = ng * p.map_gn + (r - tmg * p.map_gn);
     } else {
-      const int rn = tiles_n - full * gn, r = tid_lin - full * gsz;
-      tmg = r / rn;
-      tn = full * gn + (r - tmg * rn);
+      const int r = tid_lin - p.map_full_gsz;
+      tmg = fdiv(r, p.fd_map_rn);
+      tn = p.map_full * p.map_gn + (r - tmg * p.map_rn);
     }
   };
   int tile_n, tile_mg;
@@ -1457,6 +1449,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
 }
 
+// host side of map_tile: n-tiles are walked in groups of gn (L2-aware raster), the last group may be narrower
+static inline void prep_tile_map(GemmParams& p, int tiles_m, int tiles_n) {
+  const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
+  p.map_gn = gn;
+  p.map_gsz = tiles_m * gn;
+  p.map_full = tiles_n / gn;
+  p.map_full_gsz = p.map_full * p.map_gsz;
+  p.map_rn = tiles_n - p.map_full * gn;
+  p.fd_map_gsz = make_fastdiv(p.map_gsz);
+  p.fd_map_gn = make_fastdiv(gn);
+  p.fd_map_rn = make_fastdiv(p.map_rn);
+}
+
 template <typename T, int AMODE, int PP>
 static int launch_256(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 256, BN = 256;
@@ -1470,6 +1475,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   const long blocks = (long)tiles_m * cdiv(p.N, BN);
   if (blocks <= 0) return MD_OK;
   if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
+  prep_tile_map(p, tiles_m, cdiv(p.N, BN));
   constexpr int smem = 5 * 256 * 128;  // 160 KB: the whole LDS of a CU
   const dim3 grid((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1));
   auto go = [&](auto kern, bool* attr_set) -> int {
@@ -1513,6 +1519,7 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
   const long blocks = (long)tiles_m * tiles_n;
   if (blocks <= 0) return MD_OK;
   if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
+  prep_tile_map(p, tiles_m, tiles_n);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = gemm_kernel<T, BM, BN, WGM, WGN, AMODE>;
   static bool attr_set = false;
