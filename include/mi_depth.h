@@ -231,7 +231,12 @@ int md_op_fov_to_focal(float fovx_deg, int H, int W, float* focal_px, float* fov
 /* Kernel micro-benchmark: times `iters` launches of the GEMM kernel (random bf16/f32 operands resident
  * in HBM, plain store epilogue, out element = operand type) with HIP events on the launch stream and
  * returns the average milliseconds per launch. mode: 0 dense GEMM [M,K]x[N,K]^T; 1 conv3x3 over an
- * NHWC [1,H,W,K] image with M = H*W (pass H in `aux0`, W in `aux1`), N = Cout. */
+ * NHWC [1,H,W,K] image with M = H*W (pass H in `aux0`, W in `aux1`), N = Cout.
+ * Timing-only ablation flags ride in `tile >> 8` (results are then meaningless): 1 no in-loop global loads, 2 every
+ * k-tile re-reads k-tile 0, 4 bias + GELU epilogue (fc1), 8 pixel-shuffle epilogue of a k2s2 deconvolution (mode 0:
+ * `aux0` x `aux1` = input pixel grid, N = 4*Cout), 16 fp32 read-modify-write epilogue (proj / fc2), 32 per-workgroup
+ * phase stamps of one launch printed to stderr (s_memrealtime at seven points + shader clock around the main loop),
+ * 64 no global stores, 128 no staging writes. tools/kernel_bench.py names the combinations. */
 int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int aux1, int precision, int tile, int iters,
                   float* avg_ms);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
