@@ -475,3 +475,13 @@ def test_depth_anything3_error_paths(dev):
     out = m.infer(torch.zeros(1, 3, 70, 70, device="cuda"))
     assert tuple(out.depth.shape) == (1, 70, 70) and torch.isfinite(out.depth).all()
     m.destroy()
+
+
+@pytest.mark.gpu
+def test_gemm_is_bit_exact_on_integer_operands(dev):
+    """Small-integer operands make every product and partial sum exact in fp32, so the staggered 256x256 schedule
+    (ring slots, counted waits, two-group barriers) must reproduce the CPU product bit for bit, launch after launch,
+    through both the fp32 and the bf16 store epilogue."""
+    sys.path.insert(0, ROOT)
+    from tools import soak_gemm
+    assert soak_gemm.run(dev, iters=4) == []
