@@ -478,10 +478,10 @@ def test_depth_anything3_error_paths(dev):
 
 
 @pytest.mark.gpu
-def test_gemm_is_bit_exact_on_integer_operands(dev):
+def test_gemm_family_is_bit_exact_on_integer_operands(dev):
     """Small-integer operands make every product and partial sum exact in fp32, so the staggered 256x256 schedule
     (ring slots, counted waits, two-group barriers) must reproduce the CPU product bit for bit, launch after launch,
-    through both the fp32 and the bf16 store epilogue."""
+    through both the fp32 and the bf16 store epilogue; likewise the 3x3 convolution and the k2s2 deconvolution."""
     sys.path.insert(0, ROOT)
     from tools import soak_gemm
     assert soak_gemm.run(dev, iters=4) == []

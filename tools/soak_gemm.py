@@ -1,5 +1,6 @@
-"""Determinism / exactness soak of the 256x256 GEMM: small-integer operands (every product and partial sum exact in
-fp32), `iters` launches per shape, fp32-store and bf16-store epilogues, bit-exact against the CPU product."""
+"""Determinism / exactness soak of the 256x256 GEMM family (dense, 3x3 convolution, k2s2 deconvolution): small-integer
+operands (every product and partial sum exact in fp32), repeated launches per shape, fp32-store and bf16-store epilogues,
+bit-exact against the CPU result."""
 import os
 import sys
 
@@ -30,6 +31,34 @@ def run(dev, iters=25, verbose=False):
                 bad.append((M, N, K, it, d, d16))
         if verbose:
             print("shape", M, N, K, "ok" if not bad else "MISMATCH", flush=True)
+    # the implicit-GEMM convolution (tap masks, 32-bit pixel index) and the one-division pixel-shuffle epilogue
+    import torch.nn.functional as F
+    for (B, Cin, H, W, Cout) in [(2, 128, 160, 120, 256), (1, 64, 33, 17, 32)]:
+        x = torch.randint(-2, 3, (B, Cin, H, W), generator=g).float()
+        w = torch.randint(-1, 2, (Cout, Cin, 3, 3), generator=g).float()
+        b = torch.randint(-5, 6, (Cout,), generator=g).float()
+        want = F.conv2d(x.double(), w.double(), b.double(), padding=1).float().cuda()
+        want16 = want.to(torch.bfloat16).float()
+        for it in range(max(1, iters // 4)):
+            d = (ops.conv3x3(dev, x.cuda(), w.cuda(), b.cuda(), False, 0) - want).abs().max().item()
+            d16 = (ops.conv3x3(dev, x.cuda(), w.cuda(), b.cuda(), False, 0, storage_out=True) - want16).abs().max().item()
+            if d != 0.0 or d16 != 0.0:
+                bad.append(("conv3x3", B, Cin, H, W, Cout, it, d, d16))
+        if verbose:
+            print("conv3x3", B, Cin, H, W, Cout, "ok" if not bad else "MISMATCH", flush=True)
+    for (B, Cin, H, W, Cout) in [(2, 256, 97, 88, 128), (1, 128, 150, 130, 64)]:
+        x = torch.randint(-2, 3, (B, Cin, H, W), generator=g).float()
+        w = torch.randint(-1, 2, (Cin, Cout, 2, 2), generator=g).float()
+        b = torch.randint(-5, 6, (Cout,), generator=g).float()
+        want = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2).float().cuda()
+        want16 = want.to(torch.bfloat16).float()
+        for it in range(max(1, iters // 4)):
+            d = (ops.deconv2x2(dev, x.cuda(), w.cuda(), b.cuda(), 0) - want).abs().max().item()
+            d16 = (ops.deconv2x2(dev, x.cuda(), w.cuda(), b.cuda(), 0, storage_out=True) - want16).abs().max().item()
+            if d != 0.0 or d16 != 0.0:
+                bad.append(("deconv2x2", B, Cin, H, W, Cout, it, d, d16))
+        if verbose:
+            print("deconv2x2", B, Cin, H, W, Cout, "ok" if not bad else "MISMATCH", flush=True)
     return bad
 
 
