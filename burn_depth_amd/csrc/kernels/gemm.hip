@@ -2,6 +2,7 @@
 // The kernel template lives in gemm_impl.h and is instantiated per precision in
 // gemm_bf16.hip / gemm_f32.hip (separate translation units so they compile in parallel).
 #include "gemm.h"
+#include <cstdlib>
 
 namespace md {
 
@@ -73,7 +74,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   {
     const int bn = (tile == TILE_128x128) ? 128 : (tile == TILE_256x32 ? 32 : 256);
     const int tn = cdiv(p.N, bn);
-    p.raster_gn = tn <= 4 ? 0 : 4;
+    // raster group width, from a sweep on the Depth Pro step (B = 8): up to 12 n-tiles (qkv) plain n-fastest order is
+    // best (qkv 24.3 -> 23.3 ms per step against groups of 4); the 16 n-tiles of fc1 run the same in groups of 4 or 8 and
+    // slower ungrouped (34.5 / 34.7 / 34.9 ms)
+    static const int gn_env = getenv("MD_RASTER_GN") ? atoi(getenv("MD_RASTER_GN")) : -1;  // A/B override
+    p.raster_gn = gn_env >= 0 ? (tn <= gn_env ? 0 : gn_env) : (tn <= 12 ? 0 : 4);
   }
   if (p.epi == EPI_HEAD) tile = TILE_256x32;
   if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);
