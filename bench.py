@@ -1,43 +1,52 @@
 """bench.py -- frames/s of DepthPro::infer on synthetic [B,3,1536,1536] (BASELINE.json metric).
 
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under torch.distributed.run with
-one rank per GPU.  A step = one DepthPro::infer over one batch of `--batch` synthetic images that are
-already resident in HBM.  Independent images shard over ranks (data parallel, weak scaling: every
-rank runs the same per-GPU batch); the only collectives are the one-time weight broadcast from rank 0
-(outside the timed region) and, per step, the gather of the depth maps to rank 0 over RCCL/xGMI
-(inside the timed region).
+`python bench.py --gpus N --steps K --warmup W`. With N > 1 and no WORLD_SIZE in the environment the
+script starts its own N ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py`) as a
+CHILD process before anything touches the GPU, relays the child's output and exits with its code; under
+an external `torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
+
+A step = one DepthPro::infer over one batch of `--batch` synthetic images per GPU. Independent images
+shard over ranks (data parallel, weak scaling: every rank runs the same per-GPU batch). N = 1: the
+batch is resident in HBM when the timed region starts. N > 1 (BASELINE config 4): the whole global
+batch is resident in rank 0's HBM; every step scatters the shards from rank 0 (RCCL over xGMI), runs
+the engine and gathers the depth maps back to rank 0 -- scatter and gather are INSIDE the timed
+region, double-buffered so that the transfers of step k+1 / k-1 overlap the
+compute of step k; the one-time weight broadcast from rank 0 is outside it and reported separately.
 
 The JSON line also carries
   * "roofline": MFMA roofline of the dominant kernel family, from HIP events recorded on the launch
     stream around every launch of that family during the timed steps (md_model_enable_timing);
   * "kernels": the same for every kernel family (ms per step, achieved TFLOP/s or GB/s);
   * "cpu_baseline": the CPU oracle (a port of the reference's NdArray path; the Rust reference
-    cannot be built here) timed on this host's cores on a bounded sample of the same workload.
+    cannot be built here) timed on this host's cores on ONE whole frame (BASELINE config 1: zeros
+    [1,3,1536,1536], bench/inference.rs:21-48), or on a bounded sample when a frame would not fit
+    the time budget.
+
+`--dry-run` replaces the engine by a CPU stand-in and RCCL by gloo: it exercises the launcher, the
+scatter / gather pipeline and the JSON contract without a GPU (tests/test_bench_launcher.py).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch, torch.distributed and the engine are imported inside the functions that need them: the parent of a
+# self-spawned multi-rank run must not touch the GPU.
 
-from burn_depth_amd import weights as Wt  # noqa: E402
-from burn_depth_amd.config import DepthProConfig, Precision  # noqa: E402
-from burn_depth_amd.depth_pro import DepthPro, Device  # noqa: E402
-
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / f16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def work_model(cfg: DepthProConfig, B: int):
+def work_model(cfg, B: int):
     """Algorithmic FLOPs (2*MAC) / bytes per kernel family for one batch (SURVEY 8d derivation)."""
     v = cfg.patch_vit()
     D, P, NT, depth, heads = v.embed_dim, v.grid_size() ** 2, v.num_tokens, v.depth, v.num_heads
@@ -78,48 +87,91 @@ def work_model(cfg: DepthProConfig, B: int):
     fl["head_deconv"] = 2.0 * 4 * (F // 2) ** 2 * px(hw[0])
     fl["head_conv1_fused"] = 2.0 * (9 * (F // 2) * 32 + 32) * px(2 * hw[0])
     by = {}
-    by["pyramid_patchify"] = B * 3 * S * S * 4.0 + (35 * B) * P * 3 * v.patch_size ** 2 * 2.0
-    by["layernorm"] = (2 * depth + 1) * nseq * NT * D * (4.0 + 2.0)
+    esz = 4.0 if int(cfg.precision) == 1 else 2.0
+    by["pyramid_patchify"] = B * 3 * S * S * 4.0 + (35 * B) * P * 3 * v.patch_size ** 2 * esz
+    by["layernorm"] = (2 * depth + 1) * nseq * NT * D * (4.0 + esz)
     by["depth_post"] = B * S * S * 8.0
-    by["hook_copy"] = 2 * 25 * B * NT * D * 6.0
+    by["hook_copy"] = 2 * 25 * B * NT * D * (4.0 + esz)
     return fl, by
 
 
-def main() -> int:
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Parent of a self-launched multi-rank run. Makes NO GPU call (never imports torch): starts the ranks as a child
+    process tree through torch.distributed.run, relays stdout / stderr unchanged and returns the child's exit code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (B of DepthPro::infer([B,3,S,S])); default 8 for depth_pro (BASELINE config 4's 8 images/GPU), 1 for da3_* (single-image configs 2 / 5)")
-    ap.add_argument("--precision", choices=["bf16", "f32", "fp8"], default="bf16",
-                    help="fp8 (da3_* only, BASELINE config 5): e4m3 operands for the four ViT linear layers, bf16 elsewhere")
+    ap.add_argument("--precision", choices=["bf16", "f16", "f32", "fp8"], default="bf16",
+                    help="MFMA operand type. bf16 = the BASELINE metric; f16 = same rate, 3 more mantissa bits (the accurate fast mode); "
+                         "f32 = parity mode; fp8 (da3_* only, BASELINE config 5): e4m3 operands for the four ViT linear layers")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
     ap.add_argument("--model", choices=["depth_pro", "da3_large", "da3_small"], default="depth_pro",
                     help="depth_pro = the BASELINE headline; da3_large / da3_small = Depth-Anything-v3 (BASELINE configs 5 / 2)")
     ap.add_argument("--image-size", type=int, default=0, help="da3_* only: square input side (multiple of 14), default 518")
     ap.add_argument("--streams", type=int, default=1,
-                    help="independent in-flight batches per GPU, each on its own HIP stream with its own workspace")
+                    help="independent in-flight batches per GPU, each on its own HIP stream with its own workspace; the weights are shared (md_model_fork)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the launch schedule from a hipGraph and drop the per-kernel HIP events from the timed region "
                          "(no `kernels` / `roofline` in the line: latency mode for the single-image configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the whole-frame CPU baseline may take (predicted from a 2-tile probe); beyond it the sampled estimate is reported")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: no depth gather to rank 0")
+    ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank synthesises its own batch instead of receiving it from rank 0")
+    ap.add_argument("--accuracy", action="store_true", help="also report depth max-rel / mean-rel / L_inf of this precision against the fp32 CPU oracle on one seeded frame of the 512^2 ViT-L preset (`accuracy` object in the line)")
+    ap.add_argument("--side-kernels", action="store_true", help="also time the stand-alone HBM-bound kernels (resize_bilinear / resize_nhwc at the shapes of bench/interpolate.rs) into `kernels`")
+    ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the engine + gloo instead of RCCL: tests the launcher / scatter / gather / JSON contract without a GPU")
     ap.add_argument("--dump-launch-order", default="", help="write the per-launch kernel-family list of one infer (json)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
     if args.batch <= 0:
         args.batch = 8 if args.model == "depth_pro" else 1
+    if args.gpus < 1:
+        print("--gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, argv)  # before any torch / HIP import in this process
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} ranks", file=sys.stderr)
+    if args.dry_run:
+        return bench_dry(args, world, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world
-    if args.gpus != world and rank == 0:
-        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro, Device
+    from burn_depth_amd.parallel import broadcast_weights
 
     dev = Device(local_rank)
     tdev = torch.device("cuda", local_rank)
@@ -130,12 +182,11 @@ def main() -> int:
               file=sys.stderr)
         return 2
     cfg = {"full": DepthProConfig(), "small": DepthProConfig.small_test(), "tiny": DepthProConfig.tiny_test()}[args.preset]
-    cfg.precision = Precision.BF16 if args.precision == "bf16" else Precision.F32
+    cfg.precision = {"bf16": Precision.BF16, "f16": Precision.F16, "f32": Precision.F32}[args.precision]
     cfg.max_batch = args.batch
     S, B = cfg.img_size(), args.batch
     # weights: random init (DepthPro::new, bench/inference.rs:25). Rank 0 generates, the others receive
     # the fp32 weight arena over RCCL (one-time, outside the timed region).
-    from burn_depth_amd.parallel import broadcast_weights, gather_depth
     model = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
     t_bcast = 0.0
     if world > 1:
@@ -145,40 +196,76 @@ def main() -> int:
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
 
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    img = torch.rand(B, 3, S, S, generator=g)
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    x = ((img - mean) / std).to(tdev)  # resident in HBM before the timed region
-    depth = torch.empty((B, S, S), dtype=torch.float32, device=tdev)
+
+    def synth(n, seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        return (torch.rand(n, 3, S, S, generator=g) - mean) / std
+
+    do_scatter = world > 1 and not args.no_scatter
+    do_gather = world > 1 and not args.no_gather
+    nbuf = 2 if (do_scatter or do_gather) else 1  # double buffering: transfers of neighbouring steps overlap this step's compute
+    if do_scatter:
+        # the whole global batch lives in rank 0's HBM before the timed region; the other ranks own receive buffers only
+        global_in = torch.cat([synth(B, 1234 + r) for r in range(world)], 0).to(tdev) if rank == 0 else None
+        xs = [torch.empty(B, 3, S, S, dtype=torch.float32, device=tdev) for _ in range(nbuf)]
+    else:
+        global_in = None
+        xs = [synth(B, 1234 + rank).to(tdev)] * nbuf
+    depths = [torch.empty((B, S, S), dtype=torch.float32, device=tdev) for _ in range(nbuf)]
     focal = torch.empty((B,), dtype=torch.float32, device=tdev)
     fovx = torch.empty((B,), dtype=torch.float32, device=tdev)
     fovy = torch.empty((B,), dtype=torch.float32, device=tdev)
-    gathered = None
-    do_gather = world > 1 and not args.no_gather
-    if do_gather and rank == 0:
-        gathered = [torch.empty_like(depth) for _ in range(world)]
+    gathered = [[torch.empty_like(depths[0]) for _ in range(world)] for _ in range(nbuf)] if (do_gather and rank == 0) else None
+    scatter_chunks = list(global_in.split(B, 0)) if (do_scatter and rank == 0) else None
 
-    extra = []  # additional in-flight batches: (model, stream, x, depth, focal, fovx, fovy)
+    extra = []  # additional in-flight batches: (forked model sharing the weights, stream, x, depth, focal, fovx, fovy)
     for si in range(1, args.streams):
-        m2 = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
-        extra.append((m2, torch.cuda.Stream(device=tdev), x.clone(), torch.empty_like(depth), torch.empty_like(focal),
+        m2 = model.fork()
+        extra.append((m2, torch.cuda.Stream(device=tdev), xs[0].clone(), torch.empty_like(depths[0]), torch.empty_like(focal),
                       torch.empty_like(fovx), torch.empty_like(fovy)))
     main_stream = torch.cuda.Stream(device=tdev) if args.streams > 1 else None
 
+    pending = {"scatter": None, "gather": [None] * nbuf, "k": 0}
+
+    def issue_scatter(slot):
+        pending["scatter"] = dist.scatter(xs[slot], scatter_chunks, src=0, async_op=True)
+
     def step():
+        k = pending["k"]
+        slot = k % nbuf
+        if do_scatter:
+            if pending["scatter"] is None:
+                issue_scatter(slot)          # first step of a run: nothing was prefetched
+            pending["scatter"].wait()        # the compute stream waits for this step's shard
+            issue_scatter((k + 1) % nbuf)    # the next step's shard travels while this step computes
+        if do_gather and pending["gather"][slot] is not None:
+            pending["gather"][slot].wait()   # depth buffer `slot` was handed to a gather two steps ago
+            pending["gather"][slot] = None
         if args.streams > 1:
             with torch.cuda.stream(main_stream):
-                model.infer_into(x, depth, focal, fovx, fovy)
+                model.infer_into(xs[slot], depths[slot], focal, fovx, fovy)
             for (m2, st2, x2, d2, f2, fx2, fy2) in extra:
                 with torch.cuda.stream(st2):
                     m2.infer_into(x2, d2, f2, fx2, fy2)
         else:
-            model.infer_into(x, depth, focal, fovx, fovy)
+            model.infer_into(xs[slot], depths[slot], focal, fovx, fovy)
         if do_gather:
-            gather_depth(depth, gathered, dst=0)
+            pending["gather"][slot] = dist.gather(depths[slot], gathered[slot] if rank == 0 else None, dst=0, async_op=True)
+        pending["k"] = k + 1
 
-    if args.dump_launch_order and rank == 0:
+    def drain():
+        if pending["scatter"] is not None:
+            pending["scatter"].wait()
+            pending["scatter"] = None
+        for i, w in enumerate(pending["gather"]):
+            if w is not None:
+                w.wait()
+                pending["gather"][i] = None
+        torch.cuda.synchronize()
+
+    if args.dump_launch_order and rank == 0 and world == 1:
         model.enable_timing(True)
         step()
         torch.cuda.synchronize()
@@ -190,7 +277,7 @@ def main() -> int:
         model.enable_graph(True)
     for _ in range(max(args.warmup, 3 if args.graph else 0)):
         step()
-    torch.cuda.synchronize()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -198,7 +285,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    drain()  # every scatter / gather issued for the timed steps has completed (the one prefetched shard beyond them included)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -209,13 +296,15 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ok = bool(torch.isfinite(depth).all().item())
+    ok = all(bool(torch.isfinite(d).all().item()) for d in depths)
+    if do_gather and rank == 0:
+        ok = ok and all(bool(torch.isfinite(t).all().item()) for t in gathered[(pending["k"] - 1) % nbuf])
 
     if rank == 0:
         frames = args.steps * B * world * args.streams
         fps = frames / elapsed
         fl, by = work_model(cfg, B)
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if args.precision == "f32" else PEAK_BF16_TFLOPS
         kernels = {}
         for name, (ms, calls) in timing.items():
             per_step = ms / args.steps
@@ -227,30 +316,32 @@ def main() -> int:
                 e["gbs"] = round(by[name] / (per_step * 1e-3) / 1e9, 1)
                 e["frac_hbm_peak"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
             kernels[name] = e
-        mfma = {k: v for k, v in kernels.items() if "tflops" in k or "tflops" in v}
+        mfma = {k: v for k, v in kernels.items() if "tflops" in v}
         dom = max(mfma, key=lambda k: mfma[k]["ms_per_step"]) if mfma else None
         roofline = None
         if dom:
             e = kernels[dom]
-            symbols = {"fc1_gemm": "md::gemm256_kernel<md::bf16_t, 0, 2, 4> (dense A, 16x16x32 ping-pong, fused bias+GELU store)"}
+            symbols = {"fc1_gemm": "md::gemm256_kernel<md::bf16_t, 0, 4> (dense A, 16x16x32 two-group schedule, fused bias+GELU store)"}
             roofline = {"kernel": dom, "kernel_symbol": symbols.get(dom) if args.precision == "bf16" else None,
                         "bound": "mfma", "achieved": e["tflops"], "peak": peak, "unit": "TFLOP/s",
                         "frac": e["frac_mfma_peak"], "traffic": pmc_traffic(dom, B, args),
                         "avg_launch_ms": round(e["ms_per_step"] / max(e["launches_per_step"], 1), 4),
                         "flops_per_launch": fl[dom] / max(e["launches_per_step"], 1)}
         gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
+        if args.side_kernels:
+            kernels.update(side_kernels(dev, tdev))
         total_flops = sum(fl.values())
         out = {
             "metric": "frames/sec Depth Pro @1536^2 bf16" if args.preset == "full" and args.precision == "bf16"
             else f"frames/sec Depth Pro preset={args.preset} {args.precision}",
-            "value": round(fps, 4), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded U[0,1) images, ImageNet-normalised; random-init weights)",
             "config": {"workload": f"DepthPro::infer [{B},3,{S},{S}] per GPU, default DepthProConfig" if args.preset == "full"
                        else f"DepthPro::infer [{B},3,{S},{S}] preset {args.preset}",
                        "batch_per_gpu": B, "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
                        "parallelism": f"dp{world}",
-                       "gather_depth_to_rank0": do_gather},
+                       "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather},
             "finite_output": ok,
             "frame_tflops_algorithmic": round(total_flops / B / 1e12, 3),
             "frame_mfma_frac": round((total_flops / B) * (fps / world) / 1e12 / peak, 4),
@@ -259,25 +350,90 @@ def main() -> int:
             "roofline": roofline,
             "kernels": kernels,
         }
+        if args.accuracy:
+            out["accuracy"] = accuracy_report(dev, cfg.precision)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_budget)
+        print(json.dumps(out), flush=True)
+    for e in extra:
+        e[0].destroy()
     model.destroy()
     if world > 1:
         dist.destroy_process_group()
     return 0
 
 
+def bench_dry(args, world: int, rank: int) -> int:
+    """The launcher / data-path contract without a GPU: gloo instead of RCCL, a CPU stand-in for the engine
+    (depth = a per-image reduction, so that every gathered map can be checked against the scattered images)."""
+    import torch
+    import torch.distributed as dist
+    from burn_depth_amd.parallel import shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    S = {"full": 96, "small": 64, "tiny": 32}[args.preset]
+    B = args.batch
+    g = torch.Generator().manual_seed(7)
+    full = torch.rand(B * world, 3, S, S, generator=g)  # seeded, so every rank can check its shard; only rank 0's copy is sent
+    x = torch.empty(B, 3, S, S)
+    depth = torch.empty(B, S, S)
+    gathered = [torch.empty_like(depth) for _ in range(world)] if rank == 0 else None
+    chunks = list(full.split(B, 0)) if rank == 0 else None
+
+    def step():
+        if world > 1:
+            dist.scatter(x, chunks, src=0)
+        else:
+            x.copy_(full)
+        torch.sum(x, 1, out=depth)
+        depth.add_(1.0)
+        if world > 1:
+            dist.gather(depth, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    b, e = shard_range(B * world, rank, world)
+    ok = torch.equal(depth, full[b:e].sum(1) + 1.0)
+    if rank == 0 and world > 1:
+        ok = ok and torch.equal(torch.cat(gathered, 0), full.sum(1) + 1.0)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec dry run (CPU stand-in, gloo)", "value": round(args.steps * B * world / elapsed, 3), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"dry run [{B},3,{S},{S}] per rank", "batch_per_gpu": B, "global_batch": B * world,
+                                     "parallelism": f"dp{world}", "scatter_inputs_from_rank0": world > 1, "gather_depth_to_rank0": world > 1},
+                          "finite_output": bool(ok), "dry_run": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def bench_da3(args, dev, tdev, world, rank) -> int:
     """frames/s of DepthAnything3::infer (metric_large, mono head) on synthetic [B,3,S,S]; same timing
     contract as the Depth Pro path (barrier + synchronize, max over ranks, weak scaling)."""
-    from burn_depth_amd.config import DepthAnything3Config
+    import torch
+    import torch.distributed as dist
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, Precision
     from burn_depth_amd.depth_anything3 import DepthAnything3
     small = args.model == "da3_small"
     cfg = DepthAnything3Config.small() if small else DepthAnything3Config.metric_large()
     if args.image_size:
         cfg.image_size = args.image_size
-    cfg.precision = {"bf16": Precision.BF16, "f32": Precision.F32, "fp8": Precision.FP8}[args.precision]
+    cfg.precision = {"bf16": Precision.BF16, "f16": Precision.F16, "f32": Precision.F32, "fp8": Precision.FP8}[args.precision]
     cfg.max_batch = args.batch
     S, B = cfg.image_size, args.batch
     model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
@@ -336,61 +492,134 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
                "backbone_tflops_algorithmic": round(vit_flops / B / 1e12, 3),
                "attention_tflops": round(4.0 * B * v.num_heads * NT * NT * 64 * depth_n / (attn_ms * 1e-3) / 1e12, 1) if attn_ms else None,
                "kernels": kernels}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     model.destroy()
     if world > 1:
         dist.destroy_process_group()
     return 0
 
 
+def side_kernels(dev, tdev):
+    """The HBM-bound stand-alone kernels at the shapes of the reference's interpolation bench (bench/interpolate.rs:32-113:
+    [1,3,1536,1536] -> 768^2 / 384^2, [1,1,1536,1536] -> 1080x1920) plus the DA3 NHWC upsample (dpt.rs:611-631: the
+    128-channel map at 592^2 -> 1036^2 of config 5, 296^2 -> 518^2 of config 2). HIP events on the launch stream;
+    algorithmic bytes = input read once + output written once."""
+    import torch
+    from burn_depth_amd import ops
+    res = {}
+
+    def timed(fn, iters=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    def entry(ms, nbytes):
+        return {"ms_per_step": round(ms, 4), "launches_per_step": 1, "gbs": round(nbytes / ms / 1e6, 1),
+                "frac_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)}
+
+    for (shape, out, m) in [((1, 3, 1536, 1536), (768, 768), 0), ((1, 3, 1536, 1536), (384, 384), 0), ((1, 1, 1536, 1536), (1080, 1920), 0),
+                            ((8, 3, 1536, 1536), (768, 768), 0), ((8, 1, 1536, 1536), (1080, 1920), 1)]:
+        x = torch.randn(shape, device=tdev)
+        y = torch.empty(shape[:2] + out, device=tdev)
+        ms = timed(lambda: ops.resize_bilinear_into(dev, x, y, m))
+        res[f"side:resize_bilinear {list(shape)}->{list(out)} m{m}"] = entry(ms, (x.numel() + y.numel()) * 4.0)
+    for (B, H, C, OH) in [(1, 592, 128, 1036), (8, 296, 128, 518), (1, 148, 256, 296)]:
+        x = torch.randn(B, H, H, C, device=tdev).to(torch.bfloat16)
+        y = torch.empty(B, OH, OH, C, device=tdev, dtype=torch.bfloat16)
+        ms = timed(lambda: ops.resize_nhwc_into(dev, x, y, 1))
+        res[f"side:resize_nhwc bf16 [{B},{H},{H},{C}]->{OH}^2 align_corners"] = entry(ms, (x.numel() + y.numel()) * 2.0)
+    return res
+
+
+def accuracy_report(dev, precision):
+    """Depth error of this precision mode against the fp32 CPU oracle on one seeded frame of the CI preset (ViT-L, 512^2;
+    src/lib.rs:102-112): the reference's own statistics (example/correctness.rs:486-509, thresholds :887-897)."""
+    import torch
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    from oracle import depth_pro_ref as R
+    cfg = DepthProConfig.small_test()
+    cfg.precision = precision
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
+    torch.manual_seed(0)
+    x = (torch.rand(1, 3, 512, 512) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
+    d = m.infer(x.cuda()).depth.cpu()
+    m.destroy()
+    with torch.no_grad():
+        rd = R.infer(x, W, cfg)["depth"]
+    err = (d - rd).abs()
+    return {"preset": "small (ViT-L, 512^2)", "vs": "fp32 CPU oracle", "depth_max_rel": float((err / rd.abs()).max()), "depth_mean_rel": float((err / rd.abs()).mean()),
+            "depth_linf": float(err.max()), "depth_mean_abs": float(err.mean()), "depth_range": [float(rd.min()), float(rd.max())],
+            "reference_bar": {"max_abs": 5e-3, "mean_abs": 1e-3, "max_rel": 5e-3}}
+
+
 def pmc_traffic(kernel: str, B: int, args):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
-    gfx950 corrections of MI355X_MICROARCH.md and writes profiles/r01_traffic.json). None if the
+    gfx950 corrections of MI355X_MICROARCH.md and writes profiles/rNN_traffic.json). None if the
     passes were made for another batch/precision."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("batch") == B and t.get("precision") == args.precision and t.get("preset") == args.preset:
-            return t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError, KeyError):
-        pass
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if t.get("batch") == B and t.get("precision") == args.precision and t.get("preset") == args.preset:
+                return t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
-def cpu_baseline(cfg: DepthProConfig):
-    """Times the CPU oracle (a port: the Rust reference cannot be built here) on a bounded sample:
-    the ViT-L patch encoder over 16 of the 37 tiles of one frame, scaled by algorithmic FLOPs.
-    ViT work is 73 % of a frame and the oracle runs every part through the same oneDNN/MKL GEMMs."""
+def cpu_baseline(cfg, budget_s: float):
+    """The CPU oracle (a port: the Rust reference cannot be built here) on this process's cores.
+    BASELINE config 1 (bench/inference.rs:21-48): DepthPro::infer on zeros [1,3,S,S], random-init weights, one whole
+    frame. A 2-tile ViT probe first predicts the frame time; beyond `budget_s` the probe-scaled estimate is reported."""
+    import torch
+    from burn_depth_amd import weights as Wt
     from oracle import depth_pro_ref as R
-    import numpy as np
     # use this process's CPU share (a 1-GPU box gets 16 cores of the host), not every core of the host
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    threads = max(1, min(avail, 16))
+    threads = max(1, min(avail, 64))
     torch.set_num_threads(threads)
     v = cfg.patch_vit()
-    torch.manual_seed(0)
-    tiles = 16
-    specs = [s for s in Wt.depth_pro_param_specs(cfg, Wt.INIT_PARITY) if s.name.startswith("encoder.patch_encoder.")]
-    W = {s.name: torch.from_numpy(Wt.uniform_stream(s.name, 0, int(np.prod(s.shape)), s.lo, s.hi).reshape(s.shape)) for s in specs}
-    x = torch.randn(tiles, 3, v.img_size, v.img_size)
-    t0 = time.perf_counter()
-    R.vit_forward(x, W, "encoder.patch_encoder", v, v.encoder_feature_layer_ids)
-    dt = time.perf_counter() - t0
     fl, _ = work_model(cfg, 1)
     frame_flops = sum(fl.values())
     nseq = 25 + 9 + 1 + 1 + (1 if cfg.fov_encoder_preset else 0)
     vit_flops_per_tile = (fl["patch_embed"] + fl["qkv_gemm"] + fl["attention"] + fl["proj_gemm"] + fl["fc1_gemm"] + fl["fc2_gemm"]) / nseq
-    sample_flops = tiles * vit_flops_per_tile
-    est_frame_s = dt * frame_flops / sample_flops
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
+    with torch.no_grad():
+        tiles = 2
+        x = torch.zeros(tiles, 3, v.img_size, v.img_size)
+        R.vit_forward(x[:1], W, "encoder.patch_encoder", v, v.encoder_feature_layer_ids)  # warm the thread pool / allocator
+        t0 = time.perf_counter()
+        R.vit_forward(x, W, "encoder.patch_encoder", v, v.encoder_feature_layer_ids)
+        dt = time.perf_counter() - t0
+        probe_tflops = tiles * vit_flops_per_tile / dt / 1e12
+        est_frame_s = frame_flops / (probe_tflops * 1e12)
+        if est_frame_s <= budget_s:
+            S = cfg.img_size()
+            t0 = time.perf_counter()
+            out = R.infer(torch.zeros(1, 3, S, S), W, cfg)
+            frame_s = time.perf_counter() - t0
+            ok = tuple(out["depth"].shape) == (1, S, S) and bool(torch.isfinite(out["depth"]).all())
+            return {"value": round(1.0 / frame_s, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": f"full frame: oracle DepthPro::infer on zeros [1,3,{S},{S}] (BASELINE config 1), {frame_flops / 1e12:.2f} TFLOP in {frame_s:.1f} s",
+                    "seconds_per_frame": round(frame_s, 2), "finite_output": ok, "cpu_tflops": round(frame_flops / frame_s / 1e12, 3)}
     return {"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle ViT-L/16 forward on {tiles} of {nseq} 384^2 tiles ({sample_flops / 1e12:.3f} of {frame_flops / 1e12:.2f} TFLOP/frame) "
-                      f"in {dt:.2f} s, scaled by algorithmic FLOPs", "sample_seconds": round(dt, 3),
-            "cpu_tflops": round(sample_flops / dt / 1e12, 3)}
+            "sample": f"oracle ViT-L/16 forward on {tiles} of {nseq} tiles in {dt:.2f} s, scaled by algorithmic FLOPs "
+                      f"({frame_flops / 1e12:.2f} TFLOP/frame; a whole frame was predicted to take {est_frame_s:.0f} s > budget {budget_s:.0f} s)",
+            "sample_seconds": round(dt, 3), "cpu_tflops": round(probe_tflops, 3)}
 
 
 if __name__ == "__main__":

@@ -73,6 +73,7 @@ SYMBOLS = {
     "md_model_commit_weights": (_I, [_P]),
     "md_model_weight_arena": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "md_model_destroy": (_I, [_P]),
+    "md_model_fork": (_I, [_P, C.POINTER(_P)]),
     "md_depth_pro_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "md_infer_from_rgb": (_I, [_P, _P, C.c_size_t, _I, _I, _I, _P, _P, _P, _I, _P]),
     "md_da3_cfg_default": (None, [C.POINTER(MdDa3Cfg)]),
@@ -90,6 +91,7 @@ SYMBOLS = {
     "md_model_read_launch_order": (_I, [_P, C.POINTER(C.c_char_p), _I, C.POINTER(_I)]),
     "md_op_rgb_to_input": (_I, [_P, _P, C.c_size_t, _I, _I, _P, _P]),
     "md_op_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "md_op_resize_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
     "md_op_resize_output_size": (_I, [_I, _I, C.c_float, C.c_float, C.POINTER(_I), C.POINTER(_I)]),
     "md_op_split": (_I, [_P, _P, _I, _I, _I, _I, C.c_float, _P, C.POINTER(_I), _P]),
     "md_op_merge": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, C.POINTER(_I), C.POINTER(_I), _P]),

@@ -18,23 +18,25 @@
 // are read from LDS) so that registers 8s..8s+7 hold the 8 consecutive keys the V^T fragment
 // of k-step s holds.
 #include "ops.h"
+#include "elem.h"
 
 namespace md {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+// v_mfma_f32_32x32x16 on bf16 or IEEE half fragments (same rate, same layout)
+template <typename T>
+__device__ __forceinline__ f32x16_t mfma32(const i32x4_t& a, const i32x4_t& b, const f32x16_t& c) {
+  typedef typename Native<T>::v8 v8;
+  if constexpr (std::is_same<T, bf16_t>::value)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void glds16a(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
-__device__ __forceinline__ int pack_bf16x2(float a, float b) {
-  bf16x2_t v = {(__bf16)a, (__bf16)b};
-  return __builtin_bit_cast(int, v);
 }
 
 // grid: 1-D, q blocks of 128 x heads x sequences; block 256. The block -> (unit, q block) map is
@@ -42,9 +44,9 @@ __device__ __forceinline__ int pack_bf16x2(float a, float b) {
 // the q blocks of one (sequence, head) run on ONE XCD -- its K and V^T (148 KB) are fetched into that
 // L2 once instead of once per q block (measured before the remap: 1.0 GB fetched per launch against
 // 0.27 GB of q/k/v).
-template <bool FP8OUT>
-__global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __restrict__ qk,
-                                                             const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
+template <typename T, bool FP8OUT>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__ qk,
+                                                             const T* __restrict__ vT, T* __restrict__ out,
                                                              int S, int n_tokens, int heads, int D, int kpad,
                                                              int qblocks, float out_fp8_inv) {
   constexpr int STAGE = 16384;  // K tile 64x128B + V^T tile 64x128B
@@ -143,8 +145,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
       for (int s = 0; s < 4; ++s) {
         const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
         const f32x16_t cin = s == 0 ? (f32x16_t){0.f} : st[sub];  // first k-step: inline-constant 0 as C
-        st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                          __builtin_bit_cast(bf16x8_t, qf[s]), cin, 0, 0, 0);
+        st[sub] = mfma32<T>(kf, qf[s], cin);
       }
     }
     // register r of lane half h holds local key (r&7) + 8h + 16(r>>3) of the sub-tile
@@ -195,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        pf[sub][s2][0] = pack_bf16x2(p[8 * s2 + 0], p[8 * s2 + 1]);
-        pf[sub][s2][1] = pack_bf16x2(p[8 * s2 + 2], p[8 * s2 + 3]);
-        pf[sub][s2][2] = pack_bf16x2(p[8 * s2 + 4], p[8 * s2 + 5]);
-        pf[sub][s2][3] = pack_bf16x2(p[8 * s2 + 6], p[8 * s2 + 7]);
+        pf[sub][s2][0] = pack2_nosat<T>(p[8 * s2 + 0], p[8 * s2 + 1]);
+        pf[sub][s2][1] = pack2_nosat<T>(p[8 * s2 + 2], p[8 * s2 + 3]);
+        pf[sub][s2][2] = pack2_nosat<T>(p[8 * s2 + 4], p[8 * s2 + 5]);
+        pf[sub][s2][3] = pack2_nosat<T>(p[8 * s2 + 6], p[8 * s2 + 7]);
       }
     }
     l_run += psum;
@@ -210,8 +211,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const i32x4_t vf = *(const i32x4_t*)(sb + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                          __builtin_bit_cast(bf16x8_t, pf[sub][s2]), o[dt], 0, 0, 0);
+          o[dt] = mfma32<T>(vf, pf[sub][s2], o[dt]);
         }
   }
 
@@ -235,33 +235,37 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_kernel(const bf16_t* __
       }
     }
   } else if (q < n_tokens) {
-    bf16_t* orow = out + (seq_row0 + q) * (long)D + head * 64;
+    T* orow = out + (seq_row0 + q) * (long)D + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int d = dt * 32 + 8 * q4 + 4 * h;
-        bf16x4_t b = {(__bf16)(o[dt][4 * q4] * inv_l), (__bf16)(o[dt][4 * q4 + 1] * inv_l),
-                      (__bf16)(o[dt][4 * q4 + 2] * inv_l), (__bf16)(o[dt][4 * q4 + 3] * inv_l)};
-        *(bf16x4_t*)(orow + d) = b;
+        store4<T>(orow + d, (f32x4_t){o[dt][4 * q4] * inv_l, o[dt][4 * q4 + 1] * inv_l, o[dt][4 * q4 + 2] * inv_l, o[dt][4 * q4 + 3] * inv_l});
       }
   }
 }
 
-int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                          int kpad, hipStream_t s, float out_fp8_inv) {
+int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
+                     int kpad, int prec, hipStream_t s, float out_fp8_inv) {
+  if (prec != MD_PREC_BF16 && prec != MD_PREC_F16) MD_FAIL(MD_ERR_UNSUPPORTED, "fused attention takes bf16 or f16 operands (precision %d)", prec);
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
     MD_FAIL(MD_ERR_INVALID_ARG, "attention: kpad=%d must be a multiple of 64 covering %d keys", kpad, n_tokens);
   const int qblocks = (n_tokens + 127) / 128;
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
-  if (out_fp8_inv > 0.f)
-    hipLaunchKernelGGL(attention_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+  if (out_fp8_inv > 0.f) {
+    if (prec != MD_PREC_BF16) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: e4m3 output rows are built for bf16 operands");
+    hipLaunchKernelGGL((attention_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
                        (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
-  else
-    hipLaunchKernelGGL(attention_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+  } else if (prec == MD_PREC_F16) {
+    hipLaunchKernelGGL((attention_kernel<f16_t, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const f16_t*)qk, (const f16_t*)vT,
+                       (f16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+  } else {
+    hipLaunchKernelGGL((attention_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
                        (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+  }
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

@@ -98,7 +98,9 @@ struct GemmParams {
   // divisions (float-reciprocal sequences, ~150 dependent cycles each) per workgroup for it
   int map_gn = 1, map_gsz = 1, map_full = 0, map_full_gsz = 0, map_rn = 0;
   FastDiv fd_map_gsz, fd_map_gn, fd_map_rn;
-  // timing-only ablations (results are WRONG when set): bit0 = no in-loop global->LDS loads
+  // timing-only ablations and stamps: honoured by the DIAGNOSTIC instantiation only (md_bench_gemm; results are WRONG
+  // when a flag is set): bit0 no in-loop global->LDS loads, bit1 every k-tile re-reads k-tile 0, bit2 no global stores,
+  // bit3 no staging writes
   int debug_flags = 0;
   unsigned long long* stamps = nullptr;  // timing-only: [blocks][16] stamps: 8 x s_memrealtime, then 2 x shader clock around the main loop (md_bench_gemm)
   // EPI_HEAD
@@ -107,9 +109,9 @@ struct GemmParams {
   int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear, 3 exp + 1 (DA3 confidence, dpt.rs:497)
 };
 
-enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_256x256_V1 = 3, TILE_256x256_V2 = 4, TILE_256x256_PP32 = 5, TILE_AUTO = 99 };
+enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_AUTO = 99 };
 
-// Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16) or MD_PREC_F32 (T = float).
+// Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16), MD_PREC_F16 (T = f16), MD_PREC_F32 (T = float) or MD_PREC_FP8 (T = e4m3, dense only).
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream);
 
 }  // namespace md

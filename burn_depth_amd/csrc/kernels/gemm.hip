@@ -2,12 +2,12 @@
 // The kernel template lives in gemm_impl.h and is instantiated per precision in
 // gemm_bf16.hip / gemm_f32.hip (separate translation units so they compile in parallel).
 #include "gemm.h"
-#include <cstdlib>
 
 namespace md {
 
 int launch_gemm_bf16(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_f32(GemmParams& p, int amode, int tile, hipStream_t stream);
+int launch_gemm_f16(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_fp8(GemmParams& p, int amode, int tile, hipStream_t stream);
 
 static int pick_tile(const GemmParams& p) {
@@ -77,8 +77,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     // raster group width, from a sweep on the Depth Pro step (B = 8): up to 12 n-tiles (qkv) plain n-fastest order is
     // best (qkv 24.3 -> 23.3 ms per step against groups of 4); the 16 n-tiles of fc1 run the same in groups of 4 or 8 and
     // slower ungrouped (34.5 / 34.7 / 34.9 ms)
-    static const int gn_env = getenv("MD_RASTER_GN") ? atoi(getenv("MD_RASTER_GN")) : -1;  // A/B override
-    p.raster_gn = gn_env >= 0 ? (tn <= gn_env ? 0 : gn_env) : (tn <= 12 ? 0 : 4);
+    p.raster_gn = tn <= 12 ? 0 : 4;
   }
   if (p.epi == EPI_HEAD) tile = TILE_256x32;
   if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);
@@ -87,6 +86,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     return launch_gemm_fp8(p, amode, tile, stream);
   }
   if (p.out_fp8) MD_FAIL(MD_ERR_UNSUPPORTED, "fp8 output needs fp8 operands");
+  if (prec == MD_PREC_F16) return launch_gemm_f16(p, amode, tile, stream);
   return launch_gemm_bf16(p, amode, tile, stream);
 }
 

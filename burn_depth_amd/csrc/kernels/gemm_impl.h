@@ -24,15 +24,14 @@
 #pragma once
 
 #include <type_traits>
+#include "elem.h"
 #include "gemm.h"
 
 namespace md {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 #define MD_SEL_G(arr, g) ((g) == 0 ? (arr)[0] : (g) == 1 ? (arr)[1] : (g) == 2 ? (arr)[2] : (arr)[3])
 
@@ -44,6 +43,13 @@ struct Atom<bf16_t> {
   static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
                                                 0, 0, 0);
+  }
+};
+
+template <>
+struct Atom<f16_t> {
+  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
 
@@ -70,6 +76,12 @@ struct Atom16<bf16_t> {
   static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x4acc_t& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
                                                 0, 0, 0);
+  }
+};
+template <>
+struct Atom16<f16_t> {
+  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x4acc_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
 template <>
@@ -118,40 +130,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <typename T>
-__device__ __forceinline__ f32x4_t load4(const T* p);
-template <>
-__device__ __forceinline__ f32x4_t load4<float>(const float* p) {
-  return *(const f32x4_t*)p;
-}
-template <>
-__device__ __forceinline__ f32x4_t load4<bf16_t>(const bf16_t* p) {
-  bf16x4_t b = *(const bf16x4_t*)p;
-  f32x4_t r = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-  return r;
-}
-template <typename T>
-__device__ __forceinline__ void store4(T* p, f32x4_t v);
-template <>
-__device__ __forceinline__ void store4<float>(float* p, f32x4_t v) {
-  *(f32x4_t*)p = v;
-}
-template <>
-__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4_t v) {
-  bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-  *(bf16x4_t*)p = b;
-}
-template <typename T>
-__device__ __forceinline__ void store1(T* p, float v);
-template <>
-__device__ __forceinline__ void store1<float>(float* p, float v) {
-  *p = v;
-}
-template <>
-__device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) {
-  *(__bf16*)p = (__bf16)v;
-}
-
 // exact-erf GELU (burn/DINOv2 `Gelu`). fp32 mode: libm erff. bf16 mode: erf(x/sqrt2) ~ x*P(x^2), a degree-8
 // minimax polynomial on |x| <= 4.4 (clamped to +-1 outside), evaluated two elements per instruction with
 // the packed fp32 VALU ops (v_pk_fma_f32): no transcendental, ~8 issue slots per element instead of ~26.
@@ -186,7 +164,7 @@ __device__ __forceinline__ f32x2_t gelu2_poly(f32x2_t x) {
 
 template <typename T>
 __device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (!std::is_same<T, bf16_t>::value) {  // f32 and f16 modes: libm erff (the polynomial's 8.5e-5 is a bf16 budget)
     f32x4_t r = {gelu_erf<T>(v[0]), gelu_erf<T>(v[1]), gelu_erf<T>(v[2]), gelu_erf<T>(v[3])};
     return r;
   } else {
@@ -515,24 +493,25 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// v2: 256x256 tile, BK = 64, 8 waves (2 x 4, wave tile 128 x 64).  LDS is a ring of FIVE 32-KB
-// half-tile slots (160 KB): half-tile h = 2t is the A tile of k-tile t, h = 2t+1 its W tile, slot
-// = h mod 5.  While k-tile t is multiplied (2 slots busy) three more half-tiles (96 KB per CU) are
-// in flight; the loads are never drained inside the loop -- each iteration waits with a COUNTED
-// `s_waitcnt vmcnt(4)` (everything but the youngest half-tile) and one raw s_barrier.  MFMA operand
-// fragments are double-buffered in registers across the four k-steps of a tile.  The epilogue goes
-// through LDS (wave-private 64x64 fp32 sub-tiles, rows padded to 272 B) so that every global
-// load/store instruction of the epilogue covers 4 full 256-byte row segments.
-// ------------------------------------------------------------------------------------------------
-// EK selects the staged-epilogue specialisation at compile time (a runtime three-way branch around the
-// fully unrolled row loops cost 40 VGPRs and scratch spills): 0 generic (epilogue4 per vector),
-// 1 read-modify-write residual (EPI_RESID_LS), 2 bf16 store with optional residual inputs (EPI_STORE),
-// 3 pixel shuffle (EPI_PIXSHUF), 4 = 2 with the GELU fused at compile time (the fc1 GEMM: its own kernel
-// symbol, so profilers report it separately from the other store GEMMs).
-template <typename T, int AMODE, int PP, int EK>
+// 256x256 tile, BK = 128 bytes of K, 8 waves (2 x 4, wave tile 128 x 64) on v_mfma_f32_16x16x32 (bf16 / f16 / fp8) or
+// 4 x v_mfma_f32_16x16x4_f32. LDS is a ring of FIVE 32-KB half-tile slots (160 KB, the whole CU): half-tile h = 2t is
+// the A tile of k-tile t, h = 2t+1 its W tile, slot = h mod 5. While k-tile t is multiplied (2 slots busy) three more
+// half-tiles (96 KB per CU) are in flight; the loads are never drained inside the loop -- counted `s_waitcnt vmcnt`
+// and raw s_barrier. Staggered two-group schedule: waves 4..7 run one barrier behind waves 0..3 and every SIMD hosts
+// one wave of each group, so one wave's 512-cycle MFMA cluster runs while its partner reads LDS / issues LDS-DMA.
+// The epilogue goes through LDS (wave-private 64-row sub-tiles) so that every global instruction covers whole
+// 128/256-byte row segments.
+//
+// EK selects the epilogue specialisation at compile time (a runtime switch around the unrolled row loops cost 40 VGPRs
+// and scratch spills): 0 generic (epilogue4 per vector), 1 read-modify-write residual (EPI_RESID_LS), 2 2-byte store
+// with optional residual inputs (EPI_STORE / q,k of EPI_QKV), 3 pixel shuffle (EPI_PIXSHUF), 4 = 2 with the GELU fused
+// at compile time (the fc1 GEMM: its own kernel symbol, so profilers report it separately).
+// DIAG = true is the diagnostic build used by md_bench_gemm only (in-kernel stamps and timing-only ablation flags); the
+// engine never launches it and the production instantiations contain none of that code.
+template <typename T, int AMODE, int EK, bool DIAG>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
-  constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int WTM = 128, WTN = 64;
   constexpr int HALF_BYTES = 256 * 128;  // one half-tile slot
   constexpr int NSLOT = 5;
   typedef typename OutT<T>::type TO;  // element type of outputs / residuals
@@ -542,9 +521,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // timing-only instrumentation (md_bench_gemm): wave 0 / lane 0 stamps s_memrealtime (100 MHz) at five points
-  unsigned long long* stamp = (p.stamps && threadIdx.x == 0) ? p.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
-  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long* stamp = nullptr;
+  if constexpr (DIAG) {
+    stamp = (p.stamps && threadIdx.x == 0) ? p.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 : nullptr;
+    if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,23 +538,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // L2-aware raster: n-tiles are walked in groups of `gn` (host-chosen, <= 4): the 32 blocks an XCD
-  // runs together cover (32/gn) A panels x gn W panels, and a W group (gn x 256 rows) can stay in
-  // the XCD's 4-MB L2 while the A panels stream past it.
-  // (divisors prepared on the host: prep_tile_map)
-  auto map_tile = [&](int tid_lin, int& tn, int& tmg) {
-    if (tid_lin < p.map_full_gsz) {
-      const int ng = fdiv(tid_lin, p.fd_map_gsz), r = tid_lin - ng * p.map_gsz;
-      tmg = fdiv(r, p.fd_map_gn);
-      tn = ng * p.map_gn + (r - tmg * p.map_gn);
-    } else {
-      const int r = tid_lin - p.map_full_gsz;
-      tmg = fdiv(r, p.fd_map_rn);
-      tn = p.map_full * p.map_gn + (r - tmg * p.map_rn);
-    }
-  };
+  // L2-aware raster: n-tiles are walked in groups of `gn` (host-chosen): the 32 blocks an XCD runs together cover
+  // (32/gn) A panels x gn W panels (divisors prepared on the host: prep_tile_map)
   int tile_n, tile_mg;
-  map_tile(id, tile_n, tile_mg);
+  if (id < p.map_full_gsz) {
+    const int ng = fdiv(id, p.fd_map_gsz), r = id - ng * p.map_gsz;
+    tile_mg = fdiv(r, p.fd_map_gn);
+    tile_n = ng * p.map_gn + (r - tile_mg * p.map_gn);
+  } else {
+    const int r = id - p.map_full_gsz;
+    tile_mg = fdiv(r, p.fd_map_rn);
+    tile_n = p.map_full * p.map_gn + (r - tile_mg * p.map_rn);
+  }
   int g = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroups; ++i)
@@ -643,16 +619,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int cblocks = (AMODE == A_CONV3) ? p.cC / KE : 1;
 
   // issue the A / W half-tile of k-tile kt into ring slot `slot` (both wave-uniform)
-  const bool freeze_k = (p.debug_flags & 2) != 0;  // timing-only: every k-tile re-reads k-tile 0 (L2-resident)
-  auto issue_W = [&](int kt, int slot) {
+  bool freeze_k = false, no_loads = false;  // timing-only ablations of the diagnostic build
+  if constexpr (DIAG) {
+    freeze_k = (p.debug_flags & 2) != 0;  // every k-tile re-reads k-tile 0 (L2-resident)
+    no_loads = (p.debug_flags & 1) != 0;
+  }
+  auto issue_W = [&](int kt, int slot) __attribute__((always_inline)) {
     char* sbase = smem + slot * HALF_BYTES;
-    if (freeze_k) kt = 0;
+    if (DIAG && freeze_k) kt = 0;
 #pragma unroll
     for (int i = 0; i < LPH; ++i) glds16(srcW[i] + (long)kt * 128, sbase + (i * NW + wave) * 1024);
   };
-  auto issue_A_part = [&](int kt, int slot, int i0, int i1) {
+  auto issue_A = [&](int kt, int slot) __attribute__((always_inline)) {
     char* sbase = smem + slot * HALF_BYTES;
-    if (freeze_k) kt = 0;
+    if (DIAG && freeze_k) kt = 0;
     long a_delta;
     int tap = 0;
     if constexpr (AMODE == A_CONV3) {
@@ -665,7 +645,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < LPH; ++i) {
-      if (i < i0 || i >= i1) continue;
       const char* s = srcA[i] + a_delta;
       if constexpr (AMODE == A_CONV3) {
         if (!((maskA[i] >> tap) & 1u)) s = zsrc;
@@ -673,19 +652,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       glds16(s, sbase + (i * NW + wave) * 1024);
     }
   };
-  auto issue_A = [&](int kt, int slot) { issue_A_part(kt, slot, 0, LPH); };
 
-  f32x16_t acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int h = lane >> 5;
-  const int lane_off = (lane & 31) * 128 + ((((lane >> 1) & 7) ^ h) << 4);
-  // 16x16-shape state (PP == 2): acc16[n16-tile][m16-tile], lane (r = lane&15, q = lane>>4)
+  // acc16[n16-tile][m16-tile], lane (r = lane & 15, q = lane >> 4) holds 4 consecutive columns n of one row m
   f32x4acc_t acc16[4][8];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -695,14 +663,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int lane_off16 = (lane & 15) * 128 + (((((lane & 15) >> 1) & 7) ^ q16) << 4);
 
   // half-tile order: A0 W0 A1 W1 A2 | W2 A3 | W3 A4 | ...   (slot = order index mod 5)
-  if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  if (DIAG && stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
   int issued = 2, slot_i = 2;
   issue_A(0, 0);
   issue_W(0, 1);
-  // Short-K tiles (KT <= 4: the deconvolutions, K = 128 / 256) request everything up front instead: with two k-tiles
-  // the in-loop fill exposed a second full memory latency (stamps on K = 128: first wait 2.4 us + 4.2 us for two
-  // k-tiles that multiply in 1.4 us each).
-  const bool pro_full = PP != 2 || KT <= 4;
+  // SHORT prologue: only k-tile 0 is requested up front; A1, W1, A2 are issued from the load segments of k-tile 0 (every
+  // ring slot is free then). In-kernel stamps showed the five-half-tile prologue costing 1.9 us of issue + 1.8 us until
+  // k-tile 0 had landed behind the other 96 KB of the queue. Short-K tiles (KT <= 4: the deconvolutions, K = 128 / 256)
+  // request everything up front instead: with two k-tiles the in-loop fill exposed a second full memory latency.
+  const bool pro_full = KT <= 4;
   if (pro_full) {
     if (KT > 1) {
       issue_A(1, 2);
@@ -716,13 +685,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       slot_i = 0;
     }
   }
-  // PP == 2 (production schedule): SHORT prologue. Only k-tile 0 is requested up front; A1, W1, A2 are issued
-  // from the load segments of k-tile 0 (every ring slot is free then). In-kernel stamps showed the five-half-tile
-  // prologue costing 1.9 us of issue + 1.8 us until k-tile 0 had landed behind the other 96 KB of the queue.
   int slot_c = 0;  // slot of the current tile's A half
 
   // counted wait for the two half-tiles of k-tile `t`: all but the `younger` most recent half-tiles
-  auto wait_tile = [&](int t) {
+  auto wait_tile = [&](int t) __attribute__((always_inline)) {
     const int younger = issued - (2 * t + 2);
     if (younger >= 3) {
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -734,189 +700,90 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   };
-  const bool no_loads = (p.debug_flags & 1) != 0;
-  auto issue_next_W = [&](int t) {
-    if (t >= 1 && t + 1 < KT && !no_loads) {
+  auto issue_next_W = [&](int t) __attribute__((always_inline)) {
+    if (t >= 1 && t + 1 < KT && !(DIAG && no_loads)) {
       issue_W(t + 1, slot_i);
       ++issued;
       slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
     }
   };
-  auto issue_next_A = [&](int t) {
-    if (t >= 1 && t + 2 < KT && !no_loads) {
+  auto issue_next_A = [&](int t) __attribute__((always_inline)) {
+    if (t >= 1 && t + 2 < KT && !(DIAG && no_loads)) {
       issue_A(t + 2, slot_i);
       ++issued;
       slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
     }
   };
-  auto issue_next_A_lo = [&](int t) {  // first two of the four A loads of k-tile t+2
-    if (t >= 1 && t + 2 < KT && !no_loads) issue_A_part(t + 2, slot_i, 0, 2);
-  };
-  auto issue_next_A_hi = [&](int t) {  // the other two; the half-tile now counts as issued
-    if (t >= 1 && t + 2 < KT && !no_loads) {
-      issue_A_part(t + 2, slot_i, 2, 4);
-      ++issued;
-      slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1;
-    }
-  };
 
-  if constexpr (PP == 0) {
-    for (int t = 0; t < KT; ++t) {
-      wait_tile(t);
+  // ---- the staggered two-group schedule on 16x16x32 MFMAs, with 512-cycle MFMA clusters ----
+  // Two phases per k-tile (one per 32-deep k-step): R = 4 W + 8 A fragment reads (+ the LDS-DMA issue of the next
+  // half-tiles), M = 32 MFMAs = 512 cycles, so the ~100-cycle s_barrier round trip is paid 4 times per k-tile. Every R
+  // ends with lgkmcnt(0) BEFORE its barrier (R has 512 cycles of cover), so the slots of tile t are free one interval
+  // after its last R and the loads that reuse them go out in R(0) of tile t+1. Both groups stay at priority 0
+  // (s_setprio 1 around the cluster cost 0.65 % of the step).
+  const bool g1 = wm == 1;
+  if (DIAG && stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
+  wait_tile(0);
+  __builtin_amdgcn_s_barrier();
+  if (DIAG && stamp) {
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    stamp[8] = __builtin_readcyclecounter();
+  }
+  if (g1) __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < KT; ++t) {
+    const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+    const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+    const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+    slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int off = lane_off16 ^ (ks << 6);
+      i32x4_t wf[4], af[8];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 2048 + off);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) af[b] = *(const i32x4_t*)(As + b * 2048 + off);
+      if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
+        if (!(DIAG && no_loads) && !pro_full) {
+          if (ks == 0 && KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
+          if (ks == 1 && KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
+        }
+      } else {
+        if (ks == 0) issue_next_W(t);
+        if (ks == 1) issue_next_A(t);
+      }
+      if (g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      issue_next_W(t);  // the two slots of tile t-1 are free now
-      issue_next_A(t);
-      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
-      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
-      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
-      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
-      i32x4_t af[2][TM], wf[2][TN];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < TM; ++b) af[0][b] = *(const i32x4_t*)(As + b * 4096 + lane_off);
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[0][a] = *(const i32x4_t*)(Ws + a * 4096 + lane_off);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s < 3) {
-          const int off = lane_off ^ ((s + 1) << 5);
-#pragma unroll
-          for (int b = 0; b < TM; ++b) af[nxt][b] = *(const i32x4_t*)(As + b * 4096 + off);
-#pragma unroll
-          for (int a = 0; a < TN; ++a) wf[nxt][a] = *(const i32x4_t*)(Ws + a * 4096 + off);
-        }
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[cur][a], af[cur][b], acc[a][b]);
-      }
+        for (int b = 0; b < 8; ++b) Atom16<T>::mma(wf[a], af[b], acc16[a][b]);
+      if (!g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
-  } else if constexpr (PP == 1) {
-    // ---- staggered two-group schedule ("ping-pong") ----
-    // Each k-step is a phase of two segments separated by raw barriers: R = issue the 6 ds_read_b128 of
-    // the k-step, M = the 8 MFMAs that consume them.  Waves 4..7 (group 1, wm == 1) run ONE barrier
-    // behind waves 0..3 (group 0), and every SIMD hosts one wave of each group: while group 0 is in
-    // its MFMA segment group 1 is reading LDS and vice versa, so the matrix pipe of each SIMD goes
-    // from one wave's MFMA cluster straight into the other's.  I_k = interval after physical barrier
-    // k; group 0 has R(p) in I_2p and M(p) in I_2p+1, group 1 has R(p) in I_2p+1 and M(p) in I_2p+2.
-    //  * reads of tile t finish (group 1's lgkmcnt) inside I_8t+8, so its two ring slots are
-    //    re-filled from I_8t+9 on: group 1 from R(4t+4) = I_8t+9, group 0 from R(4t+5) = I_8t+10;
-    //  * tile t+1 is first read in I_8t+8 (group 0), so every wave retires its loads of tile t+1
-    //    with a counted vmcnt inside I_8t+7: group 0 at the end of M(4t+3), group 1 in R(4t+3).
-    const bool g1 = wm == 1;  // wave-uniform
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    if (g1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < KT; ++t) {
-      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
-      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
-      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
-      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int off = lane_off ^ (s << 5);
-        i32x4_t af[TM], wf[TN];
-        // ---- R segment ----
-#pragma unroll
-        for (int a = 0; a < TN; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 4096 + off);
-#pragma unroll
-        for (int b = 0; b < TM; ++b) af[b] = *(const i32x4_t*)(As + b * 4096 + off);
-        // global->LDS loads are issued in R segments only (an LDS-DMA instruction costs ~60-100
-        // issue cycles: in front of an MFMA cluster it would idle the matrix pipe, here it hides under
-        // the other group's cluster). Group 1: W in R0, A in R1+R2; group 0 (one interval earlier, its
-        // R0 precedes the slot release): W in R1, A in R2+R3.
-        if (g1) {
-          if (s == 0) issue_next_W(t);
-          if (s == 1) issue_next_A_lo(t);
-          if (s == 2) issue_next_A_hi(t);
-          if (s == 3 && t + 1 < KT) wait_tile(t + 1);
-        } else {
-          if (s == 1) issue_next_W(t);
-          if (s == 2) issue_next_A_lo(t);
-          if (s == 3) issue_next_A_hi(t);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- M segment ----
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[a], af[b], acc[a][b]);
-        __builtin_amdgcn_s_setprio(0);
-        if (!g1) {
-          if (s == 3 && t + 1 < KT) wait_tile(t + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (!g1) __builtin_amdgcn_s_barrier();
   }
-  if constexpr (PP == 2) {
-    // ---- the staggered schedule on 16x16x32 MFMAs, with 512-cycle MFMA clusters ----
-    // The shader-clock stamps (md_bench_gemm, flag 32) showed a 256-cycle cluster costing 374 cycles per
-    // interval: the s_barrier round trip (~100 cycles) is paid per cluster, so the clusters are made
-    // twice as long instead (one phase per 32-deep k-step, both m-halves).
-    const bool g1 = wm == 1;
-    if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    if (stamp) { stamp[3] = __builtin_amdgcn_s_memrealtime(); stamp[8] = __builtin_readcyclecounter(); }
-    if (g1) __builtin_amdgcn_s_barrier();
-    // Two phases per k-tile (one per 32-deep k-step): R = 4 W + 8 A fragment reads, M = 32 MFMAs = 512
-    // cycles, so the ~120-cycle barrier round trip is paid 4 times per k-tile instead of 8. Every R
-    // ends with lgkmcnt(0) BEFORE its barrier (R has 512 cycles of cover), so the slots of tile t are
-    // free one interval after its last R and the loads that reuse them go out in R(0) of tile t+1.
-    for (int t = 0; t < KT; ++t) {
-      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
-      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
-      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
-      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int off = lane_off16 ^ (ks << 6);
-        i32x4_t wf[4], af[8];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 2048 + off);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) af[b] = *(const i32x4_t*)(As + b * 2048 + off);
-        if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
-          if (!no_loads && !pro_full) {
-            if (ks == 0 && KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
-            if (ks == 1 && KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
-          }
-        } else {
-          if (ks == 0) issue_next_W(t);
-          if (ks == 1) { issue_next_A_lo(t); issue_next_A_hi(t); }
-        }
-        if (g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // (no s_setprio around the cluster: with both groups at priority 0 the step measured +0.65 %, 8192^3 +2.4 %;
-        // the loader's few VALU / LDS-DMA issues between the other wave's MFMAs cost less than starving them)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 8; ++b) Atom16<T>::mma(wf[a], af[b], acc16[a][b]);
-        if (!g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (!g1) __builtin_amdgcn_s_barrier();
-  }
+  if (!g1) __builtin_amdgcn_s_barrier();
 
   // ---------------- epilogue ----------------
-  if (stamp) { stamp[4] = __builtin_amdgcn_s_memrealtime(); stamp[9] = __builtin_readcyclecounter(); }
+  if (DIAG && stamp) {
+    stamp[4] = __builtin_amdgcn_s_memrealtime();
+    stamp[9] = __builtin_readcyclecounter();
+  }
+  auto stamp_end = [&]() __attribute__((always_inline)) {
+    if (DIAG && stamp) {
+      stamp[6] = __builtin_amdgcn_s_memrealtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store drain of this wave (s_endpgm waits for it too)
+      stamp[7] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
-    if constexpr (PP == 2 && sizeof(TO) == 2) {
+    if constexpr (sizeof(TO) == 2) {
       // V^T[seq][head][d][token] tiles: staged TRANSPOSED through the wave-private LDS area (64 n-rows x 64 tokens
       // per half) so that a lane stores 4 consecutive tokens of one (head, d) row -- 8-byte stores, 4 full 128-byte
       // row segments per instruction -- instead of 2-byte scatter stores (4x the store instructions). Needs whole
@@ -967,32 +834,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         return;
       }
     }
-    if constexpr (PP == 2) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const int m = m_base + wm * WTM + b * 16 + (lane & 15);
-          const int n = n0 + wn * WTN + a * 16 + 4 * q16;
-          if (m < m_end && n < p.N) {
-            f32x4_t v = {acc16[a][b][0], acc16[a][b][1], acc16[a][b][2], acc16[a][b][3]};
-            epilogue4<TO>(p, g, m, n, v, out_boff);
-          }
-        }
-      return;
-    }
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        const int m = m_base + wm * WTM + b * 32 + (lane & 31);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int n = n0 + wn * WTN + a * 32 + 8 * q4 + 4 * h;
-          if (m < m_end && n < p.N) {
-            f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
-            epilogue4<TO>(p, g, m, n, v, out_boff);
-          }
+      for (int b = 0; b < 8; ++b) {
+        const int m = m_base + wm * WTM + b * 16 + (lane & 15);
+        const int n = n0 + wn * WTN + a * 16 + 4 * q16;
+        if (m < m_end && n < p.N) {
+          f32x4_t v = {acc16[a][b][0], acc16[a][b][1], acc16[a][b][2], acc16[a][b][3]};
+          epilogue4<TO>(p, g, m, n, v, out_boff);
         }
       }
     return;
@@ -1003,65 +853,68 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int SROW = 272;
   char* st = smem + wave * (64 * SROW);
   __builtin_amdgcn_s_barrier();
-  if (stamp) stamp[5] = __builtin_amdgcn_s_memrealtime();
+  if (DIAG && stamp) stamp[5] = __builtin_amdgcn_s_memrealtime();
   const int col = (lane & 15) * 4;
   const int n = n0 + wn * WTN + col;
   const bool nvalid = n < p.N;
-  // The residual / read-modify-write epilogues prefetch all 16 row vectors of a half BEFORE the
-  // staging pass, so 16 loads per lane are in flight at once instead of a dependent load->store chain
-  // (that chain, not bandwidth, set the cost of the proj / fc2 / residual-conv epilogues).
   constexpr bool rmw = EK == 1;
   constexpr bool fast_store = (EK == 2 || EK == 4) && sizeof(TO) == 2;  // EK 4: GELU fused at compile time (fc1)
   constexpr bool pixshuf = EK == 3;
-  // pixel shuffle: the lane's 4 columns fix (tap, channel) once; rows only move the output pixel
-  int ps_co = 0, ps_dy = 0, ps_dx = 0;
-  if constexpr (pixshuf) {
-    const int tap = fdiv(n, p.fd_psC);
-    ps_co = n - tap * p.psC;
-    ps_dy = p.ps_f == 4 ? tap >> 2 : tap >> 1;
-    ps_dx = tap - ps_dy * p.ps_f;
-  }
-  if constexpr (pixshuf && PP == 2 && sizeof(TO) == 2) {
+  const float* biasp = MD_SEL_G(p.bias, g);
+  const int r16 = lane & 15;
+  const int c8 = (lane & 7) * 8, rsub = lane >> 3;
+  const int n8 = n0 + wn * WTN + c8;
+  const bool nv8 = n8 < p.N;
+  const bool interior = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform: no per-row predicates needed
+  // bf16 / f16 staging of a 64-row half: 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7): conflict-free for the
+  // 8-byte writes from the accumulator layout and for the 16-byte reads (a lane then owns 8 consecutive columns)
+  auto stage_half_2b = [&](int half, auto&& xform) __attribute__((always_inline)) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4acc_t c = acc16[a][half * 4 + bb];
+        const f32x4_t v = xform(a, (f32x4_t){c[0], c[1], c[2], c[3]});
+        const int row = bb * 16 + r16;
+        const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
+        *(i32x2_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = pack4<TO>(v);
+      }
+  };
+  auto stage_half_f32 = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4acc_t c = acc16[a][half * 4 + bb];
+        *(f32x4_t*)(st + (bb * 16 + r16) * SROW + (a * 16 + 4 * q16) * 4) = (f32x4_t){c[0], c[1], c[2], c[3]};
+      }
+  };
+  if constexpr (pixshuf && sizeof(TO) == 2) {
     // ---- pixel shuffle, fast form (launch_gemm sets ps_fast) ----
     // out row of input pixel m = y'*psW + x (y' = b*psH + y) and tap (dy, dx): (f*y' + dy)*(f*psW) + f*x + dx
     //   = f*m + f*(f-1)*psW*y' + (dy*f*psW + dx): ONE multiply-high division per row instead of two divisions and a
-    // chain of 64-bit products. Bias is added in the accumulator layout, the tile is staged as bf16 (XOR-swizzled
-    // 128-byte rows, as in the store epilogue) and a lane stores 8 channels = 16 bytes of one output pixel.
+    // chain of 64-bit products. Bias is added in the accumulator layout and a lane stores 8 channels = 16 bytes of one
+    // output pixel.
     if (p.ps_fast) {
       const int f = p.ps_f;
-      const int c8 = (lane & 7) * 8, rsub = lane >> 3;
-      const int n8 = n0 + wn * WTN + c8;
-      const bool nv8 = n8 < p.N;
-      const bool interior = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform
       const int tap8 = fdiv(nv8 ? n8 : 0, p.fd_psC);
       const int co8 = (nv8 ? n8 : 0) - tap8 * p.psC;
       const int dy8 = f == 4 ? tap8 >> 2 : tap8 >> 1, dx8 = tap8 - dy8 * f;
       const unsigned ldo_u = (unsigned)p.ldo;
       const unsigned c_lane = (unsigned)(dy8 * f * p.psW + dx8) * ldo_u + (unsigned)(p.ps_coff + co8);
       const unsigned k1 = (unsigned)f * ldo_u, k2 = (unsigned)(f * (f - 1) * p.psW) * ldo_u;
-      const float* biasq = MD_SEL_G(p.bias, g);
       f32x4_t bq[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int na = n0 + wn * WTN + a * 16 + 4 * q16;
         const int ca = na - fdiv(na, p.fd_psC) * p.psC;
-        bq[a] = (biasq && na < p.N) ? *(const f32x4_t*)(biasq + ca) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + ca) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
       }
-      const int r16 = lane & 15;
       char* ob = (char*)p.out;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         asm volatile("" ::: "memory");
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const f32x4acc_t c = acc16[a][half * 4 + bb];
-            const f32x4_t v = (f32x4_t){c[0], c[1], c[2], c[3]} + bq[a];
-            const int row = bb * 16 + r16;
-            const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
-            *(bf16x4_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = (bf16x4_t){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-          }
+        stage_half_2b(half, [&](int a, f32x4_t v) { return v + bq[a]; });
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1076,149 +929,95 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         }
         asm volatile("" ::: "memory");
       }
-      if (stamp) {
-        stamp[6] = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[7] = __builtin_amdgcn_s_memrealtime();
-      }
+      stamp_end();
       return;
     }
   }
-  const float* biasp = MD_SEL_G(p.bias, g);
-  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {0.f, 0.f, 0.f, 0.f};
-  if (pixshuf && nvalid && biasp) bias4 = *(const f32x4_t*)(biasp + ps_co);
-  if ((rmw || fast_store) && nvalid) {
-    if (biasp) bias4 = *(const f32x4_t*)(biasp + n);
-    if (rmw) scale4 = *(const f32x4_t*)(MD_SEL_G(p.scale, g) + n);
-  }
-  f32x4_t ws4 = {1.f, 1.f, 1.f, 1.f};  // fp8 operands: dequantisation scale of the lane's 4 columns
-  if (rmw && nvalid && MD_SEL_G(p.wscale, g)) ws4 = *(const f32x4_t*)(MD_SEL_G(p.wscale, g) + n) * p.ascale;
   if constexpr (fast_store) {
-    // ---- bf16 store epilogue (EPI_STORE / q,k tiles of EPI_QKV; launcher guarantees N, ldo, ldr % 8 == 0) ----
-    // A lane owns 8 consecutive columns of a row: per 64-row half 8 iterations of {2 ds_read_b128, math,
-    // ONE 16-byte store} instead of 16 x {1 read, 8-byte store}; runtime options are folded into wave-uniform
-    // flags once, and interior tiles (the common case) run without per-row predicates. In-kernel stamps
-    // showed this epilogue costing 8-11 us of a 37-44 us K=1024 tile, ~6 us of it instruction overhead.
+    // ---- 2-byte store epilogue (EPI_STORE / q,k tiles of EPI_QKV; launcher guarantees N, ldo, ldr % 8 == 0) ----
+    // A lane owns 8 consecutive columns of a row: per 64-row half 8 iterations of {LDS read, math, ONE 16-byte store};
+    // runtime options are folded into wave-uniform flags once, and interior tiles run without per-row predicates.
     const long ldo8 = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
-    const int c8 = (lane & 7) * 8, rsub = lane >> 3;
-    const int n8 = n0 + wn * WTN + c8;
-    const bool nv8 = n8 < p.N;
-    const bool interior = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform
     const bool f32o = p.out_f32 != 0, relu = p.act == ACT_RELU, has_o2 = p.out2 != nullptr;
     const bool r1 = p.res1 != nullptr, r2 = p.res2 != nullptr, any_res = r1 || r2;
+    const float* wsp = MD_SEL_G(p.wscale, g);  // fp8 operands: acc * (ascale * wscale[n]) before the bias
+    const bool fp8o = p.out_fp8 != 0;
+    const long tb = (long)m_base * ldo8 + n0 + out_boff;
+    char* ob = (char*)p.out + tb * (fp8o ? 1 : (f32o ? 4 : 2));
+    char* o2b = (char*)p.out2 + tb * 2;
+    const unsigned lc8 = (unsigned)(wn * WTN + c8);
+    // No residual inputs and a plain 2-byte output (fc1, the q/k tiles of qkv, most convolutions): bias, scale and
+    // activation are applied in the ACCUMULATOR layout and the tile is staged in the output type -- half the LDS bytes
+    // of the fp32 staging (LDS bandwidth was half of that epilogue's 4.2 us).
+    if (!any_res && !f32o && !fp8o && !has_o2) {
+      f32x4_t bq[4], wq[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int na = n0 + wn * WTN + a * 16 + 4 * q16;
+        bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        wq[a] = (wsp && na < p.N) ? *(const f32x4_t*)(wsp + na) * p.ascale : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        asm volatile("" ::: "memory");
+        if (!(DIAG && (p.debug_flags & 8)))  // timing-only ablation: skip the staging writes
+          stage_half_2b(half, [&](int a, f32x4_t v) {
+            v = v * wq[a] + bq[a];
+            if constexpr (EK == 4) {
+              v = gelu4<TO>(v);
+            } else if (relu) {
+              v = relu4(v);
+            }
+            return v;
+          });
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + rsub;
+          const int lrow_t = wm * WTM + half * 64 + row;
+          const i32x4_t raw = *(const i32x4_t*)(st + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+          if (DIAG && (p.debug_flags & 4)) {  // timing-only ablation: no global stores (keep the value alive)
+            if (raw[0] == 0x12345678) *(i32x4_t*)(ob + ((unsigned)lrow_t * (unsigned)ldo8 + lc8) * 2u) = raw;
+          } else if (interior || (m_base + lrow_t < m_end && nv8)) {
+            *(i32x4_t*)(ob + ((unsigned)lrow_t * (unsigned)ldo8 + lc8) * 2u) = raw;
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+      stamp_end();
+      return;
+    }
+    // residual inputs / fp32, fp8 or second output: fp32 staging, the raw residual vectors of a half prefetched before
+    // its staging pass (the dependent load -> store chain, not bandwidth, set the cost of the residual-conv epilogue)
     f32x4_t bl = {0.f, 0.f, 0.f, 0.f}, bh = bl;
     if (biasp && nv8) {
       bl = *(const f32x4_t*)(biasp + n8);
       bh = *(const f32x4_t*)(biasp + n8 + 4);
     }
-    const float* wsp = MD_SEL_G(p.wscale, g);  // fp8 operands: acc * (ascale * wscale[n]) before the bias
     f32x4_t wl = {1.f, 1.f, 1.f, 1.f}, wh = wl;
     if (wsp && nv8) {
       wl = *(const f32x4_t*)(wsp + n8) * p.ascale;
       wh = *(const f32x4_t*)(wsp + n8 + 4) * p.ascale;
     }
-    const bool fp8o = p.out_fp8 != 0;
-    const long tb = (long)m_base * ldo8 + n0 + out_boff;
-    char* ob = (char*)p.out + tb * (fp8o ? 1 : (f32o ? 4 : 2));
-    char* o2b = (char*)p.out2 + tb * 2;
     const long trb = (long)m_base * p.ldr + n0;
     const char* q1b = (const char*)p.res1 + trb * 2;
     const char* q2b = (const char*)p.res2 + trb * 2;
-    const unsigned lc8 = (unsigned)(wn * WTN + c8);
-    if constexpr (PP == 2) {
-      // No residual inputs and a plain bf16 output (fc1, the q/k tiles of qkv, most convolutions): bias, scale and
-      // activation are applied in the ACCUMULATOR layout and the tile is staged as bf16 -- 8-byte writes, ONE
-      // 16-byte read per 8 columns -- which halves the LDS bytes of the epilogue (LDS bandwidth, 2 x 128 KB per
-      // half through a 128 B/clk port, was half of its 4.2 us). Rows are 128 B; 16-byte chunks are XOR-swizzled
-      // by (row & 7), conflict-free for both the b64 writes and the b128 reads.
-      if (!any_res && !f32o && !fp8o && !has_o2) {
-        f32x4_t bq[4], wq[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int na = n0 + wn * WTN + a * 16 + 4 * q16;
-          bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          wq[a] = (wsp && na < p.N) ? *(const f32x4_t*)(wsp + na) * p.ascale : (f32x4_t){1.f, 1.f, 1.f, 1.f};
-        }
-        const int r16 = lane & 15;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              const f32x4acc_t c = acc16[a][half * 4 + bb];
-              f32x4_t v = (f32x4_t){c[0], c[1], c[2], c[3]} * wq[a] + bq[a];
-              if constexpr (EK == 4) {
-                v = gelu4<TO>(v);
-              } else if (relu) {
-                v = relu4(v);
-              }
-              const int row = bb * 16 + r16;
-              const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
-              *(bf16x4_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = (bf16x4_t){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            }
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + rsub;
-            const int lrow = wm * WTM + half * 64 + row;
-            const i32x4_t raw = *(const i32x4_t*)(st + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-            if (interior || (m_base + lrow < m_end && nv8)) *(i32x4_t*)(ob + ((unsigned)lrow * (unsigned)ldo8 + lc8) * 2u) = raw;
-          }
-          asm volatile("" ::: "memory");
-        }
-        if (stamp) {
-          stamp[6] = __builtin_amdgcn_s_memrealtime();
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          stamp[7] = __builtin_amdgcn_s_memrealtime();
-        }
-        return;
-      }
-    }
-    i32x4_t pr1[2][8], pr2[2][8];  // raw bf16x8 residual vectors
-    auto pf8 = [&](int half, int it) {
+    i32x4_t pr1[2][8], pr2[2][8];  // raw 8-element residual vectors
+    auto pf8 = [&](int half, int it) __attribute__((always_inline)) {
       if (!any_res) return;
-      const int lrow = wm * WTM + half * 64 + it * 8 + rsub;
-      const bool ok = interior || (m_base + lrow < m_end && nv8);
-      const unsigned ro = ((unsigned)lrow * (unsigned)p.ldr + lc8) * 2u;
+      const int lrow_t = wm * WTM + half * 64 + it * 8 + rsub;
+      const bool ok = interior || (m_base + lrow_t < m_end && nv8);
+      const unsigned ro = ((unsigned)lrow_t * (unsigned)p.ldr + lc8) * 2u;
       i32x4_t z = {0, 0, 0, 0};
       pr1[half][it] = (r1 && ok) ? *(const i32x4_t*)(q1b + ro) : z;
       pr2[half][it] = (r2 && ok) ? *(const i32x4_t*)(q2b + ro) : z;
-    };
-    auto add_raw = [](f32x4_t& lo, f32x4_t& hi, const i32x4_t& raw) {  // 8 bf16 -> += 8 f32
-      const unsigned u0 = (unsigned)raw[0], u1 = (unsigned)raw[1], u2 = (unsigned)raw[2], u3 = (unsigned)raw[3];
-      lo += (f32x4_t){__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
-                      __uint_as_float(u1 & 0xffff0000u)};
-      hi += (f32x4_t){__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 << 16),
-                      __uint_as_float(u3 & 0xffff0000u)};
     };
 #pragma unroll
     for (int it = 0; it < 4; ++it) pf8(0, it);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       asm volatile("" ::: "memory");
-      if constexpr (PP == 2) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const f32x4acc_t c = acc16[a][half * 4 + bb];
-            *(f32x4_t*)(st + (bb * 16 + (lane & 15)) * SROW + (a * 16 + 4 * q16) * 4) = (f32x4_t){c[0], c[1], c[2], c[3]};
-          }
-      } else {
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int b = half * 2 + bb;
-#pragma unroll
-          for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
-              *(f32x4_t*)(st + (bb * 32 + (lane & 31)) * SROW + (a * 32 + 8 * q4 + 4 * h) * 4) = v;
-            }
-        }
-      }
+      stage_half_f32(half);
       asm volatile("" ::: "memory");
       if (half == 0) {
 #pragma unroll
@@ -1227,15 +1026,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + rsub;
-        const int lrow = wm * WTM + half * 64 + row;
+        const int lrow_t = wm * WTM + half * 64 + row;
         f32x4_t lo = *(const f32x4_t*)(st + row * SROW + c8 * 4);
         f32x4_t hi = *(const f32x4_t*)(st + row * SROW + c8 * 4 + 16);
-        if (interior || (m_base + lrow < m_end && nv8)) {
+        if (interior || (m_base + lrow_t < m_end && nv8)) {
           lo = lo * wl + bl;
           hi = hi * wh + bh;
           if (any_res) {
-            add_raw(lo, hi, pr1[half][it]);
-            add_raw(lo, hi, pr2[half][it]);
+            f32x4_t a0, a1;
+            widen8<TO>(pr1[half][it], a0, a1);
+            lo += a0;
+            hi += a1;
+            widen8<TO>(pr2[half][it], a0, a1);
+            lo += a0;
+            hi += a1;
           }
           if constexpr (EK == 4) {
             lo = gelu4<TO>(lo);
@@ -1244,7 +1048,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             lo = relu4(lo);
             hi = relu4(hi);
           }
-          const unsigned eo = (unsigned)lrow * (unsigned)ldo8 + lc8;
+          const unsigned eo = (unsigned)lrow_t * (unsigned)ldo8 + lc8;
           if (fp8o) {  // e4m3 (saturating) for the next GEMM's A operand
             const float is = p.out_inv_scale;
             auto cl = [&](float a) __attribute__((always_inline)) { return __builtin_amdgcn_fmed3f(a * is, -448.f, 448.f); };
@@ -1257,16 +1061,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             *(f32x4_t*)(ob + eo * 4u) = lo;
             *(f32x4_t*)(ob + eo * 4u + 16) = hi;
           } else {
-            const bf16x4_t a = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3]};
-            const bf16x4_t b = {(__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
-            *(bf16x8_t*)(ob + eo * 2u) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+            *(i32x4_t*)(ob + eo * 2u) = pack8<TO>(lo, hi);
           }
-          if (has_o2) {
-            const f32x4_t rl = relu4(lo), rh = relu4(hi);
-            const bf16x4_t a = {(__bf16)rl[0], (__bf16)rl[1], (__bf16)rl[2], (__bf16)rl[3]};
-            const bf16x4_t b = {(__bf16)rh[0], (__bf16)rh[1], (__bf16)rh[2], (__bf16)rh[3]};
-            *(bf16x8_t*)(o2b + eo * 2u) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
+          if (has_o2) *(i32x4_t*)(o2b + eo * 2u) = pack8<TO>(relu4(lo), relu4(hi));
         }
         if (half == 0 && it == 3) {
 #pragma unroll
@@ -1279,77 +1076,51 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         for (int j = 4; j < 8; ++j) pf8(1, j);
       }
     }
-    if (stamp) {
-      stamp[6] = __builtin_amdgcn_s_memrealtime();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stamp[7] = __builtin_amdgcn_s_memrealtime();
-    }
+    stamp_end();
     return;
   }
-  // wave-uniform tile bases + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
-  const long ldo = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;  // q,k rows are [M, 2D]
-  const long tile_o = (long)m_base * ldo + n0, tile_r = (long)m_base * p.ldr + n0;
-  char* out_b = (char*)p.out + (out_boff + tile_o) * (p.out_f32 || rmw ? 4 : (long)sizeof(TO));
-  char* out2_b = (char*)p.out2 + (out_boff + tile_o) * (long)sizeof(TO);
-  const char* res1_b = (const char*)p.res1 + tile_r * (long)sizeof(TO);
-  const char* res2_b = (const char*)p.res2 + tile_r * (long)sizeof(TO);
-  const bool has_res = fast_store && (p.res1 || p.res2);
-  const bool interior_t = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform: no per-row predicates needed
-  // one register array per half serves both prefetches: RMW -> the fp32 x vector; residual store -> the
-  // raw bf16x4 of res1 in lanes .xy and of res2 in .zw
-  f32x4_t pre2[2][16];
+  // ---- fp32-staged forms: read-modify-write residual (EK 1), generic pixel shuffle (EK 3), generic (EK 0) ----
+  f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f}, scale4 = {0.f, 0.f, 0.f, 0.f};
+  int ps_co = 0, ps_dy = 0, ps_dx = 0;  // pixel shuffle: the lane's 4 columns fix (tap, channel) once
+  if constexpr (pixshuf) {
+    const int tap = fdiv(n, p.fd_psC);
+    ps_co = n - tap * p.psC;
+    ps_dy = p.ps_f == 4 ? tap >> 2 : tap >> 1;
+    ps_dx = tap - ps_dy * p.ps_f;
+    if (nvalid && biasp) bias4 = *(const f32x4_t*)(biasp + ps_co);
+  }
+  f32x4_t ws4 = {1.f, 1.f, 1.f, 1.f};  // fp8 operands: dequantisation scale of the lane's 4 columns
+  if constexpr (rmw) {
+    if (nvalid) {
+      if (biasp) bias4 = *(const f32x4_t*)(biasp + n);
+      scale4 = *(const f32x4_t*)(MD_SEL_G(p.scale, g) + n);
+      if (MD_SEL_G(p.wscale, g)) ws4 = *(const f32x4_t*)(MD_SEL_G(p.wscale, g) + n) * p.ascale;
+    }
+  }
+  // wave-uniform tile base + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
+  char* out_b = (char*)p.out + (out_boff + (long)m_base * p.ldo + n0) * 4;
   const unsigned lcol = (unsigned)(wn * WTN + col);
-  auto prefetch = [&](int half, int it) {
-    const int lrow = wm * WTM + half * 64 + (lane >> 4) + it * 4;
-    const int m = m_base + lrow;
-    const unsigned lr = (unsigned)lrow;
+  // The read-modify-write epilogue prefetches the fp32 x vectors of a half BEFORE its staging pass, so 16 loads per
+  // lane are in flight at once instead of a dependent load -> store chain (that chain, not bandwidth, set the cost of
+  // the proj / fc2 epilogues). Register budget: 128 accumulators are live until half 0 is staged: 8 rows of half 0
+  // before its staging pass and its other 8 right after it; the first 8 rows of half 1 once rows 0-7 of half 0 have
+  // been stored, the last 8 after rows 8-15. Every slot is assigned unconditionally (zeros when out of range).
+  f32x4_t pre2[2][16];
+  auto prefetch = [&](int half, int it) __attribute__((always_inline)) {
     if constexpr (rmw) {
-      if (interior_t || (m < m_end && nvalid)) pre2[half][it] = *(const f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u);
-    } else if constexpr (fast_store) {
-      if (!has_res) return;
-      f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
-      if (m < m_end && nvalid) {
-        const unsigned ro = (lr * (unsigned)p.ldr + lcol) * (unsigned)sizeof(TO);
-        if (p.res1) a1 = *(const f32x2_t*)(res1_b + ro);
-        if (p.res2) a2 = *(const f32x2_t*)(res2_b + ro);
-      }
-      pre2[half][it] = (f32x4_t){a1[0], a1[1], a2[0], a2[1]};
+      const int lrow_t = wm * WTM + half * 64 + (lane >> 4) + it * 4;
+      const bool ok = interior || (m_base + lrow_t < m_end && nvalid);
+      pre2[half][it] = ok ? *(const f32x4_t*)(out_b + ((unsigned)lrow_t * (unsigned)p.ldo + lcol) * 4u) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   };
-  // Prefetch schedule (register budget: 128 accumulators are live until half 0 is staged): 8 rows of half 0
-  // before its staging pass and its other 8 rows right after it (64 accumulators are dead by then); the
-  // first 8 rows of half 1 once rows 0-7 of half 0 have been stored, the last 8 after rows 8-15.
 #pragma unroll
   for (int it = 0; it < 8; ++it) prefetch(0, it);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const int lrow0 = wm * WTM + half * 64 + (lane >> 4);  // tile-local row of iteration 0
     const int m0 = m_base + lrow0;
-    f32x4_t(&pre)[16] = pre2[half];
     asm volatile("" ::: "memory");
-    if constexpr (PP == 2) {
-      if (!(p.debug_flags & 8)) {  // timing-only ablation: skip the staging writes
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const f32x4acc_t c = acc16[a][half * 4 + bb];
-            *(f32x4_t*)(st + (bb * 16 + (lane & 15)) * SROW + (a * 16 + 4 * q16) * 4) = (f32x4_t){c[0], c[1], c[2], c[3]};
-          }
-      }
-    } else {
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int b = half * 2 + bb;
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            f32x4_t v = {acc[a][b][4 * q4], acc[a][b][4 * q4 + 1], acc[a][b][4 * q4 + 2], acc[a][b][4 * q4 + 3]};
-            *(f32x4_t*)(st + (bb * 32 + (lane & 31)) * SROW + (a * 32 + 8 * q4 + 4 * h) * 4) = v;
-          }
-      }
-    }
+    if (!(DIAG && (p.debug_flags & 8))) stage_half_f32(half);
     asm volatile("" ::: "memory");
     if (half == 0) {
 #pragma unroll
@@ -1363,43 +1134,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int m = m0 + it * 4;
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (interior_t || (m < m_end && nvalid)) *(f32x4_t*)(out_b + (lr * (unsigned)ldo + lcol) * 4u) = pre[it] + scale4 * (v * ws4 + bias4);
-        if (half == 0 && it == 7) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) prefetch(1, j);
-        }
-      }
-    } else if constexpr (fast_store) {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const int m = m0 + it * 4;
-        const unsigned lr = (unsigned)(lrow0 + it * 4);
-        f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (m < m_end && nvalid) {
-          v += bias4;
-          if (has_res) {  // raw bf16 pairs: low half = even element, high half = odd element
-            const unsigned u0 = __float_as_uint(pre[it][0]), u1 = __float_as_uint(pre[it][1]);
-            const unsigned u2 = __float_as_uint(pre[it][2]), u3 = __float_as_uint(pre[it][3]);
-            v += (f32x4_t){__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
-                           __uint_as_float(u1 & 0xffff0000u)};
-            v += (f32x4_t){__uint_as_float(u2 << 16), __uint_as_float(u2 & 0xffff0000u), __uint_as_float(u3 << 16),
-                           __uint_as_float(u3 & 0xffff0000u)};
-          }
-          if constexpr (EK == 4) {
-            v = gelu4<TO>(v);
-          } else {
-            if (p.act == ACT_RELU) v = relu4(v);
-          }
-          const unsigned eo = lr * (unsigned)ldo + lcol;
-          if (p.debug_flags & 4) {  // timing-only ablation: no global stores (keep the value alive)
-            if (v[0] == 123.456f) store4<TO>((TO*)(out_b + eo * (unsigned)sizeof(TO)), v);
-          } else if (p.out_f32)
-            store4<float>((float*)(out_b + eo * 4u), v);
-          else
-            store4<TO>((TO*)(out_b + eo * (unsigned)sizeof(TO)), v);
-          if (p.out2) store4<TO>((TO*)(out2_b + eo * (unsigned)sizeof(TO)), relu4(v));
-        }
+        if (interior || (m < m_end && nvalid))
+          *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = pre2[half][it] + scale4 * (v * ws4 + bias4);
         if (half == 0 && it == 7) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) prefetch(1, j);
@@ -1442,11 +1178,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       for (int it = 8; it < 16; ++it) prefetch(1, it);
     }
   }
-  if (stamp) {
-    stamp[6] = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the store drain of this wave (s_endpgm waits for it too)
-    stamp[7] = __builtin_amdgcn_s_memrealtime();
-  }
+  stamp_end();
 }
 
 // host side of map_tile: n-tiles are walked in groups of gn (L2-aware raster), the last group may be narrower
@@ -1462,7 +1194,7 @@ static inline void prep_tile_map(GemmParams& p, int tiles_m, int tiles_n) {
   p.fd_map_rn = make_fastdiv(p.map_rn);
 }
 
-template <typename T, int AMODE, int PP>
+template <typename T, int AMODE>
 static int launch_256(GemmParams& p, hipStream_t stream) {
   constexpr int BM = 256, BN = 256;
   int tiles_m = 0;
@@ -1487,22 +1219,44 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     MD_HIP(hipGetLastError());
     return MD_OK;
   };
-  static bool set0 = false, set1 = false, set2 = false, set3 = false, set4 = false;
-  if constexpr (PP == 2) {  // the production schedule carries the specialised epilogues
-    if (p.epi == EPI_RESID_LS) return go(gemm256_kernel<T, AMODE, PP, 1>, &set1);
-    if (p.epi == EPI_PIXSHUF) return go(gemm256_kernel<T, AMODE, PP, 3>, &set3);
-    if constexpr (sizeof(typename OutT<T>::type) == 2) {
-      const long ldo_e = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
-      const bool vec8 = p.N % 8 == 0 && ldo_e % 8 == 0 && (!(p.res1 || p.res2) || p.ldr % 8 == 0);
-      if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) return go(gemm256_kernel<T, AMODE, PP, 4>, &set4);
-      if (vec8 && ((p.epi == EPI_STORE && p.res_mod == 0 && p.act != ACT_GELU) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0))) return go(gemm256_kernel<T, AMODE, PP, 2>, &set2);
+  // epilogue specialisation (EK) from the runtime parameters
+  int ek = 0;
+  if (p.epi == EPI_RESID_LS) ek = 1;
+  else if (p.epi == EPI_PIXSHUF) ek = 3;
+  else if (sizeof(typename OutT<T>::type) == 2) {
+    const long ldo_e = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
+    const bool vec8 = p.N % 8 == 0 && ldo_e % 8 == 0 && (!(p.res1 || p.res2) || p.ldr % 8 == 0);
+    if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = 4;
+    else if (vec8 && ((p.epi == EPI_STORE && p.res_mod == 0 && p.act != ACT_GELU) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0))) ek = 2;
+  }
+  const bool diag = p.stamps != nullptr || p.debug_flags != 0;
+  static bool set[5] = {false, false, false, false, false}, dset[5] = {false, false, false, false, false};
+  if (diag) {  // md_bench_gemm only: the stamped / ablation build exists for dense bf16 operands
+    if constexpr (std::is_same<T, bf16_t>::value && AMODE == A_DENSE) {
+      switch (ek) {
+        case 1: return go(gemm256_kernel<T, AMODE, 1, true>, &dset[1]);
+        case 2: return go(gemm256_kernel<T, AMODE, 2, true>, &dset[2]);
+        case 3: return go(gemm256_kernel<T, AMODE, 3, true>, &dset[3]);
+        case 4: return go(gemm256_kernel<T, AMODE, 4, true>, &dset[4]);
+        default: return go(gemm256_kernel<T, AMODE, 0, true>, &dset[0]);
+      }
+    } else {
+      MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the diagnostic build (stamps / ablation flags) exists for dense bf16 operands only");
     }
   }
-  (void)set1;
-  (void)set2;
-  (void)set3;
-  (void)set4;
-  return go(gemm256_kernel<T, AMODE, PP, 0>, &set0);
+  (void)dset;
+  switch (ek) {
+    case 1: return go(gemm256_kernel<T, AMODE, 1, false>, &set[1]);
+    case 3: return go(gemm256_kernel<T, AMODE, 3, false>, &set[3]);
+    case 2:
+      if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);
+      break;
+    case 4:
+      if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
+      break;
+    default: break;
+  }
+  return go(gemm256_kernel<T, AMODE, 0, false>, &set[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1536,13 +1290,7 @@ template <typename T, int AMODE>
 static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
     case TILE_256x256:
-      return launch_256<T, AMODE, 2>(p, stream);
-    case TILE_256x256_PP32:
-      return launch_256<T, AMODE, 1>(p, stream);
-    case TILE_256x256_V2:
-      return launch_256<T, AMODE, 0>(p, stream);
-    case TILE_256x256_V1:
-      return launch_cfg<T, 256, 256, 2, 4, AMODE>(p, stream);
+      return launch_256<T, AMODE>(p, stream);
     case TILE_128x128:
       return launch_cfg<T, 128, 128, 2, 2, AMODE>(p, stream);
     case TILE_256x32:

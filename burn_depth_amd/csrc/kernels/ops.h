@@ -112,9 +112,10 @@ int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad
                      hipStream_t s);
 int launch_unpad_rows(const void* in, int T, int N, int SS, int D, float* out, int prec, hipStream_t s);
 
-// fused multi-head attention, bf16 (K5): qk [rows, 2D] (q | k), vT [seq][heads][64][kpad], out [rows, D].
-// out_fp8_inv > 0: the output rows are OCP e4m3 bytes (value * out_fp8_inv, saturating) instead of bf16.
-int launch_attention_bf16(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                          int kpad, hipStream_t s, float out_fp8_inv = 0.f);
+// fused multi-head attention on bf16 / f16 operands (K5; prec = MD_PREC_BF16 | MD_PREC_F16): qk [rows, 2D] (q | k),
+// vT [seq][heads][64][kpad], out [rows, D].
+// out_fp8_inv > 0 (bf16 only): the output rows are OCP e4m3 bytes (value * out_fp8_inv, saturating).
+int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
+                     int kpad, int prec, hipStream_t s, float out_fp8_inv = 0.f);
 
 }  // namespace md

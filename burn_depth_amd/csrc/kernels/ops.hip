@@ -2,12 +2,9 @@
 // where the layout allows it, blocks are 256 threads (4 waves of 64), grids are capped and
 // grid-strided (MI355X: 256 CUs x 8 blocks).
 #include "ops.h"
+#include "elem.h"
 
 namespace md {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 static inline int grid_for(long work_items, int block = 256, int cap = 256 * 8) {
   long g = (work_items + block - 1) / block;
@@ -125,20 +122,6 @@ int launch_resize_bilinear(const float* in, int planes, int H, int W, float* out
 // a2+a3 fused pyramid + split + patchify -> A matrix of the patch-embed GEMM
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void store8(T* p, const float* v);
-template <>
-__device__ __forceinline__ void store8<float>(float* p, const float* v) {
-  *(f32x4_t*)p = (f32x4_t){v[0], v[1], v[2], v[3]};
-  *(f32x4_t*)(p + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
-}
-template <>
-__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* v) {
-  bf16x8_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3],
-                (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
-  *(bf16x8_t*)p = b;
-}
-
-template <typename T>
 __global__ void pyramid_patchify_kernel(const float* __restrict__ x, PyramidGeom g, T* __restrict__ out) {
   const int grid = g.win / g.ps;             // patches per tile side
   const int P = grid * grid;
@@ -192,11 +175,7 @@ int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches,
   const int grid = g.win / g.ps;
   const long total = (long)(g.steps0 * g.steps0 * g.B + g.steps1 * g.steps1 * g.B + g.B) * grid * grid *
                      (3 * g.ps * g.ps / 8);
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(pyramid_patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, g, (float*)patches);
-  else
-    hipLaunchKernelGGL(pyramid_patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, g,
-                       (bf16_t*)patches);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(pyramid_patchify_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, g, (T*)patches));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -221,36 +200,16 @@ __global__ void patchify_kernel(const float* __restrict__ x, int B, int H, int W
       const int b = (int)(t / ph);
       v = x[(((long)b * 3 + c) * H + py * ps + ky) * W + px * ps + kx];
     }
-    if constexpr (sizeof(T) == 4)
-      ((float*)out)[e] = v;
-    else
-      *((__bf16*)out + e) = (__bf16)v;
+    st1<T>(out + e, v);
   }
 }
 
 int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s) {
   if (ps <= 0 || H % ps || W % ps || Kp < 3 * ps * ps) MD_FAIL(MD_ERR_SHAPE, "patchify: %dx%d / patch %d / K %d", H, W, ps, Kp);
   const long total = (long)B * (H / ps) * (W / ps) * Kp;
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (float*)out);
-  else
-    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (bf16_t*)out);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (T*)out));
   MD_HIP(hipGetLastError());
   return MD_OK;
-}
-
-template <typename T>
-__device__ __forceinline__ void load8f(const T* p, float* v);
-template <>
-__device__ __forceinline__ void load8f<float>(const float* p, float* v) {
-  const f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 4);
-  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-}
-template <>
-__device__ __forceinline__ void load8f<bf16_t>(const bf16_t* p, float* v) {
-  const bf16x8_t a = *(const bf16x8_t*)p;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
 }
 
 // one thread = 8 channels of one output pixel (16-byte bf16 / 32-byte f32 accesses)
@@ -290,12 +249,7 @@ int launch_resize_nhwc(const void* in, int B, int H, int W, int C, long ld_in, v
                        int method, const float* addend, int prec, hipStream_t s) {
   if (C % 8 != 0 || OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_UNSUPPORTED, "resize_nhwc: C=%d must be a multiple of 8", C);
   const long total = (long)B * OH * OW * (C / 8);
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(resize_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, B, H, W, C, ld_in,
-                       (float*)out, OH, OW, ld_out, method, addend);
-  else
-    hipLaunchKernelGGL(resize_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, B, H, W, C,
-                       ld_in, (bf16_t*)out, OH, OW, ld_out, method, addend);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(resize_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, B, H, W, C, ld_in, (T*)out, OH, OW, ld_out, method, addend));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -465,8 +419,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           y = y * fp8_inv_scale;
           *(int*)((char*)out + row * D + i) = pack4_fp8(y[0], y[1], y[2], y[3]);
         } else {
-          bf16x4_t b = {(__bf16)y[0], (__bf16)y[1], (__bf16)y[2], (__bf16)y[3]};
-          *(bf16x4_t*)((bf16_t*)out + row * D + i) = b;
+          store4<TO>(out + row * D + i, y);
         }
       }
     }
@@ -486,6 +439,8 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
   else if (fp8o)                                                                                                    \
     hipLaunchKernelGGL((layernorm_kernel<fp8_t, NV>), dim3(grid), dim3(256), 0, s, x, (fp8_t*)out, rows, D, eps, S, g, \
                        fp8_inv_scale);                                                                              \
+  else if (prec == MD_PREC_F16)                                                                                     \
+    hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16_t*)out, rows, D, eps, S, g, 1.f); \
   else                                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g, 1.f);
   switch (nv) {
@@ -505,27 +460,18 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
 template <typename T>
 __global__ void f32_to_rows_kernel(const float* __restrict__ in, long n, T* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    if constexpr (sizeof(T) == 4)
-      ((float*)out)[i] = in[i];
-    else
-      *((__bf16*)out + i) = (__bf16)in[i];
+    st1<T>(out + i, in[i]);
   }
 }
 template <typename T>
 __global__ void rows_to_f32_kernel(const T* __restrict__ in, long n, float* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    if constexpr (sizeof(T) == 4)
-      out[i] = ((const float*)in)[i];
-    else
-      out[i] = (float)*((const __bf16*)in + i);
+    out[i] = ld1<T>(in + i);
   }
 }
 
 int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s) {
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(f32_to_rows_kernel<float>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (float*)out);
-  else
-    hipLaunchKernelGGL(f32_to_rows_kernel<bf16_t>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (bf16_t*)out);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(f32_to_rows_kernel<T>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (T*)out));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -533,11 +479,7 @@ int launch_convert_rows(const float* x, void* out, long count, int prec, hipStre
   return launch_f32_to_rows(x, count, out, prec, s);
 }
 int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s) {
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(rows_to_f32_kernel<float>, dim3(grid_for(count)), dim3(256), 0, s, (const float*)in, count, out);
-  else
-    hipLaunchKernelGGL(rows_to_f32_kernel<bf16_t>, dim3(grid_for(count)), dim3(256), 0, s, (const bf16_t*)in, count,
-                       out);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(rows_to_f32_kernel<T>, dim3(grid_for(count)), dim3(256), 0, s, (const T*)in, count, out));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -555,10 +497,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, 
     const int b = (int)(t / H);
     float v = in[(((long)b * C + c) * H + y) * W + xw];
     if (relu) v = fmaxf(v, 0.f);
-    if constexpr (sizeof(T) == 4)
-      ((float*)out)[e] = v;
-    else
-      *((__bf16*)out + e) = (__bf16)v;
+    st1<T>(out + e, v);
   }
 }
 template <typename T>
@@ -573,33 +512,20 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, int B, int C, int 
     const int c = (int)(t % C);
     const int b = (int)(t / C);
     const long src = (((long)b * H + y) * W + xw) * ld + coff + c;
-    if constexpr (sizeof(T) == 4)
-      out[e] = ((const float*)in)[src];
-    else
-      out[e] = (float)*((const __bf16*)in + src);
+    out[e] = ld1<T>(in + src);
   }
 }
 
 int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s) {
   const long total = (long)B * C * H * W;
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W, (float*)out,
-                       relu);
-  else
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W,
-                       (bf16_t*)out, relu);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W, (T*)out, relu));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
 int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int coff, float* out, int prec,
                         hipStream_t s) {
   const long total = (long)B * C * H * W;
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, B, C, H, W,
-                       ld, coff, out);
-  else
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, B, C, H,
-                       W, ld, coff, out);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, B, C, H, W, ld, coff, out));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -610,15 +536,9 @@ int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int
 // once and reused for the CO weight rows.
 // ------------------------------------------------------------------------------------------------
 template <typename TI>
-__device__ inline void load4(const TI* in, long src, float v[4]) {
-  if constexpr (sizeof(TI) == 4) {
-    const float4 t = *(const float4*)((const float*)in + src);
-    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
-  } else {
-    const uint2 t = *(const uint2*)((const uint16_t*)in + src);
-    v[0] = __uint_as_float(t.x << 16), v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16), v[3] = __uint_as_float(t.y & 0xffff0000u);
-  }
+__device__ inline void load4v(const TI* in, long src, float v[4]) {
+  const f32x4_t t = load4<TI>(in + src);
+  v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
 }
 
 template <typename TI, int CO, int VEC>
@@ -651,16 +571,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__
       const long src = (((long)b * H + iy) * W + ix) * Cin + ci;
       float v[4];
       if constexpr (VEC == 4) {
-        load4<TI>(in, src, v);
+        load4v<TI>(in, src, v);
         if (add) {
           const float4 a4 = *(const float4*)(add + src);
           v[0] += a4.x, v[1] += a4.y, v[2] += a4.z, v[3] += a4.w;
         }
       } else {
-        if constexpr (sizeof(TI) == 4)
-          v[0] = ((const float*)in)[src];
-        else
-          v[0] = (float)*((const __bf16*)in + src);
+        v[0] = ld1<TI>(in + src);
         if (add) v[0] += add[src];
       }
 #pragma unroll
@@ -714,11 +631,7 @@ int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int
                        const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s) {
   const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
   if (OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_SHAPE, "conv_direct: input %dx%d smaller than kernel %d", H, W, k);
-  if (in_prec == MD_PREC_F32)
-    conv_direct_dispatch<float>((const float*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW, s);
-  else
-    conv_direct_dispatch<bf16_t>((const bf16_t*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW,
-                                 s);
+  MD_BY_PREC(in_prec, conv_direct_dispatch<T>((const T*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW, s));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -791,11 +704,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, l
     const int t = (int)(row % S);
     if (t >= NT) continue;  // wave-uniform
     T* p = qk + row * 2L * D + (long)which * D + hd * 64 + lane;
-    float v;
-    if constexpr (sizeof(T) == 4)
-      v = *(const float*)p;
-    else
-      v = (float)*(const __bf16*)p;
+    const float v = ld1<T>(p);
     const float mean = wave_sum(v) * (1.0f / 64.0f);
     const float c = v - mean;
     const float rstd = 1.0f / sqrtf(wave_sum(c * c) * (1.0f / 64.0f) + eps);
@@ -816,10 +725,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, l
     const float cs = rope_cos[pos * 16 + f], sn = rope_sin[pos * 16 + f];
     const float partner = __shfl_xor(y, 16);
     const float o = jj < 16 ? y * cs - partner * sn : y * cs + partner * sn;
-    if constexpr (sizeof(T) == 4)
-      *(float*)p = o;
-    else
-      *(__bf16*)p = (__bf16)o;
+    st1<T>(p, o);
   }
 }
 
@@ -828,12 +734,7 @@ int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int hea
                         const float* rope_sin, int global_pos, int prec, hipStream_t s) {
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "qk_norm_rope: head_dim must be 64");
   const int grid = grid_for(rows * heads * 2 * 64);
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(qk_norm_rope_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)qk, rows, S, n_tokens, D, heads, pw,
-                       q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos);
-  else
-    hipLaunchKernelGGL(qk_norm_rope_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)qk, rows, S, n_tokens, D, heads,
-                       pw, q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(qk_norm_rope_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)qk, rows, S, n_tokens, D, heads, pw, q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -910,13 +811,8 @@ __global__ __launch_bounds__(256) void hook_cat_ln_kernel(const float* __restric
         const int i = lane + 64 * k;
         const float y1 = (a[k] - mean) * rstd * hg[i] + hb[i];
         const float y2 = (b[k] - mean) * rstd * hg[D + i] + hb[D + i];
-        if constexpr (sizeof(TO) == 4) {
-          ((float*)out)[row * 2 * D + i] = y1;
-          ((float*)out)[row * 2 * D + D + i] = y2;
-        } else {
-          *((__bf16*)out + row * 2 * D + i) = (__bf16)y1;
-          *((__bf16*)out + row * 2 * D + D + i) = (__bf16)y2;
-        }
+        st1<TO>(out + row * 2 * D + i, y1);
+        st1<TO>(out + row * 2 * D + D + i, y2);
       }
   }
 }
@@ -926,12 +822,7 @@ int launch_hook_cat_ln(const float* x_local, const float* x, long rows, int S, i
                        void* out, float* cam_out, int prec, hipStream_t s) {
   if (D % 64 != 0 || D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "hook_cat_ln: D=%d must be a multiple of 64 and <= 1024", D);
   const int grid = grid_for(rows * 64);
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(hook_cat_ln_kernel<float>, dim3(grid), dim3(256), 0, s, x_local, x, rows, S, n_tokens, D, norm_g,
-                       norm_b, eps_final, head_g, head_b, eps_head, (float*)out, cam_out);
-  else
-    hipLaunchKernelGGL(hook_cat_ln_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x_local, x, rows, S, n_tokens, D, norm_g,
-                       norm_b, eps_final, head_g, head_b, eps_head, (bf16_t*)out, cam_out);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(hook_cat_ln_kernel<T>, dim3(grid), dim3(256), 0, s, x_local, x, rows, S, n_tokens, D, norm_g, norm_b, eps_final, head_g, head_b, eps_head, (T*)out, cam_out));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -1089,22 +980,14 @@ __global__ void qkv_split_kernel(const float* __restrict__ qkv, int Tn, int N, i
       base = vT;
       dst = (((long)seq * heads + (cc >> 6)) * 64 + (cc & 63)) * kpad + i;
     }
-    if constexpr (sizeof(T) == 4)
-      ((float*)base)[dst] = v;
-    else
-      *((__bf16*)base + dst) = (__bf16)v;
+    st1<T>(base + dst, v);
   }
 }
 
-int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad, void* qk, void* vT, int prec,
+int launch_qkv_split(const float* qkv, int Tn, int N, int heads, int SS, int kpad, void* qk, void* vT, int prec,
                      hipStream_t s) {
-  const long total = (long)T * N * 3 * heads * 64;
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, qkv, T, N, heads, SS, kpad,
-                       (float*)qk, (float*)vT);
-  else
-    hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, qkv, T, N, heads, SS, kpad,
-                       (bf16_t*)qk, (bf16_t*)vT);
+  const long total = (long)Tn * N * 3 * heads * 64;
+  MD_BY_PREC(prec, hipLaunchKernelGGL(qkv_split_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, qkv, Tn, N, heads, SS, kpad, (T*)qk, (T*)vT));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -1118,21 +1001,13 @@ __global__ void unpad_rows_kernel(const T* __restrict__ in, int Tn, int N, int S
     const int i = (int)(t % N);
     const int seq = (int)(t / N);
     const long src = ((long)seq * SS + i) * D + d;
-    if constexpr (sizeof(T) == 4)
-      out[e] = ((const float*)in)[src];
-    else
-      out[e] = (float)*((const __bf16*)in + src);
+    out[e] = ld1<T>(in + src);
   }
 }
 
-int launch_unpad_rows(const void* in, int T, int N, int SS, int D, float* out, int prec, hipStream_t s) {
-  const long total = (long)T * N * D;
-  if (prec == MD_PREC_F32)
-    hipLaunchKernelGGL(unpad_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, T, N, SS, D,
-                       out);
-  else
-    hipLaunchKernelGGL(unpad_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in, T, N, SS,
-                       D, out);
+int launch_unpad_rows(const void* in, int Tn, int N, int SS, int D, float* out, int prec, hipStream_t s) {
+  const long total = (long)Tn * N * D;
+  MD_BY_PREC(prec, hipLaunchKernelGGL(unpad_rows_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, Tn, N, SS, D, out));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

@@ -131,6 +131,7 @@ int md_model_param_info(md_model_t m, int index, const char** name, size_t* coun
 
 int md_model_set_tensor(md_model_t m, const char* name, const float* host_data, size_t count) {
   if (!m || !name || !host_data) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: set tensors on the root model");
   auto it = m->pindex.find(name);
   if (it == m->pindex.end()) MD_FAIL(MD_ERR_INVALID_ARG, "unknown parameter `%s`", name);
   if (m->params[it->second].count() != count)
@@ -159,6 +160,7 @@ int md_model_commit_weights(md_model_t m) {
 
 int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes) {
   if (!m || !device_ptr || !bytes) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: take the arena of the root model");
   *device_ptr = m->w32_base;
   *bytes = m->w32_bytes;
   m->committed = false;  // the caller is about to overwrite it (broadcast); commit afterwards
@@ -166,6 +168,8 @@ int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes) {
 }
 
 int md_model_destroy(md_model_t m) { return model_destroy(m); }
+
+int md_model_fork(md_model_t m, md_model_t* out) { return model_fork(m, out); }
 
 int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                        float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream) {
@@ -206,9 +210,11 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
     for (auto& p : m->params) n += (int64_t)p.count();
     *out = n;
   } else if (k == "workspace_bytes") *out = (int64_t)m->ws.cap;
-  else if (k == "weight_bytes") *out = (int64_t)(m->w32_bytes + m->wpk_bytes);
+  else if (k == "weight_bytes") *out = m->parent ? 0 : (int64_t)(m->w32_bytes + m->wpk_bytes);  // a fork owns none
   else if (k == "tiles_per_image") *out = m->steps0 * m->steps0 + m->steps1 * m->steps1 + 1;
   else if (k == "seq_stride") *out = m->SS;
+  else if (k == "is_fork") *out = m->parent ? 1 : 0;
+  else if (k == "forks") *out = m->forks;
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
 }
@@ -301,6 +307,16 @@ int md_op_resize_bilinear(md_device_t dev, const float* in_dev, int B, int C, in
   return launch_resize_bilinear(in_dev, B * C, H, W, out_dev, OH, OW, method, 0, pick_stream(dev, stream));
 }
 
+int md_op_resize_nhwc(md_device_t dev, const void* in_dev, int B, int H, int W, int C, void* out_dev, int OH, int OW, int method,
+                      int precision, void* stream) {
+  if (!dev || !in_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  if (method != MD_INTERP_CUSTOM && method != MD_INTERP_BURN) MD_FAIL(MD_ERR_INVALID_ARG, "unknown interpolation method %d", method);
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  return launch_resize_nhwc(in_dev, B, H, W, C, C, out_dev, OH, OW, C, method, nullptr, precision, pick_stream(dev, stream));
+}
+
 int md_op_resize_output_size(int H, int W, float scale_h, float scale_w, int* oh, int* ow) {
   if (!oh || !ow) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   // interpolate.rs:24-27
@@ -363,7 +379,7 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
   if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
   const bool storage_out = (precision & MD_OP_STORAGE_OUT) && (precision & 0xff) != MD_PREC_F32;
   precision &= 0xff;
-  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
   if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = pick_stream(dev, stream);
@@ -392,7 +408,7 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
     p.out_f32 = 0; p.out = ob.p;
   }
   MD_TRY(launch_gemm(p, A_DENSE, precision, tile, st));
-  if (storage_out) MD_TRY(launch_rows_to_f32(ob.p, (long)M * N, out_dev, MD_PREC_BF16, st));
+  if (storage_out) MD_TRY(launch_rows_to_f32(ob.p, (long)M * N, out_dev, precision == MD_PREC_F16 ? MD_PREC_F16 : MD_PREC_BF16, st));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
@@ -409,8 +425,8 @@ int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int hea
   MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * es));
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * es));
   MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, precision, st));
-  if (precision == MD_PREC_BF16) {
-    MD_TRY(launch_attention_bf16(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, st));
+  if (precision != MD_PREC_F32) {
+    MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st));
   } else {
     MD_TRY(sc.alloc((size_t)T * heads * SS * kpad * 4));
     GemmParams p;
@@ -460,7 +476,7 @@ int md_op_conv3x3(md_device_t dev, const float* x_dev, const float* w_dev, const
   p.A = xa.p; p.cH = H; p.cW = W; p.cC = Cin; p.zero_page = zp.p;
   p.epi = EPI_STORE; p.out_f32 = storage_out ? 0 : 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
   MD_TRY(launch_gemm(p, A_CONV3, precision, TILE_AUTO, st));
-  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, H, W, Cout, 0, out_dev, storage_out ? MD_PREC_BF16 : MD_PREC_F32, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, H, W, Cout, 0, out_dev, storage_out ? precision : MD_PREC_F32, st));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
@@ -489,7 +505,7 @@ int md_op_deconv2x2(md_device_t dev, const float* x_dev, const float* w_dev, con
   p.epi = EPI_PIXSHUF; p.out_f32 = storage_out ? 0 : 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
   p.psH = H; p.psW = W; p.psC = Cout; p.ps_coff = 0;
   MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_AUTO, st));
-  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, 2 * H, 2 * W, Cout, 0, out_dev, storage_out ? MD_PREC_BF16 : MD_PREC_F32, st));
+  MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, 2 * H, 2 * W, Cout, 0, out_dev, storage_out ? precision : MD_PREC_F32, st));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
@@ -639,12 +655,12 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * 2));
   MD_TRY(fill_random(qk.p, (size_t)T * SS * 2 * D, MD_PREC_BF16, 3, 2.0f, st));
   MD_TRY(fill_random(vT.p, (size_t)T * heads * 64 * kpad, MD_PREC_BF16, 4, 1.0f, st));
-  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention_bf16(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, st));
+  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, MD_PREC_BF16, st));
   hipEvent_t e0, e1;
   MD_HIP(hipEventCreate(&e0));
   MD_HIP(hipEventCreate(&e1));
   MD_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention_bf16(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, st));
+  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, MD_PREC_BF16, st));
   MD_HIP(hipEventRecord(e1, st));
   MD_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -698,7 +714,7 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
   d.precision = c->precision;
   d.max_batch = c->max_batch > 0 ? c->max_batch : 1;
   d.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
-  if (d.precision != MD_PREC_BF16 && d.precision != MD_PREC_F32 && d.precision != MD_PREC_FP8)
+  if (d.precision != MD_PREC_BF16 && d.precision != MD_PREC_F32 && d.precision != MD_PREC_FP8 && d.precision != MD_PREC_F16)
     MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", d.precision);
   *out = d;
   return MD_OK;

@@ -46,8 +46,11 @@ struct fp8_t {
   uint8_t bits;
 };
 
-// ---- bf16 storage type ------------------------------------------------------------------------
+// ---- bf16 / IEEE half storage types -----------------------------------------------------------
 struct bf16_t {
+  uint16_t bits;
+};
+struct f16_t {
   uint16_t bits;
 };
 

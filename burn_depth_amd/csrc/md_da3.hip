@@ -629,9 +629,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
                                  is_global ? 1 : 0, m->prec, st));
       r.end();
     }
-    if (m->prec == MD_PREC_BF16) {
+    if (m->prec != MD_PREC_F32) {
       r.begin("attention");
-      MD_TRY(launch_attention_bf16(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, st, f8 ? a_inv : 0.f));
+      MD_TRY(launch_attention(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, m->prec, st, f8 ? a_inv : 0.f));
       r.end();
     } else {
       GemmParams p;
@@ -702,6 +702,13 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
           MD_TRY(launch_hook_cat_ln(xl, d->xres, rows, SS, NT, D, d->vit.norm_g, d->vit.norm_b, c.ln_eps, Bi(hp + ".norm.gamma"),
                                     Bi(hp + ".norm.beta"), 1e-5f, d->hookn[hk], hk == 3 ? d->cam_raw : nullptr, m->prec, st));
           r.end();
+          if (m->taps_enabled) {  // DepthTrace::backbone_tokens (mod.rs:241-246,344-347): cat(x_local, LayerNorm_final(x)) patch rows
+            const std::string tn = "backbone_tokens_" + std::to_string(hk);
+            sg.a[0] = d->vit.norm_g; sg.b[0] = d->vit.norm_b;
+            MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
+            MD_TRY(r.tap_token_rows(tn.c_str(), xl, SS, 1, P, D, 2 * D, 0));
+            MD_TRY(r.tap_token_rows(tn.c_str(), d->lnf, SS, 1, P, D, 2 * D, D));
+          }
           ++hook_slot;
         }
       (void)hooked;
@@ -719,6 +726,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
           r.begin("layernorm");
           MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
           r.end();
+          if (m->taps_enabled) {  // DepthTrace::backbone_tokens (mod.rs:241-246,344-347)
+            const std::string tn = "backbone_tokens_" + std::to_string(hk);
+            MD_TRY(r.tap_token_rows(tn.c_str(), d->lnf, SS, 1, P, D, D, 0));
+          }
           sg.a[0] = nullptr; sg.b[0] = nullptr;
           r.begin("layernorm");
           MD_TRY(launch_layernorm(d->lnf, d->hookn[hk], rows, D, 1e-5f, SS, sg, m->prec, 0, st));
@@ -771,6 +782,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     // layerN_rn: 3x3, no bias -> features (+ relu copy for the residual units)
     MD_TRY(conv3(r, "head_conv3x3", feat, sh[s], sw[s], ocp, Wk(hp + ".scratch.layer" + std::to_string(s + 1) + "_rn.weight"), nullptr,
                  F, d->rn[s], Fp, ACT_NONE, nullptr, nullptr, d->rnr[s]));
+    if (m->taps_enabled) {  // prepare_stage output and its layerN_rn map (dpt.rs:649-703)
+      MD_TRY(r.tap_nhwc(("stage_" + std::to_string(s)).c_str(), feat, oc[s], sh[s], sw[s], ocp));
+      MD_TRY(r.tap_nhwc(("layer" + std::to_string(s + 1) + "_rn").c_str(), d->rn[s], F, sh[s], sw[s], Fp));
+    }
   }
   // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
   auto rcu = [&](const std::string& name, int hh, int ww, const void* x, const void* xr, const void* extra, void* out, void* out_relu) -> int {
@@ -801,6 +816,8 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * targw[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
                        Bi(rf + ".out_conv.bias"), d->o, Fp));
       top = d->o;
+      if (m->taps_enabled)  // FeatureFusionBlock outputs (dpt.rs:705-720), main and aux pyramids
+        MD_TRY(r.tap_nhwc(("refinenet" + std::to_string(lvl + 1) + suffix).c_str(), d->o, F, target[lvl], targw[lvl], Fp));
     }
     return MD_OK;
   };
@@ -827,6 +844,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   r.begin("head_resize");
   MD_TRY(launch_resize_nhwc(d->c1, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, IH, IW, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
   r.end();
+  if (m->taps_enabled) {
+    MD_TRY(r.tap_nhwc("output_conv1", d->c1, F2, 8 * ph, 8 * pw, F2p));
+    MD_TRY(r.tap_nhwc("head_input", d->c1r, F2, IH, IW, F2p));  // resized + UV table: the input of output_conv2
+  }
   const size_t out_elems = (size_t)B * IH * IW;
   float* depth_dev = outp.depth;
   if (out_kind == MD_MEM_HOST) {
@@ -869,6 +890,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       r.begin("head_resize");
       MD_TRY(launch_resize_nhwc(cur, B, ah, aw, F2, F2p, hin, ah, aw, F2p, MD_INTERP_BURN, d->pos_aux, m->prec, st));
       r.end();
+      if (m->taps_enabled) {  // DepthTrace::aux_stage_necks (last level) / aux_head_input (mod.rs:241-246)
+        MD_TRY(r.tap_nhwc("aux_neck", cur, F2, ah, aw, F2p));
+        MD_TRY(r.tap_nhwc("aux_head_input", hin, F2, ah, aw, F2p));
+      }
       const std::string oh = hp + ".scratch.output_conv2_aux." + lv;
       const size_t plane = (size_t)ah * aw;
       const int K7 = c.aux_output_dim;

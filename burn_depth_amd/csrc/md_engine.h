@@ -121,6 +121,12 @@ struct md_model_s {
   };
   std::map<std::vector<uintptr_t>, GraphEntry> graphs;  // key: stream, shapes and every in/out pointer
 
+  // ---- md_model_fork: a fork shares the parameter / packed-weight arenas of its root model (never frees them) and
+  //      owns its workspace, index tables, taps, timing, graphs and default stream ----
+  md_model_s* parent = nullptr;   // root model of a fork (forks of forks attach to the root)
+  int forks = 0;                  // live forks of this root
+  hipStream_t own_stream = nullptr;  // a fork's default stream (stream == NULL in infer)
+
   // ---- model kind: 0 = Depth Pro, 1 = Depth-Anything-v3 (state in md_da3.hip) ----
   int kind = 0;
   struct Da3State;
@@ -138,6 +144,8 @@ int model_init_seeded(md_model_t m, uint64_t seed, int scheme);
 int model_load_container(md_model_t m, const char* path);
 int model_commit(md_model_t m);
 int model_destroy(md_model_t m);
+int model_fork(md_model_t src, md_model_t* out);
+inline md_model_s* model_root(md_model_s* m) { return m->parent ? m->parent : m; }
 int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s);

@@ -12,6 +12,7 @@
 //     the token->map reshape + overlap-trim merge (encoder.rs:234-319) a row-index table.
 #include "md_engine.h"
 #include "md_engine_util.h"
+#include "kernels/elem.h"
 
 #include <algorithm>
 #include <cmath>
@@ -88,10 +89,7 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
       const long co = t / k;
       v = src[((co * d1 + ci) * k + ky) * k + kx];
     }
-    if constexpr (sizeof(T) == 4)
-      ((float*)dst)[e] = v;
-    else
-      *((__bf16*)dst + e) = (__bf16)v;
+    st1<T>(dst + e, v);
   }
 }
 
@@ -120,12 +118,8 @@ int compose_deconv_conv(const float* wd, const float* wo, int cin, int cmid, int
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s) {
   const long total = (long)pack_elems(e);
   const int grid = (int)std::min<long>((total + 255) / 256, 4096);
-  if (e.f32 || prec == MD_PREC_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)e.dst, e.kind, e.d0, e.d1, e.k,
-                       e.kp, total);
-  else
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, src, (bf16_t*)e.dst, e.kind, e.d0, e.d1, e.k,
-                       e.kp, total);
+  const int pk_prec = e.f32 ? MD_PREC_F32 : prec;
+  MD_BY_PREC(pk_prec, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid), dim3(256), 0, s, src, (T*)e.dst, e.kind, e.d0, e.d1, e.k, e.kp, total));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -463,8 +457,15 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
 
 int model_destroy(md_model_t m) {
   if (!m) return MD_OK;
+  if (m->forks > 0) MD_FAIL(MD_ERR_INVALID_ARG, "model has %d live fork(s) sharing its weights: destroy them first", m->forks);
   if (m->dev) (void)hipSetDevice(m->dev->ordinal);
   (void)hipDeviceSynchronize();
+  if (m->parent) {  // a fork owns no weights
+    m->parent->forks -= 1;
+    m->w32_base = nullptr;
+    m->wpk_base = nullptr;
+  }
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->w32_base) (void)hipFree(m->w32_base);
   if (m->wpk_base) (void)hipFree(m->wpk_base);
   if (m->ws.base) (void)hipFree(m->ws.base);
@@ -485,6 +486,60 @@ int model_destroy(md_model_t m) {
     delete m->buf;
   }
   delete m;
+  return MD_OK;
+}
+
+// `DepthPro` is `Module + Clone` and `infer(&self)` takes a shared reference (depth_pro/mod.rs:119-126,312;
+// crates/bevy_burn_depth/src/lib.rs:18,29): a second in-flight inference needs a second workspace, not a second copy
+// of the 5.6 GB of weights. The fork aliases the root's fp32 parameter arena and packed MFMA operand arena.
+int model_fork(md_model_t src, md_model_t* out) {
+  if (!src || !out) MD_FAIL(MD_ERR_INVALID_ARG, "model/out is null");
+  if (src->kind != 0)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "md_model_fork: Depth-Anything-v3 models keep per-shape tables beside their workspace "
+                                "(the reference's CachedDepthAnything3 is not Sync either, depth_anything3/mod.rs:44,67-70)");
+  md_model_s* root = model_root(src);
+  if (!root->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights before forking");
+  MD_HIP(hipSetDevice(root->dev->ordinal));
+  md_model_s* m = new md_model_s();
+  m->dev = root->dev;
+  m->cfg = root->cfg;
+  m->prec = root->prec; m->esz = root->esz; m->ke = root->ke;
+  m->params = root->params; m->pindex = root->pindex; m->w32 = root->w32;
+  m->w32_base = root->w32_base; m->w32_bytes = root->w32_bytes;
+  m->packs = root->packs; m->pack_index = root->pack_index;
+  m->wpk_base = root->wpk_base; m->wpk_bytes = root->wpk_bytes;
+  m->committed = true;
+  m->ngroups = root->ngroups;
+  for (int g = 0; g < 3; ++g) m->vit[g] = root->vit[g];
+  m->head_b_host = root->head_b_host;
+  m->S = root->S; m->win = root->win; m->g = root->g; m->P = root->P; m->NT = root->NT; m->SS = root->SS; m->kpad = root->kpad;
+  m->steps0 = root->steps0; m->stride0 = root->stride0; m->steps1 = root->steps1; m->stride1 = root->stride1;
+  m->pad_hi = root->pad_hi; m->pad_mid = root->pad_mid; m->mh_hi = root->mh_hi; m->mh_mid = root->mh_mid;
+  m->parent = root;
+  root->forks += 1;
+  auto fail = [&](int code) {
+    model_destroy(m);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return fail(MD_ERR_HIP);
+  }
+  m->buf = new md_model_s::Buffers();
+  size_t need = 0;
+  plan_workspace(m, true, &need);
+  if (hipMalloc((void**)&m->ws.base, need) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the fork's workspace failed (max_batch=%d)", need, m->cfg.max_batch);
+    return fail(MD_ERR_OOM);
+  }
+  m->ws.cap = need;
+  if (hipMemset(m->ws.base, 0, need) != hipSuccess) return fail(MD_ERR_HIP);  // padding rows / channels / keys: finite zeros
+  int st = plan_workspace(m, false, nullptr);
+  if (st != MD_OK) return fail(st);
+  if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
+  (void)hipMemset(m->zero_page, 0, 4096);
+  (void)hipDeviceSynchronize();
+  *out = m;
   return MD_OK;
 }
 
@@ -543,6 +598,7 @@ int model_load_container(md_model_t m, const char* path) {
 }
 
 int model_commit(md_model_t m) {
+  if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: commit on the root model");
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t s = m->dev->stream;
   float* composed = nullptr;
@@ -681,9 +737,9 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
     }
-    if (m->prec == MD_PREC_BF16) {
+    if (m->prec != MD_PREC_F32) {
       r.begin("attention");
-      MD_TRY(launch_attention_bf16(b->qk, b->vT, b->ao, nseq, SS, NT, heads, D, m->kpad, r.st));
+      MD_TRY(launch_attention(b->qk, b->vT, b->ao, nseq, SS, NT, heads, D, m->kpad, m->prec, r.st));
       r.end();
     } else {
       // fp32: scores = q k^T (batched GEMM) -> row softmax -> P V^T^T (batched GEMM)
@@ -891,7 +947,7 @@ static int run_decoder_head(Run& r) {
     GemmParams p;
     p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = r.B * 4 * hw[0] * hw[0]; p.W[0] = W("head.conv1.weight");
     p.A = b->h1; p.cH = 2 * hw[0]; p.cW = 2 * hw[0]; p.cC = F2p; p.zero_page = m->zero_page;
-    p.epi = EPI_HEAD; p.bias[0] = Bi("head.conv1.bias"); p.head_w = Bi("head.conv_out.weight"); p.head_b = m->head_b_host;
+    p.epi = EPI_HEAD; p.bias[0] = Bi("head.conv1.bias"); p.head_w = Bi("head.conv_out.weight"); p.head_b = model_root(m)->head_b_host;
     p.out = b->canonical;
     r.begin("head_conv1_fused");
     MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, r.st));
@@ -1010,8 +1066,8 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
   auto body = [&]() { return model_infer_eager(m, nchw, B, H, W, in_kind, depth, focal, fovx, fovy, out_kind, stream, rgb, rgb_len); };
   if (!m->graph_enabled) return body();
   MD_HIP(hipSetDevice(m->dev->ordinal));
-  hipStream_t st = stream ? stream : m->dev->stream;
-  const bool eligible = nchw && !rgb && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
+  hipStream_t st = stream ? stream : (m->own_stream ? m->own_stream : m->dev->stream);
+  const bool eligible = nchw && !rgb && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && model_root(m)->committed && B > 0 &&
                         B <= m->cfg.max_batch && H == m->S && W == m->S;
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)depth,
                                       (uintptr_t)focal, (uintptr_t)fovx, (uintptr_t)fovy};
@@ -1021,13 +1077,13 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
 static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                              float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len) {
   if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
-  if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
+  if (!model_root(m)->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
   if (!nchw && !rgb) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");
   if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
   if (B > m->cfg.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
   if (!m->cfg.use_fov_head) MD_FAIL(MD_ERR_NO_FOV, "FOV head required for focal length");  // mod.rs:329
   MD_HIP(hipSetDevice(m->dev->ordinal));
-  hipStream_t st = stream ? stream : m->dev->stream;
+  hipStream_t st = stream ? stream : (m->own_stream ? m->own_stream : m->dev->stream);
   md_model_s::Buffers* b = m->buf;
   Run r{m, st, B};
   const int S = m->S;

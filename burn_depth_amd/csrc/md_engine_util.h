@@ -132,6 +132,23 @@ struct Run {
     t.dims[0] = B; t.dims[1] = C; t.dims[2] = H; t.dims[3] = W;
     return launch_nhwc_to_nchw(p, B, C, H, W, ld, coff, t.dev, m->prec, st);
   }
+  // token rows of an fp32 [B*S, width] tensor -> tap [B, nrows, dst_width] columns [coff, coff + width): rows row0 .. row0+nrows of
+  // every sequence (the patch tokens of a hook, depth_anything3/mod.rs:344-347). Call once per column block.
+  int tap_token_rows(const char* name, const float* src, int S, int row0, int nrows, int width, int dst_width, int coff) {
+    if (!m->taps_enabled) return MD_OK;
+    Tap& t = m->taps[name];
+    const size_t n = (size_t)B * nrows * dst_width;
+    if (t.count != n) {
+      if (t.dev) (void)hipFree(t.dev);
+      MD_HIP(hipMalloc((void**)&t.dev, n * 4));
+      t.count = n;
+    }
+    t.dims[0] = B; t.dims[1] = nrows; t.dims[2] = dst_width; t.dims[3] = 0;
+    for (int b = 0; b < B; ++b)
+      MD_HIP(hipMemcpy2DAsync(t.dev + ((size_t)b * nrows) * dst_width + coff, (size_t)dst_width * 4, src + ((size_t)b * S + row0) * width,
+                              (size_t)width * 4, (size_t)width * 4, (size_t)nrows, hipMemcpyDeviceToDevice, st));
+    return MD_OK;
+  }
   int tap_f32(const char* name, const float* p, int64_t d0, int64_t d1, int64_t d2, int64_t d3) {
     if (!m->taps_enabled) return MD_OK;
     Tap& t = m->taps[name];

@@ -100,9 +100,17 @@ class DepthPro:
                                                              C.byref(h)))
         return DepthPro(device, h, config)
 
+    def fork(self) -> "DepthPro":
+        """`model.clone()` / sharing `&DepthPro` across threads (depth_pro/mod.rs:119-126,312): a second inference
+        context (own workspace, own default stream) on the SAME device weights (md_model_fork). Destroy forks before
+        the model they were forked from."""
+        h = C.c_void_p()
+        _lib.check(self._lib.md_model_fork(self._h, C.byref(h)))
+        return type(self)(self.device, h, self.config)
+
     def destroy(self) -> None:
         if self._h:
-            self._lib.md_model_destroy(self._h)
+            _lib.check(self._lib.md_model_destroy(self._h))
             self._h = None
 
     def __del__(self):

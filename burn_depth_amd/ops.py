@@ -29,6 +29,30 @@ def resize_bilinear(dev: Device, x: torch.Tensor, out_hw: Tuple[int, int], metho
     return out
 
 
+def resize_bilinear_into(dev: Device, x: torch.Tensor, out: torch.Tensor, method: int = 0) -> None:
+    """Allocation-free form (bench.py): fp32 NCHW x -> out, both contiguous device tensors."""
+    B, Cn, H, W = x.shape
+    _lib.check(_lib.load().md_op_resize_bilinear(dev.handle, _p(x), B, Cn, H, W, _p(out), int(out.shape[2]), int(out.shape[3]),
+                                                 int(method), _stream_ptr(dev.ordinal)))
+
+
+_NHWC_PREC = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 3}
+
+
+def resize_nhwc_into(dev: Device, x: torch.Tensor, out: torch.Tensor, method: int = 1) -> None:
+    """NHWC bilinear resize of the Depth-Anything-v3 head (md_op_resize_nhwc): x [B,H,W,C] -> out [B,OH,OW,C]."""
+    assert x.is_cuda and out.is_cuda and x.is_contiguous() and out.is_contiguous() and x.dtype == out.dtype
+    B, H, W, Cn = x.shape
+    _lib.check(_lib.load().md_op_resize_nhwc(dev.handle, _p(x), B, H, W, Cn, _p(out), int(out.shape[1]), int(out.shape[2]), int(method),
+                                             _NHWC_PREC[x.dtype], _stream_ptr(dev.ordinal)))
+
+
+def resize_nhwc(dev: Device, x: torch.Tensor, out_hw: Tuple[int, int], method: int = 1) -> torch.Tensor:
+    out = torch.empty((x.shape[0], int(out_hw[0]), int(out_hw[1]), x.shape[3]), dtype=x.dtype, device=x.device)
+    resize_nhwc_into(dev, x.contiguous(), out, method)
+    return out
+
+
 def resize_output_size(H: int, W: int, scale: Tuple[float, float]) -> Tuple[int, int]:
     oh, ow = C.c_int(), C.c_int()
     _lib.check(_lib.load().md_op_resize_output_size(H, W, C.c_float(scale[0]), C.c_float(scale[1]), C.byref(oh), C.byref(ow)))

@@ -43,7 +43,10 @@ typedef enum md_mem_kind { MD_MEM_HOST = 0, MD_MEM_DEVICE = 1 } md_mem_kind;
 /* MD_PREC_FP8 (Depth-Anything-v3 only, BASELINE config 5): bf16 everywhere except the four ViT linear layers
  * (qkv, proj, fc1, fc2), which run on OCP e4m3 MFMA operands -- weights quantised per output channel at commit,
  * activations with static per-tensor scales -- with fp32 accumulation. */
-typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1, MD_PREC_FP8 = 2 } md_precision;
+/* MD_PREC_F16: IEEE half MFMA operands (v_mfma_f32_*_f16, the bf16 rate) -- the reference stores its weights as f16
+ * (`HalfPrecisionSettings`, depth_pro/mod.rs:206), so checkpoint weights are exact operands and activations carry 3
+ * more mantissa bits than bf16; stores saturate at +-65504. The accurate fast mode. */
+typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1, MD_PREC_FP8 = 2, MD_PREC_F16 = 3 } md_precision;
 /* depth_pro/interpolate.rs:11-22 */
 /* Stand-alone operator checks only (md_op_linear*, md_op_conv3x3, md_op_deconv2x2): OR into `precision` to route the
  * result through the engine's storage type (bf16 in the BF16 / FP8 modes) before it is widened to the fp32 output --
@@ -101,6 +104,16 @@ int md_model_commit_weights(md_model_t m);
 /* The packed device-resident weight arena (for an RCCL broadcast from rank 0). */
 int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes);
 int md_model_destroy(md_model_t m);
+/* `Clone` of a loaded model / sharing `&DepthPro` between threads (`DepthPro` is `Module + Clone + Debug`,
+ * depth_pro/mod.rs:119-126; `infer(&self)`, mod.rs:312; the viewer shares one model behind an Arc,
+ * crates/bevy_burn_depth/src/lib.rs:18,29): a second inference context on the SAME weights. The fork aliases the root
+ * model's parameter and packed-operand arenas (no copy of the 5.6 GB) and owns a workspace arena, index tables, taps,
+ * timing, graphs and a default stream of its own, so one infer per context may be in flight concurrently (the
+ * threading rule at the top of this file then holds per context). set_tensor / commit / weight_arena are rejected on
+ * a fork; the root must be destroyed after its forks (MD_ERR_INVALID_ARG otherwise). Depth Pro models only:
+ * Depth-Anything-v3 models keep per-shape tables beside their workspace, like the reference's `CachedDepthAnything3`
+ * (depth_anything3/mod.rs:44,67-70, not Sync) -> MD_ERR_UNSUPPORTED. */
+int md_model_fork(md_model_t m, md_model_t* out);
 
 /* `DepthPro::infer(&self, x)` (depth_pro/mod.rs:312-364). Input NCHW fp32, ImageNet-normalised,
  * any H x W (resized to img_size^2 and back like the reference). Outputs (DepthProInference,
@@ -171,7 +184,7 @@ int md_model_enable_graph(md_model_t m, int enable);
 
 /* `img_size()` (mod.rs:296), `interpolation_method()` (mod.rs:308) and friends.
  * keys: "img_size", "patch_window", "interpolation", "precision", "max_batch", "num_params",
- *       "workspace_bytes", "weight_bytes", "tiles_per_image". */
+ *       "workspace_bytes", "weight_bytes", "tiles_per_image", "seq_stride", "is_fork", "forks". */
 int md_model_query(md_model_t m, const char* key, int64_t* out);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs
@@ -180,7 +193,11 @@ int md_model_query(md_model_t m, const char* key, int64_t* out);
  * example/correctness.rs:98-122: encoder_feature_{0..4}, encoder_merge_latent{0,1},
  * encoder_merge_x{0,1,2}, decoder_fusion_{0..4}, decoder_feature, decoder_lowres_feature,
  * head_conv0, head_deconv, canonical_inverse_depth, fov_deg, split_x{0,1,2}.
- * Pass host_data = NULL to query dims only. Taps must be enabled before the infer. */
+ * Pass host_data = NULL to query dims only. Taps must be enabled before the infer.
+ * Depth-Anything-v3 models (`DepthTrace` / `infer_with_trace`, depth_anything3/mod.rs:241-246,329-362, and the head's
+ * stages, dpt.rs:587-731): backbone_tokens_{0..3} [B, P, D | 2D] (the hook patch tokens the head receives),
+ * stage_{0..3} (prepare_stage outputs), layer{1..4}_rn, refinenet{4..1} (+ "_aux" for the dual head's second pyramid),
+ * output_conv1, head_input (resized + UV table), aux_neck, aux_head_input. */
 int md_model_enable_taps(md_model_t m, int enable);
 int md_model_read_tap(md_model_t m, const char* name, float* host_data, size_t capacity, int64_t dims[4]);
 
@@ -192,6 +209,11 @@ int md_op_rgb_to_input(md_device_t dev, const uint8_t* rgb_dev, size_t rgb_len, 
 /* `resize_bilinear_align_corners_false(x, [oh,ow], method)` (interpolate.rs:123-134), fp32 NCHW. */
 int md_op_resize_bilinear(md_device_t dev, const float* in_dev, int B, int C, int H, int W, float* out_dev,
                           int OH, int OW, int method, void* stream);
+/* `resize_bilinear(tensor, [oh, ow], _)` of the Depth-Anything-v3 head (depth_anything3/interpolate.rs:7-47) on the
+ * engine's NHWC feature-map layout: in [B,H,W,C] -> out [B,OH,OW,C], elements of `precision`'s storage type (bf16 / f16
+ * / f32), C a multiple of 8. method MD_INTERP_BURN = align_corners=True (what that head uses), MD_INTERP_CUSTOM = False. */
+int md_op_resize_nhwc(md_device_t dev, const void* in_dev, int B, int H, int W, int C, void* out_dev, int OH, int OW,
+                      int method, int precision, void* stream);
 /* `resize_bilinear_scale` (interpolate.rs:136-145): writes the output dims to oh/ow. */
 int md_op_resize_output_size(int H, int W, float scale_h, float scale_w, int* oh, int* ow);
 /* `DepthProEncoder::split` (encoder.rs:190-232): fp32 NCHW [B,C,S,S] -> [steps^2*B,C,win,win]. */

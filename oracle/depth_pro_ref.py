@@ -13,8 +13,8 @@ PARITY STATUS:
   definition with the switches the reference sets (vit.rs:60-63) and is **parity unpinned**.
 
 Every function cites the reference lines it follows.  ``q`` arguments are operand-quantisers:
-identity for the fp32 oracle; ``bf16_round`` reproduces the points at which the bf16 engine
-stores MFMA operands, so the bf16 GPU path can be checked against a matched CPU emulation.
+identity for the fp32 oracle; ``bf16_round`` / ``f16_round`` reproduce the points at which the bf16 / f16
+engine stores MFMA operands, so those GPU paths can be checked against a matched CPU emulation.
 """
 from __future__ import annotations
 
@@ -38,6 +38,13 @@ def identity(x: Tensor) -> Tensor:
 def bf16_round(x: Tensor) -> Tensor:
     """Round-to-nearest-even to bfloat16 and back (what ``v_cvt_pk_bf16_f32`` does)."""
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def f16_round(x: Tensor) -> Tensor:
+    """Saturate at +-65504, round-to-nearest-even to IEEE half and back (the engine's MD_PREC_F16 stores:
+    ``v_med3_f32`` + ``v_cvt_pk_f16_f32``). The reference's checkpoints are f16 (mod.rs:206), so real weights pass through
+    unchanged."""
+    return x.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
 
 
 # ---------------------------------------------------------------------------------------------
