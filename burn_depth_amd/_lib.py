@@ -91,6 +91,7 @@ SYMBOLS = {
     "md_model_read_launch_order": (_I, [_P, C.POINTER(C.c_char_p), _I, C.POINTER(_I)]),
     "md_op_rgb_to_input": (_I, [_P, _P, C.c_size_t, _I, _I, _P, _P]),
     "md_op_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P]),
+    "md_op_pyramid_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, C.POINTER(_I), C.POINTER(_I), _P]),
     "md_op_resize_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
     "md_op_resize_output_size": (_I, [_I, _I, C.c_float, C.c_float, C.POINTER(_I), C.POINTER(_I)]),
     "md_op_split": (_I, [_P, _P, _I, _I, _I, _I, C.c_float, _P, C.POINTER(_I), _P]),
@@ -105,6 +106,7 @@ SYMBOLS = {
     "md_op_fov_to_focal": (_I, [C.c_float, _I, _I, _F, _F]),
     "md_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
     "md_bench_attention": (_I, [_P, _I, _I, _I, _I, _F]),
+    "md_bench_attention_ex": (_I, [_P, _I, _I, _I, _I, C.c_float, _I, _F]),
     "md_param_inventory": (_I, [C.POINTER(MdDepthProCfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_uniform_stream": (_I, [C.c_char_p, C.c_uint64, C.c_size_t, C.c_float, C.c_float, _P]),
     "md_split_geometry": (_I, [_I, _I, C.c_float, C.POINTER(_I), C.POINTER(_I)]),

@@ -3,7 +3,7 @@
 //   out[q, h*64 + d] = sum_k softmax_k(q.k / 8) * v[k, d]        head_dim = 64 (ViT-L/16, ViT-S/14)
 //
 // Layout contract (produced by the QKV GEMM epilogue, gemm.hip EPI_QKV):
-//   qk  [rows, 2D]  bf16, row = seq*S + token; q at column h*64, k at column D + h*64
+//   qk  [rows, 2D]  bf16 / f16, row = seq*S + token; q (pre-scaled by kAttnQScale) at column h*64, k at column D + h*64
 //   vT  [seq][head][64][kpad] bf16: V transposed so that keys are contiguous (the P.V MFMA wants
 //       both operands K-contiguous; the transpose is paid once in the GEMM epilogue).
 //
@@ -39,18 +39,37 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// grid: 1-D, q blocks of 128 x heads x sequences; block 256. The block -> (unit, q block) map is
+// grid: 1-D, workgroups of 4 waves = 4 x 32 queries of one (sequence, head); block 256. The block -> (unit, q block) map is
 // XCD-aware: blocks b and b+8 share an XCD, so logical ids are dealt in contiguous ranges per XCD and
 // the q blocks of one (sequence, head) run on ONE XCD -- its K and V^T (148 KB) are fetched into that
 // L2 once instead of once per q block (measured before the remap: 1.0 GB fetched per launch against
 // 0.27 GB of q/k/v).
-template <typename T, bool FP8OUT>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__ qk,
-                                                             const T* __restrict__ vT, T* __restrict__ out,
-                                                             int S, int n_tokens, int heads, int D, int kpad,
-                                                             int qblocks, float out_fp8_inv) {
+//
+// Softmax arithmetic. q arrives PRE-SCALED by head_dim^-0.5 * log2(e) (ops.h kAttnQScale), so the MFMA result is the
+// logit in log2 units and p = 2^(s - m) is one v_exp_f32 with no multiply. Two softmax bodies:
+//  * FAST (bf16 operands): m = 0 for the whole row -- p = 2^s, no running maximum, no subtraction, no rescale of O.
+//    bf16 has the fp32 exponent range, so p, the fp32 sums l and O and the final O / l are exact in the same sense as
+//    with a maximum subtracted as long as nothing leaves the fp32 range. That is CHECKED, not assumed: the true row
+//    maxima of tile 0 must lie within +-32 (no underflow of a whole row), and the row sums must stay below 2^100 (an
+//    overflow to inf or a NaN fails that test too). A wave that fails raises a flag in LDS and the WHOLE workgroup (the
+//    tiles are shared through LDS) runs the pass again in the safe body: rare by construction, and tested with inputs
+//    that force it (tools/gpu_diag.py check_attention).
+//  * SAFE (f16 operands always; bf16 workgroups that failed a check): running maximum with deferred rescale (raised, and
+//    O, l rescaled, only when some row of the wave saw a score more than 2^kDefer above it); p <= 2^kDefer fits f16.
+// Either way the result is softmax(q k^T / 8) v; which body ran only changes rounding.
+//
+// What bounds it (MI355X, T x N = 296 x 577, profiles/r02_attention_*.json and DESIGN.md section 5.2): the first form of
+// this round (running maximum, scale multiply) spent 75 % of the SIMD cycles issuing vector instructions; the fast body
+// issues 34 % fewer and runs 14-16 % faster, after which neither pipe is saturated (vector issue 59 %, matrix 42 %) and
+// the time is the waves' dependent chains: ablations of this kernel -- no exponentials / sums +12 %, no in-loop LDS-DMA
+// +20 %, no barrier 0 %, all three +48 % (837 TFLOP/s) -- and instruction-order experiments (softmax of one key half
+// pinned beside the MFMAs of the other, batched fragment reads, 8-wave workgroups) that all measured within +-4 %.
+template <typename T, bool FP8OUT, bool FAST>
+__global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+                                                           int S, int n_tokens, int heads, int D, int kpad, int qblocks,
+                                                           float out_fp8_inv) {
   constexpr int STAGE = 16384;  // K tile 64x128B + V^T tile 64x128B
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 16];  // two stages | redo flag
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,31 +97,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
     for (int s = 0; s < 4; ++s) qf[s] = *(const i32x4_t*)(qp + s * 32);
   }
 
-  // ---- global->LDS sources: 16 row-groups per stage (8 K + 8 V^T), 4 per wave ----
-  const int lrow = lane >> 3, pc = lane & 7;
-  const char* ksrc[2];
-  const char* vsrc[2];
-  int kmaxrow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (i * 4 + wave) * 8 + lrow;  // tile row 0..63
-    const int lc = pc ^ ((r >> 1) & 7);
-    ksrc[i] = (const char*)(qk + D + head * 64) + lc * 16;  // + key row * two_d * 2 per tile
-    kmaxrow[i] = r;
-    vsrc[i] = (const char*)(vT + (((long)seq * heads + head) * 64 + r) * kpad) + lc * 16;  // + kv0*2 per tile
-  }
-
-  auto issue = [&](int stage, int t) {
-    char* sb = smem + stage * STAGE;
-    const int kv0 = t * 64;
+  // ---- global->LDS: 16 row-groups of 8 rows per stage (8 K + 8 V^T), 2 + 2 per wave: rows r0 .. r0+7 and r0+32 .. r0+39 of
+  //      each tile (the two share one swizzled chunk index). LDS-DMA through buffer descriptors of this (sequence, head):
+  //      the per-lane byte offset is tile-invariant (one VGPR each for K and V^T) and the tile's offset is a scalar, so
+  //      issuing a tile costs no vector instruction (with per-lane 64-bit addresses it cost 12, and 3-6 % of the kernel) ----
+  const int r0 = wave * 8 + (lane >> 3);
+  const int lc0 = (lane & 7) ^ ((r0 >> 1) & 7);
+  const unsigned krow_bytes = (unsigned)(two_d * sizeof(T));
+  // K descriptor: the n_tokens key rows of this (sequence, head). The last tile addresses up to 63 rows past them: whether the
+  // hardware's range check (which covers the vector offset; the scalar offset is implementation-defined) returns zeros for
+  // them or reads them, they are masked below -- the callers keep >= 64 rows of slack behind the last sequence for the latter.
+  const auto ksrd = __builtin_amdgcn_make_buffer_rsrc((void*)(qk + seq_row0 * two_d + D + head * 64), 0, (int)((unsigned)(n_tokens - 1) * krow_bytes + 128u), 0x00020000);
+  const auto vsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
+  const int kvoff = r0 * (int)krow_bytes + lc0 * 16;
+  const int vvoff = r0 * kpad * (int)sizeof(T) + lc0 * 16;
+  const int NT = (n_tokens + 63) / 64;
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(smem + (t & 1) * STAGE + wave * 1024);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int key = kv0 + kmaxrow[i];
-      key = key < n_tokens ? key : n_tokens - 1;  // clamped rows are masked below
-      glds16a(ksrc[i] + (seq_row0 + key) * two_d * 2, sb + (i * 4 + wave) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, sb + i * 4096, 16, kvoff, (t * 64 + i * 32) * (int)krow_bytes, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd, sb + 8192 + i * 4096, 16, vvoff, t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16a(vsrc[i] + (long)kv0 * 2, sb + 8192 + (i * 4 + wave) * 1024);
   };
 
   // LDS read offsets. K rows are read through the bit-2/bit-3 swap; V^T rows (= d) directly.
@@ -119,101 +135,155 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
     voff[dt] = 8192 + R * 128 + ((((R >> 1) & 7) ^ h) << 4);  // chunk (sub*4 + 2s' + h) ^ swz
   }
 
-  f32x16_t o[2];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float cs = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e)
+  constexpr float kDefer = 6.0f;        // log2 units: p <= 64 in the safe body
+  constexpr float kFastRange = 32.0f;   // |row max of tile 0| allowed for the fast body (log2 units)
+  constexpr float kFastSumMax = 1.2676506e30f;  // 2^100: a row sum at or above it (inf / NaN included) fails the fast body
 
-  const int NT = (n_tokens + 63) / 64;
-  issue(0, 0);
-  for (int t = 0; t < NT; ++t) {
-    const int cur = t & 1;
+  f32x16_t o[2];
+  float m_run, l_run;
+  bool bad = false;  // wave-uniform: a fast-body range check failed
+
+  // every wave of the workgroup runs these statements exactly once per tile
+  auto top = [&](int t) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < NT) issue(cur ^ 1, t + 1);
-    if (!active) continue;
-    const char* sb = smem + cur * STAGE;
-
-    // ---- S^T[sub] = K[sub] . Q^T ----
-    f32x16_t st[2];
+    if (t + 1 < NT) issue(t + 1);
+  };
+  // S^T[sub] = K[sub] . Q^T (log2 units: q is pre-scaled); register r of lane half h holds local key (r&7) + 8h + 16(r>>3)
+  auto scores_sub = [&](int t, int sub, f32x16_t& st) __attribute__((always_inline)) {
+    const char* sb = smem + (t & 1) * STAGE;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
-        const f32x16_t cin = s == 0 ? (f32x16_t){0.f} : st[sub];  // first k-step: inline-constant 0 as C
-        st[sub] = mfma32<T>(kf, qf[s], cin);
-      }
+    for (int s = 0; s < 4; ++s) {
+      const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
+      const f32x16_t cin = s == 0 ? (f32x16_t){0.f} : st;  // first k-step: inline-constant 0 as C
+      st = mfma32<T>(kf, qf[s], cin);
     }
-    // register r of lane half h holds local key (r&7) + 8h + 16(r>>3) of the sub-tile
-    const int kv0 = t * 64;
-    if (kv0 + 64 > n_tokens) {
+  };
+  // keys beyond the sequence get -inf (2^-inf = 0); last tile only
+  auto mask_sub = [&](int t, int sub, f32x16_t& st) __attribute__((always_inline)) {
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+    for (int r = 0; r < 16; ++r) {
+      const int key = t * 64 + sub * 32 + (r & 7) + 8 * h + 16 * (r >> 3);
+      if (key >= n_tokens) st[r] = -INFINITY;
+    }
+  };
+  auto max16 = [&](const f32x16_t& st) __attribute__((always_inline)) {
+    float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + sub * 32 + (r & 7) + 8 * h + 16 * (r >> 3);
-          if (key >= n_tokens) st[sub][r] = -INFINITY;
+    for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+    return fmaxf(mx, st[15]);
+  };
+  // p = 2^(s - m) for 32 keys, packed as the B operand of the P.V MFMAs; adds the lane's partial row sums into ps[4]
+  auto exp_pack_sub = [&](const f32x16_t& st, float m, i32x4_t (&pf)[2], float (&ps)[4], auto no_offset) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p[j] = __builtin_amdgcn_exp2f(decltype(no_offset)::value ? st[8 * s2 + j] : st[8 * s2 + j] - m);
+        ps[j & 3] += p[j];
+      }
+      pf[s2][0] = pack2_nosat<T>(p[0], p[1]);
+      pf[s2][1] = pack2_nosat<T>(p[2], p[3]);
+      pf[s2][2] = pack2_nosat<T>(p[4], p[5]);
+      pf[s2][3] = pack2_nosat<T>(p[6], p[7]);
+    }
+  };
+  // O^T[dt] += V^T[dt][keys of sub] . P^T[sub]: k-step s2 holds local keys 16 s2 .. 16 s2 + 15 of the 32-key block
+  auto pv_sub = [&](int t, int sub, const i32x4_t (&pf)[2], int nsteps) __attribute__((always_inline)) {
+    const char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (s2 < nsteps) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const i32x4_t vf = *(const i32x4_t*)(sb + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+          o[dt] = mfma32<T>(vf, pf[s2], o[dt]);
         }
-    }
-    // ---- online softmax (one query per lane; the two lane halves share a query) ----
-    // Deferred rescale: the running max m_run is only raised (and O, l rescaled) when some row of the
-    // wave saw a score more than 2^kDefer above it; otherwise exponentials stay relative to the old
-    // max (p <= 2^kDefer, harmless for bf16's floating-point rounding and the fp32 sums).  With
-    // softmax logits of O(1) spread this fires on the first tile and then almost never, which removes
-    // the 32-register O rescale from nearly every tile.  The final result is exact either way.
-    constexpr float kDefer = 6.0f;  // in log2 units
-    float mx = fmaxf(fmaxf(st[0][0], st[0][1]), st[0][2]);
-#pragma unroll
-    for (int r = 3; r + 1 < 16; r += 2) mx = fmaxf(fmaxf(mx, st[0][r]), st[0][r + 1]);
-    mx = fmaxf(mx, st[0][15]);
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[1][r]), st[1][r + 1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (__any((mx - m_run) * cs > kDefer)) {  // wave-uniform branch
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    const float mc = m_run * cs;
-    float psum = 0.f;
-    i32x4_t pf[2][2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      float p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(st[sub][r] * cs - mc);
-        psum += p[r];
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        pf[sub][s2][0] = pack2_nosat<T>(p[8 * s2 + 0], p[8 * s2 + 1]);
-        pf[sub][s2][1] = pack2_nosat<T>(p[8 * s2 + 2], p[8 * s2 + 3]);
-        pf[sub][s2][2] = pack2_nosat<T>(p[8 * s2 + 4], p[8 * s2 + 5]);
-        pf[sub][s2][3] = pack2_nosat<T>(p[8 * s2 + 6], p[8 * s2 + 7]);
       }
     }
-    l_run += psum;
-    // ---- O^T[dt] += V^T[dt] . P^T ----
+  };
+  // One 64-key tile. SAFE: running maximum; PARTIAL: the sequence ends inside the tile -- blocks and k-steps without a
+  // valid key are skipped (Depth Pro: 577 = 9 x 64 + 1 keys, the last tile costs 4 + 2 MFMAs instead of 16); CHECK: the
+  // fast body's one-time range check on the true row maxima (first tile: key 0 is always valid: finite, +inf or NaN).
+  auto tile = [&](int t, auto safe_c, auto partial_c, auto check_c) __attribute__((always_inline)) {
+    constexpr bool SAFE = decltype(safe_c)::value, PARTIAL = decltype(partial_c)::value, CHECK = decltype(check_c)::value;
+    const int rem = PARTIAL ? n_tokens - t * 64 : 64;  // valid keys of this tile (wave-uniform)
+    const bool two = !PARTIAL || rem > 32;             // the second 32-key block holds valid keys
+    f32x16_t st0, st1;
+    i32x4_t pf0[2], pf1[2];
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    scores_sub(t, 0, st0);
+    if (two) scores_sub(t, 1, st1);
+    if constexpr (PARTIAL) {
+      mask_sub(t, 0, st0);
+      if (two) mask_sub(t, 1, st1);
+    }
+    if constexpr (SAFE || CHECK) {
+      float mx = max16(st0);
+      if (two) mx = fmaxf(mx, max16(st1));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if constexpr (CHECK) bad = __any(!(fabsf(mx) <= kFastRange));
+      if constexpr (SAFE) {
+        if (__any((mx - m_run) > kDefer)) {  // wave-uniform branch
+          const float m_new = fmaxf(m_run, mx);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+          l_run *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+      }
+    }
+    exp_pack_sub(st0, m_run, pf0, ps, std::integral_constant<bool, !SAFE>());
+    pv_sub(t, 0, pf0, PARTIAL && rem <= 16 ? 1 : 2);
+    if (two) {
+      exp_pack_sub(st1, m_run, pf1, ps, std::integral_constant<bool, !SAFE>());
+      pv_sub(t, 1, pf1, PARTIAL && rem <= 48 ? 1 : 2);
+    }
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+  };
+  const bool last_partial = (n_tokens & 63) != 0;
+  const int NFULL = last_partial ? NT - 1 : NT;  // tiles without masked keys
+  // one pass over the keys in the fast (m = 0) or the safe body
+  auto pass = [&](auto safe_c) __attribute__((always_inline)) {
+    constexpr bool SAFE = decltype(safe_c)::value;
+    typedef std::integral_constant<bool, !SAFE> check_t;  // the fast pass checks its first tile
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const i32x4_t vf = *(const i32x4_t*)(sb + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
-          o[dt] = mfma32<T>(vf, pf[sub][s2], o[dt]);
-        }
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    m_run = SAFE ? -INFINITY : 0.f;  // safe: alpha = 2^-inf = 0 multiplies zeros at the first tile
+    l_run = 0.f;
+    issue(0);
+    top(0);
+    if (active) {
+      if (NFULL == 0) tile(0, safe_c, std::true_type(), check_t());
+      else tile(0, safe_c, std::false_type(), check_t());
+    }
+    for (int t = 1; t < NFULL; ++t) {
+      top(t);
+      if (active) tile(t, safe_c, std::false_type(), std::false_type());
+    }
+    if (last_partial && NT > 1) {
+      top(NT - 1);
+      if (active) tile(NT - 1, safe_c, std::true_type(), std::false_type());
+    }
+  };
+  bool use_safe = !FAST;
+  if constexpr (FAST) {
+    int* redo = (int*)(smem + 2 * STAGE);
+    if (tid == 0) *redo = 0;
+    pass(std::false_type());
+    if (active) bad = bad || __any(!(l_run < kFastSumMax));  // a tile row sum >= 2^100, inf or NaN shows in the total
+    if (bad && lane == 0) *redo = 1;
+    __syncthreads();
+    use_safe = *(volatile int*)redo != 0;  // workgroup-uniform
+    if (use_safe) __syncthreads();        // everyone has read the flag and left the last tiles before stage 0 is reloaded
   }
+  if (use_safe) pass(std::true_type());
 
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -221,18 +291,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
   const int q = q0 + c;
   if constexpr (FP8OUT) {  // e4m3 rows for an fp8-operand output projection
     if (q < n_tokens) {
-    char* orow8 = (char*)out + (seq_row0 + q) * (long)D + head * 64;
-    const float sc = inv_l * out_fp8_inv;
+      char* orow8 = (char*)out + (seq_row0 + q) * (long)D + head * 64;
+      const float sc = inv_l * out_fp8_inv;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int d = dt * 32 + 8 * q4 + 4 * h;
-        auto cl = [&](float a) { return __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f); };
-        int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(o[dt][4 * q4]), cl(o[dt][4 * q4 + 1]), 0, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(o[dt][4 * q4 + 2]), cl(o[dt][4 * q4 + 3]), w, true);
-        *(int*)(orow8 + d) = w;
-      }
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int d = dt * 32 + 8 * q4 + 4 * h;
+          auto cl = [&](float a) { return __builtin_amdgcn_fmed3f(a * sc, -448.f, 448.f); };
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(o[dt][4 * q4]), cl(o[dt][4 * q4 + 1]), 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(o[dt][4 * q4 + 2]), cl(o[dt][4 * q4 + 3]), w, true);
+          *(int*)(orow8 + d) = w;
+        }
     }
   } else if (q < n_tokens) {
     T* orow = out + (seq_row0 + q) * (long)D + head * 64;
@@ -252,19 +322,21 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
     MD_FAIL(MD_ERR_INVALID_ARG, "attention: kpad=%d must be a multiple of 64 covering %d keys", kpad, n_tokens);
+  if ((long)S * 2 * D * 2 >= (1L << 31)) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: one sequence of q|k rows exceeds the 2-GB descriptor range");
   const int qblocks = (n_tokens + 127) / 128;
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
+  const dim3 grid((unsigned)blocks), block(256);
   if (out_fp8_inv > 0.f) {
     if (prec != MD_PREC_BF16) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: e4m3 output rows are built for bf16 operands");
-    hipLaunchKernelGGL((attention_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
-                       (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+    hipLaunchKernelGGL((attention_kernel<bf16_t, true, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
+                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
   } else if (prec == MD_PREC_F16) {
-    hipLaunchKernelGGL((attention_kernel<f16_t, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const f16_t*)qk, (const f16_t*)vT,
-                       (f16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+    hipLaunchKernelGGL((attention_kernel<f16_t, false, false>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
+                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
   } else {
-    hipLaunchKernelGGL((attention_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
-                       (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+    hipLaunchKernelGGL((attention_kernel<bf16_t, false, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
+                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
   }
   MD_HIP(hipGetLastError());
   return MD_OK;

@@ -88,6 +88,9 @@ struct GemmParams {
   int heads = 0;
   int kpad = 0;                 // padded key count of V^T rows
   void* vT = nullptr;
+  float qscale = 1.f;           // EPI_QKV: the q columns (n < embed) are stored as (acc + bias) * qscale -- the softmax scale
+                                // head_dim^-0.5 * log2(e) folded into q BEFORE its one rounding to the operand type, so that the
+                                // attention kernel exponentiates the MFMA result directly (v_exp_f32 = 2^x)
   // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = f*f*psC (f = ps_f, 2 or 4); out NHWC [B, f*psH, f*psW, ldo] at +ps_coff
   int psH = 0, psW = 0, psC = 0, ps_coff = 0, ps_f = 2;
   int ps_fast = 0;  // set by launch_gemm: bf16 out, no second output, 8-column groups inside one tap, 32-bit element offsets

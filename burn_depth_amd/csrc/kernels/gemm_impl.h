@@ -232,6 +232,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
     case EPI_QKV: {
       v += *(const f32x4_t*)(bias + n);
       const int two_d = 2 * p.embed;
+      if (n < p.embed) v *= p.qscale;  // embed % 4 == 0: a 4-column vector never straddles q | k
       if (n < two_d) {
         store4<T>((T*)p.out + (long)m * two_d + n, v);
       } else {
@@ -956,6 +957,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int na = n0 + wn * WTN + a * 16 + 4 * q16;
         bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         wq[a] = (wsp && na < p.N) ? *(const f32x4_t*)(wsp + na) * p.ascale : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        if (p.epi == EPI_QKV && na < p.embed) {  // q columns: (acc * w + b) * qscale, folded into the two vectors
+          bq[a] *= p.qscale;
+          wq[a] *= p.qscale;
+        }
       }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {

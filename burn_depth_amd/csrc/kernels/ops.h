@@ -23,7 +23,8 @@ struct PyramidGeom {
   int steps1, stride1;       // level 1 (overlap .5)
   int method;                // MD_INTERP_*
 };
-int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s);
+// force_generic: the grid-stride kernel that serves InterpolationMethod::Burn / odd geometries also for Custom (parity tests).
+int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s, bool force_generic = false);
 
 // Generic ViT patch extraction (any patch size, e.g. 14 for DA3): fp32 NCHW [B,3,H,W] ->
 // A[(b*ph + py)*pw + px][c*ps*ps + ky*ps + kx], row length Kp >= 3*ps*ps (tail zero-filled).
@@ -85,7 +86,7 @@ int launch_pack_fp8_rows(const float* w, int N, int K, int Kp, void* out, float*
 // rope_cos/rope_sin: [max_pos + 1][16] tables (angle = pos * base^(-f/16)). global_pos: every patch at (1,1).
 int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int heads, int pw, const float* q_gamma,
                         const float* q_beta, const float* k_gamma, const float* k_beta, float eps, const float* rope_cos,
-                        const float* rope_sin, int global_pos, int prec, hipStream_t s);
+                        const float* rope_sin, int global_pos, float q_scale, int prec, hipStream_t s);
 // x[b*S + 0, :] = src[0:D] for every sequence (the learned camera token replaces the cls slot)
 int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s);
 // hook = LayerNorm_head( cat( x_local, LayerNorm_final(x) ) ) -> T rows [rows, 2D]; optional raw token-0 concat
@@ -108,12 +109,18 @@ int launch_softmax_rows(float* s, long rows, int n_valid, int ld, float scale, h
 
 // test helpers for the stand-alone attention op: fused fp32 qkv [T, N, 3*heads*64] (timm layout) ->
 // engine layout (qk rows padded to SS per sequence, V transposed), and padded rows -> [T, N, D] fp32.
-int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad, void* qk, void* vT, int prec,
+int launch_qkv_split(const float* qkv, int T, int N, int heads, int SS, int kpad, void* qk, void* vT, float q_scale, int prec,
                      hipStream_t s);
 int launch_unpad_rows(const void* in, int T, int N, int SS, int D, float* out, int prec, hipStream_t s);
 
+// The softmax scale the fused attention expects to find folded into q: head_dim^-0.5 * log2(e) (head_dim = 64). The QKV
+// epilogue (GemmParams::qscale), the q/k-norm + RoPE kernel and the stand-alone op's splitter apply it before q's one
+// rounding to the operand type; the kernel then computes p = 2^(q'.k - m). The fp32 three-kernel path keeps q unscaled.
+constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;
+inline float attn_qscale(int prec) { return prec == MD_PREC_F32 ? 1.0f : kAttnQScale; }
+
 // fused multi-head attention on bf16 / f16 operands (K5; prec = MD_PREC_BF16 | MD_PREC_F16): qk [rows, 2D] (q | k),
-// vT [seq][heads][64][kpad], out [rows, D].
+// q PRE-SCALED by kAttnQScale, vT [seq][heads][64][kpad], out [rows, D].
 // out_fp8_inv > 0 (bf16 only): the output rows are OCP e4m3 bytes (value * out_fp8_inv, saturating).
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
                      int kpad, int prec, hipStream_t s, float out_fp8_inv = 0.f);

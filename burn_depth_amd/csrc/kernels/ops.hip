@@ -169,9 +169,103 @@ __global__ void pyramid_patchify_kernel(const float* __restrict__ x, PyramidGeom
   }
 }
 
-int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s) {
+// The same result from ONE read of the image (InterpolationMethod::Custom, patch size 16): a workgroup owns a
+// 64 x 64 block of one channel plane (= 4 x 4 level-0 patches, 2 x 2 level-1 patches, 1 level-2 patch; every tile origin
+// of every level is a multiple of the patch size, so patches never straddle blocks). The block is staged once in LDS
+// with whole 256-byte row segments; each (patch, channel) is then ONE contiguous run of 256 elements of an A-matrix row
+// and a wave writes it with one instruction per destination tile (overlapping windows: up to 2 x 2 tiles hold a patch).
+// The x0.5 / x0.25 taps of align_corners=False land inside the block (src = 2o + 0.5 and 4o + 1.5), and the values go
+// through the same axis_tap / bilerp arithmetic as the stand-alone resize: bit-identical to the generic kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void pyramid_patchify_blocks_kernel(const float* __restrict__ x, PyramidGeom g, T* __restrict__ out) {
+  constexpr int BS = 64, LD = 68;  // LDS row stride 68 floats: the 16-byte row reads of a 16-row patch spread over the banks
+  __shared__ __attribute__((aligned(16))) float blk[BS * LD];
+  const int S = g.S, nb = S / BS;           // blocks per image side
+  const int grid = g.win / 16, P = grid * grid, K = 3 * 256;
+  const int st0 = g.stride0 / 16, st1 = g.stride1 / 16;  // tile strides in patches
+  int id = blockIdx.x;
+  const int bx = id % nb; id /= nb;
+  const int by = id % nb; id /= nb;
+  const int c = id % 3;
+  const int b = id / 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* plane = x + ((long)b * 3 + c) * (long)S * S + (long)by * BS * S + bx * BS;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // 16 lanes per 256-byte row segment, 4 rows per wave-instruction
+    const int row = (i * 4 + wave) * 4 + (lane >> 4), col = (lane & 15) * 4;
+    *(f32x4_t*)(blk + row * LD + col) = *(const f32x4_t*)(plane + (long)row * S + col);
+  }
+  __syncthreads();
+  const int n0 = g.steps0 * g.steps0 * g.B, n1 = g.steps1 * g.steps1 * g.B;
+  const int ky = lane >> 2, kx = (lane & 3) * 4;  // the lane's 4 pixels of a 16 x 16 patch
+  // destination rows of global patch (gy, gx) of a level: every tile (j, i) of that level whose window holds it
+  auto emit = [&](int level, int gy, int gx, const float* v) __attribute__((always_inline)) {
+    const int steps = level == 0 ? g.steps0 : (level == 1 ? g.steps1 : 1);
+    const int stp = level == 0 ? st0 : (level == 1 ? st1 : 0);
+    const int base = level == 0 ? 0 : (level == 1 ? n0 : n0 + n1);
+    int j0 = 0, j1 = 0, i0 = 0, i1 = 0;
+    if (steps > 1) {
+      j1 = gy / stp; j1 = j1 < steps - 1 ? j1 : steps - 1;            // last tile starting at or before gy
+      j0 = gy - grid + stp >= 0 ? (gy - grid + stp) / stp : 0;        // first tile whose window [stp*j, stp*j + grid) holds gy
+      i1 = gx / stp; i1 = i1 < steps - 1 ? i1 : steps - 1;
+      i0 = gx - grid + stp >= 0 ? (gx - grid + stp) / stp : 0;
+    }
+    for (int j = j0; j <= j1; ++j)
+      for (int i = i0; i <= i1; ++i) {
+        const long tile = base + (long)(j * steps + i) * g.B + b;
+        const long row = tile * P + (gy - j * stp) * grid + (gx - i * stp);
+        store4<T>(out + row * K + c * 256 + ky * 16 + kx, (f32x4_t){v[0], v[1], v[2], v[3]});
+      }
+  };
+  // level 0: 16 patches, 4 per wave (copies)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pi = wave * 4 + q, py = pi >> 2, px = pi & 3;
+    const f32x4_t a = *(const f32x4_t*)(blk + (py * 16 + ky) * LD + px * 16 + kx);
+    const float v[4] = {a[0], a[1], a[2], a[3]};
+    emit(0, by * 4 + py, bx * 4 + px, v);
+  }
+  // level 1 (x0.5): 4 patches, one per wave; level 2 (x0.25): 1 patch, wave 0 again
+  {
+    const int py = wave >> 1, px = wave & 1;
+    const int oy = by * 32 + py * 16 + ky;
+    const AxisTap ty = axis_tap(oy, S, S / 2, MD_INTERP_CUSTOM);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const AxisTap tx = axis_tap(bx * 32 + px * 16 + kx + e, S, S / 2, MD_INTERP_CUSTOM);
+      AxisTap ly = ty, lx = tx;  // block-local taps
+      ly.i0 -= by * BS; ly.i1 -= by * BS; lx.i0 -= bx * BS; lx.i1 -= bx * BS;
+      v[e] = bilerp(blk, LD, ly, lx);
+    }
+    emit(1, by * 2 + py, bx * 2 + px, v);
+  }
+  if (wave == 0) {
+    const AxisTap ty = axis_tap(by * 16 + ky, S, S / 4, MD_INTERP_CUSTOM);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const AxisTap tx = axis_tap(bx * 16 + kx + e, S, S / 4, MD_INTERP_CUSTOM);
+      AxisTap ly = ty, lx = tx;
+      ly.i0 -= by * BS; ly.i1 -= by * BS; lx.i0 -= bx * BS; lx.i1 -= bx * BS;
+      v[e] = bilerp(blk, LD, ly, lx);
+    }
+    emit(2, by, bx, v);
+  }
+}
+
+int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches, int prec, hipStream_t s, bool force_generic) {
   if (g.ps % 8 != 0 || g.win % g.ps != 0 || g.S % 4 != 0)
     MD_FAIL(MD_ERR_UNSUPPORTED, "pyramid: patch %d / window %d / size %d unsupported", g.ps, g.win, g.S);
+  // one-read block kernel: patch 16, whole 64-pixel blocks, tile strides on the patch grid, align_corners=False taps
+  const bool blocks_ok = !force_generic && g.method == MD_INTERP_CUSTOM && g.ps == 16 && g.S % 64 == 0 && g.S == 4 * g.win && g.stride0 % 16 == 0 &&
+                         g.stride1 % 16 == 0 && (g.steps0 - 1) * g.stride0 + g.win == g.S && (g.steps1 - 1) * g.stride1 + g.win == g.S / 2;
+  if (blocks_ok) {
+    const long nblocks = (long)g.B * 3 * (g.S / 64) * (g.S / 64);
+    MD_BY_PREC(prec, hipLaunchKernelGGL(pyramid_patchify_blocks_kernel<T>, dim3((unsigned)nblocks), dim3(256), 0, s, x, g, (T*)patches));
+    MD_HIP(hipGetLastError());
+    return MD_OK;
+  }
   const int grid = g.win / g.ps;
   const long total = (long)(g.steps0 * g.steps0 * g.B + g.steps1 * g.steps1 * g.B + g.B) * grid * grid *
                      (3 * g.ps * g.ps / 8);
@@ -692,7 +786,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, l
                                                            const float* __restrict__ qb, const float* __restrict__ kg,
                                                            const float* __restrict__ kb, float eps,
                                                            const float* __restrict__ rope_cos,
-                                                           const float* __restrict__ rope_sin, int global_pos) {
+                                                           const float* __restrict__ rope_sin, int global_pos, float q_scale) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -724,17 +818,18 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, l
     const int jj = lane & 31, f = jj & 15;
     const float cs = rope_cos[pos * 16 + f], sn = rope_sin[pos * 16 + f];
     const float partner = __shfl_xor(y, 16);
-    const float o = jj < 16 ? y * cs - partner * sn : y * cs + partner * sn;
+    float o = jj < 16 ? y * cs - partner * sn : y * cs + partner * sn;
+    if (!which) o *= q_scale;  // the softmax scale rides on q (see GemmParams::qscale); the LayerNorm above removed the epilogue's
     st1<T>(p, o);
   }
 }
 
 int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int heads, int pw, const float* q_gamma,
                         const float* q_beta, const float* k_gamma, const float* k_beta, float eps, const float* rope_cos,
-                        const float* rope_sin, int global_pos, int prec, hipStream_t s) {
+                        const float* rope_sin, int global_pos, float q_scale, int prec, hipStream_t s) {
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "qk_norm_rope: head_dim must be 64");
   const int grid = grid_for(rows * heads * 2 * 64);
-  MD_BY_PREC(prec, hipLaunchKernelGGL(qk_norm_rope_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)qk, rows, S, n_tokens, D, heads, pw, q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos));
+  MD_BY_PREC(prec, hipLaunchKernelGGL(qk_norm_rope_kernel<T>, dim3(grid), dim3(256), 0, s, (T*)qk, rows, S, n_tokens, D, heads, pw, q_gamma, q_beta, k_gamma, k_beta, eps, rope_cos, rope_sin, global_pos, q_scale));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -961,7 +1056,7 @@ int launch_softmax_rows(float* s, long rows, int n_valid, int ld, float scale, h
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void qkv_split_kernel(const float* __restrict__ qkv, int Tn, int N, int heads, int SS, int kpad,
-                                 T* __restrict__ qk, T* __restrict__ vT) {
+                                 T* __restrict__ qk, T* __restrict__ vT, float q_scale) {
   const int D = heads * 64;
   const long total = (long)Tn * N * 3 * D;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -969,7 +1064,7 @@ __global__ void qkv_split_kernel(const float* __restrict__ qkv, int Tn, int N, i
     const long t = e / (3 * D);
     const int i = (int)(t % N);
     const int seq = (int)(t / N);
-    const float v = qkv[e];
+    const float v = c < D ? qkv[e] * q_scale : qkv[e];
     long dst;
     T* base;
     if (c < 2 * D) {
@@ -984,10 +1079,10 @@ __global__ void qkv_split_kernel(const float* __restrict__ qkv, int Tn, int N, i
   }
 }
 
-int launch_qkv_split(const float* qkv, int Tn, int N, int heads, int SS, int kpad, void* qk, void* vT, int prec,
+int launch_qkv_split(const float* qkv, int Tn, int N, int heads, int SS, int kpad, void* qk, void* vT, float q_scale, int prec,
                      hipStream_t s) {
   const long total = (long)Tn * N * 3 * heads * 64;
-  MD_BY_PREC(prec, hipLaunchKernelGGL(qkv_split_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, qkv, Tn, N, heads, SS, kpad, (T*)qk, (T*)vT));
+  MD_BY_PREC(prec, hipLaunchKernelGGL(qkv_split_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, qkv, Tn, N, heads, SS, kpad, (T*)qk, (T*)vT, q_scale));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

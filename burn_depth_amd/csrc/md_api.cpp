@@ -307,6 +307,23 @@ int md_op_resize_bilinear(md_device_t dev, const float* in_dev, int B, int C, in
   return launch_resize_bilinear(in_dev, B * C, H, W, out_dev, OH, OW, method, 0, pick_stream(dev, stream));
 }
 
+int md_op_pyramid_patchify(md_device_t dev, const float* x_dev, int B, int S, int window, int patch, int method, int precision,
+                           int force_generic, void* out_dev, int* rows_out, int* cols_out, void* stream) {
+  if (!dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || S <= 0 || window <= 0 || patch <= 0 || S != 4 * window || window % patch != 0) MD_FAIL(MD_ERR_SHAPE, "pyramid: S must be 4 * window and window a multiple of the patch size");
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
+  PyramidGeom g;
+  g.B = B; g.S = S; g.win = window; g.ps = patch; g.method = method;
+  split_geometry(S, window, 0.25f, &g.stride0, &g.steps0);      // encoder.rs:329
+  split_geometry(S / 2, window, 0.5f, &g.stride1, &g.steps1);   // encoder.rs:330
+  const int grid = window / patch;
+  if (rows_out) *rows_out = (g.steps0 * g.steps0 + g.steps1 * g.steps1 + 1) * B * grid * grid;
+  if (cols_out) *cols_out = 3 * patch * patch;
+  if (!x_dev || !out_dev) return MD_OK;  // geometry query
+  MD_HIP(hipSetDevice(dev->ordinal));
+  return launch_pyramid_patchify(x_dev, g, out_dev, precision, pick_stream(dev, stream), force_generic != 0);
+}
+
 int md_op_resize_nhwc(md_device_t dev, const void* in_dev, int B, int H, int W, int C, void* out_dev, int OH, int OW, int method,
                       int precision, void* stream) {
   if (!dev || !in_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
@@ -424,7 +441,7 @@ int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int hea
   MD_TRY(qk.alloc(((size_t)T * SS + 64) * 2 * D * es));
   MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * es));
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * es));
-  MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, precision, st));
+  MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, attn_qscale(precision), precision, st));
   if (precision != MD_PREC_F32) {
     MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st));
   } else {
@@ -644,8 +661,9 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   return MD_OK;
 }
 
-int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms) {
+int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int precision, float qk_scale, int iters, float* avg_ms) {
   if (!dev || !avg_ms || T <= 0 || n_tokens <= 0 || heads <= 0 || iters <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "invalid argument");
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "attention bench: bf16 or f16");
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = dev->stream;
   const int D = heads * 64, SS = (n_tokens + 3) / 4 * 4, kpad = (n_tokens + 63) / 64 * 64;
@@ -653,14 +671,14 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
   MD_TRY(qk.alloc(((size_t)T * SS + 64) * 2 * D * 2));
   MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * 2));
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * 2));
-  MD_TRY(fill_random(qk.p, (size_t)T * SS * 2 * D, MD_PREC_BF16, 3, 2.0f, st));
-  MD_TRY(fill_random(vT.p, (size_t)T * heads * 64 * kpad, MD_PREC_BF16, 4, 1.0f, st));
-  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, MD_PREC_BF16, st));
+  MD_TRY(fill_random(qk.p, (size_t)T * SS * 2 * D, precision, 3, qk_scale, st));
+  MD_TRY(fill_random(vT.p, (size_t)T * heads * 64 * kpad, precision, 4, 1.0f, st));
+  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st));
   hipEvent_t e0, e1;
   MD_HIP(hipEventCreate(&e0));
   MD_HIP(hipEventCreate(&e1));
   MD_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, MD_PREC_BF16, st));
+  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st));
   MD_HIP(hipEventRecord(e1, st));
   MD_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -669,6 +687,10 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
   (void)hipEventDestroy(e1);
   *avg_ms = ms / iters;
   return MD_OK;
+}
+
+int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms) {
+  return md_bench_attention_ex(dev, T, n_tokens, heads, MD_PREC_BF16, 0.7f, iters, avg_ms);
 }
 
 namespace {

@@ -615,7 +615,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     {
       GemmParams p;
       p.N = 3 * D; p.K = D; dense(p); p.W[0] = k.qkv_w; p.bias[0] = k.qkv_b; p.A = d->xn; p.lda = D;
-      p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad;
+      p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad; p.qscale = attn_qscale(m->prec);
       if (f8) { p.W[0] = d->w8[i].w[0]; p.wscale[0] = d->w8[i].s[0]; p.ascale = md_model_s::Da3State::kActScale; }
       r.begin("qkv_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
@@ -626,7 +626,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       r.begin("qk_norm_rope");
       MD_TRY(launch_qk_norm_rope(d->qk, rows, SS, NT, D, heads, pw, Bi(a + "q_norm.gamma"), Bi(a + "q_norm.beta"),
                                  Bi(a + "k_norm.gamma"), Bi(a + "k_norm.beta"), c.qk_norm_eps, d->rope_cos, d->rope_sin,
-                                 is_global ? 1 : 0, m->prec, st));
+                                 is_global ? 1 : 0, attn_qscale(m->prec), m->prec, st));
       r.end();
     }
     if (m->prec != MD_PREC_F32) {

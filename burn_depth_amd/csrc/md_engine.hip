@@ -732,7 +732,7 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       p.N = 3 * D; p.K = D; group_rows(p);
       for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].qkv_w; p.bias[g] = m->vit[g].blk[i].qkv_b; }
       p.A = b->xn; p.lda = D;
-      p.epi = EPI_QKV; p.out = b->qk; p.vT = b->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = m->kpad;
+      p.epi = EPI_QKV; p.out = b->qk; p.vT = b->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = m->kpad; p.qscale = attn_qscale(m->prec);
       r.begin("qkv_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();

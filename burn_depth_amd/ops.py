@@ -53,6 +53,25 @@ def resize_nhwc(dev: Device, x: torch.Tensor, out_hw: Tuple[int, int], method: i
     return out
 
 
+_PREC_DTYPE = {0: torch.bfloat16, 1: torch.float32, 3: torch.float16}
+
+
+def pyramid_patchify(dev: Device, x: torch.Tensor, window: int, patch: int = 16, method: int = 0, precision: int = 1,
+                     force_generic: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Pyramid + sliding-window split + patch extraction of DepthProEncoder::forward (encoder.rs:326-344) as the A matrix
+    of the patch-embed GEMM (md_op_pyramid_patchify): x [B,3,S,S] fp32, S = 4 * window -> [35B * (window/patch)^2, 3 * patch^2]."""
+    x = _f32c(x)
+    B, _, S, _ = x.shape
+    rows, cols = C.c_int(), C.c_int()
+    lib = _lib.load()
+    _lib.check(lib.md_op_pyramid_patchify(dev.handle, None, B, S, window, patch, method, precision, 0, None, C.byref(rows), C.byref(cols), None))
+    if out is None:
+        out = torch.empty((rows.value, cols.value), dtype=_PREC_DTYPE[precision], device=x.device)
+    _lib.check(lib.md_op_pyramid_patchify(dev.handle, _p(x), B, S, window, patch, method, precision, int(force_generic), _p(out),
+                                          C.byref(rows), C.byref(cols), _stream_ptr(dev.ordinal)))
+    return out
+
+
 def resize_output_size(H: int, W: int, scale: Tuple[float, float]) -> Tuple[int, int]:
     oh, ow = C.c_int(), C.c_int()
     _lib.check(_lib.load().md_op_resize_output_size(H, W, C.c_float(scale[0]), C.c_float(scale[1]), C.byref(oh), C.byref(ow)))

@@ -209,6 +209,14 @@ int md_op_rgb_to_input(md_device_t dev, const uint8_t* rgb_dev, size_t rgb_len, 
 /* `resize_bilinear_align_corners_false(x, [oh,ow], method)` (interpolate.rs:123-134), fp32 NCHW. */
 int md_op_resize_bilinear(md_device_t dev, const float* in_dev, int B, int C, int H, int W, float* out_dev,
                           int OH, int OW, int method, void* stream);
+/* The front of `DepthProEncoder::forward` as the engine runs it (encoder.rs:326-344): pyramid x1 = resize(x, 0.5),
+ * x2 = resize(x, 0.25); split(x0, 0.25) | split(x1, 0.5) | x2 concatenated on dim 0 ([35B,3,win,win]); and the ViT's
+ * patch extraction, written as the A matrix of the patch-embed GEMM: out[(tile * P + py * g + px)][c * ps^2 + ky * ps + kx]
+ * in `precision`'s storage type. x [B,3,S,S] fp32 with S = 4 * window. rows_out / cols_out receive the matrix shape (pass
+ * x_dev = out_dev = NULL to query it). force_generic != 0 selects the grid-stride kernel that serves
+ * InterpolationMethod::Burn also for Custom (the one-read LDS-staged kernel is the default for Custom, patch 16). */
+int md_op_pyramid_patchify(md_device_t dev, const float* x_dev, int B, int S, int window, int patch, int method, int precision,
+                           int force_generic, void* out_dev, int* rows_out, int* cols_out, void* stream);
 /* `resize_bilinear(tensor, [oh, ow], _)` of the Depth-Anything-v3 head (depth_anything3/interpolate.rs:7-47) on the
  * engine's NHWC feature-map layout: in [B,H,W,C] -> out [B,OH,OW,C], elements of `precision`'s storage type (bf16 / f16
  * / f32), C a multiple of 8. method MD_INTERP_BURN = align_corners=True (what that head uses), MD_INTERP_CUSTOM = False. */
@@ -263,6 +271,11 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
                   float* avg_ms);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
+/* The same with the operand type (MD_PREC_BF16 | MD_PREC_F16) and the range of the random q / k values, uniform in
+ * +-qk_scale (q is taken as already carrying the softmax scale): 0.7 gives logits of a few units (the bf16 kernel's fast
+ * body), 4.0 and above logits beyond its +-32 check (the running-maximum body). */
+int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int precision, float qk_scale, int iters,
+                          float* avg_ms);
 
 /* ---- host-only utilities (no GPU needed) ---------------------------------------------------- */
 /* The parameter inventory of `DepthPro::new` for a config: returns the number of parameters; for

@@ -197,7 +197,7 @@ def rope2d(t: Tensor, pos: Tensor, base: float) -> Tensor:
 
 def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8: bool = False):
     """Returns (hooks: 4 x [B, P, 2D] with the second half final-norm'ed, camera feature [B, 2D] of the last hook)."""
-    from oracle.depth_pro_ref import interpolate_pos_encoding, linear_quantisers
+    from oracle.depth_pro_ref import interpolate_pos_encoding, linear_quantisers, round_q_prescaled
     qn, qo, qh, qw = linear_quantisers(q, fp8)
     v = cfg.vit()
     bp = "backbone.pretrained"
@@ -221,14 +221,14 @@ def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8:
             xs = torch.cat([p("camera_token")[:, :1].expand(B, 1, D), xs[:, 1:]], 1)
         is_global = ext and i % 2 == 1
         xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
-        qkv = q(F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
+        qkv = F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias"))
         qkv = qkv.reshape(B, N, 3, Hn, hd).permute(2, 0, 3, 1, 4)
-        qq, kk, vv = qkv[0], qkv[1], qkv[2]
+        qq, kk, vv = round_q_prescaled(qkv[0], q), q(qkv[1]), q(qkv[2])
         if ext:
             pos = pos_g if is_global else pos_l
             qq = F.layer_norm(qq, (hd,), p(f"{b}.attn.q_norm.gamma"), p(f"{b}.attn.q_norm.beta"), cfg.qk_norm_eps)
             kk = F.layer_norm(kk, (hd,), p(f"{b}.attn.k_norm.gamma"), p(f"{b}.attn.k_norm.beta"), cfg.qk_norm_eps)
-            qq, kk = q(rope2d(qq, pos, cfg.rope_frequency)), q(rope2d(kk, pos, cfg.rope_frequency))
+            qq, kk = round_q_prescaled(rope2d(qq, pos, cfg.rope_frequency), q), q(rope2d(kk, pos, cfg.rope_frequency))
         sc = (qq @ kk.transpose(-2, -1)) * hd ** -0.5
         pu = torch.exp(sc - sc.amax(-1, keepdim=True))
         o = (q(pu) @ vv) / pu.sum(-1, keepdim=True)

@@ -277,6 +277,18 @@ def interpolate_pos_encoding(pos: Tensor, gh: int, gw: int) -> Tensor:
     return torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], 1)
 
 
+ATTN_QSCALE = float(np.float32(0.125) * np.float32(1.4426950408889634))  # head_dim^-0.5 * log2(e), head_dim = 64
+
+
+def round_q_prescaled(qq: Tensor, q: Quant) -> Tensor:
+    """Operand-rounding emulation of the engine's q: the softmax scale is folded into q BEFORE its one rounding to the
+    operand type (csrc/kernels/ops.h kAttnQScale), so the rounded value is q * scale; returned un-scaled again so that the
+    caller's softmax(q k^T * head_dim^-0.5) stays as the reference writes it. Identity for the fp32 oracle."""
+    if q is identity:
+        return qq
+    return q(qq * ATTN_QSCALE) / ATTN_QSCALE
+
+
 def _vit_forward_chunk(x, W, prefix, v, hook_ids, q, fp8=False):
     B = x.shape[0]
     qn, qo, qh, qw = linear_quantisers(q, fp8)
@@ -292,9 +304,9 @@ def _vit_forward_chunk(x, W, prefix, v, hook_ids, q, fp8=False):
     for i in range(v.depth):
         b = f"blocks.{i}"
         xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
-        qkv = q(F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias")))
+        qkv = F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias"))
         qkv = qkv.reshape(B, N, 3, Hn, hd).permute(2, 0, 3, 1, 4)
-        qq, kk, vv = qkv[0], qkv[1], qkv[2]
+        qq, kk, vv = round_q_prescaled(qkv[0], q), q(qkv[1]), q(qkv[2])
         s = (qq @ kk.transpose(-2, -1)) * scale
         pu = torch.exp(s - s.amax(-1, keepdim=True))
         o = (q(pu) @ vv) / pu.sum(-1, keepdim=True)
