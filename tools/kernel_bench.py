@@ -20,7 +20,7 @@ def main():
     big = 37 * 580 * 4
     gemms += [("qkvB4", 0, big, 3072, 1024, 0, 0), ("fc1B4", 0, big, 4096, 1024, 0, 0), ("projB4", 0, big, 1024, 1024, 0, 0),
               ("fc2B4", 0, big, 1024, 4096, 0, 0)]
-    tiles = [(0, "256pp16"), (0 + 1024, "256pp16_gelu"), (0 + 8 * 256, "pixshuf"), (0 + (8 + 32) * 256, "pixshuf_stamps"), (0 + 16 * 256, "256pp16_rmw"), (0 + (16 + 32) * 256, "rmw_stamps"), (0 + 32 * 256, "256pp16_stamps"), (0 + (32 + 64) * 256, "stamps_nostore"), (0 + (32 + 128) * 256, "stamps_nostage"), (0 + (32 + 64 + 128) * 256, "stamps_nostore_nostage"), (0 + (32 + 4) * 256, "256pp16_gelu_stamps"), (5, "256pp"), (4, "256v2"), (3, "256v1"), (1, "128v1"), (0 + 256, "256pp16_noloads"), (5 + 256, "256pp_noloads"), (4 + 256, "256v2_noloads"), (0 + 512, "256pp_freezek"), (0 + 512 + 256, "256pp16_freezek_noloads")]
+    tiles = [(0, "256pp16"), (0 + 1024, "256pp16_gelu"), (0 + 8 * 256, "pixshuf"), (0 + (8 + 32) * 256, "pixshuf_stamps"), (0 + 16 * 256, "256pp16_rmw"), (0 + (16 + 32) * 256, "rmw_stamps"), (0 + 32 * 256, "256pp16_stamps"), (0 + (32 + 64) * 256, "stamps_nostore"), (0 + (32 + 128) * 256, "stamps_nostage"), (0 + (32 + 64 + 128) * 256, "stamps_nostore_nostage"), (0 + (32 + 4) * 256, "256pp16_gelu_stamps"), (1, "128v1"), (0 + 256, "256pp16_noloads"), (0 + 512, "256pp_freezek"), (0 + 512 + 256, "256pp16_freezek_noloads")]
     gemms += [("hd_k128", 0, 4 * 768 * 768, 512, 128, 0, 0), ("hd_k256", 0, 4 * 768 * 768, 512, 256, 0, 0), ("hd_k512", 0, 4 * 768 * 768, 512, 512, 0, 0)]
     gemms += [("dense768_2304", 0, 768 * 768, 256, 2304, 0, 0)]
     gemms += [("headdeconv", 0, 4 * 768 * 768, 256, 128, 4 * 768, 768), ("decdeconv", 0, 4 * 384 * 384, 1024, 256, 4 * 384, 384)]
