@@ -84,8 +84,9 @@ def work_model(cfg, B: int):
     fl["dec_deconv_out"] = sum(2.0 * 4 * F * F * px(hw[l]) for l in range(1, 5))
     fl["dec_out_conv"] = 2.0 * F * F * px(hw[0])
     fl["head_conv0"] = 2.0 * 9 * F * (F // 2) * px(hw[0])
-    fl["head_deconv"] = 2.0 * 4 * (F // 2) ** 2 * px(hw[0])
-    fl["head_conv1_fused"] = 2.0 * (9 * (F // 2) * 32 + 32) * px(2 * hw[0])
+    # deconv k2s2 -> conv1 3x3 -> conv_out 1x1 (mod.rs:106-111) run as one composed 3x3 convolution with 4 x 32 columns on
+    # conv0's output: executed flops (the unfused pair is 1.45x that)
+    fl["head_tail_fused"] = 2.0 * (9 * (F // 2) * 128 + 4 * 32) * px(hw[0])
     by = {}
     esz = 4.0 if int(cfg.precision) == 1 else 2.0
     by["pyramid_patchify"] = B * 3 * S * S * 4.0 + (35 * B) * P * 3 * v.patch_size ** 2 * esz

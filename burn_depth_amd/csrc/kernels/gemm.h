@@ -18,7 +18,9 @@ enum EpiMode : int {
   EPI_PATCH_EMBED = 2,  // x(f32)[seq*S + 1 + p] = acc + bias + pos[1+p]     (patch embed + pos embed)
   EPI_QKV = 3,          // q,k -> row-major T; v -> transposed V^T[seq][head][d][key]
   EPI_PIXSHUF = 4,      // ConvTranspose2d k=s=2 as GEMM: pixel-shuffle scatter (+bias, + relu copy)
-  EPI_HEAD = 5          // depth head tail: relu(conv1) . w_out + b_out, relu  -> f32 [M]
+  EPI_HEAD = 5,         // depth head tail: relu(conv1) . w_out + b_out, relu  -> f32 [M]
+  EPI_HEAD_UP2 = 6      // the same tail behind the composed `deconv k2s2 -> conv 3x3` (N = 4 x 32: one 32-column group per
+                        // output parity, bias = nine position-class vectors [9][32]) -> f32 [B][2H][2W]; conv3x3 A mode only
 };
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
@@ -106,7 +108,7 @@ struct GemmParams {
   // bit3 no staging writes
   int debug_flags = 0;
   unsigned long long* stamps = nullptr;  // timing-only: [blocks][16] stamps: 8 x s_memrealtime, then 2 x shader clock around the main loop (md_bench_gemm)
-  // EPI_HEAD
+  // EPI_HEAD / EPI_HEAD_UP2
   const float* head_w = nullptr;  // [32]
   float head_b = 0.f;
   int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear, 3 exp + 1 (DA3 confidence, dpt.rs:497)

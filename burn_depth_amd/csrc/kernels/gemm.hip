@@ -43,6 +43,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   if (p.batch > 1 && (p.epi != EPI_STORE || p.res1 || p.res2 || p.batch > 65535 || p.batch_inner < 1))
     MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: batching supports the plain store epilogue only (batch=%d)", p.batch);
   if (p.epi == EPI_HEAD && p.N != 32) MD_FAIL(MD_ERR_UNSUPPORTED, "head epilogue needs N == 32");
+  if (p.epi == EPI_HEAD_UP2) {
+    if (p.N != 128 || amode != A_CONV3 || p.cstride != 1 || p.cOW > 0 || p.cOH > 0 || p.ngroups != 1 || !p.bias[0] || !p.head_w)
+      MD_FAIL(MD_ERR_UNSUPPORTED, "composed head epilogue: a stride-1 3x3 convolution with N == 4 x 32 and the 9 x 32 bias table");
+    tile = TILE_128x128;
+  }
   for (int g = 0; g < p.ngroups; ++g) {
     if (p.g_rows[g] <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has %d rows", g, p.g_rows[g]);
     if (!p.W[g]) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: group %d has no weights", g);

@@ -477,6 +477,52 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     }
     return;
   }
+  if (p.epi == EPI_HEAD_UP2) {
+    // Depth Pro's head behind the composed deconv -> conv1 (mod.rs:105-111; weights: compose_head_kernel): GEMM row m is
+    // input pixel (img, y, x), the 32-column group q = 2*py + px is output pixel (2y+py, 2x+px). This wave's columns
+    // wn*64 + a*32 are the groups (py = wn, px = a): one 8-byte store per row covers both px. The bias vector is picked
+    // by the output pixel's position class (first / interior / last row x column), see compose_head_bias_kernel.
+    if constexpr (AMODE == A_CONV3 && BN == 128 && WGN == 2 && TN == 2) {
+      const float* bias9 = MD_SEL_G(p.bias, g);
+      f32x4_t hw4[4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) hw4[q4] = *(const f32x4_t*)(p.head_w + 8 * q4 + 4 * h);
+      const int H2 = 2 * p.cH, W2 = 2 * p.cW;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = m_base + wm * WTM + b * 32 + (lane & 31);
+        const int mc = m < m_end ? m : m_end - 1;
+        const int t2 = fdiv(mc, p.fd_ow);
+        const int x = mc - t2 * p.cW;
+        const int img = fdiv(t2, p.fd_oh);
+        const int y = t2 - img * p.cH;
+        const int Y = 2 * y + wn;
+        const int ry = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
+        float z[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int X = 2 * x + a;
+          const int rx = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
+          const float* bc = bias9 + (ry * 3 + rx) * 32 + 4 * h;
+          float part = 0.f;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4_t bv = *(const f32x4_t*)(bc + 8 * q4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part += fmaxf(acc[a][b][4 * q4 + j] + bv[j], 0.f) * hw4[q4][j];
+          }
+          part += __shfl_xor(part, 32);
+          const float zz = part + p.head_b;
+          z[a] = p.head_act == 1 ? expf(zz) : (p.head_act == 2 ? zz : (p.head_act == 3 ? expf(zz) + 1.0f : fmaxf(zz, 0.f)));
+        }
+        if (h == 0 && m < m_end) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+          *(f32x2_t*)((float*)p.out + ((long)img * H2 + Y) * W2 + 2 * x) = (f32x2_t){z[0], z[1]};
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll

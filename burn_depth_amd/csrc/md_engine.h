@@ -37,13 +37,17 @@ int feature_padding(int patch_size, int stride, int feature_patch_size);
 void merge_source(int Y, int X, int h, int w, int steps, int pad, int* j, int* i, int* ty, int* tx);
 int merged_extent(int h, int steps, int pad);
 
-enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT = 3 };
+// PACK_HEAD_W / PACK_HEAD_B: the depth head's `deconv k2s2 (+bias) -> conv 3x3` pair (mod.rs:105-108, nothing between
+// them) composed at commit into ONE 3x3 convolution on the deconv's input grid with 4 x Cout output columns (one group
+// per output parity) and its nine position-class bias vectors (compose_head_kernel in md_engine.hip).
+enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT = 3, PACK_HEAD_W = 4, PACK_HEAD_B = 5 };
 
 struct PackEntry {
-  int param = -1;   // index into params
-  int param2 = -1;  // PACK_DECONV only: 1x1 conv weight [Cout,Cout] composed behind the deconv at commit
+  int param = -1;   // index into params (PACK_HEAD_*: the deconv weight [Cin,Cmid,2,2])
+  int param2 = -1;  // PACK_DECONV only: 1x1 conv weight [Cout,Cout] composed behind the deconv at commit; PACK_HEAD_*: conv weight [Cout,Cmid,3,3]
+  int param3 = -1, param4 = -1;  // PACK_HEAD_B: deconv bias [Cmid], conv bias [Cout]
   int kind = PACK_NK;
-  int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k
+  int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k | HEAD_W/B: Cout, Cin (k = Cmid)
   int kp = 0;       // padded contraction length per tap (elements)
   int f32 = 0;      // packed as f32 regardless of precision (direct conv)
   void* dst = nullptr;

@@ -115,6 +115,70 @@ int compose_deconv_conv(const float* wd, const float* wo, int cin, int cmid, int
   return MD_OK;
 }
 
+// Depth head, mod.rs:105-108: ConvTranspose2d k2 s2 (Wd [Cin,Cmid,2,2], bias bd) -> Conv2d 3x3 pad 1 (W1 [Cout,Cmid,3,3],
+// bias b1) with nothing between them. Output pixel (2y+py, 2x+px) of the pair reads deconv pixels (2y+py+u-1, 2x+px+v-1),
+// u, v in 0..2, i.e. input pixels (y+a, x+b) with a = floor((py+u-1)/2), through deconv tap ((py+u-1)&1, (px+v-1)&1):
+// the pair is ONE 3x3 convolution on the deconv's INPUT grid with 4*Cout output columns, column (py, px, co):
+//   Wc[(2py+px)*Cout + co][ci][a+1][b+1] = sum_{u -> a} sum_{v -> b} sum_mid W1[co][mid][u][v] * Wd[ci][mid][dy][dx]
+// (4 of the 9 input taps are non-zero per parity). `out` has the [N][Cin][3][3] layout pack_kernel(PACK_CONV3) reads.
+__global__ void compose_head_kernel(const float* __restrict__ wd, const float* __restrict__ w1, int cin, int cmid, int cout,
+                                    float* __restrict__ out) {
+  const long total = 4L * cout * cin * 9;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e % 9);
+    const int ci = (int)((e / 9) % cin);
+    const int n = (int)(e / 9 / cin);
+    const int q = n / cout, co = n - q * cout, py = q >> 1, px = q & 1;
+    const int a = tap / 3 - 1, b = tap % 3 - 1;
+    float acc = 0.f;
+    for (int u = 0; u < 3; ++u) {
+      if ((py + u + 1) / 2 - 1 != a) continue;
+      const int dy = (py + u + 1) & 1;
+      for (int v = 0; v < 3; ++v) {
+        if ((px + v + 1) / 2 - 1 != b) continue;
+        const int dx = (px + v + 1) & 1;
+        for (int mid = 0; mid < cmid; ++mid)
+          acc += w1[(((long)co * cmid + mid) * 3 + u) * 3 + v] * wd[(((long)ci * cmid + mid) * 2 + dy) * 2 + dx];
+      }
+    }
+    out[e] = acc;
+  }
+}
+
+// The deconv bias reaches the conv through every tap that lies INSIDE the 2H x 2W map (the conv zero-pads the deconv's
+// output, bias included), so the pair's bias depends on the position class of the output pixel:
+//   bias[3*ry + rx][co] = b1[co] + sum_{u valid for ry} sum_{v valid for rx} sum_mid W1[co][mid][u][v] * bd[mid]
+// ry = 0 first row (u = 0 outside), 1 interior, 2 last row (u = 2 outside); rx likewise.
+__global__ void compose_head_bias_kernel(const float* __restrict__ w1, const float* __restrict__ bd, const float* __restrict__ b1,
+                                         int cmid, int cout, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 9 * cout) return;
+  const int cls = e / cout, co = e - cls * cout, ry = cls / 3, rx = cls % 3;
+  float acc = b1[co];
+  for (int u = 0; u < 3; ++u) {
+    if ((ry == 0 && u == 0) || (ry == 2 && u == 2)) continue;
+    for (int v = 0; v < 3; ++v) {
+      if ((rx == 0 && v == 0) || (rx == 2 && v == 2)) continue;
+      for (int mid = 0; mid < cmid; ++mid) acc += w1[(((long)co * cmid + mid) * 3 + u) * 3 + v] * bd[mid];
+    }
+  }
+  out[e] = acc;
+}
+
+int compose_head(const float* wd, const float* w1, int cin, int cmid, int cout, float* out, hipStream_t s) {
+  const long total = 4L * cout * cin * 9;
+  hipLaunchKernelGGL(compose_head_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, wd, w1, cin,
+                     cmid, cout, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+int compose_head_bias(const float* w1, const float* bd, const float* b1, int cmid, int cout, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(compose_head_bias_kernel, dim3((9 * cout + 255) / 256), dim3(256), 0, s, w1, bd, b1, cmid, cout, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s) {
   const long total = (long)pack_elems(e);
   const int grid = (int)std::min<long>((total + 255) / 256, 4096);
@@ -381,7 +445,7 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   }
   add_pack(m, "head.conv0.weight", PACK_CONV3, F / 2, F, 3);
   add_pack(m, "head.deconv.weight", PACK_DECONV, F / 2, F / 2, 2);
-  add_pack(m, "head.conv1.weight", PACK_CONV3, 32, F / 2, 3);
+  add_pack_head_fused(m, "head.deconv_conv1", "head.deconv", "head.conv1", F / 2, F / 2, 32);
   if (cfg.use_fov_head) {
     if (cfg.has_fov_vit) {
       add_pack(m, "fov.encoder_proj.weight", PACK_NK, F / 2, cfg.fv.D, 1);
@@ -601,16 +665,27 @@ int model_commit(md_model_t m) {
   if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: commit on the root model");
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t s = m->dev->stream;
-  float* composed = nullptr;
+  float* composed = nullptr;  // fp32 staging of a composed weight
+  size_t composed_elems = 0;
   for (auto& e : m->packs) {
-    if (e.param2 < 0) {
+    if (e.kind == PACK_HEAD_W) composed_elems = std::max(composed_elems, (size_t)4 * e.d0 * e.d1 * 9);
+    else if (e.param2 >= 0) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * 4);
+  }
+  if (composed_elems) MD_HIP(hipMalloc((void**)&composed, composed_elems * sizeof(float)));
+  for (auto& e : m->packs) {
+    if (e.kind == PACK_HEAD_W) {  // deconv -> conv3x3 of the depth head as one conv (d0 = Cout, d1 = Cin, k = Cmid)
+      MD_TRY(compose_head(m->w32[e.param], m->w32[e.param2], e.d1, e.k, e.d0, composed, s));
+      PackEntry c3 = e;
+      c3.kind = PACK_CONV3; c3.d0 = 4 * e.d0; c3.k = 3;
+      MD_TRY(pack_weight(composed, c3, m->prec, s));
+    } else if (e.kind == PACK_HEAD_B) {
+      MD_TRY(compose_head_bias(m->w32[e.param2], m->w32[e.param3], m->w32[e.param4], e.k, e.d0, (float*)e.dst, s));
+    } else if (e.param2 < 0) {
       MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
-      continue;
+    } else {
+      MD_TRY(compose_deconv_conv(m->w32[e.param], m->w32[e.param2], e.d0, e.d1, e.d1, composed, s));
+      MD_TRY(pack_weight(composed, e, m->prec, s));
     }
-    if (!composed) MD_HIP(hipMalloc((void**)&composed, (size_t)m->cfg.F * m->cfg.F * 4 * sizeof(float)));
-    if ((size_t)e.d0 * e.d1 > (size_t)m->cfg.F * m->cfg.F) MD_FAIL(MD_ERR_UNSUPPORTED, "composed deconv larger than the staging buffer");
-    MD_TRY(compose_deconv_conv(m->w32[e.param], m->w32[e.param2], e.d0, e.d1, e.d1, composed, s));
-    MD_TRY(pack_weight(composed, e, m->prec, s));
   }
   auto it = m->pindex.find(m->kind == 1 ? "head_mono.scratch.output_conv2.conv2.bias" : "head.conv_out.bias");
   if (it != m->pindex.end()) MD_HIP(hipMemcpyAsync(&m->head_b_host, m->w32[it->second], 4, hipMemcpyDeviceToHost, s));
@@ -937,20 +1012,25 @@ static int run_decoder_head(Run& r) {
   const int F2 = F / 2, F2p = cpad(m, F2);
   MD_TRY(conv3(r, "head_conv0", feats, hw[0], hw[0], Fp, W("head.conv0.weight"), Bi("head.conv0.bias"), F2, b->h0, F2p,
                ACT_NONE, nullptr, nullptr, nullptr));
-  MD_TRY(deconv2(r, "head_deconv", b->h0, F2p, nullptr, hw[0], hw[0], W("head.deconv.weight"), F2p, F2,
-                 Bi("head.deconv.bias"), b->h1, F2p, 0));
   if (m->taps_enabled) {
+    // the deconv's output exists only as a debug tap: the product path below never materialises the 2x-resolution map
+    MD_TRY(deconv2(r, "head_deconv_tap", b->h0, F2p, nullptr, hw[0], hw[0], W("head.deconv.weight"), F2p, F2,
+                   Bi("head.deconv.bias"), b->h1, F2p, 0));
     MD_TRY(r.tap_nhwc("head_conv0", b->h0, F2, hw[0], hw[0], F2p));
     MD_TRY(r.tap_nhwc("head_deconv", b->h1, F2, 2 * hw[0], 2 * hw[0], F2p));
   }
   {
+    // deconv k2s2 -> conv1 3x3 -> relu -> conv_out 1x1 -> relu (mod.rs:106-111) as ONE 3x3 convolution on conv0's output:
+    // deconv and conv1 have nothing between them, so their product is packed at commit (add_pack_head_fused) as a 3x3
+    // weight with 4 x 32 output columns, one 32-column group per output parity; the epilogue finishes the 1x1 tail.
     GemmParams p;
-    p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = r.B * 4 * hw[0] * hw[0]; p.W[0] = W("head.conv1.weight");
-    p.A = b->h1; p.cH = 2 * hw[0]; p.cW = 2 * hw[0]; p.cC = F2p; p.zero_page = m->zero_page;
-    p.epi = EPI_HEAD; p.bias[0] = Bi("head.conv1.bias"); p.head_w = Bi("head.conv_out.weight"); p.head_b = model_root(m)->head_b_host;
+    p.N = 4 * 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = r.B * hw[0] * hw[0]; p.W[0] = W("head.deconv_conv1.weight");
+    p.A = b->h0; p.cH = hw[0]; p.cW = hw[0]; p.cC = F2p; p.zero_page = m->zero_page;
+    p.epi = EPI_HEAD_UP2; p.bias[0] = (const float*)PK(m, "head.deconv_conv1.bias"); p.head_w = Bi("head.conv_out.weight");
+    p.head_b = model_root(m)->head_b_host;
     p.out = b->canonical;
-    r.begin("head_conv1_fused");
-    MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, r.st));
+    r.begin("head_tail_fused");
+    MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_128x128, r.st));
     r.end();
   }
   MD_TRY(r.tap_f32("canonical_inverse_depth", b->canonical, r.B, 1, 2 * hw[0], 2 * hw[0]));

@@ -15,6 +15,8 @@ inline size_t pack_elems(const PackEntry& e) {
     case PACK_NK: return (size_t)e.d0 * e.kp;
     case PACK_CONV3: return (size_t)e.d0 * 9 * e.kp;
     case PACK_DECONV: return (size_t)e.k * e.k * e.d1 * e.kp;
+    case PACK_HEAD_W: return (size_t)4 * e.d0 * 9 * e.kp;
+    case PACK_HEAD_B: return (size_t)9 * e.d0;
     default: return (size_t)e.d0 * e.d1 * e.k * e.k;
   }
 }
@@ -62,6 +64,28 @@ inline void add_pack_composed(md_model_s* m, const std::string& name, const std:
   e.kp = round_up(cin, m->ke);
   e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
   m->pack_index[name] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
+// depth head: deconv k2s2 (+bias) -> conv 3x3 (+bias) composed into one 3x3 conv with 4 * cout columns on the deconv's
+// input grid (`name`.weight, PACK_CONV3 layout) and nine position-class bias vectors (`name`.bias, f32 [9][cout])
+inline void add_pack_head_fused(md_model_s* m, const std::string& name, const std::string& deconv, const std::string& conv,
+                                int cin, int cmid, int cout) {
+  auto wd = m->pindex.find(deconv + ".weight"), bd = m->pindex.find(deconv + ".bias");
+  auto wc = m->pindex.find(conv + ".weight"), bc = m->pindex.find(conv + ".bias");
+  if (wd == m->pindex.end() || bd == m->pindex.end() || wc == m->pindex.end() || bc == m->pindex.end()) return;
+  PackEntry e;
+  e.param = wd->second; e.param2 = wc->second; e.param3 = bd->second; e.param4 = bc->second;
+  e.kind = PACK_HEAD_W;
+  e.d0 = cout; e.d1 = cin; e.k = cmid;
+  e.kp = round_up(cin, m->ke);
+  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  m->pack_index[name + ".weight"] = (int)m->packs.size();
+  m->packs.push_back(e);
+  e.kind = PACK_HEAD_B;
+  e.f32 = 1;
+  e.bytes = pack_elems(e) * 4;
+  m->pack_index[name + ".bias"] = (int)m->packs.size();
   m->packs.push_back(e);
 }
 
