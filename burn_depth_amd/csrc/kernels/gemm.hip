@@ -20,11 +20,13 @@ static int pick_tile(const GemmParams& p) {
     t128 += cdiv(p.g_rows[g], 128);
   }
   if (p.N < 256 || rows < 256) return TILE_128x128;
-  // estimated time in units of one 128x128 tile-pass per CU; 256^2 tiles run ~1.25x more
-  // efficiently per flop but leave CUs idle when there are few of them.
+  // Wave quantisation decides between the two: a launch takes whole rounds (256 CUs x one 256^2 tile, or x two 128^2
+  // tiles), and a 128^2 round costs 0.78 of a 256^2 round -- measured on the Depth-Anything-v3 1036^2 shapes (M = 5477,
+  // tools/kernel_bench.py da3_*): qkv 2 rounds of 256^2 54 us against 3 rounds of 128^2 64 us, fc2 1 round 81 us against
+  // 1 round 74 us; the same ratio holds for the e4m3 operands. Large M always lands on 256^2 (half the rounds).
   const long b256 = (long)t256 * cdiv(p.N, 256), b128 = (long)t128 * cdiv(p.N, 128);
-  const double c256 = (double)cdiv(b256, 256) * 4.0 / 1.25;
-  const double c128 = (double)cdiv(b128, 512) * 2.0;
+  const double c256 = (double)cdiv(b256, 256);
+  const double c128 = (double)cdiv(b128, 512) * 0.78;
   return c256 <= c128 ? TILE_256x256 : TILE_128x128;
 }
 

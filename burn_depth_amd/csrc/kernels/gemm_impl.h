@@ -115,6 +115,22 @@ struct Atom16<fp8_t> {
     c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
   }
 };
+// Block-scaled (MX) e4m3 MFMA, `v_mfma_scale_f32_{16x16x128,32x32x64}_f8f6f4`: 32 operand bytes per lane and instruction,
+// twice the FLOPs per clock of the non-scaled fp8 / bf16 forms (MI355X_MICROARCH.md, Matrix cores). Every block scale is
+// the E8M0 byte 127 = 2^0, so the products are the plain e4m3 products and the result equals the non-scaled forms' up to
+// fp32 summation order. A lane's 32 bytes are two 16-byte LDS fragments (k sub-steps s and s+1, read at the same offsets
+// for both operands): which k a lane holds is free as long as A and B agree.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+constexpr int kMxUnitScale = 0x7f7f7f7f;
+__device__ __forceinline__ i32x8_t mx_cat(const i32x4_t& lo, const i32x4_t& hi) {
+  return (i32x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ void mx_mma16(const i32x4_t& a0, const i32x4_t& a1, const i32x4_t& b0, const i32x4_t& b1, f32x4acc_t& c) {
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mx_cat(a0, a1), mx_cat(b0, b1), c, 0, 0, 0, kMxUnitScale, 0, kMxUnitScale);
+}
+__device__ __forceinline__ void mx_mma32(const i32x4_t& a0, const i32x4_t& a1, const i32x4_t& b0, const i32x4_t& b1, f32x16_t& c) {
+  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_cat(a0, a1), mx_cat(b0, b1), c, 0, 0, 0, kMxUnitScale, 0, kMxUnitScale);
+}
 // element type of everything the epilogue reads / writes as "T" (outputs, residuals): bf16 for fp8 operands
 template <typename T>
 struct OutT {
@@ -438,18 +454,40 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     if (kt + 1 < KT) issue(cur ^ 1, kt + 1);
     const char* As = smem + cur * STAGE_BYTES + wm * WTM * 128;
     const char* Ws = smem + cur * STAGE_BYTES + BM * 128 + wn * WTN * 128;
+    if constexpr (std::is_same<T, fp8_t>::value) {  // block-scaled MFMA: two 16-byte sub-steps per instruction
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int off = lane_off ^ (s << 5);
-      i32x4_t af[TM], wf[TN];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int off0 = lane_off ^ ((2 * s2) << 5), off1 = lane_off ^ ((2 * s2 + 1) << 5);
+        i32x4_t af[2][TM], wf[2][TN];
 #pragma unroll
-      for (int b = 0; b < TM; ++b) af[b] = *(const i32x4_t*)(As + b * 4096 + off);
+        for (int b = 0; b < TM; ++b) {
+          af[0][b] = *(const i32x4_t*)(As + b * 4096 + off0);
+          af[1][b] = *(const i32x4_t*)(As + b * 4096 + off1);
+        }
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+        for (int a = 0; a < TN; ++a) {
+          wf[0][a] = *(const i32x4_t*)(Ws + a * 4096 + off0);
+          wf[1][a] = *(const i32x4_t*)(Ws + a * 4096 + off1);
+        }
 #pragma unroll
-      for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[a], af[b], acc[a][b]);
+          for (int b = 0; b < TM; ++b) mx_mma32(wf[0][a], wf[1][a], af[0][b], af[1][b], acc[a][b]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int off = lane_off ^ (s << 5);
+        i32x4_t af[TM], wf[TN];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) af[b] = *(const i32x4_t*)(As + b * 4096 + off);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 4096 + off);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) Atom<T>::mma(wf[a], af[b], acc[a][b]);
+      }
     }
   }
 
@@ -777,6 +815,47 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     stamp[8] = __builtin_readcyclecounter();
   }
   if (g1) __builtin_amdgcn_s_barrier();
+  if constexpr (std::is_same<T, fp8_t>::value) {
+    // e4m3 operands: ONE phase per 128-deep k-tile -- R = 8 W + 16 A fragment reads (both 64-deep halves; a block-scaled
+    // MFMA consumes a half of each) + both LDS-DMA issues, M = 32 x v_mfma_scale_f32_16x16x128_f8f6f4 = 1024 cycles.
+    for (int t = 0; t < KT; ++t) {
+      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+      i32x4_t wf[2][4], af[2][8];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = lane_off16 ^ (ks << 6);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wf[ks][a] = *(const i32x4_t*)(Ws + a * 2048 + off);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) af[ks][b] = *(const i32x4_t*)(As + b * 2048 + off);
+      }
+      if (t == 0) {  // rest of the pipeline fill (see the prologue)
+        if (!(DIAG && no_loads) && !pro_full) {
+          if (KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
+          if (KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
+        }
+      } else {
+        issue_next_W(t);
+        issue_next_A(t);
+      }
+      if (g1 && t + 1 < KT) wait_tile(t + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) mx_mma16(wf[0][a], wf[1][a], af[0][b], af[1][b], acc16[a][b]);
+      if (!g1 && t + 1 < KT) wait_tile(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   for (int t = 0; t < KT; ++t) {
     const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
     const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
@@ -813,6 +892,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
   }
   if (!g1) __builtin_amdgcn_s_barrier();
 

@@ -24,6 +24,9 @@ def main():
     gemms += [("hd_k128", 0, 4 * 768 * 768, 512, 128, 0, 0), ("hd_k256", 0, 4 * 768 * 768, 512, 256, 0, 0), ("hd_k512", 0, 4 * 768 * 768, 512, 512, 0, 0)]
     gemms += [("dense768_2304", 0, 768 * 768, 256, 2304, 0, 0)]
     gemms += [("headdeconv", 0, 4 * 768 * 768, 256, 128, 4 * 768, 768), ("decdeconv", 0, 4 * 384 * 384, 1024, 256, 4 * 384, 384)]
+    n3 = 74 * 74 + 1  # Depth-Anything-v3 at 1036^2 (BASELINE config 5): one sequence of 5477 tokens
+    gemms += [("da3_qkv", 0, n3, 3072, 1024, 0, 0), ("da3_proj", 0, n3, 1024, 1024, 0, 0), ("da3_fc1", 0, n3, 4096, 1024, 0, 0),
+              ("da3_fc2", 0, n3, 1024, 4096, 0, 0)]
     prec = int(os.environ.get("PREC", "0"))
     only = os.environ.get("ONLY")
     if only:
