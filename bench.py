@@ -82,7 +82,7 @@ def work_model(cfg, B: int):
     fl["dec_conv3x3"] = c3
     # deconv + 1x1 out_conv run as one GEMM on the weight product (executed flops, not the unfused count)
     fl["dec_deconv_out"] = sum(2.0 * 4 * F * F * px(hw[l]) for l in range(1, 5))
-    fl["dec_out_conv"] = 2.0 * F * F * px(hw[0])
+    fl["dec_out_conv"] = 2.0 * F * F * px(hw[0])  # composed into head.conv0 at commit: only launched (for its tap) in debug runs
     fl["head_conv0"] = 2.0 * 9 * F * (F // 2) * px(hw[0])
     # deconv k2s2 -> conv1 3x3 -> conv_out 1x1 (mod.rs:106-111) run as one composed 3x3 convolution with 4 x 32 columns on
     # conv0's output: executed flops (the unfused pair is 1.45x that)
@@ -331,7 +331,8 @@ def main(argv=None) -> int:
         gpu_ms = sum(v["ms_per_step"] for v in kernels.values())
         if args.side_kernels:
             kernels.update(side_kernels(dev, tdev))
-        total_flops = sum(fl.values())
+        # executed FLOPs: a family the schedule no longer launches (a layer composed into its neighbour at commit) does not count
+        total_flops = sum(v for k, v in fl.items() if k in kernels)
         out = {
             "metric": "frames/sec Depth Pro @1536^2 bf16" if args.preset == "full" and args.precision == "bf16"
             else f"frames/sec Depth Pro preset={args.preset} {args.precision}",

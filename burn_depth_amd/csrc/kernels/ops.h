@@ -36,6 +36,12 @@ int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* o
 int launch_resize_nhwc(const void* in, int B, int H, int W, int C, long ld_in, void* out, int OH, int OW, long ld_out,
                        int method, const float* addend, int prec, hipStream_t s);
 
+// Border correction of a 3x3 convolution (pad 1) that was composed with a preceding biased 1x1 convolution: the 1x1's bias
+// reaches the output only through taps inside the map, so the composed bias is one of nine position-class vectors
+// bias9[3*ry + rx][C] (ry, rx: 0 first, 1 interior, 2 last row / column). The convolution itself adds the interior vector;
+// this adds bias9[class] - bias9[4] to the 2H + 2W - 4 border pixels of every image of the NHWC map (needs H, W >= 2).
+int launch_border_bias_fix(void* map, int B, int H, int W, int C, long ld, const float* bias9, int prec, hipStream_t s);
+
 // a3 stand-alone split on fp32 NCHW (debug tap / md_op_split).
 int launch_split(const float* x, int B, int C, int S, int win, int stride, int steps, float* out, hipStream_t s);
 // a6 stand-alone merge on fp32 NCHW (encoder.rs:234-282).

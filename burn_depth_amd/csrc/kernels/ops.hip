@@ -394,6 +394,33 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* __restrict__ 
   }
 }
 
+template <typename T>
+__global__ void border_bias_fix_kernel(T* __restrict__ map, int B, int H, int W, int C, long ld, const float* __restrict__ bias9) {
+  const int nb = 2 * W + 2 * H - 4;  // border pixels of one image: top row, bottom row, then the two columns without corners
+  const long total = (long)B * nb * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int t = (int)(e / C);
+    const int k = t % nb, b = t / nb;
+    int Y, X;
+    if (k < W) { Y = 0; X = k; }
+    else if (k < 2 * W) { Y = H - 1; X = k - W; }
+    else if (k < 2 * W + H - 2) { Y = k - 2 * W + 1; X = 0; }
+    else { Y = k - (2 * W + H - 2) + 1; X = W - 1; }
+    const int cls = (Y == 0 ? 0 : (Y == H - 1 ? 2 : 1)) * 3 + (X == 0 ? 0 : (X == W - 1 ? 2 : 1));
+    T* p = map + (((long)b * H + Y) * W + X) * ld + c;
+    st1<T>(p, ld1<T>(p) + (bias9[cls * C + c] - bias9[4 * C + c]));
+  }
+}
+
+int launch_border_bias_fix(void* map, int B, int H, int W, int C, long ld, const float* bias9, int prec, hipStream_t s) {
+  if (H < 2 || W < 2) MD_FAIL(MD_ERR_UNSUPPORTED, "border bias fix: %dx%d map", H, W);
+  const long total = (long)B * (2 * W + 2 * H - 4) * C;
+  MD_BY_PREC(prec, hipLaunchKernelGGL(border_bias_fix_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (T*)map, B, H, W, C, ld, bias9));
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int launch_resize_nhwc(const void* in, int B, int H, int W, int C, long ld_in, void* out, int OH, int OW, long ld_out,
                        int method, const float* addend, int prec, hipStream_t s) {
   if (C % 8 != 0 || OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_UNSUPPORTED, "resize_nhwc: C=%d must be a multiple of 8", C);

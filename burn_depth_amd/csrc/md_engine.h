@@ -40,14 +40,17 @@ int merged_extent(int h, int steps, int pad);
 // PACK_HEAD_W / PACK_HEAD_B: the depth head's `deconv k2s2 (+bias) -> conv 3x3` pair (mod.rs:105-108, nothing between
 // them) composed at commit into ONE 3x3 convolution on the deconv's input grid with 4 x Cout output columns (one group
 // per output parity) and its nine position-class bias vectors (compose_head_kernel in md_engine.hip).
-enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT = 3, PACK_HEAD_W = 4, PACK_HEAD_B = 5 };
+// PACK_C1C3_W / PACK_C1C3_B: a biased 1x1 convolution followed by a 3x3 convolution (the decoder's last `out_conv` and the
+// head's `conv0`, decoder.rs:137 -> mod.rs:105: nothing between them) composed into one 3x3 convolution and its nine
+// position-class bias vectors (compose_c1c3_kernel; the border classes are applied by launch_border_bias_fix).
+enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT = 3, PACK_HEAD_W = 4, PACK_HEAD_B = 5, PACK_C1C3_W = 6, PACK_C1C3_B = 7 };
 
 struct PackEntry {
-  int param = -1;   // index into params (PACK_HEAD_*: the deconv weight [Cin,Cmid,2,2])
+  int param = -1;   // index into params (PACK_HEAD_*: the deconv weight [Cin,Cmid,2,2]; PACK_C1C3_*: the 1x1 weight [Cmid,Cin])
   int param2 = -1;  // PACK_DECONV only: 1x1 conv weight [Cout,Cout] composed behind the deconv at commit; PACK_HEAD_*: conv weight [Cout,Cmid,3,3]
   int param3 = -1, param4 = -1;  // PACK_HEAD_B: deconv bias [Cmid], conv bias [Cout]
   int kind = PACK_NK;
-  int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k | HEAD_W/B: Cout, Cin (k = Cmid)
+  int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k | HEAD_W/B, C1C3_W/B: Cout, Cin (k = Cmid)
   int kp = 0;       // padded contraction length per tap (elements)
   int f32 = 0;      // packed as f32 regardless of precision (direct conv)
   void* dst = nullptr;

@@ -165,6 +165,29 @@ __global__ void compose_head_bias_kernel(const float* __restrict__ w1, const flo
   out[e] = acc;
 }
 
+// conv 1x1 (W1 [Cmid,Cin], bias) -> conv 3x3 (W3 [Cout,Cmid,3,3]): Wc[co][ci][tap] = sum_m W3[co][m][tap] * W1[m][ci];
+// the bias classes are compose_head_bias_kernel's formula with (W3, the 1x1's bias, the 3x3's bias).
+__global__ void compose_c1c3_kernel(const float* __restrict__ w1, const float* __restrict__ w3, int cin, int cmid, int cout,
+                                    float* __restrict__ out) {
+  const long total = (long)cout * cin * 9;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(e % 9);
+    const int ci = (int)((e / 9) % cin);
+    const int co = (int)(e / 9 / cin);
+    float acc = 0.f;
+    for (int mth = 0; mth < cmid; ++mth) acc += w3[((long)co * cmid + mth) * 9 + tap] * w1[(long)mth * cin + ci];
+    out[e] = acc;
+  }
+}
+
+int compose_c1c3(const float* w1, const float* w3, int cin, int cmid, int cout, float* out, hipStream_t s) {
+  const long total = (long)cout * cin * 9;
+  hipLaunchKernelGGL(compose_c1c3_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, w1, w3, cin, cmid,
+                     cout, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int compose_head(const float* wd, const float* w1, int cin, int cmid, int cout, float* out, hipStream_t s) {
   const long total = 4L * cout * cin * 9;
   hipLaunchKernelGGL(compose_head_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, wd, w1, cin,
@@ -444,6 +467,7 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
       add_pack(m, f + ".out_conv.weight", PACK_NK, F, F, 1);
   }
   add_pack(m, "head.conv0.weight", PACK_CONV3, F / 2, F, 3);
+  add_pack_c1c3(m, "head.outconv_conv0", "decoder.fusions.0.out_conv", "head.conv0", F, F, F / 2);
   add_pack(m, "head.deconv.weight", PACK_DECONV, F / 2, F / 2, 2);
   add_pack_head_fused(m, "head.deconv_conv1", "head.deconv", "head.conv1", F / 2, F / 2, 32);
   if (cfg.use_fov_head) {
@@ -669,6 +693,8 @@ int model_commit(md_model_t m) {
   size_t composed_elems = 0;
   for (auto& e : m->packs) {
     if (e.kind == PACK_HEAD_W) composed_elems = std::max(composed_elems, (size_t)4 * e.d0 * e.d1 * 9);
+    else if (e.kind == PACK_C1C3_W) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * 9);
+    else if (e.kind == PACK_HEAD_B || e.kind == PACK_C1C3_B) continue;
     else if (e.param2 >= 0) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * 4);
   }
   if (composed_elems) MD_HIP(hipMalloc((void**)&composed, composed_elems * sizeof(float)));
@@ -678,8 +704,13 @@ int model_commit(md_model_t m) {
       PackEntry c3 = e;
       c3.kind = PACK_CONV3; c3.d0 = 4 * e.d0; c3.k = 3;
       MD_TRY(pack_weight(composed, c3, m->prec, s));
-    } else if (e.kind == PACK_HEAD_B) {
+    } else if (e.kind == PACK_HEAD_B || e.kind == PACK_C1C3_B) {
       MD_TRY(compose_head_bias(m->w32[e.param2], m->w32[e.param3], m->w32[e.param4], e.k, e.d0, (float*)e.dst, s));
+    } else if (e.kind == PACK_C1C3_W) {  // d0 = Cout, d1 = Cin, k = Cmid
+      MD_TRY(compose_c1c3(m->w32[e.param], m->w32[e.param2], e.d1, e.k, e.d0, composed, s));
+      PackEntry c3 = e;
+      c3.kind = PACK_CONV3; c3.k = 3;
+      MD_TRY(pack_weight(composed, c3, m->prec, s));
     } else if (e.param2 < 0) {
       MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
     } else {
@@ -967,6 +998,7 @@ static int run_decoder_head(Run& r) {
     return conv3(r, "dec_conv3x3", t, hw[l], hw[l], Fp, W(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp,
                  ACT_NONE, x, extra, out_relu);
   };
+  const bool fused_c0 = PK(m, "head.outconv_conv0.weight") != nullptr && hw[0] >= 2;
   const void* feats = nullptr;
   for (int l = 4; l >= 0; --l) {
     const std::string f = "decoder.fusions." + std::to_string(l);
@@ -997,7 +1029,8 @@ static int run_decoder_head(Run& r) {
       MD_TRY(deconv2(r, "dec_deconv_out", b->dy[l], Fp, nullptr, hw[l], hw[l], W(f + ".deconv_out_conv"), Fp, F,
                      Bi(f + ".out_conv.bias"), b->df[l], Fp, 0));
       ohw = 2 * hw[l];
-    } else {
+    } else if (!fused_c0 || m->taps_enabled) {  // level 0: the product path composes this 1x1 into head.conv0 (below);
+                                                // its output exists only for the taps
       MD_TRY(gemm_rows(r, "dec_out_conv", b->dy[l], Fp, nullptr, (long)r.B * ohw * ohw, W(f + ".out_conv.weight"), F, Fp,
                        Bi(f + ".out_conv.bias"), b->df[l], Fp));
     }
@@ -1010,8 +1043,19 @@ static int run_decoder_head(Run& r) {
   if (m->taps_enabled) MD_TRY(r.tap_nhwc("decoder_feature", feats, F, hw[0], hw[0], Fp));
   // depth head (mod.rs:105-112)
   const int F2 = F / 2, F2p = cpad(m, F2);
-  MD_TRY(conv3(r, "head_conv0", feats, hw[0], hw[0], Fp, W("head.conv0.weight"), Bi("head.conv0.bias"), F2, b->h0, F2p,
-               ACT_NONE, nullptr, nullptr, nullptr));
+  if (fused_c0) {
+    // out_conv 1x1 (+bias) -> conv0 3x3 (decoder.rs:137 -> mod.rs:105) as ONE 3x3 convolution on the last residual block's
+    // output: the convolution adds the interior bias class, the border pixels get their class afterwards
+    const float* bias9 = (const float*)PK(m, "head.outconv_conv0.bias");
+    MD_TRY(conv3(r, "head_conv0", b->dy[0], hw[0], hw[0], Fp, W("head.outconv_conv0.weight"), bias9 + 4 * F2, F2, b->h0, F2p,
+                 ACT_NONE, nullptr, nullptr, nullptr));
+    r.begin("head_conv0");
+    MD_TRY(launch_border_bias_fix(b->h0, r.B, hw[0], hw[0], F2, F2p, bias9, m->prec, r.st));
+    r.end();
+  } else {
+    MD_TRY(conv3(r, "head_conv0", feats, hw[0], hw[0], Fp, W("head.conv0.weight"), Bi("head.conv0.bias"), F2, b->h0, F2p,
+                 ACT_NONE, nullptr, nullptr, nullptr));
+  }
   if (m->taps_enabled) {
     // the deconv's output exists only as a debug tap: the product path below never materialises the 2x-resolution map
     MD_TRY(deconv2(r, "head_deconv_tap", b->h0, F2p, nullptr, hw[0], hw[0], W("head.deconv.weight"), F2p, F2,

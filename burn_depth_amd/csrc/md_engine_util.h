@@ -17,6 +17,8 @@ inline size_t pack_elems(const PackEntry& e) {
     case PACK_DECONV: return (size_t)e.k * e.k * e.d1 * e.kp;
     case PACK_HEAD_W: return (size_t)4 * e.d0 * 9 * e.kp;
     case PACK_HEAD_B: return (size_t)9 * e.d0;
+    case PACK_C1C3_W: return (size_t)e.d0 * 9 * e.kp;
+    case PACK_C1C3_B: return (size_t)9 * e.d0;
     default: return (size_t)e.d0 * e.d1 * e.k * e.k;
   }
 }
@@ -83,6 +85,28 @@ inline void add_pack_head_fused(md_model_s* m, const std::string& name, const st
   m->pack_index[name + ".weight"] = (int)m->packs.size();
   m->packs.push_back(e);
   e.kind = PACK_HEAD_B;
+  e.f32 = 1;
+  e.bytes = pack_elems(e) * 4;
+  m->pack_index[name + ".bias"] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
+// conv 1x1 (+bias) -> conv 3x3 pad 1 (+bias) composed into one 3x3 convolution (`name`.weight, PACK_CONV3 layout) and nine
+// position-class bias vectors (`name`.bias, f32 [9][cout]); c1 = the 1x1 conv [cmid, cin], c3 = the 3x3 conv [cout, cmid]
+inline void add_pack_c1c3(md_model_s* m, const std::string& name, const std::string& c1, const std::string& c3, int cin, int cmid,
+                          int cout) {
+  auto w1 = m->pindex.find(c1 + ".weight"), b1 = m->pindex.find(c1 + ".bias");
+  auto w3 = m->pindex.find(c3 + ".weight"), b3 = m->pindex.find(c3 + ".bias");
+  if (w1 == m->pindex.end() || b1 == m->pindex.end() || w3 == m->pindex.end() || b3 == m->pindex.end()) return;
+  PackEntry e;
+  e.param = w1->second; e.param2 = w3->second; e.param3 = b1->second; e.param4 = b3->second;
+  e.kind = PACK_C1C3_W;
+  e.d0 = cout; e.d1 = cin; e.k = cmid;
+  e.kp = round_up(cin, m->ke);
+  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  m->pack_index[name + ".weight"] = (int)m->packs.size();
+  m->packs.push_back(e);
+  e.kind = PACK_C1C3_B;
   e.f32 = 1;
   e.bytes = pack_elems(e) * 4;
   m->pack_index[name + ".bias"] = (int)m->packs.size();
