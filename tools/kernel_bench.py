@@ -27,6 +27,9 @@ def main():
     n3 = 74 * 74 + 1  # Depth-Anything-v3 at 1036^2 (BASELINE config 5): one sequence of 5477 tokens
     gemms += [("da3_qkv", 0, n3, 3072, 1024, 0, 0), ("da3_proj", 0, n3, 1024, 1024, 0, 0), ("da3_fc1", 0, n3, 4096, 1024, 0, 0),
               ("da3_fc2", 0, n3, 1024, 4096, 0, 0)]
+    ns = 37 * 37 + 1  # Depth-Anything-v3 at 518^2 (BASELINE config 2: small, D = 384): one sequence of 1370 tokens
+    gemms += [("s_qkv", 0, ns, 1152, 384, 0, 0), ("s_proj", 0, ns, 384, 384, 0, 0), ("s_fc1", 0, ns, 1536, 384, 0, 0),
+              ("s_fc2", 0, ns, 384, 1536, 0, 0), ("s_conv148", 1, 148 * 148, 64, 64, 148, 148), ("s_conv74", 1, 74 * 74, 64, 64, 74, 74)]
     prec = int(os.environ.get("PREC", "0"))
     only = os.environ.get("ONLY")
     if only:
