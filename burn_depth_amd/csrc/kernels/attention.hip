@@ -55,8 +55,12 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 //    below 2^100 and |v| far below 2^27 nothing in O overflows either). Trained ViT logits sit well inside +-44. A wave that fails raises a flag in LDS and the WHOLE workgroup (the
 //    tiles are shared through LDS) runs the pass again in the safe body: rare by construction, and tested with inputs
 //    that force it (tools/gpu_diag.py check_attention).
-//  * SAFE (f16 operands always; bf16 workgroups that failed a check): running maximum with deferred rescale (raised, and
-//    O, l rescaled, only when some row of the wave saw a score more than 2^kDefer above it); p <= 2^kDefer fits f16.
+//    f16 operands run the same body with ONE fixed offset per row, m = the row's maximum over tile 0 (the range check
+//    computes it anyway): p = 2^(s - m) costs a subtraction per score but still no running maximum, no dependent
+//    reduction in front of the exponentials and no rescale. P must fit f16 (65504): checked through the row sums, which
+//    bound every p and must stay below 57000.
+//  * SAFE (workgroups that failed a check): running maximum with deferred rescale (raised, and O, l rescaled, only when
+//    some row of the wave saw a score more than 2^kDefer above it); p <= 2^kDefer fits f16.
 // Either way the result is softmax(q k^T / 8) v; which body ran only changes rounding.
 //
 // What bounds it (MI355X, T x N = 296 x 577, profiles/r02_attention_*.json and DESIGN.md section 5.2): the first form of
@@ -138,7 +142,9 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
 
   constexpr float kDefer = 6.0f;        // log2 units: p <= 64 in the safe body
   constexpr float kFastRange = 64.0f;   // |row max of tile 0| allowed for the fast body (log2 units)
-  constexpr float kFastSumMax = 1.2676506e30f;  // 2^100: a row sum at or above it (inf / NaN included) fails the fast body
+  constexpr bool kOffsetFast = std::is_same<T, f16_t>::value;  // fast body with the tile-0 row maximum as a fixed offset
+  // a (partial) row sum at or above this (inf / NaN included) fails the fast body: 2^100 for bf16; f16: every p < 65504
+  constexpr float kFastSumMax = kOffsetFast ? 57000.0f : 1.2676506e30f;
 
   f32x16_t o[2];
   float m_run, l_run;
@@ -224,7 +230,10 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
       float mx = max16(st0);
       if (two) mx = fmaxf(mx, max16(st1));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if constexpr (CHECK) bad = __any(!(fabsf(mx) <= kFastRange));
+      if constexpr (CHECK) {
+        bad = __any(!(fabsf(mx) <= kFastRange));
+        if constexpr (kOffsetFast && !SAFE) m_run = mx;  // the row's fixed offset for the rest of the pass
+      }
       if constexpr (SAFE) {
         if (__any((mx - m_run) > kDefer)) {  // wave-uniform branch
           const float m_new = fmaxf(m_run, mx);
@@ -238,10 +247,11 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
         }
       }
     }
-    exp_pack_sub(st0, m_run, pf0, ps, std::integral_constant<bool, !SAFE>());
+    typedef std::integral_constant<bool, !SAFE && !kOffsetFast> no_offset_t;
+    exp_pack_sub(st0, m_run, pf0, ps, no_offset_t());
     pv_sub(t, 0, pf0, PARTIAL && rem <= 16 ? 1 : 2);
     if (two) {
-      exp_pack_sub(st1, m_run, pf1, ps, std::integral_constant<bool, !SAFE>());
+      exp_pack_sub(st1, m_run, pf1, ps, no_offset_t());
       pv_sub(t, 1, pf1, PARTIAL && rem <= 48 ? 1 : 2);
     }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
@@ -333,7 +343,7 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
     hipLaunchKernelGGL((attention_kernel<bf16_t, true, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
   } else if (prec == MD_PREC_F16) {
-    hipLaunchKernelGGL((attention_kernel<f16_t, false, false>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
+    hipLaunchKernelGGL((attention_kernel<f16_t, false, true>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
   } else {
     hipLaunchKernelGGL((attention_kernel<bf16_t, false, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
