@@ -137,6 +137,38 @@ def test_load_container_matches_seeded_create(dev, tmp_path):
         m.destroy()
 
 
+def test_imported_upstream_checkpoint_matches_the_oracle(dev, tmp_path):
+    """SURVEY 8f rank 1 end to end: an upstream-style `depth_pro.pt` (timm / nn.Sequential key spellings, written out by
+    the test-side inverse map of tests/test_importer.py) -> importer -> f16 container (the reference's
+    HalfPrecisionSettings, mod.rs:206) -> DepthPro::load_with_config -> infer, against the CPU oracle running the very
+    tensors the container holds. No real checkpoint exists in this environment; this pins the whole path on a synthetic one."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_importer import burn_to_upstream_depth_pro
+    from burn_depth_amd import importer, weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    from oracle import depth_pro_ref as R
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = Precision.F32
+    W = Wt.generate_depth_pro_weights(cfg, 5, Wt.INIT_PARITY)
+    upstream = {burn_to_upstream_depth_pro(k): torch.from_numpy(v.copy()) for k, v in W.items()}
+    upstream["encoder.patch_encoder.mask_token"] = torch.zeros(1, 1, 256)  # dropped by the importer, as by the reference tool
+    src, dst = str(tmp_path / "depth_pro.pt"), str(tmp_path / "depth_pro.safetensors")
+    torch.save(upstream, src)
+    importer.import_depth_pro(src, dst, cfg, dtype="F16")
+    held, meta = Wt.load_container(dst)  # f16-rounded values, widened
+    assert meta["model"] == "depth_pro" and set(held) == set(W)
+    model = DepthPro.load_with_config(dev, cfg, dst)
+    torch.manual_seed(2)
+    x = (torch.rand(1, 3, 512, 512) - 0.45) / 0.225
+    out = model.infer(x.cuda())
+    ref = R.infer(x, R.weights_to_torch(held), cfg)
+    d, rd = out.depth.cpu(), ref["depth"]
+    assert ((d - rd).abs() / rd.abs()).max().item() < 1e-3
+    assert abs(out.fovx_deg.cpu().item() - ref["fovx_deg"].item()) < 1e-2
+    model.destroy()
+
+
 def test_error_paths(dev, tmp_path):
     from burn_depth_amd import _lib
     from burn_depth_amd.config import DepthProConfig

@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU suite + smoke on the final binary
+# full `-m gpu` suite + smoke() on a GPU box (run through gpurun from the repo root); logs under gpurun_out/
 set -o pipefail
 export PYTHONUNBUFFERED=1
 mkdir -p gpurun_out
