@@ -30,6 +30,11 @@ def main():
     ns = 37 * 37 + 1  # Depth-Anything-v3 at 518^2 (BASELINE config 2: small, D = 384): one sequence of 1370 tokens
     gemms += [("s_qkv", 0, ns, 1152, 384, 0, 0), ("s_proj", 0, ns, 384, 384, 0, 0), ("s_fc1", 0, ns, 1536, 384, 0, 0),
               ("s_fc2", 0, ns, 384, 1536, 0, 0), ("s_conv148", 1, 148 * 148, 64, 64, 148, 148), ("s_conv74", 1, 74 * 74, 64, 64, 74, 74)]
+    # wave-quantisation study (Depth Pro at B = 1: proj / fc2 have 336 tiles of 256^2 = 1.31 rounds): one full round of 256^2
+    # tiles against the remaining rows on 128^2 tiles
+    gemms += [("full_proj", 0, 16384, 1024, 1024, 0, 0), ("rem_proj", 0, 5076, 1024, 1024, 0, 0), ("full_fc2", 0, 16384, 1024, 4096, 0, 0),
+              ("rem_fc2", 0, 5076, 1024, 4096, 0, 0)]
+    tiles += [(1 + 16 * 256, "128v1_rmw"), (1 + 1024, "128v1_gelu")]
     prec = int(os.environ.get("PREC", "0"))
     only = os.environ.get("ONLY")
     if only:
