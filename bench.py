@@ -66,7 +66,9 @@ def work_model(cfg, B: int):
     fl["fc2_gemm"] = fl["fc1_gemm"]
     px = lambda s: B * s * s  # noqa: E731
     enc_proj = 2.0 * D * (px(hi) * (dims[0] * 2 + dims[1]) + px(mid) * dims[2] + px(g) * dims[3])
-    enc_dec = 2.0 * 4 * (px(hi) * dims[0] * F + px(2 * hi) * F * F + px(4 * hi) * F * F + px(hi) * dims[0] * dims[0] +
+    # executed: the last two k2s2 deconvolutions of latent0 / latent1 run as one k4s4 on their weight product (16 taps from the
+    # coarser grid = the FLOPs of the finer deconvolution alone; the middle one is gone)
+    enc_dec = 2.0 * 4 * (px(hi) * dims[0] * F + px(4 * hi) * F * F +
                          px(2 * hi) * dims[0] * dims[0] + px(hi) * dims[1] * dims[1] + px(mid) * dims[2] * dims[2] +
                          px(g) * dims[3] * dims[3] + px(g) * D * dims[3])
     fl["enc_proj"] = enc_proj

@@ -48,7 +48,7 @@ enum PackKind : int { PACK_NK = 0, PACK_CONV3 = 1, PACK_DECONV = 2, PACK_DIRECT 
 struct PackEntry {
   int param = -1;   // index into params (PACK_HEAD_*: the deconv weight [Cin,Cmid,2,2]; PACK_C1C3_*: the 1x1 weight [Cmid,Cin])
   int param2 = -1;  // PACK_DECONV only: 1x1 conv weight [Cout,Cout] composed behind the deconv at commit; PACK_HEAD_*: conv weight [Cout,Cmid,3,3]
-  int param3 = -1, param4 = -1;  // PACK_HEAD_B: deconv bias [Cmid], conv bias [Cout]
+  int param3 = -1, param4 = -1;  // PACK_HEAD_B / C1C3_B: bias of the first layer [Cmid], bias of the second [Cout]; PACK_DECONV pair (k == 4): param3 = Cmid
   int kind = PACK_NK;
   int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k | HEAD_W/B, C1C3_W/B: Cout, Cin (k = Cmid)
   int kp = 0;       // padded contraction length per tap (elements)

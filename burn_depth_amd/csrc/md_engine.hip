@@ -107,6 +107,30 @@ __global__ void compose_deconv_conv_kernel(const float* __restrict__ wd, const f
   }
 }
 
+// Wa [Cin, Cmid, 2, 2], Wb [Cmid, Cout, 2, 2] (both bias-free ConvTranspose2d k2 s2) -> out [Cin, Cout, 4, 4]:
+// output pixel (4y + 2 dy1 + dy2, 4x + 2 dx1 + dx2) = sum_m (in[y, x] . Wa[:, m, dy1, dx1]) * Wb[m, co, dy2, dx2]
+__global__ void compose_deconv_pair_kernel(const float* __restrict__ wa, const float* __restrict__ wb, int cin, int cmid, int cout,
+                                           float* __restrict__ out) {
+  const long total = (long)cin * cout * 16;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int tx = (int)(e & 3), ty = (int)((e >> 2) & 3);
+    const int co = (int)((e >> 4) % cout);
+    const int ci = (int)((e >> 4) / cout);
+    const int qa = (ty >> 1) * 2 + (tx >> 1), qb = (ty & 1) * 2 + (tx & 1);
+    float acc = 0.f;
+    for (int mth = 0; mth < cmid; ++mth) acc += wa[((long)ci * cmid + mth) * 4 + qa] * wb[((long)mth * cout + co) * 4 + qb];
+    out[e] = acc;
+  }
+}
+
+int compose_deconv_pair(const float* wa, const float* wb, int cin, int cmid, int cout, float* out, hipStream_t s) {
+  const long total = (long)cin * cout * 16;
+  hipLaunchKernelGGL(compose_deconv_pair_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, wa, wb, cin,
+                     cmid, cout, out);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int compose_deconv_conv(const float* wd, const float* wo, int cin, int cmid, int cout, float* out, hipStream_t s) {
   const long total = (long)cin * cout * 4;
   hipLaunchKernelGGL(compose_deconv_conv_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, wd,
@@ -448,6 +472,11 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   };
   pub("encoder.upsample_latent0", D, F, 3, dims[0]);
   pub("encoder.upsample_latent1", D, dims[0], 2, 0);
+  // the last two k2s2 deconvolutions of each latent chain run as one k4s4 (their 2x intermediate is never written)
+  add_pack_deconv_pair(m, "encoder.upsample_latent0.upsample.1x2", "encoder.upsample_latent0.upsample.1.weight",
+                       "encoder.upsample_latent0.upsample.2.weight", F, F, F);
+  add_pack_deconv_pair(m, "encoder.upsample_latent1.upsample.0x1", "encoder.upsample_latent1.upsample.0.weight",
+                       "encoder.upsample_latent1.upsample.1.weight", dims[0], dims[0], dims[0]);
   pub("encoder.upsample0", D, dims[1], 1, 0);
   pub("encoder.upsample1", D, dims[2], 1, 0);
   pub("encoder.upsample2", D, dims[3], 1, 0);
@@ -695,7 +724,7 @@ int model_commit(md_model_t m) {
     if (e.kind == PACK_HEAD_W) composed_elems = std::max(composed_elems, (size_t)4 * e.d0 * e.d1 * 9);
     else if (e.kind == PACK_C1C3_W) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * 9);
     else if (e.kind == PACK_HEAD_B || e.kind == PACK_C1C3_B) continue;
-    else if (e.param2 >= 0) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * 4);
+    else if (e.param2 >= 0) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * e.k * e.k);
   }
   if (composed_elems) MD_HIP(hipMalloc((void**)&composed, composed_elems * sizeof(float)));
   for (auto& e : m->packs) {
@@ -713,6 +742,9 @@ int model_commit(md_model_t m) {
       MD_TRY(pack_weight(composed, c3, m->prec, s));
     } else if (e.param2 < 0) {
       MD_TRY(pack_weight(m->w32[e.param], e, m->prec, s));
+    } else if (e.k == 4) {  // deconv k2s2 -> deconv k2s2 as one k4s4 (d0 = Cin, d1 = Cout, param3 = Cmid)
+      MD_TRY(compose_deconv_pair(m->w32[e.param], m->w32[e.param2], e.d0, e.param3, e.d1, composed, s));
+      MD_TRY(pack_weight(composed, e, m->prec, s));
     } else {
       MD_TRY(compose_deconv_conv(m->w32[e.param], m->w32[e.param2], e.d0, e.d1, e.d1, composed, s));
       MD_TRY(pack_weight(composed, e, m->prec, s));
@@ -936,18 +968,14 @@ static int run_encoder_tail(Run& r, const md_model_s::IndexSet& ix) {
                    nullptr, b->l0p, cpad(m, dims[0])));
   MD_TRY(deconv2(r, "enc_deconv", b->l0p, cpad(m, dims[0]), nullptr, hi, hi, W("encoder.upsample_latent0.upsample.0.weight"),
                  cpad(m, dims[0]), F, nullptr, b->l0a, cpad(m, F), 0));
-  MD_TRY(deconv2(r, "enc_deconv", b->l0a, cpad(m, F), nullptr, 2 * hi, 2 * hi, W("encoder.upsample_latent0.upsample.1.weight"),
-                 cpad(m, F), F, nullptr, b->l0b, cpad(m, F), 0));
-  MD_TRY(deconv2(r, "enc_deconv", b->l0b, cpad(m, F), nullptr, 4 * hi, 4 * hi, W("encoder.upsample_latent0.upsample.2.weight"),
-                 cpad(m, F), F, nullptr, b->enc0, cpad(m, F), 0, b->enc0r));
-  // latent1: 1x1 (D -> dims0), 2 deconvs @ 4x (encoder.rs:152,424)
+  // upsample.1 and upsample.2 (k2s2, no bias, nothing between them) as ONE k4s4 deconvolution on their weight product
+  MD_TRY(deconv2(r, "enc_deconv", b->l0a, cpad(m, F), nullptr, 2 * hi, 2 * hi, W("encoder.upsample_latent0.upsample.1x2"),
+                 cpad(m, F), F, nullptr, b->enc0, cpad(m, F), 0, b->enc0r, 4));
+  // latent1: 1x1 (D -> dims0), 2 deconvs @ 4x (encoder.rs:152,424): the two deconvolutions as one k4s4
   MD_TRY(gemm_rows(r, "enc_proj", b->hook[1], D, ix.hi, Mhi, W("encoder.upsample_latent1.projection.weight"), dims[0], D,
                    nullptr, b->l1p, cpad(m, dims[0])));
-  MD_TRY(deconv2(r, "enc_deconv", b->l1p, cpad(m, dims[0]), nullptr, hi, hi, W("encoder.upsample_latent1.upsample.0.weight"),
-                 cpad(m, dims[0]), dims[0], nullptr, b->l1a, cpad(m, dims[0]), 0));
-  MD_TRY(deconv2(r, "enc_deconv", b->l1a, cpad(m, dims[0]), nullptr, 2 * hi, 2 * hi,
-                 W("encoder.upsample_latent1.upsample.1.weight"), cpad(m, dims[0]), dims[0], nullptr, b->enc1,
-                 cpad(m, dims[0]), 0));
+  MD_TRY(deconv2(r, "enc_deconv", b->l1p, cpad(m, dims[0]), nullptr, hi, hi, W("encoder.upsample_latent1.upsample.0x1"),
+                 cpad(m, dims[0]), dims[0], nullptr, b->enc1, cpad(m, dims[0]), 0, nullptr, 4));
   // x0 (encoder.rs:153,425)
   MD_TRY(gemm_rows(r, "enc_proj", b->tok, D, ix.hi, Mhi, W("encoder.upsample0.projection.weight"), dims[1], D, nullptr,
                    b->x0p, cpad(m, dims[1])));

@@ -113,6 +113,26 @@ inline void add_pack_c1c3(md_model_s* m, const std::string& name, const std::str
   m->packs.push_back(e);
 }
 
+// two bias-free k2s2 deconvolutions in a row (encoder.rs:146-152, nothing between them) = ONE k4s4 deconvolution on the
+// weight product W''[ci][co][2 dy1 + dy2][2 dx1 + dx2] = sum_m Wa[ci][m][dy1][dx1] * Wb[m][co][dy2][dx2]
+inline void add_pack_deconv_pair(md_model_s* m, const std::string& name, const std::string& a, const std::string& b, int cin,
+                                 int cmid, int cout) {
+  auto wa = m->pindex.find(a), wb = m->pindex.find(b);
+  if (wa == m->pindex.end() || wb == m->pindex.end()) return;
+  PackEntry e;
+  e.param = wa->second;
+  e.param2 = wb->second;
+  e.param3 = cmid;  // PACK_DECONV with k == 4 and param2: the middle channel count rides here
+  e.kind = PACK_DECONV;
+  e.d0 = cin;
+  e.d1 = cout;
+  e.k = 4;
+  e.kp = round_up(cin, m->ke);
+  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  m->pack_index[name] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
 // Runs `body` (the launch schedule of one infer) eagerly the first time a (stream, shapes, pointers) key is
 // seen -- that call allocates index tables and sets function attributes --, captures it into a hipGraph the second
 // time and replays the instantiated graph from then on. Timing / tap modes and host-side buffers always run eagerly.
@@ -229,9 +249,9 @@ inline int gemm_rows(Run& r, const char* name, const void* A, long lda, const in
 
 // ConvTranspose2d k=2 s=2 as GEMM + pixel shuffle (encoder.rs:61-69, decoder.rs:100-105, mod.rs:81-84)
 inline int deconv2(Run& r, const char* name, const void* A, long lda, const int* idx, int h, int w, const void* W, int Cin_p,
-            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr) {
+            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr, int f = 2) {
   GemmParams p;
-  p.N = 4 * Cout; p.K = Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W;
+  p.N = f * f * Cout; p.K = Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W; p.ps_f = f;
   p.A = A; p.lda = lda; p.a_index = idx;
   p.epi = EPI_PIXSHUF; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
   p.psH = h; p.psW = w; p.psC = Cout; p.ps_coff = coff;
