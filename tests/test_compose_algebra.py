@@ -91,3 +91,20 @@ def test_conv1x1_then_conv3x3_is_one_conv_with_position_class_biases():
     fix = (b9 - b9[4])[class_map(H, W)].permute(2, 0, 1)     # border_bias_fix_kernel
     assert torch.allclose(interior + fix[None], want, rtol=0, atol=1e-11)
     assert fix[:, 1:-1, 1:-1].abs().max() == 0               # interior pixels untouched
+
+
+def test_two_k2s2_deconvolutions_are_one_k4s4():
+    """encoder.rs:146-152: ConvTranspose2d(k2, s2, no bias) twice = ConvTranspose2d(k4, s4) on the weight product
+    W''[ci][co][2 dy1 + dy2][2 dx1 + dx2] = sum_m Wa[ci][m][dy1][dx1] * Wb[m][co][dy2][dx2] (compose_deconv_pair_kernel)."""
+    g = torch.Generator().manual_seed(2)
+    B, cin, cmid, cout, H, W = 2, 4, 5, 3, 6, 7
+    x = torch.randn(B, cin, H, W, generator=g, dtype=torch.float64)
+    wa = torch.randn(cin, cmid, 2, 2, generator=g, dtype=torch.float64)
+    wb = torch.randn(cmid, cout, 2, 2, generator=g, dtype=torch.float64)
+    want = F.conv_transpose2d(F.conv_transpose2d(x, wa, None, stride=2), wb, None, stride=2)
+    wc = torch.zeros(cin, cout, 4, 4, dtype=torch.float64)
+    for ty in range(4):
+        for tx in range(4):
+            wc[:, :, ty, tx] = wa[:, :, ty >> 1, tx >> 1] @ wb[:, :, ty & 1, tx & 1]
+    got = F.conv_transpose2d(x, wc, None, stride=4)
+    assert torch.allclose(got, want, rtol=0, atol=1e-11)
