@@ -15,3 +15,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pytest_runtest_logreport(report):
+    """One unbuffered stderr line per finished test. The GPU suite runs for several minutes and a harness that watches a
+    piped stdout sees nothing of pytest's progress dots until the pipe's buffer fills or the run ends; a watchdog that reads
+    silence as a hang then kills a healthy run. The longest single test (the full-size oracle comparison) is ~100 s."""
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        try:
+            sys.__stderr__.write(f"[test] {report.outcome:7s} {report.duration:7.1f}s {report.nodeid}\n")
+            sys.__stderr__.flush()
+        except Exception:
+            pass

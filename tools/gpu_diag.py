@@ -26,6 +26,18 @@ from burn_depth_amd.depth_pro import DepthPro, Device  # noqa: E402
 from oracle import depth_pro_ref as R  # noqa: E402
 
 RESULTS = []
+_ORACLE_CACHE = {}  # (tag, ...) -> oracle result: precision sweeps of one configuration share ONE CPU oracle frame
+
+
+def cfg_key(cfg):
+    """Everything of a config that the fp32 oracle depends on (not the engine's precision mode or batch capacity)."""
+    return tuple(sorted((k, str(v)) for k, v in vars(cfg).items() if k not in ("precision", "max_batch")))
+
+
+def cached(key, fn):
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -371,8 +383,10 @@ def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY,
     print(f"      first infer {time.time() - t0:.2f}s", flush=True)
     q = {Precision.BF16: R.bf16_round, Precision.F16: R.f16_round}.get(precision, R.identity)
     t0 = time.time()
-    with torch.no_grad():
-        ref = R.infer(x, W, cfg, q=R.identity, debug=True)
+    def oracle_fp32():
+        with torch.no_grad():
+            return R.infer(x, W, cfg, q=R.identity, debug=True)
+    ref = cached(("depth_pro", cfg_key(cfg), B, tuple(hw), scheme), oracle_fp32)  # same seeds -> same x, W for every precision
     print(f"      oracle fp32 {time.time() - t0:.1f}s", flush=True)
     tol, ttol = E2E_TOL[precision]
     tol = tols or tol
@@ -496,8 +510,10 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY, taps=False):
     out = model.infer(x.cuda())
     torch.cuda.synchronize()
     t0 = time.time()
-    with torch.no_grad():
-        ref = D3.infer(x, W, cfg, debug=taps)
+    def oracle_fp32():
+        with torch.no_grad():
+            return D3.infer(x, W, cfg, debug=taps)
+    ref = cached(("da3", cfg_key(cfg), B, scheme, bool(taps)), oracle_fp32)  # same seeds -> same x, W for every precision
     print(f"      da3 oracle fp32 {time.time() - t0:.1f}s", flush=True)
     if taps:  # DepthTrace (depth_anything3/mod.rs:241-246) and the head's stages against the oracle's intermediates
         dbg = ref["debug"]
