@@ -3,8 +3,9 @@
 //   C[m][n] = sum_k A[m][k] * W[n][k]          (both operands K-contiguous)
 //
 // Design (MI355X-first; see DESIGN.md "K4/K8"):
-//  * 64-lane waves, v_mfma_f32_32x32x16_bf16 (bf16 mode) or v_mfma_f32_32x32x2_f32 (fp32 mode),
-//    fp32 accumulation in both.  The MFMA "A" operand is the WEIGHT tile and the "B" operand the
+//  * 64-lane waves, 16x16 MFMA tiles in every kernel: v_mfma_f32_16x16x32_{bf16,f16}, 4 x v_mfma_f32_16x16x4_f32 (fp32
+//    mode) or the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 operands), fp32 accumulation in all of them.
+//    The MFMA "A" operand is the WEIGHT tile and the "B" operand the
 //    activation tile, so a lane ends up holding 4 consecutive output columns n of ONE row m:
 //    the epilogue stores 8-byte (bf16) / 16-byte (f32) vectors and per-column vectors (bias,
 //    LayerScale) are loaded as float4.
@@ -13,8 +14,9 @@
 //    the bank-conflict swizzle (16-byte chunk index XOR ((row>>1)&7)) is applied on the per-lane
 //    GLOBAL source address and again on the ds_read_b128 address (the LDS image written by one
 //    wave-instruction must stay lane-linear).
-//  * Two LDS stages; the global->LDS loads of k-tile t+1 are in flight while k-tile t is
-//    multiplied; one barrier per k-tile.
+//  * gemm_kernel (128x128 / 256x32 tiles): two LDS stages; the global->LDS loads of k-tile t+1 are in flight while
+//    k-tile t is multiplied; one barrier per k-tile, two workgroups per CU. gemm256_kernel (256x256): a ring of five
+//    32-KB half-tile slots and the staggered two-group schedule described at its definition.
 //  * A-operand modes: dense rows, indexed rows (token->map "merge" gather, encoder.rs:234-319) and
 //    3x3 stride-1 pad-1 convolution taps over an NHWC tensor (out-of-image taps read a zero page).
 //  * Grouped weights: up to 4 row ranges, each with its own W / bias / scale (the three ViT-L
@@ -31,39 +33,8 @@ namespace md {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define MD_SEL_G(arr, g) ((g) == 0 ? (arr)[0] : (g) == 1 ? (arr)[1] : (g) == 2 ? (arr)[2] : (arr)[3])
-
-template <typename T>
-struct Atom;
-
-template <>
-struct Atom<bf16_t> {
-  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
-                                                0, 0, 0);
-  }
-};
-
-template <>
-struct Atom<f16_t> {
-  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-  }
-};
-
-template <>
-struct Atom<float> {
-  // one 16-byte read = 4 consecutive k per lane-half; 4 MFMAs of K=2 (k = {j, 4+j} per call)
-  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
-    f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
-  }
-};
 
 // 16x16 output tiles: v_mfma_f32_16x16x32_bf16 / 4 x v_mfma_f32_16x16x4_f32 per 16-byte operand pair.
 // Same FLOPs per LDS byte as the 32x32 forms; the chip holds a higher clock on this shape
@@ -100,14 +71,6 @@ struct Atom16<float> {
 // the LDS image, swizzle and fragment reads are byte-identical to the bf16 / f32 forms; only KE doubles to 128.
 typedef long i64x2_t __attribute__((ext_vector_type(2)));
 template <>
-struct Atom<fp8_t> {
-  static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x16_t& c) {
-    const i64x2_t av = __builtin_bit_cast(i64x2_t, a), bv = __builtin_bit_cast(i64x2_t, b);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(av[0], bv[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
-  }
-};
-template <>
 struct Atom16<fp8_t> {
   static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x4acc_t& c) {
     const i64x2_t av = __builtin_bit_cast(i64x2_t, a), bv = __builtin_bit_cast(i64x2_t, b);
@@ -115,7 +78,7 @@ struct Atom16<fp8_t> {
     c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
   }
 };
-// Block-scaled (MX) e4m3 MFMA, `v_mfma_scale_f32_{16x16x128,32x32x64}_f8f6f4`: 32 operand bytes per lane and instruction,
+// Block-scaled (MX) e4m3 MFMA, `v_mfma_scale_f32_16x16x128_f8f6f4`: 32 operand bytes per lane and instruction,
 // twice the FLOPs per clock of the non-scaled fp8 / bf16 forms (MI355X_MICROARCH.md, Matrix cores). Every block scale is
 // the E8M0 byte 127 = 2^0, so the products are the plain e4m3 products and the result equals the non-scaled forms' up to
 // fp32 summation order. A lane's 32 bytes are two 16-byte LDS fragments (k sub-steps s and s+1, read at the same offsets
@@ -127,9 +90,6 @@ __device__ __forceinline__ i32x8_t mx_cat(const i32x4_t& lo, const i32x4_t& hi) 
 }
 __device__ __forceinline__ void mx_mma16(const i32x4_t& a0, const i32x4_t& a1, const i32x4_t& b0, const i32x4_t& b1, f32x4acc_t& c) {
   c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(mx_cat(a0, a1), mx_cat(b0, b1), c, 0, 0, 0, kMxUnitScale, 0, kMxUnitScale);
-}
-__device__ __forceinline__ void mx_mma32(const i32x4_t& a0, const i32x4_t& a1, const i32x4_t& b0, const i32x4_t& b1, f32x16_t& c) {
-  c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_cat(a0, a1), mx_cat(b0, b1), c, 0, 0, 0, kMxUnitScale, 0, kMxUnitScale);
 }
 // element type of everything the epilogue reads / writes as "T" (outputs, residuals): bf16 for fp8 operands
 template <typename T>
