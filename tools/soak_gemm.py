@@ -1,5 +1,5 @@
-"""Determinism / exactness soak of the 256x256 GEMM family (dense, 3x3 convolution, k2s2 deconvolution): small-integer
-operands (every product and partial sum exact in fp32), repeated launches per shape, fp32-store and bf16-store epilogues,
+"""Determinism / exactness soak of the MFMA GEMM family (256x256 and 128x128 tiles; bf16, f16 and fp32 operands; dense,
+3x3 convolution, k2s2 deconvolution): small-integer operands (every product and partial sum exact in fp32), repeated launches per shape, fp32-store and bf16-store epilogues,
 bit-exact against the CPU result."""
 import os
 import sys
@@ -29,6 +29,15 @@ def run(dev, iters=25, verbose=False):
             d16 = (ops.linear(dev, xc, wc, bc, 0, 0, _lib.TILE_256x256, storage_out=True) - want16).abs().max().item()
             if d != 0.0 or d16 != 0.0:
                 bad.append((M, N, K, it, d, d16))
+        # the two-stage kernel (128x128 tiles, 16x16 MFMA) on the same operands, and the f16 / fp32 operand forms of both
+        for it in range(max(1, iters // 4)):
+            for tile in (_lib.TILE_128x128, _lib.TILE_256x256):
+                for prec in (0, 3, 1):
+                    if tile == _lib.TILE_256x256 and prec == 0:
+                        continue
+                    d = (ops.linear(dev, xc, wc, bc, 0, prec, tile) - want).abs().max().item()
+                    if d != 0.0:
+                        bad.append((M, N, K, it, "tile", tile, "prec", prec, d))
         if verbose:
             print("shape", M, N, K, "ok" if not bad else "MISMATCH", flush=True)
     # the implicit-GEMM convolution (tap masks, 32-bit pixel index) and the one-division pixel-shuffle epilogue
