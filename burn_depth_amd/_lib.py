@@ -87,6 +87,7 @@ SYMBOLS = {
     "md_model_enable_taps": (_I, [_P, _I]),
     "md_model_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int64 * 4)]),
     "md_model_enable_timing": (_I, [_P, _I]),
+    "md_model_set_timing_filter": (_I, [_P, C.c_char_p]),
     "md_model_read_timing": (_I, [_P, C.POINTER(C.c_char_p), _F, C.POINTER(_I), _I, C.POINTER(_I)]),
     "md_model_read_launch_order": (_I, [_P, C.POINTER(C.c_char_p), _I, C.POINTER(_I)]),
     "md_op_rgb_to_input": (_I, [_P, _P, C.c_size_t, _I, _I, _P, _P]),

@@ -244,6 +244,12 @@ int md_model_enable_timing(md_model_t m, int enable) {
   return MD_OK;
 }
 
+int md_model_set_timing_filter(md_model_t m, const char* family) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  m->timing_filter = family ? family : "";
+  return MD_OK;
+}
+
 int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls, int cap, int* n) {
   if (!m || !n) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   MD_HIP(hipSetDevice(m->dev->ordinal));

@@ -117,6 +117,7 @@ struct md_model_s {
   bool taps_enabled = false;
   std::map<std::string, md::Tap> taps;
   bool timing_enabled = false;
+  std::string timing_filter;  // non-empty: only launches of this family are timed
   std::vector<md::TimingEntry> timing;
   std::vector<std::string> timing_names_out;
 

@@ -174,6 +174,7 @@ struct Run {
   int pending = -1;
   void begin(const char* name) {
     if (!m->timing_enabled) return;
+    if (!m->timing_filter.empty() && m->timing_filter != name) return;
     TimingEntry t;
     t.name = name;
     (void)hipEventCreate(&t.a);

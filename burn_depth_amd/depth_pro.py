@@ -223,6 +223,10 @@ class DepthPro:
     def enable_timing(self, enable: bool = True) -> None:
         _lib.check(self._lib.md_model_enable_timing(self._h, int(enable)))
 
+    def set_timing_filter(self, family: Optional[str] = None) -> None:
+        """Time only the launches of one kernel family (None = all): md_model_set_timing_filter."""
+        _lib.check(self._lib.md_model_set_timing_filter(self._h, family.encode() if family else None))
+
     def enable_graph(self, enable: bool = True) -> None:
         """Replay the launch schedule from a hipGraph for repeated calls with the same buffers (md_model_enable_graph)."""
         _lib.check(self._lib.md_model_enable_graph(self._h, int(enable)))

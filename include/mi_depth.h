@@ -293,6 +293,10 @@ int md_feature_padding(int window, int stride, int feature_size);
  * first). Entries accumulate over infer calls until read; reading sums them by family name into
  * names/ms/calls (capacity `cap`, count in *n) and clears them. */
 int md_model_enable_timing(md_model_t m, int enable);
+/* Restrict the events to ONE kernel family (e.g. "fc1_gemm"); NULL or "" = every family. Two event records per launch
+ * cost about 0.7 % of a Depth Pro step when every one of its ~226 launches is timed; a throughput measurement times the
+ * family it reports against its roofline inside the timed region and the rest in a separate pass. */
+int md_model_set_timing_filter(md_model_t m, const char* family);
 int md_model_read_timing(md_model_t m, const char** names, float* ms, int* calls, int cap, int* n);
 /* Family name of every kernel launch recorded since timing was enabled / last read, in launch order
  * (one entry per kernel launch; does not clear). Lets a rocprofv3 trace be mapped to families. */
