@@ -1360,8 +1360,9 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     case 2:
       if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);
       break;
-    case 4:
-      if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
+    case 4:  // the GELU store kind is built for dense A only (the MLP's fc1); a GELU behind a gathered / convolution A operand
+             // takes the store kind's runtime activation path of the generic epilogue
+      if constexpr (sizeof(typename OutT<T>::type) == 2 && AMODE == A_DENSE) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
       break;
     default: break;
   }
