@@ -1,0 +1,83 @@
+/* The boundary from plain C: nothing but include/mi_depth.h and libmi_depth.so -- no Python, no torch, no HIP header.
+ * Mirrors the reference's README flow (README.md:18-40: device -> DepthPro::new / load -> infer_from_rgb -> depth, focal
+ * length) and `bench/inference.rs:21-48` (zeros input). Build and run (tests/test_gpu_parity.py does both on the GPU box):
+ *
+ *   gcc -O2 -Iinclude examples/infer_c_abi.c -Lburn_depth_amd -lmi_depth -Wl,-rpath,$PWD/burn_depth_amd -lm -o /tmp/infer_c_abi
+ *   /tmp/infer_c_abi [weights.safetensors]
+ *
+ * Without a weight file it creates the reduced `tiny16_128` configuration with the seeded synthetic weights the parity
+ * tests use and prints values the Python mirror must reproduce bit for bit (same library, same seed). */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "mi_depth.h"
+
+#define CHECK(call)                                                              \
+  do {                                                                           \
+    int rc_ = (call);                                                            \
+    if (rc_ != 0) {                                                              \
+      fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, md_last_error());      \
+      return 1;                                                                  \
+    }                                                                            \
+  } while (0)
+
+int main(int argc, char** argv) {
+  md_device_t dev = NULL;
+  md_model_t model = NULL;
+  CHECK(md_device_open(0, &dev));
+
+  md_depth_pro_cfg cfg;
+  md_depth_pro_cfg_default(&cfg);
+  int S = 1536;
+  if (argc > 1) { /* DepthPro::load(&device, path): the default configuration */
+    CHECK(md_depth_pro_load(dev, argv[1], &model));
+  } else { /* DepthPro::new(&device, cfg) on the reduced configuration, seeded */
+    cfg.patch_encoder_preset = "tiny16_128";
+    cfg.image_encoder_preset = "tiny16_128";
+    cfg.fov_encoder_preset = "tiny16_128";
+    cfg.decoder_features = 64;
+    cfg.precision = MD_PREC_F32;
+    cfg.max_batch = 1;
+    S = 512;
+    CHECK(md_depth_pro_create(dev, &cfg, 0, MD_INIT_PARITY, &model));
+  }
+
+  /* infer_from_rgb on a synthetic gradient image (packed RGB bytes, src/inference.rs:128-137) */
+  const int w = 96, h = 64;
+  uint8_t* rgb = (uint8_t*)malloc((size_t)w * h * 3);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      rgb[(y * w + x) * 3 + 0] = (uint8_t)(x * 255 / (w - 1));
+      rgb[(y * w + x) * 3 + 1] = (uint8_t)(y * 255 / (h - 1));
+      rgb[(y * w + x) * 3 + 2] = (uint8_t)((x + y) & 255);
+    }
+  float* depth = (float*)malloc((size_t)w * h * sizeof(float));
+  float focal = 0.f, fovy = 0.f;
+  CHECK(md_infer_from_rgb(model, rgb, (size_t)w * h * 3, w, h, MD_MEM_HOST, depth, &focal, &fovy, MD_MEM_HOST, NULL));
+  double sum = 0.0;
+  int finite = 1;
+  for (int i = 0; i < w * h; ++i) {
+    sum += depth[i];
+    finite = finite && isfinite(depth[i]) && depth[i] > 0.f;
+  }
+  printf("rgb %dx%d: depth[0]=%.9g depth[last]=%.9g mean=%.9g focallength_px=%.9g fovy_rad=%.9g finite_positive=%d\n", w, h,
+         depth[0], depth[w * h - 1], sum / (w * h), focal, fovy, finite);
+
+  /* DepthPro::infer on zeros [1,3,S,S] (bench/inference.rs:21-48), host pointers in and out */
+  float* x = (float*)calloc((size_t)3 * S * S, sizeof(float));
+  float* d2 = (float*)malloc((size_t)S * S * sizeof(float));
+  float f2 = 0.f, fovx = 0.f, fovy2 = 0.f;
+  CHECK(md_depth_pro_infer(model, x, 1, S, S, MD_MEM_HOST, d2, &f2, &fovx, &fovy2, MD_MEM_HOST, NULL));
+  printf("zeros %dx%d: depth[0]=%.9g focallength_px=%.9g fovx_deg=%.9g\n", S, S, d2[0], f2, fovx);
+
+  /* the reference's Err(String) on a wrong buffer length (src/inference.rs:90-95) is a status code here */
+  const int rc = md_infer_from_rgb(model, rgb, 10, w, h, MD_MEM_HOST, depth, &focal, &fovy, MD_MEM_HOST, NULL);
+  printf("short rgb buffer: status %d (%s)\n", rc, rc == MD_ERR_SHAPE ? "MD_ERR_SHAPE" : "unexpected");
+
+  free(x); free(d2); free(depth); free(rgb);
+  CHECK(md_model_destroy(model));
+  CHECK(md_device_close(dev));
+  return finite && rc == MD_ERR_SHAPE ? 0 : 2;
+}

@@ -169,6 +169,50 @@ def test_imported_upstream_checkpoint_matches_the_oracle(dev, tmp_path):
     model.destroy()
 
 
+def test_plain_c_program_against_the_abi(dev, tmp_path):
+    """examples/infer_c_abi.c: gcc + include/mi_depth.h + libmi_depth.so only (no Python, torch or HIP header in the program)
+    -- DepthPro::new on the reduced configuration, infer_from_rgb, infer on zeros, the short-buffer error. Its printed
+    numbers (%.9g round-trips an fp32) must equal what the Python mirror gets from the same library and seed."""
+    import re
+    import subprocess
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    exe = str(tmp_path / "infer_c_abi")
+    libdir = os.path.join(ROOT, "burn_depth_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "infer_c_abi.c"),
+                    "-L" + libdir, "-lmi_depth", "-Wl,-rpath," + libdir, "-lm", "-o", exe], check=True)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = run.stdout
+    assert "MD_ERR_SHAPE" in out and "finite_positive=1" in out
+    num = r"([-+0-9.eE]+|inf|nan)"
+    m1 = re.search(rf"rgb 96x64: depth\[0\]={num} depth\[last\]={num} mean={num} focallength_px={num} fovy_rad={num}", out)
+    m2 = re.search(rf"zeros 512x512: depth\[0\]={num} focallength_px={num} fovx_deg={num}", out)
+    assert m1 and m2, out
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = Precision.F32
+    cfg.max_batch = 1
+    model = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    w, h = 96, 64
+    rgb = bytearray(w * h * 3)
+    for y in range(h):
+        for x in range(w):
+            rgb[(y * w + x) * 3:(y * w + x) * 3 + 3] = bytes((x * 255 // (w - 1), y * 255 // (h - 1), (x + y) & 255))
+    r = model.infer_from_rgb(bytes(rgb), w, h)
+    d = r.depth.float().cpu().reshape(-1)
+    import numpy as np
+    f32 = lambda t: np.float32(torch.as_tensor(t).float().cpu().reshape(-1)[0].item())  # noqa: E731
+    p32 = lambda m, i: np.float32(float(m.group(i)))  # noqa: E731  (9 significant digits identify an fp32)
+    assert p32(m1, 1) == f32(d[0]) and p32(m1, 2) == f32(d[-1])
+    assert abs(float(m1.group(3)) - float(d.double().mean())) < 1e-6 * abs(float(d.double().mean()))
+    assert p32(m1, 4) == f32(r.focallength_px) and p32(m1, 5) == f32(r.fovy_rad)
+    z = model.infer(torch.zeros(1, 3, 512, 512, device="cuda"))
+    assert p32(m2, 1) == f32(z.depth.reshape(-1)[0]) and p32(m2, 2) == f32(z.focallength_px)
+    assert p32(m2, 3) == f32(z.fovx_deg)
+    model.destroy()
+
+
 def test_error_paths(dev, tmp_path):
     from burn_depth_amd import _lib
     from burn_depth_amd.config import DepthProConfig
