@@ -393,7 +393,8 @@ def test_resize_nhwc_operator(dev):
     from burn_depth_amd import ops
     from oracle import depth_pro_ref as R
     g = torch.Generator().manual_seed(9)
-    for (B, H, W, C, OH, OW) in [(2, 5, 7, 8, 11, 13), (1, 37, 37, 64, 74, 74), (1, 16, 12, 128, 16, 12)]:
+    for (B, H, W, C, OH, OW) in [(2, 5, 7, 8, 11, 13), (1, 37, 37, 64, 74, 74), (1, 16, 12, 128, 16, 12),
+                                 (1, 9, 40, 48, 20, 300), (2, 6, 11, 24, 13, 29)]:  # channel-group counts that are no power of two
         x = torch.randn(B, C, H, W, generator=g)
         want = R.resize_bilinear(x, (OH, OW), 1).permute(0, 2, 3, 1)
         got = ops.resize_nhwc(dev, x.permute(0, 2, 3, 1).contiguous().cuda(), (OH, OW), 1).cpu()

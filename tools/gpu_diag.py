@@ -89,7 +89,9 @@ def check_resize(dev):
     g = torch.Generator().manual_seed(1)
     for (shape, out, m) in [((1, 1, 2, 2), (4, 4), 0), ((1, 1, 2, 2), (4, 4), 1), ((1, 1, 2, 2), (3, 1), 0), ((1, 1, 2, 2), (3, 1), 1),
                             ((2, 3, 36, 54), (96, 96), 0), ((2, 3, 96, 96), (48, 48), 0), ((1, 3, 96, 96), (24, 24), 0),
-                            ((1, 1, 96, 96), (36, 54), 0), ((1, 2, 7, 5), (13, 17), 1), ((1, 2, 5, 5), (5, 5), 0)]:
+                            ((1, 1, 96, 96), (36, 54), 0), ((1, 2, 7, 5), (13, 17), 1), ((1, 2, 5, 5), (5, 5), 0),
+                            # output rows wider than one 1024-column chunk of the row-per-workgroup kernel, both modes
+                            ((1, 2, 40, 700), (23, 1500), 0), ((2, 1, 33, 1300), (50, 2100), 1), ((1, 1, 64, 2200), (32, 1100), 0)]:
         x = torch.rand(shape, generator=g)
         if shape == (1, 1, 2, 2):
             x = torch.tensor([1.0, 2.0, 3.0, 4.0]).reshape(shape) if out == (4, 4) else torch.tensor([4.0, 1.0, 0.0, 2.0]).reshape(shape)
