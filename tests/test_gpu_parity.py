@@ -95,6 +95,20 @@ def test_infer_shapes_zeros_input_reference_init(dev):
     out = model.infer(torch.zeros(1, 3, S, S, device="cuda"))
     assert tuple(out.depth.shape) == (1, S, S) and tuple(out.focallength_px.shape) == (1,)
     assert torch.isfinite(out.depth).all()
+    # per-family timing (md_model_enable_timing) and its one-family filter (md_model_set_timing_filter)
+    x = torch.zeros(1, 3, S, S, device="cuda")
+    model.enable_timing(True)
+    ref = model.infer(x).depth.clone()
+    every = model.read_timing()
+    assert {"fc1_gemm", "attention", "layernorm", "head_tail_fused"} <= set(every) and "dec_out_conv" not in every
+    model.set_timing_filter("fc1_gemm")
+    assert torch.equal(model.infer(x).depth, ref)
+    one = model.read_timing()
+    assert set(one) == {"fc1_gemm"} and one["fc1_gemm"][1] == every["fc1_gemm"][1] and one["fc1_gemm"][0] > 0
+    model.set_timing_filter(None)
+    model.infer(x)
+    assert set(model.read_timing()) == set(every)
+    model.enable_timing(False)
     model.destroy()
 
 
