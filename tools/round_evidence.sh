@@ -1,4 +1,7 @@
 #!/bin/bash
+# One gpurun call that re-creates the round's measured artifacts under gpurun_out/: tools/refresh_profiles.sh (default bench
+# line with side kernels, rocprofv3 kernel stats, PMC traffic passes) plus the other configurations quoted in DESIGN.md
+# (B = 1 eager / graph, f16 with the accuracy report, f32, config 5 in bf16 / fp8, config 2). Copy what is judged into profiles/.
 set -o pipefail
 export PYTHONUNBUFFERED=1
 bash tools/refresh_profiles.sh || exit 1
