@@ -93,7 +93,7 @@ def work_model(cfg, B: int):
     # conv0's output: executed flops (the unfused pair is 1.45x that)
     fl["head_tail_fused"] = 2.0 * (9 * (F // 2) * 128 + 4 * 32) * px(hw[0])
     by = {}
-    esz = 4.0 if int(cfg.precision) == 1 else 2.0
+    esz = 4.0 if int(cfg.precision) in (1, 4) else 2.0  # f16x2: two half planes per element
     by["pyramid_patchify"] = B * 3 * S * S * 4.0 + (35 * B) * P * 3 * v.patch_size ** 2 * esz
     by["layernorm"] = (2 * depth + 1) * nseq * NT * D * (4.0 + esz)
     by["depth_post"] = B * S * S * 8.0
@@ -124,8 +124,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (B of DepthPro::infer([B,3,S,S])); default 8 for depth_pro (BASELINE config 4's 8 images/GPU), 1 for da3_* (single-image configs 2 / 5)")
-    ap.add_argument("--precision", choices=["bf16", "f16", "f32", "fp8"], default="bf16",
-                    help="MFMA operand type. bf16 = the BASELINE metric; f16 = same rate, 3 more mantissa bits (the accurate fast mode); "
+    ap.add_argument("--precision", choices=["bf16", "f16", "f16x2", "f32", "fp8"], default="bf16",
+                    help="MFMA operand type. bf16 = the BASELINE metric; f16 = same rate, 3 more mantissa bits; f16x2 = activations as hi + lo "
+                         "half planes on f16-exact weights (the seeded weights are rounded to f16 first, as an f16 checkpoint holds them): the accurate fast mode; "
                          "f32 = parity mode; fp8 (da3_* only, BASELINE config 5): e4m3 operands for the four ViT linear layers")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full")
     ap.add_argument("--model", choices=["depth_pro", "da3_large", "da3_small"], default="depth_pro",
@@ -189,7 +190,7 @@ def main(argv=None) -> int:
               file=sys.stderr)
         return 2
     cfg = {"full": DepthProConfig(), "small": DepthProConfig.small_test(), "tiny": DepthProConfig.tiny_test()}[args.preset]
-    cfg.precision = {"bf16": Precision.BF16, "f16": Precision.F16, "f32": Precision.F32}[args.precision]
+    cfg.precision = {"bf16": Precision.BF16, "f16": Precision.F16, "f32": Precision.F32, "f16x2": Precision.F16X2}[args.precision]
     cfg.max_batch = args.batch
     S, B = cfg.img_size(), args.batch
     # weights: random init (DepthPro::new, bench/inference.rs:25). Rank 0 generates, the others receive
@@ -202,6 +203,10 @@ def main(argv=None) -> int:
         broadcast_weights(model, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
+    if args.precision == "f16x2":
+        # the reference's checkpoints are f16 records (`HalfPrecisionSettings`, depth_pro/mod.rs:206): the accurate fast mode is
+        # measured on weights an f16 checkpoint can hold (exact MFMA operands, two terms per product)
+        model.round_weights_to_f16()
 
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)

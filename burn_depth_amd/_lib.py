@@ -71,6 +71,7 @@ SYMBOLS = {
     "md_model_param_count": (_I, [_P]),
     "md_model_param_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
     "md_model_commit_weights": (_I, [_P]),
+    "md_model_round_weights_f16": (_I, [_P]),
     "md_model_weight_arena": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "md_model_destroy": (_I, [_P]),
     "md_model_fork": (_I, [_P, C.POINTER(_P)]),

@@ -36,6 +36,7 @@ class Precision:
     F32 = 1
     FP8 = 2  # Depth-Anything-v3 only: e4m3 operands for the four ViT linear layers, bf16 elsewhere (BASELINE config 5)
     F16 = 3  # IEEE half operands (the reference's checkpoint type, mod.rs:206): bf16's rate, 3 more mantissa bits
+    F16X2 = 4  # Depth Pro: activations as two half planes (hi + lo, 22 bits), f16 weights exact: the accurate FAST mode
 
 
 @dataclass(frozen=True)

@@ -30,7 +30,7 @@ __device__ __forceinline__ f32x16_t mfma32(const i32x4_t& a, const i32x4_t& b, c
   typedef typename Native<T>::v8 v8;
   if constexpr (std::is_same<T, bf16_t>::value)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
-  else
+  else  // f16_t and the planes of f16s_t
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
 }
 
@@ -69,12 +69,24 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // the time is the waves' dependent chains: ablations of this kernel -- no exponentials / sums +12 %, no in-loop LDS-DMA
 // +20 %, no barrier 0 %, all three +48 % (837 TFLOP/s) -- and instruction-order experiments (softmax of one key half
 // pinned beside the MFMAs of the other, batched fragment reads, 8-wave workgroups) that all measured within +-4 %.
-template <typename T, bool FP8OUT, bool FAST>
-__global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+//
+// Split-half operands (T = f16s_t, MD_PREC_F16X2): q, k and v arrive as hi + lo planes -- qk rows are
+// [q_hi | q_lo | k_hi | k_lo] (each D wide), V^T has its lo plane `v_plane` elements behind the hi plane. The scores run on
+// three terms, S = k_hi.q_hi + k_lo.q_hi + k_hi.q_lo (the lo.lo term is below 2^-22), and O on P.(v_hi + v_lo) with P rounded
+// to one half (PTERMS = 1: its rounding averages over the keys; tools/precision_study.py prices it) or as hi + lo as well
+// (PTERMS = 2: a third MFMA, P_lo.v_hi). A stage holds the four tiles (32 KB), two stages 64 KB: two workgroups per CU, so the
+// kernel is built for two waves per SIMD (256 registers) instead of four. Softmax, row sums and O stay fp32 as before.
+template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1>
+__global__ __launch_bounds__(256, is_split<T>::value ? 2 : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
                                                            int S, int n_tokens, int heads, int D, int kpad, int qblocks,
-                                                           float out_fp8_inv) {
-  constexpr int STAGE = 16384;  // K tile 64x128B + V^T tile 64x128B
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 16];  // two stages | redo flag
+                                                           float out_fp8_inv, long v_plane) {
+  constexpr bool SP = is_split<T>::value;
+  constexpr int STAGE = SP ? 32768 : 16384;  // K tile 64x128B + V^T tile 64x128B (split-half: hi tiles, then the lo tiles 16 KB behind)
+  constexpr int LO = 16384;                  // split-half: offset of a stage's lo tiles
+  // one-plane types: static LDS (two stages | redo flag); split-half: 64 KB + flag as dynamic LDS (above the static limit)
+  __shared__ __attribute__((aligned(16))) char smem_static[SP ? 16 : 2 * STAGE + 16];
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* const smem = SP ? smem_dyn : smem_static;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,17 +101,21 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
   const int q0 = qb * 128 + wave * 32;
   const bool active = q0 < n_tokens;  // wave-uniform
   const int h = lane >> 5, c = lane & 31;
-  const long two_d = 2L * D;
+  const long two_d = 2L * D * kPlanes<T>;  // elements per q | k row (split-half: [q_hi | q_lo | k_hi | k_lo])
   const long seq_row0 = (long)seq * S;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane (c,h) holds Q[q0+c][16s + 8h + j] ----
-  i32x4_t qf[4];
+  i32x4_t qf[4], qfl[SP ? 4 : 1];
   {
     int q = q0 + c;
     q = q < n_tokens ? q : n_tokens - 1;
     const char* qp = (const char*)(qk + (seq_row0 + q) * two_d + head * 64) + h * 16;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const i32x4_t*)(qp + s * 32);
+    if constexpr (SP) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qfl[s] = *(const i32x4_t*)(qp + (long)D * sizeof(T) + s * 32);
+    }
   }
 
   // ---- global->LDS: 16 row-groups of 8 rows per stage (8 K + 8 V^T), 2 + 2 per wave: rows r0 .. r0+7 and r0+32 .. r0+39 of
@@ -112,8 +128,11 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
   // K descriptor: the n_tokens key rows of this (sequence, head). The last tile addresses up to 63 rows past them: whether the
   // hardware's range check (which covers the vector offset; the scalar offset is implementation-defined) returns zeros for
   // them or reads them, they are masked below -- the callers keep >= 64 rows of slack behind the last sequence for the latter.
-  const auto ksrd = __builtin_amdgcn_make_buffer_rsrc((void*)(qk + seq_row0 * two_d + D + head * 64), 0, (int)((unsigned)(n_tokens - 1) * krow_bytes + 128u), 0x00020000);
+  // (split-half: k_hi starts 2D into the row and k_lo D behind it: one descriptor, its range extended by that D)
+  const int klo_bytes = SP ? D * (int)sizeof(T) : 0;
+  const auto ksrd = __builtin_amdgcn_make_buffer_rsrc((void*)(qk + seq_row0 * two_d + (SP ? 2 * D : D) + head * 64), 0, (int)((unsigned)(n_tokens - 1) * krow_bytes + 128u) + klo_bytes, 0x00020000);
   const auto vsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
+  const auto vsrd_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + (SP ? v_plane : 0) + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
   const int kvoff = r0 * (int)krow_bytes + lc0 * 16;
   const int vvoff = r0 * kpad * (int)sizeof(T) + lc0 * 16;
   const int NT = (n_tokens + 63) / 64;
@@ -123,6 +142,10 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, sb + i * 4096, 16, kvoff, (t * 64 + i * 32) * (int)krow_bytes, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd, sb + 8192 + i * 4096, 16, vvoff, t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
+      if constexpr (SP) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, sb + LO + i * 4096, 16, kvoff, (t * 64 + i * 32) * (int)krow_bytes + klo_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd_lo, sb + LO + 8192 + i * 4096, 16, vvoff, t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
+      }
     }
   };
 
@@ -142,7 +165,7 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
 
   constexpr float kDefer = 6.0f;        // log2 units: p <= 64 in the safe body
   constexpr float kFastRange = 64.0f;   // |row max of tile 0| allowed for the fast body (log2 units)
-  constexpr bool kOffsetFast = std::is_same<T, f16_t>::value;  // fast body with the tile-0 row maximum as a fixed offset
+  constexpr bool kOffsetFast = is_half<T>::value;  // fast body with the tile-0 row maximum as a fixed offset
   // a (partial) row sum at or above this (inf / NaN included) fails the fast body: 2^100 for bf16; f16: every p < 65504
   constexpr float kFastSumMax = kOffsetFast ? 57000.0f : 1.2676506e30f;
 
@@ -164,6 +187,11 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
       const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
       const f32x16_t cin = s == 0 ? (f32x16_t){0.f} : st;  // first k-step: inline-constant 0 as C
       st = mfma32<T>(kf, qf[s], cin);
+      if constexpr (SP) {  // + k_lo.q_hi + k_hi.q_lo
+        const i32x4_t kl = *(const i32x4_t*)(sb + LO + (koff[sub] ^ (s << 5)));
+        st = mfma32<T>(kl, qf[s], st);
+        st = mfma32<T>(kf, qfl[s], st);
+      }
     }
   };
   // keys beyond the sequence get -inf (2^-inf = 0); last tile only
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
     return fmaxf(mx, st[15]);
   };
   // p = 2^(s - m) for 32 keys, packed as the B operand of the P.V MFMAs; adds the lane's partial row sums into ps[4]
-  auto exp_pack_sub = [&](const f32x16_t& st, float m, i32x4_t (&pf)[2], float (&ps)[4], auto no_offset) __attribute__((always_inline)) {
+  auto exp_pack_sub = [&](const f32x16_t& st, float m, i32x4_t (&pf)[2], i32x4_t (&pfl)[2], float (&ps)[4], auto no_offset) __attribute__((always_inline)) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       float p[8];
@@ -194,10 +222,18 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
       pf[s2][1] = pack2_nosat<T>(p[2], p[3]);
       pf[s2][2] = pack2_nosat<T>(p[4], p[5]);
       pf[s2][3] = pack2_nosat<T>(p[6], p[7]);
+      if constexpr (SP && PTERMS == 2) {  // P as hi + lo: lo = f16(p - f16(p))
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          float a, b;
+          widen2<T>((unsigned)pf[s2][j2], a, b);
+          pfl[s2][j2] = pack2_nosat<T>(p[2 * j2] - a, p[2 * j2 + 1] - b);
+        }
+      }
     }
   };
   // O^T[dt] += V^T[dt][keys of sub] . P^T[sub]: k-step s2 holds local keys 16 s2 .. 16 s2 + 15 of the 32-key block
-  auto pv_sub = [&](int t, int sub, const i32x4_t (&pf)[2], int nsteps) __attribute__((always_inline)) {
+  auto pv_sub = [&](int t, int sub, const i32x4_t (&pf)[2], const i32x4_t (&pfl)[2], int nsteps) __attribute__((always_inline)) {
     const char* sb = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -206,6 +242,11 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
         for (int dt = 0; dt < 2; ++dt) {
           const i32x4_t vf = *(const i32x4_t*)(sb + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
           o[dt] = mfma32<T>(vf, pf[s2], o[dt]);
+          if constexpr (SP) {  // + v_lo.P (+ v_hi.P_lo)
+            const i32x4_t vl = *(const i32x4_t*)(sb + LO + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+            o[dt] = mfma32<T>(vl, pf[s2], o[dt]);
+            if constexpr (PTERMS == 2) o[dt] = mfma32<T>(vf, pfl[s2], o[dt]);
+          }
         }
       }
     }
@@ -218,7 +259,7 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
     const int rem = PARTIAL ? n_tokens - t * 64 : 64;  // valid keys of this tile (wave-uniform)
     const bool two = !PARTIAL || rem > 32;             // the second 32-key block holds valid keys
     f32x16_t st0, st1;
-    i32x4_t pf0[2], pf1[2];
+    i32x4_t pf0[2], pf1[2], pfl0[2], pfl1[2];
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
     scores_sub(t, 0, st0);
     if (two) scores_sub(t, 1, st1);
@@ -248,11 +289,11 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
       }
     }
     typedef std::integral_constant<bool, !SAFE && !kOffsetFast> no_offset_t;
-    exp_pack_sub(st0, m_run, pf0, ps, no_offset_t());
-    pv_sub(t, 0, pf0, PARTIAL && rem <= 16 ? 1 : 2);
+    exp_pack_sub(st0, m_run, pf0, pfl0, ps, no_offset_t());
+    pv_sub(t, 0, pf0, pfl0, PARTIAL && rem <= 16 ? 1 : 2);
     if (two) {
-      exp_pack_sub(st1, m_run, pf1, ps, no_offset_t());
-      pv_sub(t, 1, pf1, PARTIAL && rem <= 48 ? 1 : 2);
+      exp_pack_sub(st1, m_run, pf1, pfl1, ps, no_offset_t());
+      pv_sub(t, 1, pf1, pfl1, PARTIAL && rem <= 48 ? 1 : 2);
     }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
   };
@@ -285,7 +326,7 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
   };
   bool use_safe = !FAST;
   if constexpr (FAST) {
-    int* redo = (int*)(smem + 2 * STAGE);
+    int* redo = (int*)(smem + 2 * STAGE);  // behind the two stages in either LDS form
     if (tid == 0) *redo = 0;
     pass(std::false_type());
     if (active) bad = bad || __any(!(l_run < kFastSumMax));  // a tile row sum >= 2^100, inf or NaN shows in the total
@@ -316,38 +357,62 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const T* __restrict__
         }
     }
   } else if (q < n_tokens) {
-    T* orow = out + (seq_row0 + q) * (long)D + head * 64;
+    T* orow = out + (seq_row0 + q) * (long)(D * kPlanes<T>) + head * 64;  // split-half rows: [hi: D | lo: D]
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int d = dt * 32 + 8 * q4 + 4 * h;
-        store4<T>(orow + d, (f32x4_t){o[dt][4 * q4] * inv_l, o[dt][4 * q4 + 1] * inv_l, o[dt][4 * q4 + 2] * inv_l, o[dt][4 * q4 + 3] * inv_l});
+        store4p<T>(orow + d, D, (f32x4_t){o[dt][4 * q4] * inv_l, o[dt][4 * q4 + 1] * inv_l, o[dt][4 * q4 + 2] * inv_l, o[dt][4 * q4 + 3] * inv_l});
       }
   }
 }
 
+// split-half attention: P as one half (1) or as hi + lo (2). MD_ATTN_PTERMS overrides the default (a measurement knob).
+static int attn_pterms() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MD_ATTN_PTERMS");
+    v = (e && e[0] == '1') ? 1 : 2;
+  }
+  return v;
+}
+
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                     int kpad, int prec, hipStream_t s, float out_fp8_inv) {
-  if (prec != MD_PREC_BF16 && prec != MD_PREC_F16) MD_FAIL(MD_ERR_UNSUPPORTED, "fused attention takes bf16 or f16 operands (precision %d)", prec);
+                     int kpad, int prec, hipStream_t s, float out_fp8_inv, long v_plane) {
+  if (prec != MD_PREC_BF16 && prec != MD_PREC_F16 && prec != MD_PREC_F16X2) MD_FAIL(MD_ERR_UNSUPPORTED, "fused attention takes bf16, f16 or split-half operands (precision %d)", prec);
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
     MD_FAIL(MD_ERR_INVALID_ARG, "attention: kpad=%d must be a multiple of 64 covering %d keys", kpad, n_tokens);
-  if ((long)S * 2 * D * 2 >= (1L << 31)) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: one sequence of q|k rows exceeds the 2-GB descriptor range");
+  if ((long)S * 2 * D * 2 * (prec == MD_PREC_F16X2 ? 2 : 1) >= (1L << 31)) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: one sequence of q|k rows exceeds the 2-GB descriptor range");
   const int qblocks = (n_tokens + 127) / 128;
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
   const dim3 grid((unsigned)blocks), block(256);
-  if (out_fp8_inv > 0.f) {
+  if (prec == MD_PREC_F16X2) {
+    if (out_fp8_inv > 0.f || v_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "attention: split-half operands need the V^T plane offset and write split-half rows");
+    constexpr int smem = 2 * 32768 + 16;
+    auto go = [&](auto kern, bool* attr_set) -> int {
+      if (!*attr_set) {
+        MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        *attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, grid, block, smem, s, (const f16s_t*)qk, (const f16s_t*)vT, (f16s_t*)out, S, n_tokens, heads, D, kpad, qblocks, 0.f, v_plane);
+      return MD_OK;
+    };
+    static bool set1 = false, set2 = false;
+    if (attn_pterms() == 1) MD_TRY(go(attention_kernel<f16s_t, false, true, 1>, &set1));
+    else MD_TRY(go(attention_kernel<f16s_t, false, true, 2>, &set2));
+  } else if (out_fp8_inv > 0.f) {
     if (prec != MD_PREC_BF16) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: e4m3 output rows are built for bf16 operands");
     hipLaunchKernelGGL((attention_kernel<bf16_t, true, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
-                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
   } else if (prec == MD_PREC_F16) {
     hipLaunchKernelGGL((attention_kernel<f16_t, false, true>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
-                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
   } else {
     hipLaunchKernelGGL((attention_kernel<bf16_t, false, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
-                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv);
+                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
   }
   MD_HIP(hipGetLastError());
   return MD_OK;

@@ -31,6 +31,19 @@ struct Native<f16_t> {
   typedef __attribute__((ext_vector_type(8))) _Float16 v8;
 };
 
+// the split-half element (MD_PREC_F16X2): an IEEE half in each of its two planes
+template <>
+struct Native<f16s_t> : Native<f16_t> {};
+template <typename T>
+struct is_split : std::false_type {};
+template <>
+struct is_split<f16s_t> : std::true_type {};
+template <typename T>
+struct is_half : std::integral_constant<bool, std::is_same<T, f16_t>::value || std::is_same<T, f16s_t>::value> {};
+// planes per logical element of a tensor of T (host and device)
+template <typename T>
+constexpr int kPlanes = is_split<T>::value ? 2 : 1;
+
 template <typename T>
 __device__ __forceinline__ typename Native<T>::type cvt_elem(float v);
 template <>
@@ -39,6 +52,11 @@ __device__ __forceinline__ __bf16 cvt_elem<bf16_t>(float v) {
 }
 template <>
 __device__ __forceinline__ _Float16 cvt_elem<f16_t>(float v) {
+  return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+}
+
+template <>
+__device__ __forceinline__ _Float16 cvt_elem<f16s_t>(float v) {
   return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
 }
 
@@ -80,7 +98,7 @@ __device__ __forceinline__ int pack2_nosat(float a, float b) {
 // widen packed 2-byte elements to fp32. bf16 is a shift / mask of the dword (one VALU op per element), f16 a v_cvt.
 template <typename T>
 __device__ __forceinline__ void widen2(unsigned u, float& a, float& b) {
-  if constexpr (std::is_same<T, bf16_t>::value) {
+  if constexpr (std::is_same<T, bf16_t>::value) {  // (f16_t and f16s_t: v_cvt_f32_f16)
     a = __uint_as_float(u << 16);
     b = __uint_as_float(u & 0xffff0000u);
   } else {
@@ -143,6 +161,64 @@ __device__ __forceinline__ void store8(T* p, const float* v) {
   }
 }
 
+// ---- split-half tensors (MD_PREC_F16X2): value = hi + lo, the lo plane `plane` elements behind the hi plane ----
+// hi = f16(v) (saturating), lo = f16(v - hi): exact to 2^-22 relative while lo is a normal half (|v| >= 2^-3) and to
+// 2^-25 absolute below that (lo subnormal; the f16 MFMAs and conversions keep subnormals: tools/probes/f16_denorm_probe.hip)
+template <typename T>
+__device__ __forceinline__ void split4(f32x4_t v, i32x2_t& hi, i32x2_t& lo) {
+  hi = pack4<T>(v);
+  lo = pack4<T>(v - widen4<T>(hi));
+}
+template <typename T>
+__device__ __forceinline__ void split8(f32x4_t a, f32x4_t b, i32x4_t& hi, i32x4_t& lo) {
+  hi = pack8<T>(a, b);
+  f32x4_t ha, hb;
+  widen8<T>(hi, ha, hb);
+  lo = pack8<T>(a - ha, b - hb);
+}
+template <typename T>
+__device__ __forceinline__ void store1s(T* p, long plane, float v) {
+  const typename Native<T>::type h = cvt_elem<T>(v);
+  *(typename Native<T>::type*)p = h;
+  *(typename Native<T>::type*)(p + plane) = cvt_elem<T>(v - (float)h);
+}
+template <typename T>
+__device__ __forceinline__ float load1s(const T* p, long plane) {
+  return (float)*(const typename Native<T>::type*)p + (float)*(const typename Native<T>::type*)(p + plane);
+}
+template <typename T>
+__device__ __forceinline__ void store4s(T* p, long plane, f32x4_t v) {
+  i32x2_t hi, lo;
+  split4<T>(v, hi, lo);
+  *(i32x2_t*)p = hi;
+  *(i32x2_t*)(p + plane) = lo;
+}
+template <typename T>
+__device__ __forceinline__ f32x4_t load4s(const T* p, long plane) {
+  return widen4<T>(*(const i32x2_t*)p) + widen4<T>(*(const i32x2_t*)(p + plane));
+}
+// plane-aware forms: `plane` is ignored (and costs nothing) for the one-plane types
+template <typename T>
+__device__ __forceinline__ void st1p(T* p, long plane, float v) {
+  if constexpr (is_split<T>::value) store1s<T>(p, plane, v);
+  else st1<T>(p, v);
+}
+template <typename T>
+__device__ __forceinline__ float ld1p(const T* p, long plane) {
+  if constexpr (is_split<T>::value) return load1s<T>(p, plane);
+  else return ld1<T>(p);
+}
+template <typename T>
+__device__ __forceinline__ void store4p(T* p, long plane, f32x4_t v) {
+  if constexpr (is_split<T>::value) store4s<T>(p, plane, v);
+  else store4<T>(p, v);
+}
+template <typename T>
+__device__ __forceinline__ f32x4_t load4p(const T* p, long plane) {
+  if constexpr (is_split<T>::value) return load4s<T>(p, plane);
+  else return load4<T>(p);
+}
+
 // Host-side dispatch over the storage type of a precision mode: `T` is float, f16_t or bf16_t inside STMT.
 // (MD_PREC_FP8 models store everything but the four ViT linear operands as bf16.)
 #define MD_BY_PREC(prec, STMT)             \
@@ -152,6 +228,9 @@ __device__ __forceinline__ void store8(T* p, const float* v) {
       STMT;                                \
     } else if ((prec) == MD_PREC_F16) {    \
       typedef ::md::f16_t T;               \
+      STMT;                                \
+    } else if ((prec) == MD_PREC_F16X2) {  \
+      typedef ::md::f16s_t T;              \
       STMT;                                \
     } else {                               \
       typedef ::md::bf16_t T;              \

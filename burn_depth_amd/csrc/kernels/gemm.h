@@ -63,6 +63,14 @@ struct GemmParams {
   int cH = 0, cW = 0, cC = 0;   // A_CONV3: NHWC input [B, cH, cW, cC]; K = 9*cC (tap-major), pad 1
   int cOH = 0, cOW = 0, cstride = 1;  // output grid (0 = same as input) and stride; M = B*cOH*cOW
   const void* zero_page = nullptr;  // >= 256 zero bytes (A_CONV3 halo)
+  // ---- split-half operands (T = f16s_t, MD_PREC_F16X2): an A row is [hi: Kp | lo: Kp] and a W row [W | W] (f16-exact
+  //      weights, K = 2 Kp) or [Wh | Wh | Wl] (K = 3 Kp; the third block multiplies A's hi plane again). Both are plain
+  //      K-contiguous rows to the main loop; only the A column of the third block wraps:
+  int a_wrap = 0;   // > 0: A k-tile (dense / indexed) or channel block inside a tap (conv) kb reads kb - a_wrap when kb >= a_wrap
+  int cCk = 0;      // A_CONV3: contraction channels per tap (0 = cC); K = 9 * cCk while the pixel stride stays cC
+  long o_plane = 0; // element offset from the hi to the lo plane of out / out2 (the logical padded row width)
+  long r_plane = 0; // the same for res1 / res2
+  long v_plane = 0; // EPI_QKV: offset from the hi to the lo plane of V^T (q | k rows are [q_hi | q_lo | k_hi | k_lo], each `embed` wide)
   // ---- epilogue ----
   int epi = EPI_STORE;
   int act = ACT_NONE;
@@ -116,7 +124,8 @@ struct GemmParams {
 
 enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_AUTO = 99 };
 
-// Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16), MD_PREC_F16 (T = f16), MD_PREC_F32 (T = float) or MD_PREC_FP8 (T = e4m3, dense only).
+// Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16), MD_PREC_F16 (T = f16), MD_PREC_F16X2 (T = f16s: split-half planes),
+// MD_PREC_F32 (T = float) or MD_PREC_FP8 (T = e4m3, dense only).
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream);
 
 }  // namespace md

@@ -9,6 +9,7 @@ int launch_gemm_bf16(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_f32(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_f16(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_fp8(GemmParams& p, int amode, int tile, hipStream_t stream);
+int launch_gemm_f16x2(GemmParams& p, int amode, int tile, hipStream_t stream);
 
 static int pick_tile(const GemmParams& p) {
   if (p.epi == EPI_HEAD || p.N <= 32) return TILE_256x32;
@@ -37,8 +38,9 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   if (p.K <= 0 || p.K % ke != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", p.K, ke);
   if (amode == A_CONV3) {
     if (p.cstride < 1) MD_FAIL(MD_ERR_INVALID_ARG, "conv3x3: stride %d", p.cstride);
-    if (p.cC % ke != 0 || p.K != 9 * p.cC)
-      MD_FAIL(MD_ERR_UNSUPPORTED, "conv3x3: Cin=%d must be a multiple of %d (K=%d)", p.cC, ke, p.K);
+    const int cck = p.cCk > 0 ? p.cCk : p.cC;  // contraction channels per tap (split-half operands: 2 or 3 planes' worth)
+    if (p.cC % ke != 0 || cck % ke != 0 || p.K != 9 * cck)
+      MD_FAIL(MD_ERR_UNSUPPORTED, "conv3x3: Cin=%d (contraction %d per tap) must be a multiple of %d (K=%d)", p.cC, cck, ke, p.K);
     if (!p.zero_page) MD_FAIL(MD_ERR_INVALID_ARG, "conv3x3: zero page missing");
   }
   if (amode == A_INDEXED && !p.a_index) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: index table missing");
@@ -71,7 +73,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   p.fd_psH = make_fastdiv(p.psH);
   p.fd_ow = make_fastdiv(p.cOW > 0 ? p.cOW : p.cW);
   p.fd_oh = make_fastdiv(p.cOH > 0 ? p.cOH : p.cH);
-  p.fd_cblocks = make_fastdiv(p.cC / ke);
+  p.fd_cblocks = make_fastdiv((p.cCk > 0 ? p.cCk : p.cC) / ke);
   {
     long rows = 0;
     for (int g = 0; g < p.ngroups; ++g) rows = std::max<long>(rows, (long)p.g_arow0[g] + p.g_rows[g]);
@@ -94,6 +96,13 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   }
   if (p.out_fp8) MD_FAIL(MD_ERR_UNSUPPORTED, "fp8 output needs fp8 operands");
   if (prec == MD_PREC_F16) return launch_gemm_f16(p, amode, tile, stream);
+  if (prec == MD_PREC_F16X2) {
+    if (p.epi == EPI_QKV && (p.embed % 4 != 0 || p.v_plane <= 0)) MD_FAIL(MD_ERR_INVALID_ARG, "split-half qkv: V^T plane offset missing");
+    if (!p.out_f32 && (p.epi == EPI_STORE || p.epi == EPI_PIXSHUF) && p.o_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "split-half output: plane offset missing");
+    if ((p.res1 || p.res2) && p.r_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "split-half residual: plane offset missing");
+    return launch_gemm_f16x2(p, amode, tile, stream);
+  }
+  if (p.a_wrap || p.cCk || p.o_plane || p.r_plane || p.v_plane) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: split-half fields set for a one-plane precision");
   return launch_gemm_bf16(p, amode, tile, stream);
 }
 

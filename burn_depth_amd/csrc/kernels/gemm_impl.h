@@ -56,6 +56,8 @@ struct Atom16<f16_t> {
   }
 };
 template <>
+struct Atom16<f16s_t> : Atom16<f16_t> {};  // split-half planes are IEEE halves: the same instruction on each plane
+template <>
 struct Atom16<float> {
   static __device__ __forceinline__ void mma(const i32x4_t& a, const i32x4_t& b, f32x4acc_t& c) {
     f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
@@ -160,7 +162,7 @@ __device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
   if constexpr (std::is_same<T, float>::value) {  // fp32 parity mode: libm erff
     f32x4_t r = {gelu_erf<T>(v[0]), gelu_erf<T>(v[1]), gelu_erf<T>(v[2]), gelu_erf<T>(v[3])};
     return r;
-  } else if constexpr (std::is_same<T, f16_t>::value) {
+  } else if constexpr (is_half<T>::value) {
     f32x4_t r = {gelu_as(v[0]), gelu_as(v[1]), gelu_as(v[2]), gelu_as(v[3])};
     return r;
   } else {
@@ -191,8 +193,8 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
     case EPI_STORE: {
       if (bias) v += *(const f32x4_t*)(bias + n);
       const long rm = p.res_mod > 0 ? (long)(m - fdiv(m, p.fd_res_mod) * p.res_mod) : (long)m;
-      if (p.res1) v += load4<T>((const T*)p.res1 + rm * p.ldr + n);
-      if (p.res2) v += load4<T>((const T*)p.res2 + rm * p.ldr + n);
+      if (p.res1) v += load4p<T>((const T*)p.res1 + rm * p.ldr + n, p.r_plane);
+      if (p.res2) v += load4p<T>((const T*)p.res2 + rm * p.ldr + n, p.r_plane);
       if (p.act == ACT_RELU) {
         v = relu4(v);
       } else if (p.act == ACT_GELU) {
@@ -201,8 +203,8 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       if (p.out_f32)
         store4<float>((float*)p.out + boff + (long)m * p.ldo + n, v);
       else
-        store4<T>((T*)p.out + boff + (long)m * p.ldo + n, v);
-      if (p.out2) store4<T>((T*)p.out2 + boff + (long)m * p.ldo + n, relu4(v));
+        store4p<T>((T*)p.out + boff + (long)m * p.ldo + n, p.o_plane, v);
+      if (p.out2) store4p<T>((T*)p.out2 + boff + (long)m * p.ldo + n, p.o_plane, relu4(v));
       break;
     }
     case EPI_RESID_LS: {
@@ -229,7 +231,23 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       v += *(const f32x4_t*)(bias + n);
       const int two_d = 2 * p.embed;
       if (n < p.embed) v *= p.qscale;  // embed % 4 == 0: a 4-column vector never straddles q | k
-      if (n < two_d) {
+      if constexpr (is_split<T>::value) {
+        // split-half rows [q_hi | q_lo | k_hi | k_lo], each `embed` wide; V^T lo plane v_plane elements behind the hi plane
+        if (n < two_d) {
+          const int isk = n >= p.embed ? 1 : 0;
+          store4s<T>((T*)p.out + (long)m * (2L * two_d) + isk * two_d + (n - isk * p.embed), p.embed, v);
+        } else {
+          const int c = n - two_d;
+          const int hd = c >> 6, d = c & 63;
+          const int seq = fdiv(m, p.fd_seq_stride);
+          const int i = m - seq * p.seq_stride;
+          T* vt = (T*)p.vT + (((long)seq * p.heads + hd) * 64 + d) * p.kpad + i;
+          store1s<T>(vt, p.v_plane, v[0]);
+          store1s<T>(vt + p.kpad, p.v_plane, v[1]);
+          store1s<T>(vt + 2L * p.kpad, p.v_plane, v[2]);
+          store1s<T>(vt + 3L * p.kpad, p.v_plane, v[3]);
+        }
+      } else if (n < two_d) {
         store4<T>((T*)p.out + (long)m * two_d + n, v);
       } else {
         int c = n - two_d;
@@ -260,8 +278,8 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       if (p.out_f32)
         store4<float>((float*)p.out + o, v);
       else
-        store4<T>((T*)p.out + o, v);
-      if (p.out2) store4<T>((T*)p.out2 + o, relu4(v));
+        store4p<T>((T*)p.out + o, p.o_plane, v);
+      if (p.out2) store4p<T>((T*)p.out2 + o, p.o_plane, relu4(v));
       break;
     }
     default:
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 
   const int KT = p.K / KE;
   // conv bookkeeping: k-tile -> (tap, channel block); all wave-uniform
-  const int cblocks = (AMODE == A_CONV3) ? p.cC / KE : 1;
+  const int cblocks = (AMODE == A_CONV3) ? (p.cCk > 0 ? p.cCk : p.cC) / KE : 1;
 
   auto issue = [&](int stage, int kt) {
     char* sbase = smem + stage * STAGE_BYTES;
@@ -394,11 +412,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
     int tap = 0;
     if constexpr (AMODE == A_CONV3) {
       tap = fdiv(kt, p.fd_cblocks);
-      const int cb = kt - tap * cblocks;
+      int cb = kt - tap * cblocks;
+      if (p.a_wrap > 0 && cb >= p.a_wrap) cb -= p.a_wrap;  // split-half operands: the third term re-reads A's hi plane
       const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 9
       a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * ESZ + (long)cb * 128;
     } else {
-      a_delta = (long)kt * 128;
+      const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+      a_delta = (long)kta * 128;
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
   const char* zsrc = (const char*)p.zero_page + pc * 16;
   const int KT = p.K / KE;
-  const int cblocks = (AMODE == A_CONV3) ? p.cC / KE : 1;
+  const int cblocks = (AMODE == A_CONV3) ? (p.cCk > 0 ? p.cCk : p.cC) / KE : 1;
 
   // issue the A / W half-tile of k-tile kt into ring slot `slot` (both wave-uniform)
   bool freeze_k = false, no_loads = false;  // timing-only ablations of the diagnostic build
@@ -700,11 +720,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     int tap = 0;
     if constexpr (AMODE == A_CONV3) {
       tap = fdiv(kt, p.fd_cblocks);
-      const int cb = kt - tap * cblocks;
+      int cb = kt - tap * cblocks;
+      if (p.a_wrap > 0 && cb >= p.a_wrap) cb -= p.a_wrap;  // split-half operands: the third term re-reads A's hi plane
       const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 9
       a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * ESZ + (long)cb * 128;
     } else {
-      a_delta = (long)kt * 128;
+      const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+      a_delta = (long)kta * 128;
     }
 #pragma unroll
     for (int i = 0; i < LPH; ++i) {
@@ -888,7 +910,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   };
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
-    if constexpr (sizeof(TO) == 2) {
+    if constexpr (sizeof(TO) == 2 && !is_split<TO>::value) {
       // V^T[seq][head][d][token] tiles: staged TRANSPOSED through the wave-private LDS area (64 n-rows x 64 tokens
       // per half) so that a lane stores 4 consecutive tokens of one (head, d) row -- 8-byte stores, 4 full 128-byte
       // row segments per instruction -- instead of 2-byte scatter stores (4x the store instructions). Needs whole
@@ -1332,7 +1354,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   int ek = 0;
   if (p.epi == EPI_RESID_LS) ek = 1;
   else if (p.epi == EPI_PIXSHUF) ek = 3;
-  else if (sizeof(typename OutT<T>::type) == 2) {
+  else if (sizeof(typename OutT<T>::type) == 2 && !is_split<T>::value) {
     const long ldo_e = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
     const bool vec8 = p.N % 8 == 0 && ldo_e % 8 == 0 && (!(p.res1 || p.res2) || p.ldr % 8 == 0);
     if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = 4;
@@ -1356,13 +1378,15 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   (void)dset;
   switch (ek) {
     case 1: return go(gemm256_kernel<T, AMODE, 1, false>, &set[1]);
-    case 3: return go(gemm256_kernel<T, AMODE, 3, false>, &set[3]);
+    case 3:
+      if constexpr (!is_split<T>::value) return go(gemm256_kernel<T, AMODE, 3, false>, &set[3]);
+      break;
     case 2:
-      if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);
+      if constexpr (sizeof(typename OutT<T>::type) == 2 && !is_split<T>::value) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);
       break;
     case 4:  // the GELU store kind is built for dense A only (the MLP's fc1); a GELU behind a gathered / convolution A operand
              // takes the store kind's runtime activation path of the generic epilogue
-      if constexpr (sizeof(typename OutT<T>::type) == 2 && AMODE == A_DENSE) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
+      if constexpr (sizeof(typename OutT<T>::type) == 2 && AMODE == A_DENSE && !is_split<T>::value) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
       break;
     default: break;
   }

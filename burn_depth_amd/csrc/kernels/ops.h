@@ -65,14 +65,15 @@ int launch_cls_init(float* x, int nseq_total, int S, int n_tokens, int D, const 
 int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
                      int out_f32, hipStream_t s, float fp8_inv_scale = 1.f);
 // fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
-int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s);
+int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width = 0);
 
 // layout converters (debug taps, stand-alone ops)
 int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s);
 int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int coff, float* out, int prec,
                         hipStream_t s);
-int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s);
-int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s);
+// width: logical row width -- needed by MD_PREC_F16X2, whose rows are [hi: width | lo: width] (ignored otherwise)
+int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s, int width = 0);
+int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s, int width = 0);
 
 // Small direct convolution, NHWC, fp32 accumulate (FOV head, fov.rs:16-49).
 // in: element type by in_prec (MD_PREC_BF16 -> bf16, MD_PREC_F32 -> float); w packed
@@ -128,7 +129,9 @@ inline float attn_qscale(int prec) { return prec == MD_PREC_F32 ? 1.0f : kAttnQS
 // fused multi-head attention on bf16 / f16 operands (K5; prec = MD_PREC_BF16 | MD_PREC_F16): qk [rows, 2D] (q | k),
 // q PRE-SCALED by kAttnQScale, vT [seq][heads][64][kpad], out [rows, D].
 // out_fp8_inv > 0 (bf16 only): the output rows are OCP e4m3 bytes (value * out_fp8_inv, saturating).
+// prec = MD_PREC_F16X2: split-half operands -- qk rows [q_hi | q_lo | k_hi | k_lo] (4D wide), the lo plane of V^T `v_plane`
+// elements behind its hi plane, out rows [hi: D | lo: D]; scores on three MFMA terms, P.V on two or three (attention.hip).
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                     int kpad, int prec, hipStream_t s, float out_fp8_inv = 0.f);
+                     int kpad, int prec, hipStream_t s, float out_fp8_inv = 0.f, long v_plane = 0);
 
 }  // namespace md

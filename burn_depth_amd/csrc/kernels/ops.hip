@@ -203,7 +203,14 @@ __global__ void pyramid_patchify_kernel(const float* __restrict__ x, PyramidGeom
         v[q] = bilerp(plane, S, tyy, txx);
       }
     }
-    store8<T>(out + row * K + col, v);
+    if constexpr (is_split<T>::value) {  // split-half rows [hi: K | lo: K]
+      i32x4_t hi, lo;
+      split8<T>((f32x4_t){v[0], v[1], v[2], v[3]}, (f32x4_t){v[4], v[5], v[6], v[7]}, hi, lo);
+      *(i32x4_t*)(out + row * 2 * K + col) = hi;
+      *(i32x4_t*)(out + row * 2 * K + K + col) = lo;
+    } else {
+      store8<T>(out + row * K + col, v);
+    }
   }
 }
 
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void pyramid_patchify_blocks_kernel(const floa
       for (int i = i0; i <= i1; ++i) {
         const long tile = base + (long)(j * steps + i) * g.B + b;
         const long row = tile * P + (gy - j * stp) * grid + (gx - i * stp);
-        store4<T>(out + row * K + c * 256 + ky * 16 + kx, (f32x4_t){v[0], v[1], v[2], v[3]});
+        store4p<T>(out + row * (K * kPlanes<T>) + c * 256 + ky * 16 + kx, K, (f32x4_t){v[0], v[1], v[2], v[3]});
       }
   };
   // level 0: 16 patches, 4 per wave (copies)
@@ -408,8 +415,8 @@ __global__ void border_bias_fix_kernel(T* __restrict__ map, int B, int H, int W,
     else if (k < 2 * W + H - 2) { Y = k - 2 * W + 1; X = 0; }
     else { Y = k - (2 * W + H - 2) + 1; X = W - 1; }
     const int cls = (Y == 0 ? 0 : (Y == H - 1 ? 2 : 1)) * 3 + (X == 0 ? 0 : (X == W - 1 ? 2 : 1));
-    T* p = map + (((long)b * H + Y) * W + X) * ld + c;
-    st1<T>(p, ld1<T>(p) + (bias9[cls * C + c] - bias9[4 * C + c]));
+    T* p = map + (((long)b * H + Y) * W + X) * (ld * kPlanes<T>) + c;  // split-half rows: [hi: ld | lo: ld]
+    st1p<T>(p, ld, ld1p<T>(p, ld) + (bias9[cls * C + c] - bias9[4 * C + c]));
   }
 }
 
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           y = y * fp8_inv_scale;
           *(int*)((char*)out + row * D + i) = pack4_fp8(y[0], y[1], y[2], y[3]);
         } else {
-          store4<TO>(out + row * D + i, y);
+          store4p<TO>(out + row * (D * kPlanes<TO>) + i, D, y);  // split-half rows: [hi: D | lo: D]
         }
       }
     }
@@ -624,6 +631,8 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
                        fp8_inv_scale);                                                                              \
   else if (prec == MD_PREC_F16)                                                                                     \
     hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16_t*)out, rows, D, eps, S, g, 1.f); \
+  else if (prec == MD_PREC_F16X2)                                                                                   \
+    hipLaunchKernelGGL((layernorm_kernel<f16s_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16s_t*)out, rows, D, eps, S, g, 1.f); \
   else                                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g, 1.f);
   switch (nv) {
@@ -640,29 +649,42 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
 // ------------------------------------------------------------------------------------------------
 // element-type converters
 // ------------------------------------------------------------------------------------------------
+// `width` = logical row width; split-half tensors store a row as [hi: width | lo: width] (one-plane types ignore it)
 template <typename T>
-__global__ void f32_to_rows_kernel(const float* __restrict__ in, long n, T* __restrict__ out) {
+__global__ void f32_to_rows_kernel(const float* __restrict__ in, long n, T* __restrict__ out, int width) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    st1<T>(out + i, in[i]);
+    if constexpr (is_split<T>::value) {
+      const long row = i / width;
+      store1s<T>(out + row * 2 * width + (i - row * width), width, in[i]);
+    } else {
+      st1<T>(out + i, in[i]);
+    }
   }
 }
 template <typename T>
-__global__ void rows_to_f32_kernel(const T* __restrict__ in, long n, float* __restrict__ out) {
+__global__ void rows_to_f32_kernel(const T* __restrict__ in, long n, float* __restrict__ out, int width) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    out[i] = ld1<T>(in + i);
+    if constexpr (is_split<T>::value) {
+      const long row = i / width;
+      out[i] = load1s<T>(in + row * 2 * width + (i - row * width), width);
+    } else {
+      out[i] = ld1<T>(in + i);
+    }
   }
 }
 
-int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s) {
-  MD_BY_PREC(prec, hipLaunchKernelGGL(f32_to_rows_kernel<T>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (T*)out));
+int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStream_t s, int width) {
+  if (prec == MD_PREC_F16X2 && (width <= 0 || count % width != 0)) MD_FAIL(MD_ERR_INVALID_ARG, "f32_to_rows: split-half rows need the row width");
+  MD_BY_PREC(prec, hipLaunchKernelGGL(f32_to_rows_kernel<T>, dim3(grid_for(count)), dim3(256), 0, s, in, count, (T*)out, width));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
-int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s) {
-  return launch_f32_to_rows(x, count, out, prec, s);
+int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width) {
+  return launch_f32_to_rows(x, count, out, prec, s, width);
 }
-int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s) {
-  MD_BY_PREC(prec, hipLaunchKernelGGL(rows_to_f32_kernel<T>, dim3(grid_for(count)), dim3(256), 0, s, (const T*)in, count, out));
+int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStream_t s, int width) {
+  if (prec == MD_PREC_F16X2 && (width <= 0 || count % width != 0)) MD_FAIL(MD_ERR_INVALID_ARG, "rows_to_f32: split-half rows need the row width");
+  MD_BY_PREC(prec, hipLaunchKernelGGL(rows_to_f32_kernel<T>, dim3(grid_for(count)), dim3(256), 0, s, (const T*)in, count, out, width));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -680,7 +702,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, 
     const int b = (int)(t / H);
     float v = in[(((long)b * C + c) * H + y) * W + xw];
     if (relu) v = fmaxf(v, 0.f);
-    st1<T>(out + e, v);
+    st1p<T>(out + (e / C) * (C * kPlanes<T>) + c, C, v);  // split-half pixels: [hi: C | lo: C]
   }
 }
 template <typename T>
@@ -694,8 +716,8 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, int B, int C, int 
     t /= H;
     const int c = (int)(t % C);
     const int b = (int)(t / C);
-    const long src = (((long)b * H + y) * W + xw) * ld + coff + c;
-    out[e] = ld1<T>(in + src);
+    const long src = (((long)b * H + y) * W + xw) * (ld * kPlanes<T>) + coff + c;  // ld = logical row width (split-half: [hi: ld | lo: ld])
+    out[e] = ld1p<T>(in + src, ld);
   }
 }
 
@@ -719,8 +741,8 @@ int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int
 // once and reused for the CO weight rows.
 // ------------------------------------------------------------------------------------------------
 template <typename TI>
-__device__ inline void load4v(const TI* in, long src, float v[4]) {
-  const f32x4_t t = load4<TI>(in + src);
+__device__ inline void load4v(const TI* in, long src, long plane, float v[4]) {
+  const f32x4_t t = load4p<TI>(in + src, plane);
   v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
 }
 
@@ -751,16 +773,17 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__
       const int ky = tap / k, kx = tap % k;
       const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const long src = (((long)b * H + iy) * W + ix) * Cin + ci;
+      const long src = (((long)b * H + iy) * W + ix) * Cin + ci;                       // fp32 addend: one plane
+      const long srci = (((long)b * H + iy) * W + ix) * (Cin * kPlanes<TI>) + ci;      // input pixel: [hi: Cin | lo: Cin] when split
       float v[4];
       if constexpr (VEC == 4) {
-        load4v<TI>(in, src, v);
+        load4v<TI>(in, srci, Cin, v);
         if (add) {
           const float4 a4 = *(const float4*)(add + src);
           v[0] += a4.x, v[1] += a4.y, v[2] += a4.z, v[3] += a4.w;
         }
       } else {
-        v[0] = ld1<TI>(in + src);
+        v[0] = ld1p<TI>(in + srci, Cin);
         if (add) v[0] += add[src];
       }
 #pragma unroll
@@ -1154,17 +1177,13 @@ __global__ void qkv_split_kernel(const float* __restrict__ qkv, int Tn, int N, i
     const int i = (int)(t % N);
     const int seq = (int)(t / N);
     const float v = c < D ? qkv[e] * q_scale : qkv[e];
-    long dst;
-    T* base;
-    if (c < 2 * D) {
-      base = qk;
-      dst = ((long)seq * SS + i) * 2 * D + c;
-    } else {
+    if (c < 2 * D) {  // split-half rows: [q_hi | q_lo | k_hi | k_lo], each D wide
+      const int isk = c >= D ? 1 : 0;
+      st1p<T>(qk + ((long)seq * SS + i) * (2 * D * kPlanes<T>) + isk * (D * kPlanes<T>) + (c - isk * D), D, v);
+    } else {          // split-half V^T: the lo plane behind the whole hi plane
       const int cc = c - 2 * D;
-      base = vT;
-      dst = (((long)seq * heads + (cc >> 6)) * 64 + (cc & 63)) * kpad + i;
+      st1p<T>(vT + (((long)seq * heads + (cc >> 6)) * 64 + (cc & 63)) * kpad + i, (long)Tn * heads * 64 * kpad, v);
     }
-    st1<T>(base + dst, v);
   }
 }
 
@@ -1184,8 +1203,8 @@ __global__ void unpad_rows_kernel(const T* __restrict__ in, int Tn, int N, int S
     const long t = e / D;
     const int i = (int)(t % N);
     const int seq = (int)(t / N);
-    const long src = ((long)seq * SS + i) * D + d;
-    out[e] = ld1<T>(in + src);
+    const long src = ((long)seq * SS + i) * (D * kPlanes<T>) + d;
+    out[e] = ld1p<T>(in + src, D);
   }
 }
 

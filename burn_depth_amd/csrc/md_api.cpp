@@ -25,6 +25,13 @@ struct DevBuf {  // scoped device allocation for the stand-alone test operators
 };
 hipStream_t pick_stream(md_device_t dev, void* stream) { return stream ? (hipStream_t)stream : dev->stream; }
 int ke_of(int prec) { return prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64); }
+// MD_PREC_F16X2: MFMA terms of a product with these weights -- 2 when every value is an exact IEEE half, else 3
+int split_terms_of(const float* w_dev, long n, hipStream_t st, int* terms) {
+  unsigned bad = 0;
+  MD_TRY(count_inexact_f16(w_dev, n, st, &bad));
+  *terms = bad == 0 ? 2 : 3;
+  return MD_OK;
+}
 size_t esz_of(int prec) { return prec == MD_PREC_F32 ? 4 : (prec == MD_PREC_FP8 ? 1 : 2); }
 }  // namespace
 
@@ -158,6 +165,8 @@ int md_model_commit_weights(md_model_t m) {
   return model_commit(m);
 }
 
+int md_model_round_weights_f16(md_model_t m) { return model_round_weights_f16(m); }
+
 int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes) {
   if (!m || !device_ptr || !bytes) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: take the arena of the root model");
@@ -215,6 +224,7 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
   else if (k == "seq_stride") *out = m->SS;
   else if (k == "is_fork") *out = m->parent ? 1 : 0;
   else if (k == "forks") *out = m->forks;
+  else if (k == "weight_terms") *out = model_root(m)->wterms;
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
 }
@@ -317,7 +327,7 @@ int md_op_pyramid_patchify(md_device_t dev, const float* x_dev, int B, int S, in
                            int force_generic, void* out_dev, int* rows_out, int* cols_out, void* stream) {
   if (!dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   if (B <= 0 || S <= 0 || window <= 0 || patch <= 0 || S != 4 * window || window % patch != 0) MD_FAIL(MD_ERR_SHAPE, "pyramid: S must be 4 * window and window a multiple of the patch size");
-  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_F16 && precision != MD_PREC_F16X2) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
   PyramidGeom g;
   g.B = B; g.S = S; g.win = window; g.ps = patch; g.method = method;
   split_geometry(S, window, 0.25f, &g.stride0, &g.steps0);      // encoder.rs:329
@@ -402,15 +412,24 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
   if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
   const bool storage_out = (precision & MD_OP_STORAGE_OUT) && (precision & 0xff) != MD_PREC_F32;
   precision &= 0xff;
-  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8 && precision != MD_PREC_F16 && precision != MD_PREC_F16X2) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
   if (K % ke_of(precision) != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "K=%d must be a multiple of %d", K, ke_of(precision));
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = pick_stream(dev, stream);
+  const bool split = precision == MD_PREC_F16X2;
   DevBuf xa, wa, ws;
-  MD_TRY(xa.alloc((size_t)M * K * esz_of(precision)));
-  MD_TRY(wa.alloc((size_t)N * K * esz_of(precision)));
+  MD_TRY(xa.alloc((size_t)M * K * esz_of(precision) * (split ? 2 : 1)));
+  MD_TRY(wa.alloc((size_t)N * K * esz_of(precision) * (split ? 3 : 1)));
   GemmParams p;
-  if (precision == MD_PREC_FP8) {
+  int terms = 1;
+  if (split) {
+    // split-half operands: x rows [hi | lo], w rows [W | W] when every weight is an exact half, else [Wh | Wh | Wl]
+    MD_TRY(split_terms_of(w_dev, (long)N * K, st, &terms));
+    MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st, K));
+    PackEntry e;
+    e.kind = PACK_NK; e.d0 = N; e.d1 = K; e.k = 1; e.kp = K; e.terms = terms; e.dst = wa.p;
+    MD_TRY(pack_weight(w_dev, e, precision, st));
+  } else if (precision == MD_PREC_FP8) {
     // stand-alone fp8 check: activations on the static scale 8/448 (the engine's LayerNorm-output scale), weights
     // per output row
     const float xs = 8.0f / 448.0f;
@@ -423,15 +442,17 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
     MD_TRY(launch_f32_to_rows(x_dev, (long)M * K, xa.p, precision, st));
     MD_TRY(launch_f32_to_rows(w_dev, (long)N * K, wa.p, precision, st));
   }
-  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = K;
+  p.N = N; p.K = K * terms; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = wa.p; p.A = xa.p; p.lda = split ? 2 * K : K;
+  p.a_wrap = terms == 3 ? 2 * K / ke_of(precision) : 0;
   p.epi = EPI_STORE; p.act = act; p.out_f32 = 1; p.bias[0] = bias_dev; p.out = out_dev; p.ldo = N;
   DevBuf ob;
   if (storage_out) {
-    MD_TRY(ob.alloc((size_t)M * N * 2));
+    MD_TRY(ob.alloc((size_t)M * N * 2 * (split ? 2 : 1)));
     p.out_f32 = 0; p.out = ob.p;
+    if (split) { p.ldo = 2 * N; p.o_plane = N; }
   }
   MD_TRY(launch_gemm(p, A_DENSE, precision, tile, st));
-  if (storage_out) MD_TRY(launch_rows_to_f32(ob.p, (long)M * N, out_dev, precision == MD_PREC_F16 ? MD_PREC_F16 : MD_PREC_BF16, st));
+  if (storage_out) MD_TRY(launch_rows_to_f32(ob.p, (long)M * N, out_dev, (precision == MD_PREC_F16 || split) ? precision : MD_PREC_BF16, st, N));
   MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
@@ -442,14 +463,14 @@ int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int hea
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = pick_stream(dev, stream);
   const int D = heads * 64, SS = (N + 3) / 4 * 4, kpad = (N + 63) / 64 * 64;
-  const size_t es = esz_of(precision);
+  const size_t es = esz_of(precision) * (precision == MD_PREC_F16X2 ? 2 : 1);  // split-half: two planes per element
   DevBuf qk, vT, ao, sc;
   MD_TRY(qk.alloc(((size_t)T * SS + 64) * 2 * D * es));
   MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * es));
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * es));
   MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, attn_qscale(precision), precision, st));
   if (precision != MD_PREC_F32) {
-    MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st));
+    MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st, 0.f, (long)T * heads * 64 * kpad));
   } else {
     MD_TRY(sc.alloc((size_t)T * heads * SS * kpad * 4));
     GemmParams p;
@@ -485,19 +506,23 @@ int md_op_conv3x3(md_device_t dev, const float* x_dev, const float* w_dev, const
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = pick_stream(dev, stream);
   const size_t es = esz_of(precision);
+  const bool split = precision == MD_PREC_F16X2;
   DevBuf xa, wa, oa, zp;
-  MD_TRY(xa.alloc((size_t)B * H * W * Cin * es));
-  MD_TRY(wa.alloc((size_t)Cout * 9 * Cin * es));
+  MD_TRY(xa.alloc((size_t)B * H * W * Cin * es * (split ? 2 : 1)));
+  MD_TRY(wa.alloc((size_t)Cout * 9 * Cin * es * (split ? 3 : 1)));
   MD_TRY(oa.alloc((size_t)B * H * W * Cout * 4));
   MD_TRY(zp.alloc(4096));
   MD_TRY(launch_nchw_to_nhwc(x_dev, B, Cin, H, W, xa.p, precision, pre_relu, st));
   PackEntry e;
   e.kind = PACK_CONV3; e.d0 = Cout; e.d1 = Cin; e.k = 3; e.kp = Cin; e.dst = wa.p;
+  if (split) MD_TRY(split_terms_of(w_dev, (long)Cout * Cin * 9, st, &e.terms));
   MD_TRY(pack_weight(w_dev, e, precision, st));
   GemmParams p;
-  p.N = Cout; p.K = 9 * Cin; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p;
-  p.A = xa.p; p.cH = H; p.cW = W; p.cC = Cin; p.zero_page = zp.p;
+  p.N = Cout; p.K = 9 * Cin * e.terms; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p;
+  p.A = xa.p; p.cH = H; p.cW = W; p.cC = split ? 2 * Cin : Cin; p.cCk = split ? e.terms * Cin : 0; p.zero_page = zp.p;
+  p.a_wrap = e.terms == 3 ? 2 * Cin / ke_of(precision) : 0;
   p.epi = EPI_STORE; p.out_f32 = storage_out ? 0 : 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
+  if (split && storage_out) { p.ldo = 2 * Cout; p.o_plane = Cout; }
   MD_TRY(launch_gemm(p, A_CONV3, precision, TILE_AUTO, st));
   MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, H, W, Cout, 0, out_dev, storage_out ? precision : MD_PREC_F32, st));
   MD_HIP(hipStreamSynchronize(st));
@@ -515,17 +540,21 @@ int md_op_deconv2x2(md_device_t dev, const float* x_dev, const float* w_dev, con
   MD_HIP(hipSetDevice(dev->ordinal));
   hipStream_t st = pick_stream(dev, stream);
   const size_t es = esz_of(precision);
+  const bool split = precision == MD_PREC_F16X2;
   DevBuf xa, wa, oa;
-  MD_TRY(xa.alloc((size_t)B * H * W * Cin * es));
-  MD_TRY(wa.alloc((size_t)4 * Cout * Cin * es));
+  MD_TRY(xa.alloc((size_t)B * H * W * Cin * es * (split ? 2 : 1)));
+  MD_TRY(wa.alloc((size_t)4 * Cout * Cin * es * (split ? 3 : 1)));
   MD_TRY(oa.alloc((size_t)B * 4 * H * W * Cout * 4));
   MD_TRY(launch_nchw_to_nhwc(x_dev, B, Cin, H, W, xa.p, precision, 0, st));
   PackEntry e;
   e.kind = PACK_DECONV; e.d0 = Cin; e.d1 = Cout; e.k = 2; e.kp = Cin; e.dst = wa.p;
+  if (split) MD_TRY(split_terms_of(w_dev, (long)Cin * Cout * 4, st, &e.terms));
   MD_TRY(pack_weight(w_dev, e, precision, st));
   GemmParams p;
-  p.N = 4 * Cout; p.K = Cin; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p; p.A = xa.p; p.lda = Cin;
+  p.N = 4 * Cout; p.K = Cin * e.terms; p.ngroups = 1; p.g_rows[0] = B * H * W; p.W[0] = wa.p; p.A = xa.p; p.lda = split ? 2 * Cin : Cin;
+  p.a_wrap = e.terms == 3 ? 2 * Cin / ke_of(precision) : 0;
   p.epi = EPI_PIXSHUF; p.out_f32 = storage_out ? 0 : 1; p.bias[0] = bias_dev; p.out = oa.p; p.ldo = Cout;
+  if (split && storage_out) { p.ldo = 2 * Cout; p.o_plane = Cout; }
   p.psH = H; p.psW = W; p.psC = Cout; p.ps_coff = 0;
   MD_TRY(launch_gemm(p, A_DENSE, precision, TILE_AUTO, st));
   MD_TRY(launch_nhwc_to_nchw(oa.p, B, Cout, 2 * H, 2 * W, Cout, 0, out_dev, storage_out ? precision : MD_PREC_F32, st));
@@ -742,6 +771,8 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
   d.precision = c->precision;
   d.max_batch = c->max_batch > 0 ? c->max_batch : 1;
   d.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
+  if (d.precision == MD_PREC_F16X2)
+    MD_FAIL(MD_ERR_UNSUPPORTED, "MD_PREC_F16X2 (split-half operands) is built for Depth Pro; Depth-Anything-v3 has MD_PREC_F32 as its accurate mode");
   if (d.precision != MD_PREC_BF16 && d.precision != MD_PREC_F32 && d.precision != MD_PREC_FP8 && d.precision != MD_PREC_F16)
     MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", d.precision);
   *out = d;

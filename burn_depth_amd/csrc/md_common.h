@@ -53,6 +53,12 @@ struct bf16_t {
 struct f16_t {
   uint16_t bits;
 };
+// MD_PREC_F16X2: an element of a tensor kept as TWO IEEE-half planes, value = hi + lo with hi = f16(x), lo = f16(x - hi)
+// (22 significant bits). A row of C logical channels is stored [hi: C | lo: C]; a product with an f16 weight is two
+// v_mfma_f32_16x16x32_f16 (hi and lo against the same weight), three when the weight is itself kept as hi + lo.
+struct f16s_t {
+  uint16_t bits;
+};
 
 __host__ __device__ inline float bf16_to_f32(bf16_t v) {
   union {

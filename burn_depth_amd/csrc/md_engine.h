@@ -52,6 +52,7 @@ struct PackEntry {
   int kind = PACK_NK;
   int d0 = 0, d1 = 0, k = 1;  // NK: N, K | CONV3: Cout, Cin | DECONV: Cin, Cout | DIRECT: Cout, Cin, k | HEAD_W/B, C1C3_W/B: Cout, Cin (k = Cmid)
   int kp = 0;       // padded contraction length per tap (elements)
+  int terms = 1;    // MD_PREC_F16X2: copies of the contraction per row -- 2 = [W | W] (f16-exact weight), 3 = [Wh | Wh | Wl]; set at commit
   int f32 = 0;      // packed as f32 regardless of precision (direct conv)
   void* dst = nullptr;
   size_t bytes = 0;
@@ -86,6 +87,10 @@ struct md_model_s {
   int prec = MD_PREC_BF16;
   int esz = 2;  // bytes per operand element
   int ke = 64;  // contraction elements per 128-byte LDS row
+  int xm = 1;   // planes per activation element: 2 in MD_PREC_F16X2 (rows are [hi | lo])
+  int wterms = 1;  // MD_PREC_F16X2: MFMA terms of a product with a plain (not composed) weight -- 2 when every such weight is
+                   // f16-exact (an f16 checkpoint, mod.rs:206), else 3; decided by model_commit. 1 in the one-plane modes
+  size_t vt_plane = 0;  // MD_PREC_F16X2: elements from the hi to the lo plane of V^T
 
   // ---- parameters ----
   std::vector<md::ParamSpec> params;
@@ -98,6 +103,7 @@ struct md_model_s {
   char* wpk_base = nullptr;
   size_t wpk_bytes = 0;
   bool committed = false;
+  unsigned commit_gen = 0;  // bumped by every model_commit (part of the graph-replay key)
   int ngroups = 2;
   md::VitW vit[3];
   float head_b_host = 0.f;
@@ -151,12 +157,15 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out);
 int model_init_seeded(md_model_t m, uint64_t seed, int scheme);
 int model_load_container(md_model_t m, const char* path);
 int model_commit(md_model_t m);
+int model_round_weights_f16(md_model_t m);
 int model_destroy(md_model_t m);
 int model_fork(md_model_t src, md_model_t* out);
 inline md_model_s* model_root(md_model_s* m) { return m->parent ? m->parent : m; }
 int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s);
+// number of values of w[0..n) that are not exactly representable as an IEEE half (synchronises the stream)
+int count_inexact_f16(const float* w, long n, hipStream_t s, unsigned* out);
 void fov_scalar_host(float fovx_deg, int H, int W, float* focal_px, float* fovy_rad);
 
 // ---- Depth-Anything-v3 (md_da3.hip) ----

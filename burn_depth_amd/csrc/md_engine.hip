@@ -59,24 +59,34 @@ void merge_source(int Y, int X, int h, int w, int steps, int pad, int* j, int* i
 // ------------------------------------------------------------------------------------------------
 // weight packing kernels: fp32 master -> MFMA operand layouts
 // ------------------------------------------------------------------------------------------------
+// `terms` copies of the contraction per output row (MD_PREC_F16X2): blocks 0 and 1 hold f16(w) -- they multiply the hi and
+// the lo plane of the activation row --, block 2 holds f16(w - f16(w)) and multiplies the hi plane again (GemmParams::a_wrap).
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int kind, int d0, int d1, int k,
-                            int kp, long total) {
+                            int kp, int terms, long total) {
+  const int kpt = kp * terms;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (kind == PACK_NK) {  // [N][K] -> [N][kp]
-      const int kk = (int)(e % kp);
-      const long n = e / kp;
+    int blk = 0;
+    if (kind == PACK_NK) {  // [N][K] -> [N][terms][kp]
+      const int kq = (int)(e % kpt);
+      blk = kq / kp;
+      const int kk = kq - blk * kp;
+      const long n = e / kpt;
       if (kk < d1) v = src[n * d1 + kk];
-    } else if (kind == PACK_CONV3) {  // [Cout][Cin][3][3] -> [Cout][9][kp]
-      const int ci = (int)(e % kp);
-      const long t = e / kp;
+    } else if (kind == PACK_CONV3) {  // [Cout][Cin][3][3] -> [Cout][9][terms][kp]
+      const int cq = (int)(e % kpt);
+      blk = cq / kp;
+      const int ci = cq - blk * kp;
+      const long t = e / kpt;
       const int tap = (int)(t % 9);
       const long co = t / 9;
       if (ci < d1) v = src[(co * d1 + ci) * 9 + tap];
-    } else if (kind == PACK_DECONV) {  // [Cin][Cout][k][k] -> [k*k*Cout][kp], row = tap*Cout + co
-      const int ci = (int)(e % kp);
-      const long n = e / kp;
+    } else if (kind == PACK_DECONV) {  // [Cin][Cout][k][k] -> [k*k*Cout][terms][kp], row = tap*Cout + co
+      const int cq = (int)(e % kpt);
+      blk = cq / kp;
+      const int ci = cq - blk * kp;
+      const long n = e / kpt;
       const int tap = (int)(n / d1);
       const int co = (int)(n % d1);
       if (ci < d0) v = src[((long)ci * d1 + co) * (k * k) + tap];
@@ -89,8 +99,29 @@ __global__ void pack_kernel(const float* __restrict__ src, T* __restrict__ dst, 
       const long co = t / k;
       v = src[((co * d1 + ci) * k + ky) * k + kx];
     }
-    st1<T>(dst + e, v);
+    if constexpr (is_split<T>::value) {
+      const _Float16 h = cvt_elem<T>(v);
+      *(_Float16*)(dst + e) = blk < 2 ? h : cvt_elem<T>(v - (float)h);
+    } else {
+      st1<T>(dst + e, v);
+    }
   }
+}
+
+// MD_PREC_F16X2: number of values of w[0..n) that are not exactly representable as an IEEE half (the reference's
+// checkpoints are f16 records, mod.rs:206: none; an fp32 checkpoint or the seeded test weights: nearly all)
+__global__ void count_inexact_f16_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ count) {
+  unsigned c = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = w[i];
+    c += ((float)(_Float16)v != v) ? 1u : 0u;
+  }
+  if (c) atomicAdd(count, c);
+}
+// w[i] = f32(f16(w[i])): what reading the value back from an f16 record gives
+__global__ void round_f16_kernel(float* __restrict__ w, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    w[i] = (float)(_Float16)__builtin_amdgcn_fmed3f(w[i], -65504.f, 65504.f);
 }
 
 // W'[ci][co][q] = sum_m Wd[ci][m][q] * Wo[co][m]; Wd is [Cin, Cmid, 2, 2], Wo is [Cout, Cmid] (1x1 conv)
@@ -226,11 +257,24 @@ int compose_head_bias(const float* w1, const float* bd, const float* b1, int cmi
   return MD_OK;
 }
 
+int count_inexact_f16(const float* w, long n, hipStream_t s, unsigned* out) {
+  unsigned* d_cnt = nullptr;
+  MD_HIP(hipMalloc((void**)&d_cnt, 4));
+  MD_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+  hipLaunchKernelGGL(count_inexact_f16_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, w, n, d_cnt);
+  MD_HIP(hipMemcpyAsync(out, d_cnt, 4, hipMemcpyDeviceToHost, s));
+  MD_HIP(hipStreamSynchronize(s));
+  MD_HIP(hipFree(d_cnt));
+  return MD_OK;
+}
+
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s) {
-  const long total = (long)pack_elems(e);
-  const int grid = (int)std::min<long>((total + 255) / 256, 4096);
   const int pk_prec = e.f32 ? MD_PREC_F32 : prec;
-  MD_BY_PREC(pk_prec, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid), dim3(256), 0, s, src, (T*)e.dst, e.kind, e.d0, e.d1, e.k, e.kp, total));
+  const int terms = pk_prec == MD_PREC_F16X2 ? e.terms : 1;
+  if (pk_prec == MD_PREC_F16X2 && terms != 2 && terms != 3) MD_FAIL(MD_ERR_INVALID_ARG, "pack: split-half weights take 2 or 3 terms, got %d", terms);
+  const long total = (long)pack_elems(e, terms);
+  const int grid = (int)std::min<long>((total + 255) / 256, 4096);
+  MD_BY_PREC(pk_prec, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid), dim3(256), 0, s, src, (T*)e.dst, e.kind, e.d0, e.d1, e.k, e.kp, terms, total));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -291,7 +335,8 @@ static void level_sizes(const md_model_s* m, int lvl_hw[5]) {
 
 static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
   const ModelCfg& c = m->cfg;
-  const int B = c.max_batch, D = c.pv.D, F = c.F, P = m->P, SS = m->SS, esz = m->esz;
+  const int B = c.max_batch, D = c.pv.D, F = c.F, P = m->P, SS = m->SS;
+  const int esz = m->esz * m->xm;  // bytes per LOGICAL element of a T tensor (MD_PREC_F16X2: two half planes)
   const int n0 = m->steps0 * m->steps0 * B, n1 = m->steps1 * m->steps1 * B;
   const int nseq_p = n0 + n1 + B;
   const int nseq = nseq_p + B * (m->ngroups - 1);
@@ -322,6 +367,7 @@ static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
   MD_TAKE(xn, void*, rows * D * esz);
   MD_TAKE(qk, void*, rows * 2 * D * esz);
   MD_TAKE(vT, void*, (size_t)nseq * c.pv.heads * 64 * m->kpad * esz);
+  m->vt_plane = m->xm == 2 ? (size_t)nseq * c.pv.heads * 64 * m->kpad : 0;
   MD_TAKE(ao, void*, rows * D * esz);
   MD_TAKE(hbuf, void*, rows * 4 * D * esz);
   if (m->prec == MD_PREC_F32) MD_TAKE(scores, float*, (size_t)nseq * c.pv.heads * SS * m->kpad * 4);
@@ -403,6 +449,8 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   m->prec = cfg.precision;
   m->esz = cfg.precision == MD_PREC_F32 ? 4 : 2;
   m->ke = 128 / m->esz;
+  m->xm = cfg.precision == MD_PREC_F16X2 ? 2 : 1;
+  m->wterms = m->xm == 2 ? 3 : 1;
   m->ngroups = 2 + ((cfg.use_fov_head && cfg.has_fov_vit) ? 1 : 0);
   m->S = cfg.img_size();
   m->win = cfg.pv.img;
@@ -620,7 +668,7 @@ int model_fork(md_model_t src, md_model_t* out) {
   md_model_s* m = new md_model_s();
   m->dev = root->dev;
   m->cfg = root->cfg;
-  m->prec = root->prec; m->esz = root->esz; m->ke = root->ke;
+  m->prec = root->prec; m->esz = root->esz; m->ke = root->ke; m->xm = root->xm; m->wterms = root->wterms;
   m->params = root->params; m->pindex = root->pindex; m->w32 = root->w32;
   m->w32_base = root->w32_base; m->w32_bytes = root->w32_bytes;
   m->packs = root->packs; m->pack_index = root->pack_index;
@@ -727,6 +775,25 @@ int model_commit(md_model_t m) {
     else if (e.param2 >= 0) composed_elems = std::max(composed_elems, (size_t)e.d0 * e.d1 * e.k * e.k);
   }
   if (composed_elems) MD_HIP(hipMalloc((void**)&composed, composed_elems * sizeof(float)));
+  if (m->xm == 2) {
+    // split-half operands: a product with an f16-exact weight is two MFMA terms, else three. One form per model (the three
+    // ViTs share launches): two when EVERY plain weight is exact -- an f16 checkpoint -- else three. The layer products
+    // composed at commit (fp32 sums of products) are never exact: always three.
+    unsigned* d_cnt = nullptr;
+    unsigned h_cnt = 0;
+    MD_HIP(hipMalloc((void**)&d_cnt, 4));
+    MD_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
+    for (auto& e : m->packs) {
+      if (e.f32 || e.param2 >= 0 || (e.kind != PACK_NK && e.kind != PACK_CONV3 && e.kind != PACK_DECONV)) continue;
+      const long n = (long)m->params[e.param].count();
+      hipLaunchKernelGGL(count_inexact_f16_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, m->w32[e.param], n, d_cnt);
+    }
+    MD_HIP(hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, s));
+    MD_HIP(hipStreamSynchronize(s));
+    MD_HIP(hipFree(d_cnt));
+    m->wterms = h_cnt == 0 ? 2 : 3;
+    for (auto& e : m->packs) e.terms = e.f32 ? 1 : ((e.param2 >= 0 || e.kind == PACK_HEAD_W || e.kind == PACK_C1C3_W) ? 3 : m->wterms);
+  }
   for (auto& e : m->packs) {
     if (e.kind == PACK_HEAD_W) {  // deconv -> conv3x3 of the depth head as one conv (d0 = Cout, d1 = Cin, k = Cmid)
       MD_TRY(compose_head(m->w32[e.param], m->w32[e.param2], e.d1, e.k, e.d0, composed, s));
@@ -755,8 +822,31 @@ int model_commit(md_model_t m) {
   MD_HIP(hipStreamSynchronize(s));
   if (composed) MD_HIP(hipFree(composed));
   if (m->kind == 1) MD_TRY(da3_on_commit(m));
+  // captured graphs bake by-value launch parameters (the head's output bias, the split-half term count): none survives a commit
+  for (auto& kv : m->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  m->graphs.clear();
+  m->commit_gen += 1;
   m->committed = true;
   return MD_OK;
+}
+
+// `DepthPro::load` reads an f16 record (`HalfPrecisionSettings`, depth_pro/mod.rs:206): every parameter of a loaded reference
+// model is an IEEE half widened to f32. This rounds the fp32 master copy of every parameter the same way, in place.
+int model_round_weights_f16(md_model_t m) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: round them on the root model");
+  if (m->forks > 0) MD_FAIL(MD_ERR_INVALID_ARG, "model has %d live fork(s) sharing its weights", m->forks);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t s = m->dev->stream;
+  for (size_t i = 0; i < m->params.size(); ++i) {
+    const long n = (long)m->params[i].count();
+    hipLaunchKernelGGL(round_f16_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, m->w32[i], n);
+  }
+  MD_HIP(hipGetLastError());
+  MD_HIP(hipStreamSynchronize(s));
+  m->committed = false;
+  return model_commit(m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,7 +935,8 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       p.bias[g] = m->vit[g].pe_b;
       p.pos[g] = m->vit[g].pos;
     }
-    p.A = b->patches; p.lda = Kpe;
+    p.A = b->patches;
+    split_dense_a(m, p, Kpe, Kpe, 0);
     p.epi = EPI_PATCH_EMBED; p.out = b->xres; p.ldo = D; p.seq_stride = SS; p.seq_patches = P; p.embed = D;
     r.begin("patch_embed");
     MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
@@ -867,9 +958,11 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     r.end();
     {
       GemmParams p;
-      p.N = 3 * D; p.K = D; group_rows(p);
+      p.N = 3 * D; group_rows(p);
       for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].qkv_w; p.bias[g] = m->vit[g].blk[i].qkv_b; }
-      p.A = b->xn; p.lda = D;
+      p.A = b->xn;
+      split_dense_a(m, p, D, D, 0);
+      p.v_plane = (long)m->vt_plane;
       p.epi = EPI_QKV; p.out = b->qk; p.vT = b->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = m->kpad; p.qscale = attn_qscale(m->prec);
       r.begin("qkv_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
@@ -877,7 +970,7 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     }
     if (m->prec != MD_PREC_F32) {
       r.begin("attention");
-      MD_TRY(launch_attention(b->qk, b->vT, b->ao, nseq, SS, NT, heads, D, m->kpad, m->prec, r.st));
+      MD_TRY(launch_attention(b->qk, b->vT, b->ao, nseq, SS, NT, heads, D, m->kpad, m->prec, r.st, 0.f, (long)m->vt_plane));
       r.end();
     } else {
       // fp32: scores = q k^T (batched GEMM) -> row softmax -> P V^T^T (batched GEMM)
@@ -906,11 +999,13 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     }
     {
       GemmParams p;
-      p.N = D; p.K = D; group_rows(p);
+      p.N = D; group_rows(p);
       for (int g = 0; g < G; ++g) {
         p.W[g] = m->vit[g].blk[i].proj_w; p.bias[g] = m->vit[g].blk[i].proj_b; p.scale[g] = m->vit[g].blk[i].ls1;
       }
-      p.A = b->ao; p.lda = D; p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
+      p.A = b->ao;
+      split_dense_a(m, p, D, D, 0);
+      p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
       r.begin("proj_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
@@ -921,20 +1016,25 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     r.end();
     {
       GemmParams p;
-      p.N = 4 * D; p.K = D; group_rows(p);
+      p.N = 4 * D; group_rows(p);
       for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].fc1_w; p.bias[g] = m->vit[g].blk[i].fc1_b; }
-      p.A = b->xn; p.lda = D; p.epi = EPI_STORE; p.act = ACT_GELU; p.out = b->hbuf; p.ldo = 4 * D;
+      p.A = b->xn;
+      split_dense_a(m, p, D, D, 0);
+      p.epi = EPI_STORE; p.act = ACT_GELU; p.out = b->hbuf;
+      split_out(m, p, 4 * D, true);
       r.begin("fc1_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
     }
     {
       GemmParams p;
-      p.N = D; p.K = 4 * D; group_rows(p);
+      p.N = D; group_rows(p);
       for (int g = 0; g < G; ++g) {
         p.W[g] = m->vit[g].blk[i].fc2_w; p.bias[g] = m->vit[g].blk[i].fc2_b; p.scale[g] = m->vit[g].blk[i].ls2;
       }
-      p.A = b->hbuf; p.lda = 4 * D; p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
+      p.A = b->hbuf;
+      split_dense_a(m, p, 4 * D, 4 * D, 0);
+      p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
       r.begin("fc2_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
@@ -943,7 +1043,7 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     for (int hk = 0; hk < 2; ++hk)
       if (c.pv.hook_ids[hk] == i) {
         r.begin("hook_copy");
-        MD_TRY(launch_convert_rows(b->xres, b->hook[hk], (long)n0 * SS * D, m->prec, r.st));
+        MD_TRY(launch_convert_rows(b->xres, b->hook[hk], (long)n0 * SS * D, m->prec, r.st, D));
         r.end();
       }
   }
@@ -970,12 +1070,12 @@ static int run_encoder_tail(Run& r, const md_model_s::IndexSet& ix) {
                  cpad(m, dims[0]), F, nullptr, b->l0a, cpad(m, F), 0));
   // upsample.1 and upsample.2 (k2s2, no bias, nothing between them) as ONE k4s4 deconvolution on their weight product
   MD_TRY(deconv2(r, "enc_deconv", b->l0a, cpad(m, F), nullptr, 2 * hi, 2 * hi, W("encoder.upsample_latent0.upsample.1x2"),
-                 cpad(m, F), F, nullptr, b->enc0, cpad(m, F), 0, b->enc0r, 4));
+                 cpad(m, F), F, nullptr, b->enc0, cpad(m, F), 0, b->enc0r, 4, 3));
   // latent1: 1x1 (D -> dims0), 2 deconvs @ 4x (encoder.rs:152,424): the two deconvolutions as one k4s4
   MD_TRY(gemm_rows(r, "enc_proj", b->hook[1], D, ix.hi, Mhi, W("encoder.upsample_latent1.projection.weight"), dims[0], D,
                    nullptr, b->l1p, cpad(m, dims[0])));
   MD_TRY(deconv2(r, "enc_deconv", b->l1p, cpad(m, dims[0]), nullptr, hi, hi, W("encoder.upsample_latent1.upsample.0x1"),
-                 cpad(m, dims[0]), dims[0], nullptr, b->enc1, cpad(m, dims[0]), 0, nullptr, 4));
+                 cpad(m, dims[0]), dims[0], nullptr, b->enc1, cpad(m, dims[0]), 0, nullptr, 4, 3));
   // x0 (encoder.rs:153,425)
   MD_TRY(gemm_rows(r, "enc_proj", b->tok, D, ix.hi, Mhi, W("encoder.upsample0.projection.weight"), dims[1], D, nullptr,
                    b->x0p, cpad(m, dims[1])));
@@ -1055,7 +1155,7 @@ static int run_decoder_head(Run& r) {
     if (l != 0) {
       // deconv (no bias) then 1x1 out_conv (decoder.rs:124-141): one GEMM on the weight product packed at commit
       MD_TRY(deconv2(r, "dec_deconv_out", b->dy[l], Fp, nullptr, hw[l], hw[l], W(f + ".deconv_out_conv"), Fp, F,
-                     Bi(f + ".out_conv.bias"), b->df[l], Fp, 0));
+                     Bi(f + ".out_conv.bias"), b->df[l], Fp, 0, nullptr, 2, 3));
       ohw = 2 * hw[l];
     } else if (!fused_c0 || m->taps_enabled) {  // level 0: the product path composes this 1x1 into head.conv0 (below);
                                                 // its output exists only for the taps
@@ -1076,7 +1176,7 @@ static int run_decoder_head(Run& r) {
     // output: the convolution adds the interior bias class, the border pixels get their class afterwards
     const float* bias9 = (const float*)PK(m, "head.outconv_conv0.bias");
     MD_TRY(conv3(r, "head_conv0", b->dy[0], hw[0], hw[0], Fp, W("head.outconv_conv0.weight"), bias9 + 4 * F2, F2, b->h0, F2p,
-                 ACT_NONE, nullptr, nullptr, nullptr));
+                 ACT_NONE, nullptr, nullptr, nullptr, 3));
     r.begin("head_conv0");
     MD_TRY(launch_border_bias_fix(b->h0, r.B, hw[0], hw[0], F2, F2p, bias9, m->prec, r.st));
     r.end();
@@ -1096,8 +1196,9 @@ static int run_decoder_head(Run& r) {
     // deconv and conv1 have nothing between them, so their product is packed at commit (add_pack_head_fused) as a 3x3
     // weight with 4 x 32 output columns, one 32-column group per output parity; the epilogue finishes the 1x1 tail.
     GemmParams p;
-    p.N = 4 * 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = r.B * hw[0] * hw[0]; p.W[0] = W("head.deconv_conv1.weight");
-    p.A = b->h0; p.cH = hw[0]; p.cW = hw[0]; p.cC = F2p; p.zero_page = m->zero_page;
+    p.N = 4 * 32; p.ngroups = 1; p.g_rows[0] = r.B * hw[0] * hw[0]; p.W[0] = W("head.deconv_conv1.weight");
+    p.A = b->h0; p.cH = hw[0]; p.cW = hw[0]; p.zero_page = m->zero_page;
+    split_conv_a(m, p, F2p, 3);
     p.epi = EPI_HEAD_UP2; p.bias[0] = (const float*)PK(m, "head.deconv_conv1.bias"); p.head_w = Bi("head.conv_out.weight");
     p.head_b = model_root(m)->head_b_host;
     p.out = b->canonical;
@@ -1221,8 +1322,10 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
   hipStream_t st = stream ? stream : (m->own_stream ? m->own_stream : m->dev->stream);
   const bool eligible = nchw && !rgb && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && model_root(m)->committed && B > 0 &&
                         B <= m->cfg.max_batch && H == m->S && W == m->S;
+  // the commit generation of the weights is part of the key: a graph bakes by-value launch parameters (the head's output
+  // bias, the split-half term count), and a fork's graphs cannot be reached from the root's commit
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)depth,
-                                      (uintptr_t)focal, (uintptr_t)fovx, (uintptr_t)fovy};
+                                      (uintptr_t)focal, (uintptr_t)fovx, (uintptr_t)fovy, (uintptr_t)model_root(m)->commit_gen};
   return run_with_graph(m, st, key, eligible, body);
 }
 

@@ -10,17 +10,24 @@ namespace md {
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
-inline size_t pack_elems(const PackEntry& e) {
+// elements of a packed weight; `terms` copies of the contraction per row (MD_PREC_F16X2: 2 or 3, PackEntry::terms)
+inline size_t pack_elems(const PackEntry& e, int terms = 1) {
+  const size_t kpt = (size_t)e.kp * terms;
   switch (e.kind) {
-    case PACK_NK: return (size_t)e.d0 * e.kp;
-    case PACK_CONV3: return (size_t)e.d0 * 9 * e.kp;
-    case PACK_DECONV: return (size_t)e.k * e.k * e.d1 * e.kp;
-    case PACK_HEAD_W: return (size_t)4 * e.d0 * 9 * e.kp;
+    case PACK_NK: return (size_t)e.d0 * kpt;
+    case PACK_CONV3: return (size_t)e.d0 * 9 * kpt;
+    case PACK_DECONV: return (size_t)e.k * e.k * e.d1 * kpt;
+    case PACK_HEAD_W: return (size_t)4 * e.d0 * 9 * kpt;
     case PACK_HEAD_B: return (size_t)9 * e.d0;
-    case PACK_C1C3_W: return (size_t)e.d0 * 9 * e.kp;
+    case PACK_C1C3_W: return (size_t)e.d0 * 9 * kpt;
     case PACK_C1C3_B: return (size_t)9 * e.d0;
     default: return (size_t)e.d0 * e.d1 * e.k * e.k;
   }
+}
+// allocation size of a pack: split-half models reserve three terms (the form is only known once the weights are committed)
+inline size_t pack_bytes(const md_model_s* m, const PackEntry& e) {
+  if (e.f32) return pack_elems(e) * 4;
+  return pack_elems(e, m->xm == 2 ? 3 : 1) * (m->prec == MD_PREC_F32 ? 4 : 2);
 }
 
 inline const float* P32(md_model_s* m, const std::string& name) {
@@ -44,8 +51,7 @@ inline void add_pack(md_model_s* m, const std::string& name, int kind, int d0, i
   e.f32 = f32 ? 1 : 0;
   const int contraction = kind == PACK_NK ? d1 : kind == PACK_CONV3 ? d1 : kind == PACK_DECONV ? d0 : d1;
   e.kp = f32 ? contraction : round_up(contraction, m->ke);
-  const size_t esz = (f32 || m->prec == MD_PREC_F32) ? 4 : 2;
-  e.bytes = pack_elems(e) * esz;
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name] = (int)m->packs.size();
   m->packs.push_back(e);
 }
@@ -64,7 +70,7 @@ inline void add_pack_composed(md_model_s* m, const std::string& name, const std:
   e.d1 = cout;
   e.k = 2;
   e.kp = round_up(cin, m->ke);
-  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name] = (int)m->packs.size();
   m->packs.push_back(e);
 }
@@ -81,12 +87,12 @@ inline void add_pack_head_fused(md_model_s* m, const std::string& name, const st
   e.kind = PACK_HEAD_W;
   e.d0 = cout; e.d1 = cin; e.k = cmid;
   e.kp = round_up(cin, m->ke);
-  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name + ".weight"] = (int)m->packs.size();
   m->packs.push_back(e);
   e.kind = PACK_HEAD_B;
   e.f32 = 1;
-  e.bytes = pack_elems(e) * 4;
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name + ".bias"] = (int)m->packs.size();
   m->packs.push_back(e);
 }
@@ -103,12 +109,12 @@ inline void add_pack_c1c3(md_model_s* m, const std::string& name, const std::str
   e.kind = PACK_C1C3_W;
   e.d0 = cout; e.d1 = cin; e.k = cmid;
   e.kp = round_up(cin, m->ke);
-  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name + ".weight"] = (int)m->packs.size();
   m->packs.push_back(e);
   e.kind = PACK_C1C3_B;
   e.f32 = 1;
-  e.bytes = pack_elems(e) * 4;
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name + ".bias"] = (int)m->packs.size();
   m->packs.push_back(e);
 }
@@ -128,7 +134,7 @@ inline void add_pack_deconv_pair(md_model_s* m, const std::string& name, const s
   e.d1 = cout;
   e.k = 4;
   e.kp = round_up(cin, m->ke);
-  e.bytes = pack_elems(e) * (m->prec == MD_PREC_F32 ? 4 : 2);
+  e.bytes = pack_bytes(m, e);
   m->pack_index[name] = (int)m->packs.size();
   m->packs.push_back(e);
 }
@@ -235,13 +241,42 @@ struct Run {
 
 inline int cpad(const md_model_s* m, int ch) { return (ch + m->ke - 1) / m->ke * m->ke; }
 
+// ---- split-half operands (MD_PREC_F16X2; every function below is the identity on the one-plane modes) ----
+// Callers pass LOGICAL padded channel counts (row widths, K); an activation row is physically [hi | lo] and a weight row
+// `terms` copies of its contraction (2: [W | W], 3: [Wh | Wh | Wl]). terms == 0 = the model's plain-weight form
+// (md_model_s::wterms); the products composed at commit are never f16-exact and pass 3.
+inline int split_terms(const md_model_s* m, int terms) { return m->xm == 1 ? 1 : (terms > 0 ? terms : m->wterms); }
+// dense / indexed A operand of `kp` logical channels per row
+inline void split_dense_a(const md_model_s* m, GemmParams& p, int kp, long lda, int terms) {
+  const int t = split_terms(m, terms);
+  p.K = kp * t;
+  p.lda = lda * m->xm;
+  p.a_wrap = t == 3 ? 2 * kp / m->ke : 0;
+}
+// 3x3-convolution A operand: NHWC pixels of `cin_p` logical channels
+inline void split_conv_a(const md_model_s* m, GemmParams& p, int cin_p, int terms) {
+  const int t = split_terms(m, terms);
+  p.cC = cin_p * m->xm;
+  p.cCk = m->xm == 1 ? 0 : cin_p * t;
+  p.K = 9 * cin_p * t;
+  p.a_wrap = t == 3 ? 2 * cin_p / m->ke : 0;
+}
+// T-typed output (and residual inputs) with `ldo` logical channels per row
+inline void split_out(const md_model_s* m, GemmParams& p, long ldo, bool t_out) {
+  if (!t_out) { p.ldo = ldo; return; }
+  p.ldo = ldo * m->xm;
+  p.o_plane = m->xm == 2 ? ldo : 0;
+}
+
 // 1x1 conv / linear over NHWC rows.  A may be gathered through `idx`.
 inline int gemm_rows(Run& r, const char* name, const void* A, long lda, const int* idx, long M, const void* W, int N, int K,
-              const float* bias, void* out, long ldo, int out_f32 = 0, int act = ACT_NONE) {
+              const float* bias, void* out, long ldo, int out_f32 = 0, int act = ACT_NONE, int terms = 0) {
   GemmParams p;
-  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = (int)M; p.W[0] = W;
-  p.A = A; p.lda = lda; p.a_index = idx;
-  p.epi = EPI_STORE; p.act = act; p.out_f32 = out_f32; p.bias[0] = bias; p.out = out; p.ldo = ldo;
+  p.N = N; p.ngroups = 1; p.g_rows[0] = (int)M; p.W[0] = W;
+  p.A = A; p.a_index = idx;
+  split_dense_a(r.m, p, K, lda, terms);
+  p.epi = EPI_STORE; p.act = act; p.out_f32 = out_f32; p.bias[0] = bias; p.out = out;
+  split_out(r.m, p, ldo, !out_f32);
   r.begin(name);
   int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
   r.end();
@@ -250,11 +285,13 @@ inline int gemm_rows(Run& r, const char* name, const void* A, long lda, const in
 
 // ConvTranspose2d k=2 s=2 as GEMM + pixel shuffle (encoder.rs:61-69, decoder.rs:100-105, mod.rs:81-84)
 inline int deconv2(Run& r, const char* name, const void* A, long lda, const int* idx, int h, int w, const void* W, int Cin_p,
-            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr, int f = 2) {
+            int Cout, const float* bias, void* out, long ldo, int coff, void* out2 = nullptr, int f = 2, int terms = 0) {
   GemmParams p;
-  p.N = f * f * Cout; p.K = Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W; p.ps_f = f;
-  p.A = A; p.lda = lda; p.a_index = idx;
-  p.epi = EPI_PIXSHUF; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
+  p.N = f * f * Cout; p.ngroups = 1; p.g_rows[0] = r.B * h * w; p.W[0] = W; p.ps_f = f;
+  p.A = A; p.a_index = idx;
+  split_dense_a(r.m, p, Cin_p, lda, terms);
+  p.epi = EPI_PIXSHUF; p.bias[0] = bias; p.out = out; p.out2 = out2;
+  split_out(r.m, p, ldo, true);
   p.psH = h; p.psW = w; p.psC = Cout; p.ps_coff = coff;
   r.begin(name);
   int s = launch_gemm(p, idx ? A_INDEXED : A_DENSE, r.m->prec, TILE_AUTO, r.st);
@@ -264,12 +301,14 @@ inline int deconv2(Run& r, const char* name, const void* A, long lda, const int*
 
 // Conv2d 3x3 s1 p1 over NHWC as implicit GEMM (decoder.rs:55-72,167-175; mod.rs:78-87)
 inline int conv3(Run& r, const char* name, const void* in, int H, int W, int Cin_p, const void* Wp, const float* bias,
-          int Cout, void* out, long ldo, int act, const void* res1, const void* res2, void* out2) {
+          int Cout, void* out, long ldo, int act, const void* res1, const void* res2, void* out2, int terms = 0) {
   GemmParams p;
-  p.N = Cout; p.K = 9 * Cin_p; p.ngroups = 1; p.g_rows[0] = r.B * H * W; p.W[0] = Wp;
-  p.A = in; p.cH = H; p.cW = W; p.cC = Cin_p; p.zero_page = r.m->zero_page;
-  p.epi = EPI_STORE; p.act = act; p.bias[0] = bias; p.out = out; p.ldo = ldo; p.out2 = out2;
-  p.res1 = res1; p.res2 = res2; p.ldr = ldo;
+  p.N = Cout; p.ngroups = 1; p.g_rows[0] = r.B * H * W; p.W[0] = Wp;
+  p.A = in; p.cH = H; p.cW = W; p.zero_page = r.m->zero_page;
+  split_conv_a(r.m, p, Cin_p, terms);
+  p.epi = EPI_STORE; p.act = act; p.bias[0] = bias; p.out = out; p.out2 = out2;
+  split_out(r.m, p, ldo, true);
+  p.res1 = res1; p.res2 = res2; p.ldr = p.ldo; p.r_plane = (res1 || res2) ? p.o_plane : 0;
   r.begin(name);
   int s = launch_gemm(p, A_CONV3, r.m->prec, TILE_AUTO, r.st);
   r.end();

@@ -51,7 +51,7 @@ int parse_cfg(const md_depth_pro_cfg* c, ModelCfg* out) {
   if (m.F <= 0 || m.F % 64 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "decoder_features=%d must be a positive multiple of 64", m.F);
   if (m.interpolation != MD_INTERP_CUSTOM && m.interpolation != MD_INTERP_BURN)
     MD_FAIL(MD_ERR_INVALID_ARG, "unknown interpolation method %d", m.interpolation);
-  if (m.precision != MD_PREC_BF16 && m.precision != MD_PREC_F32 && m.precision != MD_PREC_F16)
+  if (m.precision != MD_PREC_BF16 && m.precision != MD_PREC_F32 && m.precision != MD_PREC_F16 && m.precision != MD_PREC_F16X2)
     MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", m.precision);
   *out = m;
   return MD_OK;

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -78,6 +79,8 @@ class DepthPro:
         self._h = handle
         self.config = config
         self._lib = _lib.load()
+        self._parent: Optional["DepthPro"] = None  # the root model of a fork (keeps it alive)
+        self._forks = weakref.WeakSet()            # live forks of a root
 
     # ---- construction ---------------------------------------------------------------------
     @staticmethod
@@ -106,17 +109,32 @@ class DepthPro:
         the model they were forked from."""
         h = C.c_void_p()
         _lib.check(self._lib.md_model_fork(self._h, C.byref(h)))
-        return type(self)(self.device, h, self.config)
+        f = type(self)(self.device, h, self.config)
+        # the fork aliases this model's weight arenas: keep the root alive until every fork is gone, and let the root
+        # find its live forks when it is destroyed first
+        f._parent = self._parent if self._parent is not None else self
+        f._parent._forks.add(f)
+        return f
 
     def destroy(self) -> None:
-        if self._h:
-            _lib.check(self._lib.md_model_destroy(self._h))
-            self._h = None
+        """md_model_destroy. A root destroys its live forks first (they alias its weights and must go before it)."""
+        if not self._h:
+            return
+        for f in list(self._forks):
+            f.destroy()
+        _lib.check(self._lib.md_model_destroy(self._h))
+        self._h = None
+        if self._parent is not None:
+            self._parent._forks.discard(self)
+            self._parent = None
 
     def __del__(self):
         try:
             self.destroy()
-        except Exception:
+        except _lib.MdError as e:  # never silent: a failed destroy leaks the weight / workspace arenas
+            import warnings
+            warnings.warn(f"DepthPro.__del__: {e}", ResourceWarning)
+        except Exception:  # interpreter shutdown: the library may already be gone
             pass
 
     # ---- introspection --------------------------------------------------------------------
@@ -151,6 +169,13 @@ class DepthPro:
 
     def commit_weights(self) -> None:
         _lib.check(self._lib.md_model_commit_weights(self._h))
+
+    def round_weights_to_f16(self) -> "DepthPro":
+        """Round every parameter to the nearest IEEE half, in place, and commit: what `DepthPro::load` of the reference's
+        f16 record (`HalfPrecisionSettings`, depth_pro/mod.rs:193-208) of these weights holds. In `Precision.F16X2` the
+        weights are then exact MFMA operands (`query("weight_terms") == 2`)."""
+        _lib.check(self._lib.md_model_round_weights_f16(self._h))
+        return self
 
     def into_record(self) -> Dict[str, np.ndarray]:
         return {n: self.get_tensor(n, c) for n, c in self.param_names()}

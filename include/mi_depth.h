@@ -46,7 +46,13 @@ typedef enum md_mem_kind { MD_MEM_HOST = 0, MD_MEM_DEVICE = 1 } md_mem_kind;
 /* MD_PREC_F16: IEEE half MFMA operands (v_mfma_f32_*_f16, the bf16 rate) -- the reference stores its weights as f16
  * (`HalfPrecisionSettings`, depth_pro/mod.rs:206), so checkpoint weights are exact operands and activations carry 3
  * more mantissa bits than bf16; stores saturate at +-65504. The accurate fast mode. */
-typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1, MD_PREC_FP8 = 2, MD_PREC_F16 = 3 } md_precision;
+/* MD_PREC_F16X2 (Depth Pro): the accurate FAST mode. Every activation that feeds an MFMA is kept as two IEEE-half planes,
+ * value = hi + lo (hi = f16(x), lo = f16(x - hi): 22 significant bits); the reference's checkpoints are f16
+ * (`HalfPrecisionSettings`, depth_pro/mod.rs:206), so a weight is an exact f16 operand and every product is two
+ * v_mfma_f32_*_f16 with fp32 accumulation (W.x_hi + W.x_lo). Weights that are NOT f16-exact (fp32 checkpoints, the layer
+ * products composed at commit) are kept as hi + lo too and cost a third MFMA (W_lo.x_hi); md_model_query("weight_terms")
+ * says which form the committed weights took. q.k^T runs on three terms, softmax and every sum stay fp32. */
+typedef enum md_precision { MD_PREC_BF16 = 0, MD_PREC_F32 = 1, MD_PREC_FP8 = 2, MD_PREC_F16 = 3, MD_PREC_F16X2 = 4 } md_precision;
 /* depth_pro/interpolate.rs:11-22 */
 /* Stand-alone operator checks only (md_op_linear*, md_op_conv3x3, md_op_deconv2x2): OR into `precision` to route the
  * result through the engine's storage type (bf16 in the BF16 / FP8 modes) before it is widened to the fp32 output --
@@ -101,6 +107,12 @@ int md_model_param_info(md_model_t m, int index, const char** name, size_t* coun
 /* Must be called after md_model_set_tensor calls and before the next infer: re-packs the
  * MFMA operand copies (bf16, [N][K] / tap-major layouts) from the fp32 master weights. */
 int md_model_commit_weights(md_model_t m);
+/* `DepthPro::load` reads an f16 record (`NamedMpkFileRecorder<HalfPrecisionSettings>`, depth_pro/mod.rs:193-208): every
+ * parameter of a loaded reference model is an IEEE half widened to f32. Rounds the fp32 master copy of every parameter the
+ * same way, in place, and commits -- turns a seeded (md_depth_pro_create) or fp32-loaded model into what the reference's
+ * f16 checkpoint of the same weights would give. In MD_PREC_F16X2 the committed weights are then exact MFMA operands
+ * (two terms per product instead of three: md_model_query "weight_terms"). */
+int md_model_round_weights_f16(md_model_t m);
 /* The packed device-resident weight arena (for an RCCL broadcast from rank 0). */
 int md_model_weight_arena(md_model_t m, void** device_ptr, size_t* bytes);
 int md_model_destroy(md_model_t m);
@@ -184,7 +196,8 @@ int md_model_enable_graph(md_model_t m, int enable);
 
 /* `img_size()` (mod.rs:296), `interpolation_method()` (mod.rs:308) and friends.
  * keys: "img_size", "patch_window", "interpolation", "precision", "max_batch", "num_params",
- *       "workspace_bytes", "weight_bytes", "tiles_per_image", "seq_stride", "is_fork", "forks". */
+ *       "workspace_bytes", "weight_bytes", "tiles_per_image", "seq_stride", "is_fork", "forks",
+ *       "weight_terms" (MFMA terms per product with a plain weight: 1; MD_PREC_F16X2: 2 = f16-exact weights, 3 otherwise). */
 int md_model_query(md_model_t m, const char* key, int64_t* out);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs

@@ -47,6 +47,12 @@ def f16_round(x: Tensor) -> Tensor:
     return x.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
 
 
+def f16x2_round(x: Tensor) -> Tensor:
+    """The engine's MD_PREC_F16X2 operand: two IEEE-half planes, hi = f16(x), lo = f16(x - hi); value hi + lo (22 bits)."""
+    hi = f16_round(x)
+    return hi + f16_round(x - hi)
+
+
 # ---------------------------------------------------------------------------------------------
 # a1  rgb_to_input_tensor  (src/inference.rs:79-121)
 # ---------------------------------------------------------------------------------------------
