@@ -223,8 +223,9 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
   else if (k == "tiles_per_image") *out = m->steps0 * m->steps0 + m->steps1 * m->steps1 + 1;
   else if (k == "seq_stride") *out = m->SS;
   else if (k == "is_fork") *out = m->parent ? 1 : 0;
-  else if (k == "forks") *out = m->forks;
+  else if (k == "forks") *out = m->forks.load();
   else if (k == "weight_terms") *out = model_root(m)->wterms;
+  else if (k == "allocs") *out = m->alloc_count;
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
 }

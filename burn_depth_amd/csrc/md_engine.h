@@ -1,6 +1,7 @@
 // Depth Pro engine: device-resident weights, static workspace plan, forward schedule.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <string>
@@ -113,6 +114,7 @@ struct md_model_s {
   struct Buffers;
   Buffers* buf = nullptr;
   void* zero_page = nullptr;
+  long alloc_count = 0;  // device / pinned-host allocations made by infer calls (staging growth, index tables): md_model_query("allocs")
   std::map<int, int*> index_tables;  // per batch size B: device int32 blob
   struct IndexSet {
     int *hi = nullptr, *mid = nullptr, *x2 = nullptr, *img = nullptr, *fov = nullptr;
@@ -138,7 +140,7 @@ struct md_model_s {
   // ---- md_model_fork: a fork shares the parameter / packed-weight arenas of its root model (never frees them) and
   //      owns its workspace, index tables, taps, timing, graphs and default stream ----
   md_model_s* parent = nullptr;   // root model of a fork (forks of forks attach to the root)
-  int forks = 0;                  // live forks of this root
+  std::atomic<int> forks{0};      // live forks of this root (model_fork / model_destroy may run on different threads)
   hipStream_t own_stream = nullptr;  // a fork's default stream (stream == NULL in infer)
 
   // ---- model kind: 0 = Depth Pro, 1 = Depth-Anything-v3 (state in md_da3.hip) ----

@@ -315,6 +315,11 @@ struct md_model_s::Buffers {
   float* canonical = nullptr;  // [B, S*S]
   float* inv = nullptr;        // [B, S*S] (resize path)
   float* depth_stage = nullptr;  // device staging for host outputs [B, Hmax*Wmax]
+  // grow-only capacities (bytes) of the staging buffers that serve host pointers and non-native input sizes, and the pinned
+  // bounce buffers between pageable caller memory and the DMA engine: a steady stream of same-sized calls allocates nothing
+  size_t rgb_cap = 0, xraw_cap = 0;
+  void *pin_in = nullptr, *pin_out = nullptr;
+  size_t pin_in_cap = 0, pin_out_cap = 0;
   // fov
   float *fovproj = nullptr, *fv0 = nullptr, *fv1 = nullptr, *fv2 = nullptr, *fv3 = nullptr, *fvr = nullptr;
   float *fov_deg = nullptr, *focal = nullptr, *fovy = nullptr, *ratio = nullptr;
@@ -622,11 +627,11 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
 
 int model_destroy(md_model_t m) {
   if (!m) return MD_OK;
-  if (m->forks > 0) MD_FAIL(MD_ERR_INVALID_ARG, "model has %d live fork(s) sharing its weights: destroy them first", m->forks);
+  if (m->forks.load() > 0) MD_FAIL(MD_ERR_INVALID_ARG, "model has %d live fork(s) sharing its weights: destroy them first", m->forks.load());
   if (m->dev) (void)hipSetDevice(m->dev->ordinal);
   (void)hipDeviceSynchronize();
   if (m->parent) {  // a fork owns no weights
-    m->parent->forks -= 1;
+    m->parent->forks.fetch_sub(1);
     m->w32_base = nullptr;
     m->wpk_base = nullptr;
   }
@@ -648,6 +653,8 @@ int model_destroy(md_model_t m) {
     if (m->buf->xraw) (void)hipFree(m->buf->xraw);
     if (m->buf->rgb) (void)hipFree(m->buf->rgb);
     if (m->buf->depth_stage) (void)hipFree(m->buf->depth_stage);
+    if (m->buf->pin_in) (void)hipHostFree(m->buf->pin_in);
+    if (m->buf->pin_out) (void)hipHostFree(m->buf->pin_out);
     delete m->buf;
   }
   delete m;
@@ -681,12 +688,14 @@ int model_fork(md_model_t src, md_model_t* out) {
   m->steps0 = root->steps0; m->stride0 = root->stride0; m->steps1 = root->steps1; m->stride1 = root->stride1;
   m->pad_hi = root->pad_hi; m->pad_mid = root->pad_mid; m->mh_hi = root->mh_hi; m->mh_mid = root->mh_mid;
   m->parent = root;
-  root->forks += 1;
+  root->forks.fetch_add(1);
   auto fail = [&](int code) {
     model_destroy(m);
     return code;
   };
-  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+  // same flags as the root's default stream (md_device_open): with stream == NULL either context is ordered against work
+  // the caller left on the legacy null stream; two contexts still run concurrently with each other
+  if (hipStreamCreateWithFlags(&m->own_stream, hipStreamDefault) != hipSuccess) {
     set_error("hipStreamCreate failed");
     return fail(MD_ERR_HIP);
   }
@@ -836,7 +845,7 @@ int model_commit(md_model_t m) {
 int model_round_weights_f16(md_model_t m) {
   if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
   if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: round them on the root model");
-  if (m->forks > 0) MD_FAIL(MD_ERR_INVALID_ARG, "model has %d live fork(s) sharing its weights", m->forks);
+  if (m->forks.load() > 0) MD_FAIL(MD_ERR_INVALID_ARG, "model has %d live fork(s) sharing its weights", m->forks.load());
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t s = m->dev->stream;
   for (size_t i = 0; i < m->params.size(); ++i) {
@@ -886,6 +895,7 @@ static int get_index_set(md_model_s* m, int B, md_model_s::IndexSet* out) {
       }
   int* d = nullptr;
   MD_HIP(hipMalloc((void**)&d, h.size() * 4));
+  m->alloc_count += 1;
   MD_HIP(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   m->index_tables[B] = d;
   md_model_s::IndexSet s;
@@ -1313,6 +1323,42 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
 static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                              float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
 
+// Grow-only staging: (re)allocates only when `need` exceeds the capacity. hipFree is a device-wide synchronisation and
+// hipMalloc takes the allocator lock, so a caller that feeds host pointers or a fixed non-native size (the reference's
+// `infer_from_rgb` path, src/inference.rs:128-137; the auto-resize of mod.rs:312-325) must not pay either per call.
+// md_model_query("allocs") counts what the infer calls of a model have allocated.
+static int ensure_device(md_model_s* m, void** p, size_t* cap, size_t need) {
+  if (*cap >= need && *p) return MD_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  MD_HIP(hipMalloc(p, need));
+  *cap = need;
+  m->alloc_count += 1;
+  return MD_OK;
+}
+static int ensure_pinned(md_model_s* m, void** p, size_t* cap, size_t need) {
+  if (*cap >= need && *p) return MD_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  MD_HIP(hipHostMalloc(p, need, hipHostMallocDefault));
+  *cap = need;
+  m->alloc_count += 1;
+  return MD_OK;
+}
+// pageable caller memory -> pinned bounce buffer -> device, asynchronously on `st` (the bounce buffer is reused by the next
+// call, which first waits for this stream's work: one in-flight infer per model, see the threading rule in mi_depth.h)
+static int stage_host_to_device(md_model_s* m, void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+  md_model_s::Buffers* b = m->buf;
+  if (b->pin_in_cap < bytes) MD_HIP(hipStreamSynchronize(st));  // nothing may still read the buffer being replaced
+  MD_TRY(ensure_pinned(m, &b->pin_in, &b->pin_in_cap, bytes));
+  MD_HIP(hipStreamSynchronize(st));  // the previous call's copy out of the bounce buffer has finished
+  memcpy(b->pin_in, src_host, bytes);
+  MD_HIP(hipMemcpyAsync(dst_dev, b->pin_in, bytes, hipMemcpyHostToDevice, st));
+  return MD_OK;
+}
+
 int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len) {
   if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
@@ -1350,15 +1396,13 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
     if (rgb_len != (size_t)W * H * 3) MD_FAIL(MD_ERR_SHAPE, "expected %zu RGB bytes for %dx%d, got %zu", (size_t)W * H * 3, W, H, rgb_len);
     const uint8_t* rgb_dev = rgb;
     if (in_kind == MD_MEM_HOST) {
-      if (b->rgb) (void)hipFree(b->rgb);
-      MD_HIP(hipMalloc((void**)&b->rgb, rgb_len));
-      MD_HIP(hipMemcpyAsync(b->rgb, rgb, rgb_len, hipMemcpyHostToDevice, st));
+      MD_TRY(ensure_device(m, (void**)&b->rgb, &b->rgb_cap, rgb_len));
+      MD_TRY(stage_host_to_device(m, b->rgb, rgb, rgb_len, st));
       rgb_dev = b->rgb;
     }
     float* dst = b->xin;
     if (resize_needed) {
-      if (b->xraw) (void)hipFree(b->xraw);
-      MD_HIP(hipMalloc((void**)&b->xraw, in_elems * 4));
+      MD_TRY(ensure_device(m, (void**)&b->xraw, &b->xraw_cap, in_elems * 4));
       dst = b->xraw;
     }
     r.begin("rgb_to_input");
@@ -1368,11 +1412,10 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
   } else if (in_kind == MD_MEM_HOST) {
     float* dst = b->xin;
     if (resize_needed) {
-      if (b->xraw) (void)hipFree(b->xraw);
-      MD_HIP(hipMalloc((void**)&b->xraw, in_elems * 4));
+      MD_TRY(ensure_device(m, (void**)&b->xraw, &b->xraw_cap, in_elems * 4));
       dst = b->xraw;
     }
-    MD_HIP(hipMemcpyAsync(dst, nchw, in_elems * 4, hipMemcpyHostToDevice, st));
+    MD_TRY(stage_host_to_device(m, dst, nchw, in_elems * 4, st));
     x_dev = dst;
   } else {
     x_dev = nchw;
@@ -1407,11 +1450,9 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
     if (out_kind == MD_MEM_DEVICE) {
       depth_dev = depth;
     } else {
-      if (b->depth_stage_elems < out_elems) {
-        if (b->depth_stage) (void)hipFree(b->depth_stage);
-        MD_HIP(hipMalloc((void**)&b->depth_stage, out_elems * 4));
-        b->depth_stage_elems = out_elems;
-      }
+      size_t cap = b->depth_stage_elems * 4;
+      MD_TRY(ensure_device(m, (void**)&b->depth_stage, &cap, out_elems * 4));
+      b->depth_stage_elems = cap / 4;
       depth_dev = b->depth_stage;
     }
     r.begin("depth_post");
@@ -1426,16 +1467,31 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
       r.end();
     }
   }
+  if (out_kind == MD_MEM_HOST) {
+    // host outputs: one pinned bounce buffer [depth | focal | fovx | fovy], asynchronous device -> pinned copies, ONE stream
+    // synchronisation, then plain memcpy into the caller's (pageable) memory
+    const size_t dbytes = depth ? out_elems * 4 : 0, need = dbytes + 3 * (size_t)B * 4;
+    MD_TRY(ensure_pinned(m, &b->pin_out, &b->pin_out_cap, need));
+    char* ph = (char*)b->pin_out;
+    if (depth) MD_HIP(hipMemcpyAsync(ph, depth_dev, dbytes, hipMemcpyDeviceToHost, st));
+    const float* srcs[3] = {b->focal, b->fov_deg, b->fovy};
+    float* dsts[3] = {focal, fovx, fovy};
+    for (int i = 0; i < 3; ++i)
+      if (dsts[i]) MD_HIP(hipMemcpyAsync(ph + dbytes + (size_t)i * B * 4, srcs[i], (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    MD_HIP(hipStreamSynchronize(st));
+    if (depth) memcpy(depth, ph, dbytes);
+    for (int i = 0; i < 3; ++i)
+      if (dsts[i]) memcpy(dsts[i], ph + dbytes + (size_t)i * B * 4, (size_t)B * 4);
+    return MD_OK;
+  }
   auto copy_out = [&](float* dst, const float* src, size_t n) -> int {
     if (!dst) return MD_OK;
-    MD_HIP(hipMemcpyAsync(dst, src, n * 4, out_kind == MD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    MD_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st));
     return MD_OK;
   };
-  if (depth && out_kind == MD_MEM_HOST) MD_TRY(copy_out(depth, depth_dev, out_elems));
   MD_TRY(copy_out(focal, b->focal, B));
   MD_TRY(copy_out(fovx, b->fov_deg, B));
   MD_TRY(copy_out(fovy, b->fovy, B));
-  if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
 

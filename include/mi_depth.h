@@ -132,7 +132,8 @@ int md_model_fork(md_model_t m, md_model_t* out);
  * mod.rs:128-133): depth[B*H*W], focallength_px[B], fovx_deg[B], fovy_rad[B]; any output pointer
  * may be NULL to skip it. in_kind/out_kind say whether the pointers are host or device memory.
  * `stream` is a hipStream_t (NULL = the model's own stream); the call is asynchronous for
- * device outputs and synchronises for host outputs. */
+ * device outputs and synchronises for host outputs. Host pointers may be pageable memory: they travel through pinned bounce
+ * buffers owned by the model (grow-only, like the device staging for H x W != img_size: no allocation per call). */
 int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                        float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream);
 
@@ -197,7 +198,10 @@ int md_model_enable_graph(md_model_t m, int enable);
 /* `img_size()` (mod.rs:296), `interpolation_method()` (mod.rs:308) and friends.
  * keys: "img_size", "patch_window", "interpolation", "precision", "max_batch", "num_params",
  *       "workspace_bytes", "weight_bytes", "tiles_per_image", "seq_stride", "is_fork", "forks",
- *       "weight_terms" (MFMA terms per product with a plain weight: 1; MD_PREC_F16X2: 2 = f16-exact weights, 3 otherwise). */
+ *       "weight_terms" (MFMA terms per product with a plain weight: 1; MD_PREC_F16X2: 2 = f16-exact weights, 3 otherwise),
+ *       "allocs" (device / pinned-host allocations the infer calls of this model have made so far: staging buffers for
+ *       host pointers and non-native input sizes grow on demand and are then reused, so the count stops moving once the
+ *       largest shapes have been seen). */
 int md_model_query(md_model_t m, const char* key, int64_t* out);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs

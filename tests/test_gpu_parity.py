@@ -286,6 +286,139 @@ def test_full_size_default_config_against_the_oracle(diag, dev):
     assert len(diag.RESULTS) - start >= 15
 
 
+def test_full_size_accurate_fast_mode_on_an_f16_checkpoint(diag, dev):
+    """MD_PREC_F16X2 (activations as hi + lo half planes, f16 weights exact operands) at [1,3,1536,1536] on the seeded weights
+    ROUNDED TO F16 -- what the reference's `HalfPrecisionSettings` record holds (depth_pro/mod.rs:206) -- against the fp32
+    CPU oracle on the same weights: the reference's own bar max-rel <= 5e-3 (example/correctness.rs:887-897) AND BASELINE's
+    depth L_inf <= 1e-3 (tools/gpu_diag.py FULL_TOL / FULL_LINF; the measured numbers are 1.6e-5 / 6e-5)."""
+    from burn_depth_amd.config import Precision
+    start = len(diag.RESULTS)
+    diag.guarded("full-size f16 checkpoint")(diag.run_full_size)(dev, (Precision.F16X2,), f16_weights=True)
+    _assert_new_results_ok(diag, start)
+    names = [r[0] for r in diag.RESULTS[start:]]
+    assert "full/f16x2/f16w depth L_inf vs fp32 oracle" in names and "full/f16x2/f16w depth max-rel vs fp32 oracle" in names
+
+
+def test_split_half_operators(diag, dev):
+    """MD_PREC_F16X2 at the operator level: linear / conv3x3 / deconv / attention on hi + lo planes against fp64 on the
+    unrounded inputs (two-term and three-term weight forms, the split store epilogues, small activations whose lo plane is a
+    subnormal half, the attention fall-back body)."""
+    start = len(diag.RESULTS)
+    diag.check_split_ops(dev)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 90
+
+
+@pytest.mark.parametrize("f16_weights", [False, True])
+def test_depth_pro_split_half_end_to_end(diag, dev, f16_weights):
+    # fp32-checkpoint weights take three MFMA terms per product, an f16 checkpoint two (md_model_query "weight_terms")
+    from burn_depth_amd.config import DepthProConfig, Precision
+    start = len(diag.RESULTS)
+    diag.guarded("tiny f16x2")(diag.run_e2e)(dev, DepthProConfig.tiny_test(), f"tiny/f16x2/w{16 if f16_weights else 32}", 1, (512, 512),
+                                             Precision.F16X2, f16_weights=f16_weights)
+    diag.guarded("small f16x2")(diag.run_e2e)(dev, DepthProConfig.small_test(), f"small/f16x2/w{16 if f16_weights else 32}", 1, (512, 512),
+                                              Precision.F16X2, f16_weights=f16_weights, timing=False)
+    if f16_weights:
+        diag.guarded("tiny f16x2 resize")(diag.run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f16x2/B2/360x540", 2, (360, 540), Precision.F16X2,
+                                                        taps=False, f16_weights=True)
+    _assert_new_results_ok(diag, start)
+
+
+def test_split_half_is_rejected_for_depth_anything3(dev):
+    from burn_depth_amd import _lib
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    c = DepthAnything3Config.tiny_test()
+    c.precision = Precision.F16X2
+    with pytest.raises(_lib.MdError) as e:
+        DepthAnything3.new(dev, c, seed=0)
+    assert e.value.code == _lib.MD_ERR_UNSUPPORTED
+
+
+def test_host_pointer_path_allocates_nothing_after_the_first_call(dev):
+    """The path a reference-side caller takes (host NCHW in, host depth out, and `infer_from_rgb`,
+    src/inference.rs:128-137) at a non-native size (540 x 360 like assets/image/test.jpg; auto-resized, mod.rs:312-325): the
+    device staging and the pinned bounce buffers grow on the first call and are reused afterwards."""
+    import ctypes as C
+    import numpy as np
+    from burn_depth_amd import _lib, weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    m = DepthPro.new(dev, DepthProConfig.tiny_test(), seed=0, init_scheme=Wt.INIT_PARITY)
+    lib = _lib.load()
+    H, W = 360, 540
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 3, H, W)).astype(np.float32)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+
+    def call(xh):
+        depth = np.full((1, H, W), -1.0, np.float32)
+        focal, fovx, fovy = (np.zeros(1, np.float32) for _ in range(3))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _lib.check(lib.md_depth_pro_infer(m._h, p(xh), 1, H, W, _lib.MD_MEM_HOST, p(depth), p(focal), p(fovx), p(fovy), _lib.MD_MEM_HOST, None))
+        return depth, focal
+
+    d0, f0 = call(x)
+    want = m.infer(torch.from_numpy(x).cuda())
+    assert np.array_equal(d0, want.depth.cpu().numpy()) and f0[0] == want.focallength_px.item()
+    allocs = m.query("allocs")
+    assert allocs >= 3  # xraw + pinned in / out (+ the index table of B = 1)
+    d1, _ = call(x)
+    d2, _ = call(x * 0.5)
+    assert m.query("allocs") == allocs, "a repeated host-pointer call must not allocate"
+    assert np.array_equal(d1, d0) and not np.array_equal(d2, d0)
+    r0 = m.infer_from_rgb(rgb.tobytes(), W, H)
+    a1 = m.query("allocs")
+    r1 = m.infer_from_rgb(rgb.tobytes(), W, H)
+    assert m.query("allocs") == a1 and torch.equal(r0.depth, r1.depth)
+    # a larger input grows the staging once more, a smaller one afterwards reuses it
+    big = rng.standard_normal((1, 3, 400, 600)).astype(np.float32)
+    m.infer(torch.from_numpy(big))
+    a2 = m.query("allocs")
+    call(x)
+    m.infer(torch.from_numpy(big))
+    assert m.query("allocs") == a2
+    m.destroy()
+
+
+def test_graph_replay_sees_recommitted_weights_on_root_and_fork(dev):
+    """A captured graph bakes by-value launch parameters (the head's output bias); the commit generation is part of the replay
+    key, so set_tensor + commit is seen by the root's AND a fork's next replayed call."""
+    import numpy as np
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    root = DepthPro.new(dev, DepthProConfig.tiny_test(), seed=0, init_scheme=Wt.INIT_PARITY)
+    fork = root.fork()
+    torch.manual_seed(1)
+    x = torch.randn(1, 3, 512, 512, device="cuda")
+    bufs = lambda: [torch.empty(1, 512, 512, device="cuda")] + [torch.empty(1, device="cuda") for _ in range(3)]  # noqa: E731
+    rb, fb = bufs(), bufs()
+    root.enable_graph(True)
+    fork.enable_graph(True)
+    for _ in range(3):  # eager, capture, replay
+        root.infer_into(x, *rb)
+        fork.infer_into(x, *fb)
+    torch.cuda.synchronize()
+    before = rb[0].clone()
+    assert torch.equal(fb[0], before)
+    bias = root.get_tensor("head.conv_out.bias", 1)
+    root.set_tensor("head.conv_out.bias", bias + np.float32(0.25))  # both contexts idle: the fork stays alive across the commit
+    root.commit_weights()
+    for _ in range(3):
+        root.infer_into(x, *rb)
+        fork.infer_into(x, *fb)
+    torch.cuda.synchronize()
+    eager = DepthPro.new(dev, DepthProConfig.tiny_test(), seed=0, init_scheme=Wt.INIT_PARITY)
+    eager.set_tensor("head.conv_out.bias", bias + np.float32(0.25))
+    eager.commit_weights()
+    want = eager.infer(x).depth
+    assert not torch.equal(rb[0], before)
+    assert torch.equal(rb[0], want) and torch.equal(fb[0], want)
+    eager.destroy()
+    root.destroy()  # destroys its live fork first
+
+
 def test_config4_shard_of_eight_images_is_batch_independent(diag, dev):
     """BASELINE config 4 (8 images per GPU): one infer over [8,3,1536,1536]; images 0 and 7 bit-equal to their B=1 runs."""
     start = len(diag.RESULTS)
