@@ -146,6 +146,10 @@ def parse_args(argv=None):
     ap.add_argument("--side-kernels", action="store_true", help="also time the stand-alone HBM-bound kernels (resize_bilinear / resize_nhwc at the shapes of bench/interpolate.rs) into `kernels`")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the engine + gloo instead of RCCL: tests the launcher / scatter / gather / JSON contract without a GPU")
     ap.add_argument("--dump-launch-order", default="", help="write the per-launch kernel-family list of one infer (json)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default N = 1 Depth Pro bf16 run only: skip the objects measured after the timed region (`configs`: the other BASELINE "
+                         "configurations; `accurate_mode` / `fp32_mode_fps`; `accuracy` at 1536^2 against the CPU-baseline frame; `host_io`)")
+    ap.add_argument("--host-io", action="store_true", help="report `host_io` (host NCHW in, host depth out through md_depth_pro_infer, as INTEGRATION.md section 2's shim calls it) for any precision / preset")
     return ap.parse_args(argv)
 
 
@@ -203,10 +207,9 @@ def main(argv=None) -> int:
         broadcast_weights(model, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-    if args.precision == "f16x2":
-        # the reference's checkpoints are f16 records (`HalfPrecisionSettings`, depth_pro/mod.rs:206): the accurate fast mode is
-        # measured on weights an f16 checkpoint can hold (exact MFMA operands, two terms per product)
-        model.round_weights_to_f16()
+    # the reference's checkpoints are f16 records (`HalfPrecisionSettings`, depth_pro/mod.rs:206): every mode is measured on
+    # weights an f16 checkpoint can hold (in f16x2 they are exact MFMA operands: two terms per product)
+    model.round_weights_to_f16()
 
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
@@ -369,7 +372,7 @@ def main(argv=None) -> int:
             symbols = {"fc1_gemm": "md::gemm256_kernel<md::bf16_t, 0, 4> (dense A, 16x16x32 two-group schedule, fused bias+GELU store)"}
             roofline = {"kernel": dom, "kernel_symbol": symbols.get(dom) if args.precision == "bf16" else None,
                         "bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tfl / peak, 4), "traffic": pmc_traffic(dom, B, args),
+                        "frac": round(tfl / peak, 4), "traffic": pmc_traffic(dom, B, args)[0], "traffic_source": pmc_traffic(dom, B, args)[1],
                         "avg_launch_ms": round(per_step / max(launches, 1), 4),
                         "flops_per_launch": fl[dom] / max(launches, 1),
                         "ms_per_step": round(per_step, 4), "launches_per_step": launches}
@@ -383,15 +386,17 @@ def main(argv=None) -> int:
             else f"frames/sec Depth Pro preset={args.preset} {args.precision}",
             "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded U[0,1) images, ImageNet-normalised; random-init weights)",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded U[0,1) images, ImageNet-normalised; random-init weights rounded to f16 like the reference's f16 checkpoint records)",
             "config": {"workload": f"DepthPro::infer [{B},3,{S},{S}] per GPU, default DepthProConfig" if args.preset == "full"
                        else f"DepthPro::infer [{B},3,{S},{S}] preset {args.preset}",
-                       "batch_per_gpu": B, "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
+                       "batch_per_gpu": B, "batch_note": "8 images per GPU = BASELINE config 4's shard; config 3 as SURVEY 8(d) words it (B = 1) is configs[0]" if B == 8 else None,
+                       "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
                        "parallelism": f"dp{world}",
                        "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather},
             "finite_output": ok,
-            "frame_tflops_algorithmic": round(total_flops / B / 1e12, 3),
-            "frame_mfma_frac": round((total_flops / B) * (fps / world) / 1e12 / peak, 4),
+            # FLOPs the schedule EXECUTES per frame (layers composed at commit count once); null when no per-family pass ran (--graph)
+            "frame_tflops_executed": round(total_flops / B / 1e12, 3) if kernels else None,
+            "frame_mfma_frac": round((total_flops / B) * (fps / world) / 1e12 / peak, 4) if kernels else None,
             "gpu_kernel_ms_per_step": round(gpu_ms, 3),
             "weight_broadcast_s": round(t_bcast, 4),
             "roofline": roofline,
@@ -401,8 +406,17 @@ def main(argv=None) -> int:
         }
         if args.accuracy:
             out["accuracy"] = accuracy_report(dev, cfg.precision)
+        ref_frame = None
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_baseline_budget)
+            out["cpu_baseline"], ref_frame = cpu_baseline(cfg, args.cpu_baseline_budget)
+        headline = world == 1 and args.preset == "full" and args.precision == "bf16" and args.streams == 1 and not args.graph
+        if args.host_io or (headline and not args.no_extras):
+            out["host_io"] = measure_host_io(model, B, S, fps)
+        if headline and not args.no_extras:
+            for e in extra:
+                e[0].destroy()
+            extra = []
+            out.update(extra_measurements(dev, tdev, model, cfg, B, ref_frame))
         print(json.dumps(out), flush=True)
     for e in extra:
         e[0].destroy()
@@ -410,6 +424,181 @@ def main(argv=None) -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def _timed_steps(step, warmup, steps):
+    import torch
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _dominant(model, step, fl, peak, steps=3):
+    """Per-family pass (HIP events on the launch stream) of `steps` eager steps: the dominant MFMA family against its roofline."""
+    import torch
+    model.enable_timing(True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    tm = model.read_timing()
+    model.enable_timing(False)
+    cand = {k: v[0] for k, v in tm.items() if k in fl}
+    if not cand:
+        return None
+    dom = max(cand, key=cand.get)
+    ms, calls = tm[dom]
+    per_step = ms / steps
+    tfl = fl[dom] / (per_step * 1e-3) / 1e12
+    return {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl / peak, 4), "traffic": None,
+            "avg_launch_ms": round(per_step / max(calls // steps, 1), 4), "ms_per_step": round(per_step, 4), "launches_per_step": calls // steps}
+
+
+def measure_host_io(model, B, S, resident_fps, steps=4):
+    """The call a reference-side host makes (INTEGRATION.md section 2: `DepthModel::infer_depth` over the C ABI): pageable
+    host NCHW in, pageable host depth out, one synchronous md_depth_pro_infer per step (PCIe inside the timed region)."""
+    import ctypes as C
+    import numpy as np
+    from burn_depth_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, 3, S, S), dtype=np.float32)
+    depth = np.empty((B, S, S), np.float32)
+    sc = [np.empty(B, np.float32) for _ in range(3)]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+    def step():
+        _lib.check(lib.md_depth_pro_infer(model._h, p(x), B, S, S, _lib.MD_MEM_HOST, p(depth), p(sc[0]), p(sc[1]), p(sc[2]), _lib.MD_MEM_HOST, None))
+    a0 = None
+    step()
+    step()
+    a0 = model.query("allocs")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 3), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": B,
+            "path": "pageable host NCHW -> pinned bounce -> device; depth device -> pinned bounce -> pageable host; synchronous call",
+            "bytes_per_step": int(B * (3 + 1) * S * S * 4), "vs_resident_inputs": round(B / dt / resident_fps, 4),
+            "allocations_during_timed_steps": int(model.query("allocs") - a0), "finite_output": bool(np.isfinite(depth).all())}
+
+
+def measure_da3(dev, tdev, variant, size, precision, steps=10):
+    """One BASELINE Depth-Anything-v3 configuration (B = 1, graph replay for the rate, one eager per-family pass for the roofline)."""
+    import ctypes as C
+    import torch
+    from burn_depth_amd import _lib as L, weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from burn_depth_amd.depth_pro import _stream_ptr
+    small = variant == "small"
+    cfg = DepthAnything3Config.small() if small else DepthAnything3Config.metric_large()
+    cfg.image_size = size
+    cfg.precision = {"bf16": Precision.BF16, "fp8": Precision.FP8}[precision]
+    cfg.max_batch = 1
+    model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    S, B = size, 1
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(99)).to(tdev)
+    depth = torch.empty((B, S, S), dtype=torch.float32, device=tdev)
+    if small:  # every output of DepthAnything3Inference, fixed buffers so that the graph key repeats
+        ah = 8 * (S // cfg.patch_size)
+        bufs = [depth] + [torch.empty(sh, dtype=torch.float32, device=tdev) for sh in
+                          ((B, S, S), (B, cfg.aux_output_dim - 1, ah, ah), (B, ah, ah), (B, 1, 9), (B, 1, 3, 4), (B, 1, 3, 3))]
+        o = L.MdDa3Outputs(*(t.data_ptr() for t in bufs))
+        step = lambda: L.check(L.load().md_da3_infer_ex(model._h, C.c_void_p(x.data_ptr()), B, S, S, L.MD_MEM_DEVICE, C.byref(o),  # noqa: E731
+                                                        L.MD_MEM_DEVICE, _stream_ptr(dev.ordinal)))
+    else:
+        step = lambda: model.infer_into(x, depth)  # noqa: E731
+    v = cfg.vit()
+    NT, D, dn = (S // 14) ** 2 + 1, v.embed_dim, v.depth
+    fl = {"qkv_gemm": 2.0 * NT * D * 3 * D * dn, "proj_gemm": 2.0 * NT * D * D * dn, "fc1_gemm": 2.0 * NT * D * 4 * D * dn,
+          "fc2_gemm": 2.0 * NT * D * 4 * D * dn, "attention": 4.0 * v.num_heads * NT * NT * 64 * dn}
+    peak = PEAK_BF16_TFLOPS
+    roof = _dominant(model, step, fl, peak)
+    if roof and precision == "fp8" and roof["kernel"] != "attention":
+        roof["peak"], roof["frac"] = 2 * peak, round(roof["achieved"] / (2 * peak), 4)  # e4m3 operands on the block-scaled MFMA: 5 PFLOP/s dense
+    model.enable_graph(True)
+    dt = _timed_steps(step, 4, steps)
+    ok = bool(torch.isfinite(depth).all())
+    model.destroy()
+    return {"value": round(B / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "dtype": precision, "graph_replay": True,
+            "workload": f"DepthAnything3::infer [1,3,{S},{S}] {cfg.variant}" + (" (dual head, every output)" if small else " (mono head)"),
+            "roofline": roof, "finite_output": ok}
+
+
+def extra_measurements(dev, tdev, model, cfg, B, ref_frame):
+    """What the default run reports beside the headline, each measured after the timed region on the same GPU:
+    `configs` (the other BASELINE configurations), `accurate_mode` (MD_PREC_F16X2 at the headline batch), `fp32_mode_fps`,
+    and `accuracy` of the three Depth Pro modes at 1536^2 against the CPU-baseline frame (one oracle frame serves both)."""
+    import torch
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    S = cfg.img_size()
+    out = {}
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+
+    def errors(m):
+        if ref_frame is None:
+            return None
+        d = m.infer(ref_frame["x"].to(tdev))
+        rd = ref_frame["depth"]
+        err = (d.depth.cpu() - rd).abs()
+        rel = err / rd.abs()
+        return {"depth_linf": float(err.max()), "depth_max_rel": float(rel.max()), "depth_mean_rel": float(rel.mean()),
+                "depth_mean_abs": float(err.mean()), "fovx_deg_abs": float((d.fovx_deg.cpu() - ref_frame["fovx_deg"]).abs().max())}
+
+    def rate(m, b, steps):
+        x = ((torch.rand(b, 3, S, S, generator=torch.Generator().manual_seed(1234)) - mean) / std).to(tdev)
+        bufs = [torch.empty((b, S, S), dtype=torch.float32, device=tdev)] + [torch.empty((b,), dtype=torch.float32, device=tdev) for _ in range(3)]
+        step = lambda: m.infer_into(x, *bufs)  # noqa: E731
+        return _timed_steps(step, 2, steps), step
+
+    acc = {"bf16": errors(model)}
+    # config 3 as SURVEY 8(d) words it: one image per call (latency)
+    fl1, _ = work_model(cfg, 1)
+    dt1, step1 = rate(model, 1, 10)
+    configs = [{"name": "config 3: Depth Pro [1,3,1536,1536], bf16, B = 1", "value": round(1.0 / dt1, 3), "unit": "frames/s", "ms_per_step": round(dt1 * 1e3, 3),
+                "dtype": "bf16", "roofline": _dominant(model, step1, fl1, PEAK_BF16_TFLOPS)}]
+    # the accurate fast mode at the headline batch, and the fp32 parity mode
+    c2 = DepthProConfig()
+    c2.precision, c2.max_batch = Precision.F16X2, B
+    m2 = DepthPro.new(dev, c2, seed=0, init_scheme=Wt.INIT_PARITY).round_weights_to_f16()
+    acc["f16x2"] = errors(m2)
+    dt2, step2 = rate(m2, B, 5)
+    flB, _ = work_model(cfg, B)
+    roof2 = _dominant(m2, step2, flB, PEAK_BF16_TFLOPS, steps=2)
+    if roof2:  # two MFMA terms per product: the executed rate is twice the algorithmic one
+        roof2["executed_tflops"] = round(2 * roof2["achieved"], 2) if roof2["kernel"] != "attention" else None
+    out["accurate_mode"] = {"precision": "f16x2", "value": round(B / dt2, 3), "unit": "frames/s", "ms_per_step": round(dt2 * 1e3, 3), "batch_per_gpu": B,
+                            "weight_terms": m2.query("weight_terms"), "roofline": roof2,
+                            "what": "activations as hi + lo IEEE-half planes (22 bits), f16 checkpoint weights exact MFMA operands: two v_mfma_f32_*_f16 per product, fp32 accumulation"}
+    m2.destroy()
+    c3 = DepthProConfig()
+    c3.precision, c3.max_batch = Precision.F32, 1
+    m3 = DepthPro.new(dev, c3, seed=0, init_scheme=Wt.INIT_PARITY).round_weights_to_f16()
+    acc["f32"] = errors(m3)
+    dt3, _ = rate(m3, 1, 3)
+    out["fp32_mode_fps"] = round(1.0 / dt3, 3)
+    m3.destroy()
+    out["accuracy"] = ({"frame": ref_frame["what"], "vs": "fp32 CPU oracle (oracle/depth_pro_ref.py, the cpu_baseline frame)", "depth_range": ref_frame["range"],
+                        "targets": {"north_star_depth_linf": 1e-3, "reference_bar_max_rel": 5e-3}, "modes": acc} if ref_frame is not None else None)
+    for (variant, size, prec, name) in (("small", 518, "bf16", "config 2: Depth-Anything-v3 small, 518^2, bf16"),
+                                        ("metric_large", 1036, "bf16", "config 5 (bf16 yardstick): Depth-Anything-v3 large, 1036^2"),
+                                        ("metric_large", 1036, "fp8", "config 5: Depth-Anything-v3 large, 1036^2, fp8 MFMA linear layers")):
+        try:
+            e = measure_da3(dev, tdev, variant, size, prec)
+        except Exception as ex:  # noqa: BLE001 -- an extra must never lose the headline line
+            e = {"error": f"{type(ex).__name__}: {ex}"}
+        e["name"] = name
+        configs.append(e)
+    out["configs"] = configs
+    return out
 
 
 def bench_dry(args, world: int, rank: int) -> int:
@@ -616,21 +805,27 @@ def pmc_traffic(kernel: str, B: int, args):
     WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
     gfx950 corrections of MI355X_MICROARCH.md and writes profiles/rNN_traffic.json). None if the
     passes were made for another batch/precision."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
             if t.get("batch") == B and t.get("precision") == args.precision and t.get("preset") == args.preset:
-                return t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+                v = t["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+                if v is not None:
+                    return v, f"profiles/{name}: committed rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.py); NOT re-measured by this run"
         except (OSError, ValueError, KeyError):
             pass
-    return None
+    return None, None
 
 
 def cpu_baseline(cfg, budget_s: float):
-    """The CPU oracle (a port: the Rust reference cannot be built here) on this process's cores.
-    BASELINE config 1 (bench/inference.rs:21-48): DepthPro::infer on zeros [1,3,S,S], random-init weights, one whole
-    frame. A 2-tile ViT probe first predicts the frame time; beyond `budget_s` the probe-scaled estimate is reported."""
+    """The CPU oracle (a port: the Rust reference cannot be built here) on this process's cores: ONE whole frame of
+    `DepthPro::infer` at [1,3,S,S] (bench/inference.rs:21-48 times exactly that call). The frame is BASELINE config 3-(ii) --
+    the seeded U[0,1) image on the seed-0 weights rounded to f16 like the reference's checkpoint records (mod.rs:206) -- so
+    that the same oracle output also serves as the reference of the `accuracy` object (the arithmetic cost does not depend
+    on the pixel values; config 1's zeros frame costs the same). A 2-tile ViT probe first predicts the frame time; beyond
+    `budget_s` the probe-scaled estimate is reported and no reference frame is returned.
+    Returns (cpu_baseline object, reference frame or None)."""
     import torch
     from burn_depth_amd import weights as Wt
     from oracle import depth_pro_ref as R
@@ -646,7 +841,7 @@ def cpu_baseline(cfg, budget_s: float):
     frame_flops = sum(fl.values())
     nseq = 25 + 9 + 1 + 1 + (1 if cfg.fov_encoder_preset else 0)
     vit_flops_per_tile = (fl["patch_embed"] + fl["qkv_gemm"] + fl["attention"] + fl["proj_gemm"] + fl["fc1_gemm"] + fl["fc2_gemm"]) / nseq
-    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
+    W = {k: R.f16_round(t) for k, t in R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY)).items()}
     with torch.no_grad():
         tiles = 2
         x = torch.zeros(tiles, 3, v.img_size, v.img_size)
@@ -658,17 +853,22 @@ def cpu_baseline(cfg, budget_s: float):
         est_frame_s = frame_flops / (probe_tflops * 1e12)
         if est_frame_s <= budget_s:
             S = cfg.img_size()
+            torch.manual_seed(0)
+            xin = (torch.rand(1, 3, S, S) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
             t0 = time.perf_counter()
-            out = R.infer(torch.zeros(1, 3, S, S), W, cfg)
+            out = R.infer(xin, W, cfg)
             frame_s = time.perf_counter() - t0
             ok = tuple(out["depth"].shape) == (1, S, S) and bool(torch.isfinite(out["depth"]).all())
-            return {"value": round(1.0 / frame_s, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                    "sample": f"full frame: oracle DepthPro::infer on zeros [1,3,{S},{S}] (BASELINE config 1), {frame_flops / 1e12:.2f} TFLOP in {frame_s:.1f} s",
-                    "seconds_per_frame": round(frame_s, 2), "finite_output": ok, "cpu_tflops": round(frame_flops / frame_s / 1e12, 3)}
-    return {"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle ViT-L/16 forward on {tiles} of {nseq} tiles in {dt:.2f} s, scaled by algorithmic FLOPs "
-                      f"({frame_flops / 1e12:.2f} TFLOP/frame; a whole frame was predicted to take {est_frame_s:.0f} s > budget {budget_s:.0f} s)",
-            "sample_seconds": round(dt, 3), "cpu_tflops": round(probe_tflops, 3)}
+            what = f"seeded U[0,1) image [1,3,{S},{S}] (BASELINE config 3-(ii)), seed-0 weights rounded to f16 (an f16 checkpoint, mod.rs:206)"
+            ref = {"x": xin, "depth": out["depth"], "fovx_deg": out["fovx_deg"], "what": what,
+                   "range": [float(out["depth"].min()), float(out["depth"].max())]}
+            return ({"value": round(1.0 / frame_s, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                     "sample": f"full frame: oracle DepthPro::infer on the {what}, {frame_flops / 1e12:.2f} TFLOP in {frame_s:.1f} s",
+                     "seconds_per_frame": round(frame_s, 2), "finite_output": ok, "cpu_tflops": round(frame_flops / frame_s / 1e12, 3)}, ref)
+    return ({"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+             "sample": f"oracle ViT-L/16 forward on {tiles} of {nseq} tiles in {dt:.2f} s, scaled by algorithmic FLOPs "
+                       f"({frame_flops / 1e12:.2f} TFLOP/frame; a whole frame was predicted to take {est_frame_s:.0f} s > budget {budget_s:.0f} s)",
+             "sample_seconds": round(dt, 3), "cpu_tflops": round(probe_tflops, 3)}, None)
 
 
 if __name__ == "__main__":

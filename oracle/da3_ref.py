@@ -21,7 +21,9 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from burn_depth_amd.config import DepthAnything3Config
+from oracle import ref_config
+
+DepthAnything3Config = object  # annotation only: the oracle checks a product config against its own table (ref_config.check_da3)
 from oracle.depth_pro_ref import identity, resize_align_corners_true, vit_forward
 
 Tensor = torch.Tensor
@@ -330,6 +332,7 @@ def camera_decode(cam: Tensor, W, height: int, width: int):
 def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False, fp8: bool = False):
     """DepthAnything3::infer (mod.rs:288-291 -> 495-564 -> 587-624): depth [B,H,W] (+ confidence, aux rays,
     aux confidence, pose encoding, extrinsics, intrinsics for the dual-head variant)."""
+    ref_config.check_da3(cfg)  # the product's variant tables against the oracle's own restatement of the reference's
     B, _, H, Wd = x.shape
     ps = cfg.patch_size
     if H % ps or Wd % ps:  # mod.rs:509-520 (panic)

@@ -25,7 +25,23 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from burn_depth_amd.config import DepthProConfig, InterpolationMethod, ViTConfig
+from oracle import ref_config
+from oracle.ref_config import RefViT as ViTConfig
+
+
+class InterpolationMethod:
+    """depth_pro/interpolate.rs:11-22 (the oracle's own copy: oracle/ref_config.py)"""
+    CUSTOM = ref_config.INTERP_CUSTOM
+    BURN = ref_config.INTERP_BURN
+
+
+def _cfg_vits(cfg):
+    """The three ViT configurations of a DepthProConfig-like object, resolved BY PRESET NAME through the oracle's own
+    tables (oracle/ref_config.py) -- never through the product's `cfg.patch_vit()`."""
+    eps = getattr(cfg, "ln_eps", None)
+    return (ref_config.vit_for(cfg.patch_encoder_preset, eps), ref_config.vit_for(cfg.image_encoder_preset, eps),
+            ref_config.vit_for(cfg.fov_encoder_preset, eps))
+
 
 Tensor = torch.Tensor
 Quant = Callable[[Tensor], Tensor]
@@ -341,9 +357,9 @@ def _project_upsample(x: Tensor, W, name: str, q: Quant) -> Tensor:
     return x
 
 
-def encoder_forward_debug(x: Tensor, W, cfg: DepthProConfig, q: Quant = identity) -> Dict[str, object]:
+def encoder_forward_debug(x: Tensor, W, cfg, q: Quant = identity) -> Dict[str, object]:
     """DepthProEncoder::forward_with_debug (encoder.rs:321-454). Keys follow ``EncoderDebug``."""
-    pv, iv = cfg.patch_vit(), cfg.image_vit()
+    pv, iv, _ = _cfg_vits(cfg)
     B = x.shape[0]
     win, out_size = pv.img_size, pv.grid_size()
     m = cfg.interpolation
@@ -468,10 +484,10 @@ def _conv_act(x: Tensor, W, name: str, stride: int, padding: int, relu: bool, me
     return F.relu(out) if relu else out
 
 
-def fov_forward(x: Tensor, lowres: Tensor, W, cfg: DepthProConfig, q: Quant = identity) -> Tensor:
+def fov_forward(x: Tensor, lowres: Tensor, W, cfg, q: Quant = identity) -> Tensor:
     """FOVNetwork::forward (fov.rs:168-227) -> [B,1,h,w] (h=w=1 for the shipped presets)."""
     m = cfg.interpolation
-    fv = cfg.fov_vit()
+    fv = _cfg_vits(cfg)[2]
     if fv is None:  # fov.rs:119-154 branch
         t = _conv_act(lowres, W, "fov.head_blocks.0.conv", 2, 1, True, m)
         t = _conv_act(t, W, "fov.head_blocks.1.conv", 2, 1, True, m)
@@ -513,7 +529,7 @@ def fovy_from_fovx_rad(fovx_rad: Tensor, h: int, w: int) -> Tensor:
     return atan_ax * s * 2.0
 
 
-def forward_debug(x: Tensor, W, cfg: DepthProConfig, q: Quant = identity) -> Dict[str, object]:
+def forward_debug(x: Tensor, W, cfg, q: Quant = identity) -> Dict[str, object]:
     """DepthPro::forward_internal (mod.rs:210-252) with every debug tap."""
     enc = encoder_forward_debug(x, W, cfg, q)
     feats, lowres, fusions = decoder_forward_debug(enc["features"], W, q)
@@ -525,10 +541,10 @@ def forward_debug(x: Tensor, W, cfg: DepthProConfig, q: Quant = identity) -> Dic
                 head=hd, canonical=hd["canonical"], fov_deg=fov)
 
 
-def infer(x: Tensor, W, cfg: DepthProConfig, q: Quant = identity, debug: bool = False):
+def infer(x: Tensor, W, cfg, q: Quant = identity, debug: bool = False):
     """DepthPro::infer (mod.rs:312-364) -> dict(depth[B,H,W], focallength_px[B], fovx_deg[B], fovy_rad[B])."""
     B, _, H, Wd = x.shape
-    S = cfg.img_size()
+    S = ref_config.img_size_for(cfg.patch_encoder_preset)
     resize_needed = (S != H) or (S != Wd)
     xin = resize_bilinear(x, (S, S), cfg.interpolation) if resize_needed else x
     dbg = forward_debug(xin, W, cfg, q)

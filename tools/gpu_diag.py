@@ -505,45 +505,64 @@ def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY,
     return out, ref
 
 
-def run_full_size(dev, precisions=(Precision.F32, Precision.F16, Precision.BF16), f16_weights=False):
-    """BASELINE config 3 at full size: the default DepthProConfig on one seeded [1,3,1536,1536] frame, every precision
-    mode against ONE fp32 CPU-oracle frame (the oracle costs ~19 TFLOP: about a minute on the GPU box's host cores)."""
+def run_full_size(dev, precisions=(Precision.F32, Precision.F16, Precision.BF16), f16_weights=False, frame="seeded", scheme=Wt.INIT_PARITY):
+    """The default DepthProConfig at full size, every precision mode in `precisions` against ONE fp32 CPU-oracle frame (the
+    oracle costs ~19 TFLOP: about a minute on the GPU box's host cores). `frame`:
+      "seeded"   BASELINE config 3-(ii): torch.manual_seed(0) U[0,1) image [1,3,1536,1536], normalised;
+      "zeros"    BASELINE config 1: zeros [1,3,1536,1536] (example/inference.rs plumbing; with scheme = INIT_REFERENCE the
+                 `DepthPro::new` initialisation of bench/inference.rs:25-27);
+      "test_jpg" BASELINE config 3-(iii): the reference's assets/image/test.jpg (540 x 360, decoded pixels committed as
+                 tests/golden/test_jpg_rgb.npy) through `infer_from_rgb` (src/inference.rs:128-137) -- both resizes of
+                 DepthPro::infer (mod.rs:317-354) run.
+    f16_weights: the weights rounded to f16 on both sides, as the reference's checkpoint records hold them (mod.rs:206)."""
     cfg = DepthProConfig()
-    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
-    if f16_weights:  # an f16 checkpoint of the seeded weights (`HalfPrecisionSettings`, mod.rs:206) on both sides
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
+    if f16_weights:
         W = {k: R.f16_round(v) for k, v in W.items()}
-    torch.manual_seed(0)
     S = cfg.img_size()
-    x = (torch.rand(1, 3, S, S) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
+    rgb = None
+    if frame == "seeded":
+        torch.manual_seed(0)
+        x = (torch.rand(1, 3, S, S) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
+    elif frame == "zeros":
+        x = torch.zeros(1, 3, S, S)
+    else:
+        rgb = np.load(os.path.join(ROOT, "tests", "golden", "test_jpg_rgb.npy"))
+        x = R.rgb_to_input_tensor(rgb.tobytes(), rgb.shape[1], rgb.shape[0])
     t0 = time.time()
     with torch.no_grad():
         ref = R.infer(x, W, cfg)
-    print(f"      full-size oracle fp32 {time.time() - t0:.1f}s", flush=True)
+    print(f"      full-size oracle fp32 {time.time() - t0:.1f}s ({frame} frame {tuple(x.shape)})", flush=True)
     del W
     rd = ref["depth"]
+    tag = ("" if frame == "seeded" else f"/{frame}") + ("/f16w" if f16_weights else "") + ("/refinit" if scheme == Wt.INIT_REFERENCE else "")
     for precision in precisions:
         c = DepthProConfig()
         c.precision = precision
         c.max_batch = 1
-        model = DepthPro.new(dev, c, seed=0, init_scheme=Wt.INIT_PARITY)
+        model = DepthPro.new(dev, c, seed=0, init_scheme=scheme)
         if f16_weights:
             model.round_weights_to_f16()
-        out = model.infer(x.cuda())
+        out = model.infer_from_rgb(rgb.tobytes(), rgb.shape[1], rgb.shape[0]) if rgb is not None else model.infer(x.cuda())
         torch.cuda.synchronize()
         tol, _ = E2E_TOL[precision]
         ftol = FOV_TOL[precision]
         d = out.depth.cpu()
         err = (d - rd).abs()
         rel = err / rd.abs()
-        label = f"full/{PNAME[int(precision)]}" + ("/f16w" if f16_weights else "")
+        label = f"full/{PNAME[int(precision)]}" + tag
         ft = FULL_TOL[int(precision)]
+        record(f"{label} output shape and finiteness", 0.0 if (tuple(d.shape) == tuple(rd.shape) and bool(torch.isfinite(d).all())) else 1.0, 0.0, f"shape={tuple(d.shape)}")
         record(f"{label} depth max-rel vs fp32 oracle", rel.max().item(), ft[0],
-               f"p99.9-rel={pctl(rel, 0.999):.2e} mean-rel={rel.mean().item():.2e} L_inf={err.max().item():.2e} mean-abs={err.mean().item():.2e} depth in [{rd.min():.3f},{rd.max():.3f}]")
-        if int(precision) in FULL_LINF:
+               f"p99.9-rel={pctl(rel, 0.999):.2e} mean-rel={rel.mean().item():.2e} L_inf={err.max().item():.2e} mean-abs={err.mean().item():.2e} depth in [{rd.min():.3g},{rd.max():.3g}]")
+        if int(precision) in FULL_LINF and float(rd.max()) < 100.0:  # an absolute bound needs depths of ordinary size
             record(f"{label} depth L_inf vs fp32 oracle", err.max().item(), FULL_LINF[int(precision)])
         record(f"{label} depth p99.9 rel vs fp32 oracle", pctl(rel, 0.999), ft[1])
         record(f"{label} depth mean-rel vs fp32 oracle", rel.mean().item(), ft[2])
-        record(f"{label} fovx_deg abs", (out.fovx_deg.cpu() - ref['fovx_deg']).abs().max().item(), ftol[0], f"fov={ref['fovx_deg'].tolist()}")
+        if rgb is None:  # infer_from_rgb returns DepthPrediction {depth, focallength_px, fovy_rad} (src/inference.rs:10-14)
+            record(f"{label} fovx_deg abs", (out.fovx_deg.cpu() - ref['fovx_deg']).abs().max().item(), ftol[0], f"fov={ref['fovx_deg'].tolist()}")
+        else:
+            record(f"{label} fovy_rad abs", (out.fovy_rad.cpu() - ref['fovy_rad']).abs().max().item(), ftol[1])
         record(f"{label} focallength rel", rel_err(out.focallength_px, ref["focallength_px"]), tol[1])
         model.destroy()
 
@@ -730,10 +749,12 @@ def main():
         guarded("tiny f16x2 B2 resize")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f16x2/B2/360x540", 2, (360, 540), Precision.F16X2, taps=False, f16_weights=True)
         if not args.skip_small:
             guarded("small f16x2 f16w")(run_e2e)(dev, DepthProConfig.small_test(), "small/f16x2/f16w", 1, (512, 512), Precision.F16X2, f16_weights=True)
-    if want("full16") and only is not None:  # the accurate fast mode on an f16 checkpoint, beside fp32 and f16 on the same weights
-        guarded("full size f16w")(run_full_size)(dev, (Precision.F16X2, Precision.F32, Precision.F16), f16_weights=True)
-    if args.full or (want("full") and only is not None):
-        guarded("full size")(run_full_size)(dev)
+    if args.full or (want("full") and only is not None):  # every mode on an f16 checkpoint of the seeded weights, one oracle frame
+        guarded("full size")(run_full_size)(dev, (Precision.F32, Precision.F16X2, Precision.F16, Precision.BF16), f16_weights=True)
+    if want("testjpg") and only is not None:
+        guarded("test.jpg")(run_full_size)(dev, (Precision.F32, Precision.F16X2), f16_weights=True, frame="test_jpg")
+    if want("config1") and only is not None:
+        guarded("config 1")(run_full_size)(dev, (Precision.F32, Precision.F16X2, Precision.BF16), frame="zeros", scheme=Wt.INIT_REFERENCE)
     if want("shard") and only is not None:
         guarded("shard")(run_shard_batch)(dev)
     if want("config5") and only is not None:
