@@ -146,6 +146,9 @@ def parse_args(argv=None):
     ap.add_argument("--side-kernels", action="store_true", help="also time the stand-alone HBM-bound kernels (resize_bilinear / resize_nhwc at the shapes of bench/interpolate.rs) into `kernels`")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the engine + gloo instead of RCCL: tests the launcher / scatter / gather / JSON contract without a GPU")
     ap.add_argument("--dump-launch-order", default="", help="write the per-launch kernel-family list of one infer (json)")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="N > 1: weight broadcast, image scatter and depth gather through the library's own RCCL entry points (md_comm_*, grouped "
+                         "ncclSend / ncclRecv on a side HIP stream) instead of torch.distributed; torch.distributed only carries the rendezvous id")
     ap.add_argument("--no-extras", action="store_true",
                     help="default N = 1 Depth Pro bf16 run only: skip the objects measured after the timed region (`configs`: the other BASELINE "
                          "configurations; `accurate_mode` / `fp32_mode_fps`; `accuracy` at 1536^2 against the CPU-baseline frame; `host_io`)")
@@ -201,10 +204,17 @@ def main(argv=None) -> int:
     # the fp32 weight arena over RCCL (one-time, outside the timed region).
     model = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
     t_bcast = 0.0
-    if world > 1:
+    ncomm = None
+    if args.native_comm:
+        from burn_depth_amd.parallel import NativeComm
+        ncomm = NativeComm.from_torch_distributed(dev) if world > 1 else NativeComm(dev, NativeComm.unique_id(), 1, 0)
+    if world > 1 or ncomm is not None:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        broadcast_weights(model, src=0)
+        if ncomm is not None:
+            ncomm.broadcast_weights(model, root=0)
+        else:
+            broadcast_weights(model, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
     # the reference's checkpoints are f16 records (`HalfPrecisionSettings`, depth_pro/mod.rs:206): every mode is measured on
@@ -218,8 +228,8 @@ def main(argv=None) -> int:
         g = torch.Generator(device="cpu").manual_seed(seed)
         return (torch.rand(n, 3, S, S, generator=g) - mean) / std
 
-    do_scatter = world > 1 and not args.no_scatter
-    do_gather = world > 1 and not args.no_gather
+    do_scatter = (world > 1 or ncomm is not None) and not args.no_scatter
+    do_gather = (world > 1 or ncomm is not None) and not args.no_gather
     nbuf = 2 if (do_scatter or do_gather) else 1  # double buffering: transfers of neighbouring steps overlap this step's compute
     if do_scatter:
         # the whole global batch lives in rank 0's HBM before the timed region; the other ranks own receive buffers only
@@ -234,6 +244,16 @@ def main(argv=None) -> int:
     fovy = torch.empty((B,), dtype=torch.float32, device=tdev)
     gathered = [[torch.empty_like(depths[0]) for _ in range(world)] for _ in range(nbuf)] if (do_gather and rank == 0) else None
     scatter_chunks = list(global_in.split(B, 0)) if (do_scatter and rank == 0) else None
+    if ncomm is not None:
+        # native path: RCCL point-to-point groups on a side stream, ordered against the compute stream by events
+        cstream = torch.cuda.Stream(device=tdev)
+        ev_sc = [torch.cuda.Event() for _ in range(nbuf)]   # shard `slot` has arrived
+        ev_inf = [torch.cuda.Event() for _ in range(nbuf)]  # infer of buffer `slot` has finished (input + depth free / ready)
+        ev_ga = [torch.cuda.Event() for _ in range(nbuf)]   # depth buffer `slot` has been gathered
+        gathered_flat = [torch.empty((world * B, S, S), dtype=torch.float32, device=tdev) for _ in range(nbuf)] if (do_gather and rank == 0) else None
+        if gathered_flat is not None:
+            gathered = [list(g.split(B, 0)) for g in gathered_flat]
+        used = {"inf": [False] * nbuf, "ga": [False] * nbuf}
 
     extra = []  # additional in-flight batches: (forked model sharing the weights, stream, x, depth, focal, fovx, fovy)
     for si in range(1, args.streams):
@@ -247,7 +267,40 @@ def main(argv=None) -> int:
     def issue_scatter(slot):
         pending["scatter"] = dist.scatter(xs[slot], scatter_chunks, src=0, async_op=True)
 
+    def native_scatter(slot):
+        if used["inf"][slot]:
+            cstream.wait_event(ev_inf[slot])  # the previous infer on this input buffer has finished
+        ncomm.scatter_images(global_in if rank == 0 else None, xs[slot], root=0, stream=cstream.cuda_stream)
+        ev_sc[slot].record(cstream)
+        pending["scatter"] = slot
+
+    def native_step():
+        k = pending["k"]
+        slot = k % nbuf
+        cur = torch.cuda.current_stream()
+        if do_scatter:
+            if pending["scatter"] is None:
+                native_scatter(slot)
+            cur.wait_event(ev_sc[slot])
+            if nbuf > 1:
+                native_scatter((k + 1) % nbuf)  # the next step's shard travels while this step computes
+            else:
+                pending["scatter"] = None
+        if do_gather and used["ga"][slot]:
+            cur.wait_event(ev_ga[slot])  # depth buffer `slot` was handed to a gather nbuf steps ago
+        model.infer_into(xs[slot], depths[slot], focal, fovx, fovy)
+        ev_inf[slot].record(cur)
+        used["inf"][slot] = True
+        if do_gather:
+            cstream.wait_event(ev_inf[slot])
+            ncomm.gather_depth(depths[slot], gathered_flat[slot] if rank == 0 else None, root=0, stream=cstream.cuda_stream)
+            ev_ga[slot].record(cstream)
+            used["ga"][slot] = True
+        pending["k"] = k + 1
+
     def step():
+        if ncomm is not None:
+            return native_step()
         k = pending["k"]
         slot = k % nbuf
         if do_scatter:
@@ -271,6 +324,11 @@ def main(argv=None) -> int:
         pending["k"] = k + 1
 
     def drain():
+        if ncomm is not None:
+            cstream.synchronize()
+            torch.cuda.synchronize()
+            pending["scatter"] = None  # a prefetched shard is dropped: the next step scatters its own
+            return
         if pending["scatter"] is not None:
             pending["scatter"].wait()
             pending["scatter"] = None
@@ -392,7 +450,8 @@ def main(argv=None) -> int:
                        "batch_per_gpu": B, "batch_note": "8 images per GPU = BASELINE config 4's shard; config 3 as SURVEY 8(d) words it (B = 1) is configs[0]" if B == 8 else None,
                        "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
                        "parallelism": f"dp{world}",
-                       "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather},
+                       "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather,
+                       "comm": "native md_comm_* (RCCL point-to-point groups on a side stream)" if ncomm is not None else ("torch.distributed (RCCL)" if world > 1 else None)},
             "finite_output": ok,
             # FLOPs the schedule EXECUTES per frame (layers composed at commit count once); null when no per-family pass ran (--graph)
             "frame_tflops_executed": round(total_flops / B / 1e12, 3) if kernels else None,
@@ -421,6 +480,8 @@ def main(argv=None) -> int:
     for e in extra:
         e[0].destroy()
     model.destroy()
+    if ncomm is not None:
+        ncomm.destroy()
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -15,7 +15,8 @@ MD_OK = 0
 MD_ERR_INVALID_ARG, MD_ERR_SHAPE, MD_ERR_IO, MD_ERR_FORMAT, MD_ERR_HIP = -1, -2, -3, -4, -5
 MD_ERR_UNSUPPORTED, MD_ERR_NO_FOV, MD_ERR_OOM, MD_ERR_LEVELS = -6, -7, -8, -9
 MD_MEM_HOST, MD_MEM_DEVICE = 0, 1
-TILE_256x256, TILE_128x128, TILE_256x32, TILE_AUTO = 0, 1, 2, 99
+MD_COMM_ID_BYTES = 128
+TILE_256x256, TILE_128x128, TILE_256x32, TILE_4W, TILE_AUTO = 0, 1, 2, 3, 99
 
 
 class MdError(RuntimeError):
@@ -109,6 +110,13 @@ SYMBOLS = {
     "md_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
     "md_bench_attention": (_I, [_P, _I, _I, _I, _I, _F]),
     "md_bench_attention_ex": (_I, [_P, _I, _I, _I, _I, C.c_float, _I, _F]),
+    "md_comm_unique_id": (_I, [_P]),
+    "md_comm_init_rank": (_I, [_P, _P, _I, _I, C.POINTER(_P)]),
+    "md_comm_rank": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "md_comm_destroy": (_I, [_P]),
+    "md_comm_broadcast_weights": (_I, [_P, _P, _I]),
+    "md_comm_scatter_images": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),
+    "md_comm_gather_depth": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),
     "md_param_inventory": (_I, [C.POINTER(MdDepthProCfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_uniform_stream": (_I, [C.c_char_p, C.c_uint64, C.c_size_t, C.c_float, C.c_float, _P]),
     "md_split_geometry": (_I, [_I, _I, C.c_float, C.POINTER(_I), C.POINTER(_I)]),

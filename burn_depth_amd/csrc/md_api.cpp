@@ -226,6 +226,7 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
   else if (k == "forks") *out = m->forks.load();
   else if (k == "weight_terms") *out = model_root(m)->wterms;
   else if (k == "allocs") *out = m->alloc_count;
+  else if (k == "da3_shape_builds") *out = da3_shape_builds(m);
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
 }
@@ -631,6 +632,7 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   GemmParams p;
   p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
   p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = (dbg & 3) | ((dbg & 64) ? 4 : 0) | ((dbg & 128) ? 8 : 0);
+  if (tile == TILE_4W) p.debug_flags = (dbg >> 8) & 15;  // the 4-wave tile's own ablation ids (gemm4w_impl.h launch_4w)
   DevBuf bias;
   DevBuf xres, lsc;
   if (dbg & 16) {  // proj / fc2-style epilogue: x(f32) += scale * (acc + bias)

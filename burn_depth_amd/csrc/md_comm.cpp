@@ -1,0 +1,135 @@
+// Native multi-GPU plumbing of the data-parallel path (BASELINE north_star: "RCCL broadcast of weights and gather
+// of depth maps over xGMI" reachable from the host language through the FFI layer): one process per GPU, RCCL over xGMI,
+// NO collective inside DepthPro::infer -- images of a batch never interact (encoder.rs:216-225,249-255).
+//   * one-time broadcast of the fp32 parameter arena from the root (1-GiB buckets: a ring broadcast is bound by one xGMI
+//     link, ~153 GB/s; the bucket keeps the counts inside 32 bits), then every rank packs its own MFMA operand copies;
+//   * per batch: the root scatters [B,3,H,W] shards and gathers the depth maps as ONE group of point-to-point
+//     ncclSend / ncclRecv on the engine's stream (xGMI is point to point: the root's 7 links carry the 7 shards in parallel).
+// The reference has no collectives at all; these entry points are what a reference-side host would call
+// next to md_depth_pro_infer.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "md_engine.h"
+
+using namespace md;
+
+struct md_comm_s {
+  md_device_t dev = nullptr;
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+};
+
+#define MD_NCCL(expr)                                                                                   \
+  do {                                                                                                  \
+    ncclResult_t _r = (expr);                                                                           \
+    if (_r != ncclSuccess) {                                                                            \
+      ::md::set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__);      \
+      return MD_ERR_HIP;                                                                                \
+    }                                                                                                   \
+  } while (0)
+
+extern "C" {
+
+int md_comm_unique_id(uint8_t id[MD_COMM_ID_BYTES]) {
+  if (!id) MD_FAIL(MD_ERR_INVALID_ARG, "id is null");
+  static_assert(MD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "md_comm id size must match ncclUniqueId");
+  ncclUniqueId u;
+  MD_NCCL(ncclGetUniqueId(&u));
+  memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return MD_OK;
+}
+
+int md_comm_init_rank(md_device_t dev, const uint8_t id[MD_COMM_ID_BYTES], int world_size, int rank, md_comm_t* out) {
+  if (!dev || !id || !out) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (world_size < 1 || rank < 0 || rank >= world_size) MD_FAIL(MD_ERR_INVALID_ARG, "rank %d of %d", rank, world_size);
+  MD_HIP(hipSetDevice(dev->ordinal));
+  ncclUniqueId u;
+  memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  md_comm_s* c = new md_comm_s();
+  c->dev = dev;
+  c->world = world_size;
+  c->rank = rank;
+  ncclResult_t r = ncclCommInitRank(&c->comm, world_size, u, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    MD_FAIL(MD_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world_size, ncclGetErrorString(r));
+  }
+  *out = c;
+  return MD_OK;
+}
+
+int md_comm_destroy(md_comm_t c) {
+  if (!c) return MD_OK;
+  if (c->dev) (void)hipSetDevice(c->dev->ordinal);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+  return MD_OK;
+}
+
+int md_comm_rank(md_comm_t c, int* rank, int* world_size) {
+  if (!c) MD_FAIL(MD_ERR_INVALID_ARG, "communicator is null");
+  if (rank) *rank = c->rank;
+  if (world_size) *world_size = c->world;
+  return MD_OK;
+}
+
+int md_comm_broadcast_weights(md_comm_t c, md_model_t m, int root) {
+  if (!c || !m) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (root < 0 || root >= c->world) MD_FAIL(MD_ERR_INVALID_ARG, "root %d of %d", root, c->world);
+  if (m->parent) MD_FAIL(MD_ERR_INVALID_ARG, "a fork shares its root's weights: broadcast into the root model");
+  if (m->dev != c->dev && m->dev->ordinal != c->dev->ordinal) MD_FAIL(MD_ERR_INVALID_ARG, "model and communicator live on different devices");
+  MD_HIP(hipSetDevice(c->dev->ordinal));
+  hipStream_t st = c->dev->stream;
+  const size_t bucket = (size_t)1 << 30;
+  for (size_t off = 0; off < m->w32_bytes; off += bucket) {
+    const size_t n = std::min(bucket, m->w32_bytes - off);
+    MD_NCCL(ncclBroadcast(m->w32_base + off, m->w32_base + off, n, ncclUint8, root, c->comm, st));
+  }
+  MD_HIP(hipStreamSynchronize(st));
+  m->committed = false;
+  return model_commit(m);
+}
+
+// root: `all` = [world][elems] (rank-major); every rank (the root included) receives its shard in `shard`
+int md_comm_scatter_images(md_comm_t c, const float* all_dev, float* shard_dev, size_t elems_per_rank, int root, void* stream) {
+  if (!c || !shard_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (root < 0 || root >= c->world) MD_FAIL(MD_ERR_INVALID_ARG, "root %d of %d", root, c->world);
+  if (c->rank == root && !all_dev) MD_FAIL(MD_ERR_INVALID_ARG, "the root rank needs the full batch");
+  MD_HIP(hipSetDevice(c->dev->ordinal));
+  hipStream_t st = stream ? (hipStream_t)stream : c->dev->stream;
+  MD_NCCL(ncclGroupStart());
+  if (c->rank == root) {
+    for (int r = 0; r < c->world; ++r)
+      if (r != root) MD_NCCL(ncclSend(all_dev + (size_t)r * elems_per_rank, elems_per_rank, ncclFloat, r, c->comm, st));
+  } else {
+    MD_NCCL(ncclRecv(shard_dev, elems_per_rank, ncclFloat, root, c->comm, st));
+  }
+  MD_NCCL(ncclGroupEnd());
+  if (c->rank == root && shard_dev != all_dev + (size_t)root * elems_per_rank)
+    MD_HIP(hipMemcpyAsync(shard_dev, all_dev + (size_t)root * elems_per_rank, elems_per_rank * 4, hipMemcpyDeviceToDevice, st));
+  return MD_OK;
+}
+
+// every rank sends `shard`; root: `all` = [world][elems] (rank-major)
+int md_comm_gather_depth(md_comm_t c, const float* shard_dev, float* all_dev, size_t elems_per_rank, int root, void* stream) {
+  if (!c || !shard_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (root < 0 || root >= c->world) MD_FAIL(MD_ERR_INVALID_ARG, "root %d of %d", root, c->world);
+  if (c->rank == root && !all_dev) MD_FAIL(MD_ERR_INVALID_ARG, "the root rank needs the gather buffer");
+  MD_HIP(hipSetDevice(c->dev->ordinal));
+  hipStream_t st = stream ? (hipStream_t)stream : c->dev->stream;
+  MD_NCCL(ncclGroupStart());
+  if (c->rank == root) {
+    for (int r = 0; r < c->world; ++r)
+      if (r != root) MD_NCCL(ncclRecv(all_dev + (size_t)r * elems_per_rank, elems_per_rank, ncclFloat, r, c->comm, st));
+  } else {
+    MD_NCCL(ncclSend(shard_dev, elems_per_rank, ncclFloat, root, c->comm, st));
+  }
+  MD_NCCL(ncclGroupEnd());
+  if (c->rank == root && shard_dev != all_dev + (size_t)root * elems_per_rank)
+    MD_HIP(hipMemcpyAsync(all_dev + (size_t)root * elems_per_rank, shard_dev, elems_per_rank * 4, hipMemcpyDeviceToDevice, st));
+  return MD_OK;
+}
+
+}  // extern "C"

@@ -34,20 +34,37 @@ struct md_model_s::Da3State {
   void *t = nullptr, *x = nullptr, *xr = nullptr, *y = nullptr, *up = nullptr, *o = nullptr, *c1 = nullptr, *c1r = nullptr;
   float* depth_stage = nullptr;
   size_t depth_stage_elems = 0;
-  // tables
-  void* pos_stage[4] = {0, 0, 0, 0};  // T [P, cp(oc)] = 0.1 * UV embedding
-  float* pos_final = nullptr;         // f32 [H*W, F/2]
-  std::map<int, int*> tok_index;      // per B: [B*P] -> row b*SS + 1 + p
-  float* pos_used = nullptr;          // [NT, D] position embedding for this grid (interpolated when ph != native)
+  // ---- per-shape tables: the reference's `PosEmbedCache` (dpt.rs:784-833: UV tables built once per (C, h, w, W, H) key and
+  //      kept) and burn_dino's position-embedding interpolation, keyed by the input size. `infer` takes any H x W that are
+  //      multiples of the patch size (mod.rs:509-520); the first call at a new size builds its tables (host work + uploads),
+  //      later calls at that size find them here. At most kMaxShapes sizes are kept (least recently used goes first).
+  struct ShapeTables {
+    void* pos_stage[4] = {0, 0, 0, 0};  // T [P, cp(oc)] = 0.1 * UV embedding
+    float* pos_final = nullptr;         // f32 [H*W, F/2]
+    float* pos_aux = nullptr;           // f32 [8ph*8pw, F/2] = 2 * 0.1 * UV table (added twice, dpt.rs:428-435)
+    float* pos_used = nullptr;          // [NT, D] position embedding interpolated to this grid (null: the native grid)
+    float *rope_cos = nullptr, *rope_sin = nullptr;  // [max(ph, pw) + 2][16]
+    std::map<int, int*> tok_index;      // per B: [B*P] -> row b*SS + 1 + p
+    unsigned long last_use = 0;
+  };
+  static constexpr int kMaxShapes = 16;
+  std::map<std::pair<int, int>, ShapeTables> shapes;
+  unsigned long use_clock = 0;
+  long table_builds = 0;              // shapes built so far (md_model_query "da3_shape_builds")
+  // the CURRENT shape's tables (aliases into `shapes`)
+  void* pos_stage[4] = {0, 0, 0, 0};
+  float* pos_final = nullptr;
+  std::map<int, int*>* tok_index = nullptr;
+  float* pos_used = nullptr;
   int native_grid = 0;
   // ---- `small` (dual head) ----
   std::string hp = "head_mono";       // head parameter prefix
   int din = 0;                        // head input width: D (mono) or 2D (concatenated hooks)
   float* xlocal = nullptr;            // [rows, D] fp32: residual stream after the last LOCAL block
-  float* rope_cos = nullptr;          // [max_pos + 1][16]
+  float* rope_cos = nullptr;          // current shape's tables (aliases)
   float* rope_sin = nullptr;
   float *cam_raw = nullptr, *cam_h1 = nullptr, *cam_h2 = nullptr, *pose = nullptr, *extr = nullptr, *intr = nullptr;
-  float* pos_aux = nullptr;           // f32 [8ph*8pw, F/2] = 2 * 0.1 * UV table (added twice, dpt.rs:428-435)
+  float* pos_aux = nullptr;
   float *conf_stage = nullptr, *aux_stage = nullptr;  // device staging when the caller wants host outputs
   std::vector<float> main_bias, aux_bias;             // output_conv2.conv2.bias, output_conv2_aux.<last>.project.bias
   // ---- MD_PREC_FP8: the four ViT linear layers on e4m3 operands (weights per output channel, static activation scales) ----
@@ -147,6 +164,9 @@ static std::vector<float> interpolate_pos_embed(const std::vector<float>& pos, i
   return out;
 }
 
+static void da3_drop_shapes(md_model_s* m);
+static int da3_set_shape(md_model_s* m, int H, int W, bool force);
+
 int da3_on_commit(md_model_t m) {
   md_model_s::Da3State* d = m->da3;
   const int D = d->cfg.vit.D, M = d->native_grid;
@@ -171,17 +191,11 @@ int da3_on_commit(md_model_t m) {
                        c.aux_output_dim * 4, hipMemcpyDeviceToHost));
     }
   }
-  const float* pos_param = P32(m, "backbone.pretrained.pos_embed");
-  if (d->ph == M && d->pw == M) {
-    d->vit.pos = pos_param;
-    return MD_OK;
-  }
-  std::vector<float> pos((size_t)(1 + M * M) * D);
-  MD_HIP(hipMemcpy(pos.data(), pos_param, pos.size() * 4, hipMemcpyDeviceToHost));
-  std::vector<float> ip = interpolate_pos_embed(pos, M, D, d->ph, d->pw);
-  MD_HIP(hipMemcpy(d->pos_used, ip.data(), ip.size() * 4, hipMemcpyHostToDevice));
-  d->vit.pos = d->pos_used;
-  return MD_OK;
+  (void)D; (void)M;
+  // the interpolated position embeddings were made from the previous weights: drop every cached shape and rebuild the
+  // current one from the committed parameters
+  da3_drop_shapes(m);
+  return da3_set_shape(m, d->ih, d->iw, /*force=*/true);
 }
 
 static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
@@ -221,15 +235,12 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   for (int s = 0; s < 4; ++s) DA3_TAKE(hookn[s], void*, rows * d->din * esz);
   if (c.dual_head) {
     DA3_TAKE(xlocal, float*, rows * D * 4);
-    DA3_TAKE(rope_cos, float*, (size_t)(std::max(ph, pw) + 2) * 16 * 4);
-    DA3_TAKE(rope_sin, float*, (size_t)(std::max(ph, pw) + 2) * 16 * 4);
     DA3_TAKE(cam_raw, float*, (size_t)B * d->din * 4);
     DA3_TAKE(cam_h1, float*, (size_t)B * d->din * 4);
     DA3_TAKE(cam_h2, float*, (size_t)B * d->din * 4);
     DA3_TAKE(pose, float*, (size_t)B * 9 * 4);
     DA3_TAKE(extr, float*, (size_t)B * 12 * 4);
     DA3_TAKE(intr, float*, (size_t)B * 9 * 4);
-    DA3_TAKE(pos_aux, float*, (size_t)64 * ph * pw * (F / 2) * 4);
     DA3_TAKE(conf_stage, float*, (size_t)B * SS2 * 4);
     DA3_TAKE(aux_stage, float*, (size_t)B * c.aux_output_dim * 64 * ph * pw * 4);
   }
@@ -249,11 +260,184 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   DA3_TAKE(o, void*, big);
   DA3_TAKE(c1, void*, (size_t)B * 64 * ph * pw * cp(F / 2) * esz);
   DA3_TAKE(c1r, void*, (size_t)B * SS2 * cp(F / 2) * esz);
-  for (int s = 0; s < 4; ++s) DA3_TAKE(pos_stage[s], void*, P * cp(oc[s]) * esz);
-  DA3_TAKE(pos_final, float*, SS2 * (F / 2) * 4);
-  DA3_TAKE(pos_used, float*, (size_t)d->NT * D * 4);
 #undef DA3_TAKE
   if (total_out) *total_out = total + 4096;
+  return MD_OK;
+}
+
+static void da3_set_geometry(md_model_s* m, int H, int W) {
+  md_model_s::Da3State* d = m->da3;
+  const ViTDims& v = d->cfg.vit;
+  d->ih = H;
+  d->iw = W;
+  d->ph = H / v.ps;
+  d->pw = W / v.ps;
+  d->P = d->ph * d->pw;
+  d->NT = d->P + 1;
+  d->SS = round_up(d->NT, 4);
+  d->kpad = round_up(d->NT, 64);
+  d->Kp = round_up(3 * v.ps * v.ps, m->ke);
+  d->h3h = (d->ph + 2 - 3) / 2 + 1;
+  d->h3w = (d->pw + 2 - 3) / 2 + 1;
+  m->SS = d->SS;
+}
+
+static void da3_free_tables(md_model_s::Da3State::ShapeTables& t) {
+  for (int s = 0; s < 4; ++s)
+    if (t.pos_stage[s]) (void)hipFree(t.pos_stage[s]);
+  if (t.pos_final) (void)hipFree(t.pos_final);
+  if (t.pos_aux) (void)hipFree(t.pos_aux);
+  if (t.pos_used) (void)hipFree(t.pos_used);
+  if (t.rope_cos) (void)hipFree(t.rope_cos);
+  if (t.rope_sin) (void)hipFree(t.rope_sin);
+  for (auto& kv : t.tok_index) (void)hipFree(kv.second);
+  t = md_model_s::Da3State::ShapeTables();
+}
+
+static void da3_drop_graphs(md_model_s* m) {  // captured graphs hold workspace / table pointers of the shape they were captured at
+  for (auto& kv : m->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  m->graphs.clear();
+}
+
+static void da3_drop_shapes(md_model_s* m) {
+  md_model_s::Da3State* d = m->da3;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : d->shapes) da3_free_tables(kv.second);
+  d->shapes.clear();
+  d->tok_index = nullptr;
+  da3_drop_graphs(m);
+}
+
+// UV position tables, interpolated position embedding and RoPE tables of one input size (PosEmbedCache::add /
+// build_positional_embedding, dpt.rs:784-932; burn_dino's pos-embed interpolation, restated: interpolate_pos_embed above)
+static int da3_build_tables(md_model_s* m, md_model_s::Da3State::ShapeTables& t) {
+  md_model_s::Da3State* d = m->da3;
+  const Da3Cfg& c = d->cfg;
+  const int IH = d->ih, IW = d->iw, F = c.features, D = c.vit.D, M = d->native_grid;
+  const int* oc = c.out_channels;
+  hipStream_t st = m->dev->stream;
+  float* tmp = nullptr;
+  size_t tmp_elems = 0;
+  for (int s = 0; s < 4; ++s) tmp_elems = std::max(tmp_elems, (size_t)d->P * round_up(oc[s], m->ke));
+  MD_HIP(hipMalloc((void**)&tmp, tmp_elems * 4));
+  for (int s = 0; s < 4; ++s) {
+    std::vector<float> tab = build_pos_table_nhwc(oc[s], d->ph, d->pw, IW, IH, 0.1f);
+    const int ld = round_up(oc[s], m->ke);
+    std::vector<float> padded((size_t)d->P * ld, 0.f);
+    for (int p = 0; p < d->P; ++p) memcpy(&padded[(size_t)p * ld], &tab[(size_t)p * oc[s]], (size_t)oc[s] * 4);
+    MD_HIP(hipMalloc(&t.pos_stage[s], padded.size() * m->esz + 256));
+    MD_HIP(hipMemcpy(tmp, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
+    MD_TRY(launch_f32_to_rows(tmp, (long)padded.size(), t.pos_stage[s], m->prec, st));
+    MD_HIP(hipStreamSynchronize(st));
+  }
+  MD_HIP(hipFree(tmp));
+  {
+    std::vector<float> tab = build_pos_table_nhwc(F / 2, IH, IW, IW, IH, 0.1f);
+    MD_HIP(hipMalloc((void**)&t.pos_final, tab.size() * 4));
+    MD_HIP(hipMemcpy(t.pos_final, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (c.dual_head) {
+    // aux head input = neck + 0.1*UV + 0.1*UV (added twice, dpt.rs:428-435)
+    std::vector<float> ta = build_pos_table_nhwc(F / 2, 8 * d->ph, 8 * d->pw, IW, IH, 0.1f);
+    for (auto& x : ta) x = x + x;
+    MD_HIP(hipMalloc((void**)&t.pos_aux, ta.size() * 4));
+    MD_HIP(hipMemcpy(t.pos_aux, ta.data(), ta.size() * 4, hipMemcpyHostToDevice));
+    // 2-D RoPE tables: angle(pos, f) = pos * base^(-2f/32), f < 16 (fp32 like the oracle)
+    const int npos = std::max(d->ph, d->pw) + 2;
+    std::vector<float> rc((size_t)npos * 16), rs((size_t)npos * 16);
+    for (int pz = 0; pz < npos; ++pz)
+      for (int f = 0; f < 16; ++f) {
+        const float inv = 1.0f / powf(c.rope_frequency, (float)(2 * f) / 32.0f);
+        const float ang = (float)pz * inv;
+        rc[(size_t)pz * 16 + f] = cosf(ang);
+        rs[(size_t)pz * 16 + f] = sinf(ang);
+      }
+    MD_HIP(hipMalloc((void**)&t.rope_cos, rc.size() * 4));
+    MD_HIP(hipMalloc((void**)&t.rope_sin, rs.size() * 4));
+    MD_HIP(hipMemcpy(t.rope_cos, rc.data(), rc.size() * 4, hipMemcpyHostToDevice));
+    MD_HIP(hipMemcpy(t.rope_sin, rs.data(), rs.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (d->ph != M || d->pw != M) {  // position embedding interpolated from the parameter's native grid
+    const float* pos_param = P32(m, "backbone.pretrained.pos_embed");
+    std::vector<float> pos((size_t)(1 + M * M) * D);
+    MD_HIP(hipMemcpy(pos.data(), pos_param, pos.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> ip = interpolate_pos_embed(pos, M, D, d->ph, d->pw);
+    MD_HIP(hipMalloc((void**)&t.pos_used, ip.size() * 4));
+    MD_HIP(hipMemcpy(t.pos_used, ip.data(), ip.size() * 4, hipMemcpyHostToDevice));
+  }
+  d->table_builds += 1;
+  return MD_OK;
+}
+
+// Makes H x W the model's current input size: geometry, workspace plan (the arena grows when the new size needs more --
+// never per call at a size seen before), and the size's tables from the cache (built on first use). A call at the current
+// size returns at once.
+static int da3_set_shape(md_model_s* m, int H, int W, bool force) {
+  md_model_s::Da3State* d = m->da3;
+  const ViTDims& v = d->cfg.vit;
+  if (H <= 0 || W <= 0 || H % v.ps != 0 || W % v.ps != 0)  // mod.rs:509-520
+    MD_FAIL(MD_ERR_SHAPE, "Input %dx%d must be divisible by patch size %d", H, W, v.ps);
+  const auto key = std::make_pair(H, W);
+  if (!force && H == d->ih && W == d->iw && d->tok_index) {
+    d->shapes[key].last_use = ++d->use_clock;
+    return MD_OK;
+  }
+  if ((long)(H / v.ps) * (W / v.ps) + 1 > 60000) MD_FAIL(MD_ERR_UNSUPPORTED, "input %dx%d: more than 60000 tokens", H, W);
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  MD_HIP(hipDeviceSynchronize());  // nothing may still run on the plan that is about to be replaced
+  const int oh = d->ih, ow = d->iw;
+  da3_set_geometry(m, H, W);
+  size_t need = 0;
+  da3_plan(m, true, &need);
+  if (need > m->ws.cap) {  // grow-only arena
+    if (m->ws.base) (void)hipFree(m->ws.base);
+    m->ws.base = nullptr;
+    m->ws.cap = 0;
+    if (hipMalloc((void**)&m->ws.base, need) != hipSuccess) {
+      if (oh > 0) da3_set_geometry(m, oh, ow);
+      d->tok_index = nullptr;  // forces a rebuild of the plan on the next call
+      MD_FAIL(MD_ERR_OOM, "hipMalloc of %zu bytes for the %dx%d workspace failed (max_batch=%d)", need, H, W, d->cfg.max_batch);
+    }
+    m->ws.cap = need;
+    m->alloc_count += 1;
+    da3_drop_graphs(m);
+  }
+  // padding rows / channels / keys must be finite zeros for every kernel: the buffers move with the plan, so the arena is
+  // cleared whenever the plan changes (a few hundred MB at HBM speed, once per change of size)
+  MD_HIP(hipMemset(m->ws.base, 0, m->ws.cap));
+  m->ws.off = 0;
+  MD_TRY(da3_plan(m, false, nullptr));
+  auto it = d->shapes.find(key);
+  if (it == d->shapes.end()) {
+    if ((int)d->shapes.size() >= md_model_s::Da3State::kMaxShapes) {  // evict the least recently used size
+      auto lru = d->shapes.begin();
+      for (auto j = d->shapes.begin(); j != d->shapes.end(); ++j)
+        if (j->second.last_use < lru->second.last_use) lru = j;
+      da3_free_tables(lru->second);
+      d->shapes.erase(lru);
+      da3_drop_graphs(m);
+    }
+    md_model_s::Da3State::ShapeTables t;
+    const int st = da3_build_tables(m, t);
+    if (st != MD_OK) {
+      da3_free_tables(t);
+      d->tok_index = nullptr;
+      return st;
+    }
+    it = d->shapes.emplace(key, t).first;
+  }
+  md_model_s::Da3State::ShapeTables& t = it->second;
+  t.last_use = ++d->use_clock;
+  for (int s = 0; s < 4; ++s) d->pos_stage[s] = t.pos_stage[s];
+  d->pos_final = t.pos_final;
+  d->pos_aux = t.pos_aux;
+  d->rope_cos = t.rope_cos;
+  d->rope_sin = t.rope_sin;
+  d->pos_used = t.pos_used;
+  d->tok_index = &t.tok_index;
+  d->vit.pos = t.pos_used ? t.pos_used : P32(m, "backbone.pretrained.pos_embed");
+  MD_HIP(hipDeviceSynchronize());
   return MD_OK;
 }
 
@@ -290,19 +474,8 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   d->hp = cfg.dual_head ? "head_dual" : "head_mono";
   d->din = cfg.dual_head ? 2 * v.D : v.D;
   d->native_grid = v.img / v.ps;  // the pos_embed parameter's grid (37 for ViT-L/14 @ 518)
-  d->ih = img_h;
-  d->iw = img_w;
-  d->ph = img_h / v.ps;
-  d->pw = img_w / v.ps;
-  d->P = d->ph * d->pw;
-  d->NT = d->P + 1;
-  d->SS = round_up(d->NT, 4);
-  d->kpad = round_up(d->NT, 64);
-  d->Kp = round_up(3 * v.ps * v.ps, m->ke);
-  d->h3h = (d->ph + 2 - 3) / 2 + 1;
-  d->h3w = (d->pw + 2 - 3) / 2 + 1;
+  da3_set_geometry(m, img_h, img_w);
   m->S = cfg.image_size;
-  m->SS = d->SS;
   auto fail = [&](int code) {
     model_destroy(m);
     return code;
@@ -416,66 +589,29 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
     w.blk.push_back(k);
   }
 
-  size_t need = 0;
-  da3_plan(m, true, &need);
-  if (hipMalloc((void**)&m->ws.base, need) != hipSuccess) {
-    set_error("hipMalloc of %zu bytes for the workspace failed (max_batch=%d)", need, cfg.max_batch);
-    return fail(MD_ERR_OOM);
-  }
-  m->ws.cap = need;
-  if (hipMemset(m->ws.base, 0, need) != hipSuccess) return fail(MD_ERR_HIP);
-  int st = da3_plan(m, false, nullptr);
-  if (st != MD_OK) return fail(st);
   if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
   (void)hipMemset(m->zero_page, 0, 4096);
-
-  // UV position tables for this image size (PosEmbedCache, dpt.rs:784-833: built once per shape)
+  // workspace for the configured size + its tables (PosEmbedCache, dpt.rs:784-833: built once per shape); other sizes get
+  // theirs on their first infer call (da3_set_shape)
   {
-    const int IH = d->ih, IW = d->iw;
-    float* tmp = nullptr;
-    size_t tmp_elems = (size_t)IH * IW * (F / 2);
-    for (int s = 0; s < 4; ++s) tmp_elems = std::max(tmp_elems, (size_t)d->P * round_up(oc[s], m->ke));
-    if (hipMalloc((void**)&tmp, tmp_elems * 4) != hipSuccess) return fail(MD_ERR_OOM);
-    for (int s = 0; s < 4; ++s) {
-      std::vector<float> t = build_pos_table_nhwc(oc[s], d->ph, d->pw, IW, IH, 0.1f);
-      const int ld = round_up(oc[s], m->ke);
-      std::vector<float> padded((size_t)d->P * ld, 0.f);
-      for (int p = 0; p < d->P; ++p) memcpy(&padded[(size_t)p * ld], &t[(size_t)p * oc[s]], (size_t)oc[s] * 4);
-      if (hipMemcpy(tmp, padded.data(), padded.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
-      if (launch_f32_to_rows(tmp, (long)padded.size(), d->pos_stage[s], m->prec, dev->stream) != MD_OK) return fail(MD_ERR_HIP);
-      (void)hipStreamSynchronize(dev->stream);
-    }
-    std::vector<float> t = build_pos_table_nhwc(F / 2, IH, IW, IW, IH, 0.1f);
-    if (hipMemcpy(d->pos_final, t.data(), t.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
-    (void)hipFree(tmp);
-    if (cfg.dual_head) {
-      // aux head input = neck + 0.1*UV + 0.1*UV (added twice, dpt.rs:428-435)
-      std::vector<float> ta = build_pos_table_nhwc(F / 2, 8 * d->ph, 8 * d->pw, IW, IH, 0.1f);
-      for (auto& x : ta) x = x + x;
-      if (hipMemcpy(d->pos_aux, ta.data(), ta.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
-      // 2-D RoPE tables: angle(pos, f) = pos * base^(-2f/32), f < 16 (fp32 like the oracle)
-      const int npos = std::max(d->ph, d->pw) + 2;
-      std::vector<float> rc((size_t)npos * 16), rs((size_t)npos * 16);
-      for (int pz = 0; pz < npos; ++pz)
-        for (int f = 0; f < 16; ++f) {
-          const float inv = 1.0f / powf(cfg.rope_frequency, (float)(2 * f) / 32.0f);
-          const float ang = (float)pz * inv;
-          rc[(size_t)pz * 16 + f] = cosf(ang);
-          rs[(size_t)pz * 16 + f] = sinf(ang);
-        }
-      if (hipMemcpy(d->rope_cos, rc.data(), rc.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
-      if (hipMemcpy(d->rope_sin, rs.data(), rs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MD_ERR_HIP);
-    }
+    d->ih = 0;
+    d->iw = 0;
+    const int st = da3_set_shape(m, img_h, img_w, true);
+    if (st != MD_OK) return fail(st);
   }
+  m->alloc_count = 0;  // count what the infer calls allocate, not the construction
   (void)hipDeviceSynchronize();
   *out = m;
   return MD_OK;
 }
 
+long da3_shape_builds(md_model_t m) { return (m && m->da3) ? m->da3->table_builds : 0; }
+
 void da3_destroy_state(md_model_t m) {
   if (m && m->da3 && m->da3->w8_base) (void)hipFree(m->da3->w8_base);
   if (!m || !m->da3) return;
-  for (auto& kv : m->da3->tok_index) (void)hipFree(kv.second);
+  for (auto& kv : m->da3->shapes) da3_free_tables(kv.second);
+  m->da3->shapes.clear();
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
   delete m->da3;
   m->da3 = nullptr;
@@ -503,8 +639,8 @@ int da3_load_container(md_model_t m, const char* path) {
 
 static int da3_tok_index(md_model_s* m, int B, int** out) {
   md_model_s::Da3State* d = m->da3;
-  auto it = d->tok_index.find(B);
-  if (it != d->tok_index.end()) {
+  auto it = d->tok_index->find(B);
+  if (it != d->tok_index->end()) {
     *out = it->second;
     return MD_OK;
   }
@@ -514,7 +650,8 @@ static int da3_tok_index(md_model_s* m, int B, int** out) {
   int* dev = nullptr;
   MD_HIP(hipMalloc((void**)&dev, h.size() * 4));
   MD_HIP(hipMemcpy(dev, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-  d->tok_index[B] = dev;
+  (*d->tok_index)[B] = dev;
+  m->alloc_count += 1;
   *out = dev;
   return MD_OK;
 }
@@ -550,10 +687,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
   if (H % v.ps != 0 || W % v.ps != 0)  // depth_anything3/mod.rs:509-520 (assert -> checked precondition)
     MD_FAIL(MD_ERR_SHAPE, "Input %dx%d must be divisible by patch size %d", H, W, v.ps);
-  if (H != d->ih || W != d->iw)
-    MD_FAIL(MD_ERR_UNSUPPORTED, "only %dx%d inputs are supported (the model was created for that size)", d->ih, d->iw);
   if (B > c.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, c.max_batch);
   MD_HIP(hipSetDevice(m->dev->ordinal));
+  MD_TRY(da3_set_shape(m, H, W, false));  // any multiple of the patch size (mod.rs:509-520); a no-op at the current size
   hipStream_t st = stream ? stream : m->dev->stream;
   Run r{m, st, B};
   const int D = v.D, heads = v.heads, SS = d->SS, NT = d->NT, P = d->P, ph = d->ph, pw = d->pw, F = c.features;

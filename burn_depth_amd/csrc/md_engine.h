@@ -198,6 +198,7 @@ struct Da3Outputs {
 int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& out, int out_kind,
                  hipStream_t stream);
 void da3_destroy_state(md_model_t m);
+long da3_shape_builds(md_model_t m);  // input sizes whose tables were built so far (0 for Depth Pro models)
 int da3_on_commit(md_model_t m);  // re-derives the (interpolated) position table from the weights
 int model_load_params_from_container(md_model_t m, const char* path);
 

@@ -117,11 +117,9 @@ class DepthPro:
         return f
 
     def destroy(self) -> None:
-        """md_model_destroy. A root destroys its live forks first (they alias its weights and must go before it)."""
+        """md_model_destroy. A root with live forks refuses (MD_ERR_INVALID_ARG): they alias its weights and go first."""
         if not self._h:
             return
-        for f in list(self._forks):
-            f.destroy()
         _lib.check(self._lib.md_model_destroy(self._h))
         self._h = None
         if self._parent is not None:
@@ -130,6 +128,8 @@ class DepthPro:
 
     def __del__(self):
         try:
+            for f in list(self._forks):  # only reachable at interpreter shutdown: a live fork holds a reference to its root
+                f.destroy()
             self.destroy()
         except _lib.MdError as e:  # never silent: a failed destroy leaks the weight / workspace arenas
             import warnings

@@ -11,6 +11,7 @@ Both also run on the gloo backend (CPU tensors), which is how the N>1 path is te
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -56,3 +57,52 @@ def scatter_images(images: Optional[torch.Tensor], n_total: int, like: torch.Ten
     chunks = list(images.split(per, 0)) if rank == src else None
     dist.scatter(out, chunks, src=src)
     return out
+
+
+class NativeComm:
+    """The library's own RCCL communicator (include/mi_depth.h md_comm_*): what a reference-side (Rust) host reaches through
+    the FFI layer -- weight broadcast, image scatter and depth gather as grouped ncclSend / ncclRecv on a HIP stream, without
+    torch.distributed on the data path. torch.distributed (or any other channel) is only needed to hand the 128-byte
+    rendezvous id from rank 0 to the other ranks."""
+
+    def __init__(self, device, unique_id: bytes, world_size: int, rank: int):
+        from . import _lib
+        self._L = _lib
+        self._lib = _lib.load()
+        assert len(unique_id) == _lib.MD_COMM_ID_BYTES
+        buf = (C.c_uint8 * _lib.MD_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(self._lib.md_comm_init_rank(device.handle, C.cast(buf, C.c_void_p), int(world_size), int(rank), C.byref(h)))
+        self._h, self.world, self.rank, self.device = h, int(world_size), int(rank), device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+        buf = (C.c_uint8 * _lib.MD_COMM_ID_BYTES)()
+        _lib.check(_lib.load().md_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @staticmethod
+    def from_torch_distributed(device) -> "NativeComm":
+        """Rank 0 draws the id and the (already initialised) torch.distributed group carries it to the others."""
+        box = [NativeComm.unique_id() if dist.get_rank() == 0 else None]
+        if dist.get_world_size() > 1:
+            dist.broadcast_object_list(box, src=0)
+        return NativeComm(device, box[0], dist.get_world_size(), dist.get_rank())
+
+    def broadcast_weights(self, model, root: int = 0) -> None:
+        self._L.check(self._lib.md_comm_broadcast_weights(self._h, model._h, int(root)))
+
+    def scatter_images(self, all_images: Optional[torch.Tensor], shard: torch.Tensor, root: int = 0, stream: int = 0) -> None:
+        """root: all_images = [world * B, 3, H, W] on this GPU; every rank receives [B, 3, H, W] into `shard`."""
+        p = C.c_void_p(all_images.data_ptr()) if all_images is not None else None
+        self._L.check(self._lib.md_comm_scatter_images(self._h, p, C.c_void_p(shard.data_ptr()), shard.numel(), int(root), C.c_void_p(stream)))
+
+    def gather_depth(self, shard: torch.Tensor, all_depth: Optional[torch.Tensor], root: int = 0, stream: int = 0) -> None:
+        p = C.c_void_p(all_depth.data_ptr()) if all_depth is not None else None
+        self._L.check(self._lib.md_comm_gather_depth(self._h, C.c_void_p(shard.data_ptr()), p, shard.numel(), int(root), C.c_void_p(stream)))
+
+    def destroy(self) -> None:
+        if self._h:
+            self._lib.md_comm_destroy(self._h)
+            self._h = None

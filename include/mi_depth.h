@@ -166,9 +166,12 @@ int md_da3_create(md_device_t dev, const md_da3_cfg* cfg, uint64_t seed, int ini
 /* `DepthAnything3::new(cfg).load_file(path, ..)` (example/correctness.rs:977-982), safetensors container. */
 int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_model_t* out);
 /* `DepthAnything3::infer(&self, x)` (depth_anything3/mod.rs:288-291): NCHW fp32 in, depth [B*H*W] out.
- * H and W must be multiples of the patch size (mod.rs:509-520 assert -> MD_ERR_SHAPE) and equal to the
- * configured image size (image_size x image_width), for which the position tables were built (else
- * MD_ERR_UNSUPPORTED). */
+ * H and W may be ANY multiples of the patch size (mod.rs:509-520 asserts only that; else MD_ERR_SHAPE). The model keeps
+ * per-size tables like the reference's `PosEmbedCache` (dpt.rs:784-833, keyed by shape) and burn_dino's interpolated
+ * position embedding: the first call at a new size builds them (host work) and, if the size needs more workspace than any
+ * size before it, grows the arena; later calls at that size find everything cached (md_model_query "da3_shape_builds" /
+ * "allocs" stop moving). image_size x image_width of the config is just the size the model is prepared for at creation.
+ * Up to 16 sizes stay cached (least recently used first out). */
 int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
                  void* stream);
 /* `DepthAnything3Inference` (depth_anything3/mod.rs:231-239) for the dual-head `small` variant. Every pointer
@@ -201,7 +204,7 @@ int md_model_enable_graph(md_model_t m, int enable);
  *       "weight_terms" (MFMA terms per product with a plain weight: 1; MD_PREC_F16X2: 2 = f16-exact weights, 3 otherwise),
  *       "allocs" (device / pinned-host allocations the infer calls of this model have made so far: staging buffers for
  *       host pointers and non-native input sizes grow on demand and are then reused, so the count stops moving once the
- *       largest shapes have been seen). */
+ *       largest shapes have been seen), "da3_shape_builds" (Depth-Anything-v3: input sizes whose tables were built). */
 int md_model_query(md_model_t m, const char* key, int64_t* out);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs
@@ -293,6 +296,32 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
  * body), 4.0 and above logits beyond its +-32 check (the running-maximum body). */
 int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int precision, float qk_scale, int iters,
                           float* avg_ms);
+
+/* ---- multi-GPU: RCCL over xGMI behind the C ABI ------------------------------------------------------------------
+ * BASELINE north_star: "independent images shard naturally across the 8 GPUs of one node with RCCL broadcast of weights and
+ * gather of depth maps over xGMI", reached by the (Rust) host through this FFI layer. One process (or thread) per GPU;
+ * DepthPro::infer itself never communicates -- B is a pure batch dimension (encoder.rs:216-225,249-255). The reference has
+ * no collectives: these calls sit next to `DepthPro::load` / `infer` in a multi-GPU host, see INTEGRATION.md
+ * section 4. All buffers are device pointers of the communicator's device; transfers are asynchronous on `stream` (NULL =
+ * the device's stream, the one md_depth_pro_infer uses for stream == NULL), so they order with the inference around them. */
+typedef struct md_comm_s* md_comm_t;
+#define MD_COMM_ID_BYTES 128
+/* A fresh rendezvous id (ncclUniqueId). The root creates it; the host hands the 128 bytes to every rank out of band
+ * (environment, file, its own RPC) -- the one thing the library cannot do for a multi-process launch. */
+int md_comm_unique_id(uint8_t id[MD_COMM_ID_BYTES]);
+/* Collective over all ranks: joins the communicator of `world_size` ranks as `rank` on this device. */
+int md_comm_init_rank(md_device_t dev, const uint8_t id[MD_COMM_ID_BYTES], int world_size, int rank, md_comm_t* out);
+int md_comm_rank(md_comm_t c, int* rank, int* world_size);
+int md_comm_destroy(md_comm_t c);
+/* Collective: `DepthPro::load` happens on `root` only; its fp32 parameter arena is broadcast into every rank's model (same
+ * config) in 1-GiB buckets and every rank commits (packs its own MFMA operand copies). Synchronises the device's stream. */
+int md_comm_broadcast_weights(md_comm_t c, md_model_t m, int root);
+/* Collective: the root holds `world_size` shards of `elems_per_rank` floats back to back (rank-major; e.g. [world*B,3,H,W]);
+ * every rank -- the root too -- ends up with its shard in `shard_dev`. One group of ncclSend / ncclRecv (xGMI is point to
+ * point: the root's links carry the shards in parallel). `all_dev` is ignored on the other ranks. */
+int md_comm_scatter_images(md_comm_t c, const float* all_dev, float* shard_dev, size_t elems_per_rank, int root, void* stream);
+/* Collective: the inverse for the results (depth [B,H,W] per rank -> [world*B,H,W] on the root). */
+int md_comm_gather_depth(md_comm_t c, const float* shard_dev, float* all_dev, size_t elems_per_rank, int root, void* stream);
 
 /* ---- host-only utilities (no GPU needed) ---------------------------------------------------- */
 /* The parameter inventory of `DepthPro::new` for a config: returns the number of parameters; for

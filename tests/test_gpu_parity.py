@@ -435,7 +435,8 @@ def test_graph_replay_sees_recommitted_weights_on_root_and_fork(dev):
     assert not torch.equal(rb[0], before)
     assert torch.equal(rb[0], want) and torch.equal(fb[0], want)
     eager.destroy()
-    root.destroy()  # destroys its live fork first
+    fork.destroy()
+    root.destroy()
 
 
 def test_config4_shard_of_eight_images_is_batch_independent(diag, dev):
@@ -799,6 +800,40 @@ def test_rccl_weight_broadcast_and_depth_gather_on_the_gpu(dev):
         dist.destroy_process_group()
 
 
+def test_native_rccl_entry_points_one_rank(dev):
+    """md_comm_* through the C ABI on a 1-rank communicator (the driver runs the real 2/4/8-GPU case; more ranks cannot share
+    the one GPU of this box): rendezvous id, init, weight broadcast + re-commit, image scatter, depth gather, all on the
+    engine's stream -- results equal to the local path bit for bit."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    from burn_depth_amd.parallel import NativeComm
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    uid = NativeComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = NativeComm(dev, uid, 1, 0)
+    try:
+        cfg = DepthProConfig.tiny_test()
+        cfg.max_batch = 2
+        m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+        torch.manual_seed(0)
+        x = torch.randn(2, 3, 512, 512, device="cuda")
+        before = m.infer(x).depth.clone()
+        comm.broadcast_weights(m, root=0)  # in place from / to rank 0, then re-commit
+        assert torch.equal(m.infer(x).depth, before)
+        shard = torch.zeros_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        comm.scatter_images(x, shard, root=0, stream=st)
+        d = m.infer(shard).depth
+        gathered = torch.zeros_like(d)
+        comm.gather_depth(d, gathered, root=0, stream=st)
+        torch.cuda.synchronize()
+        assert torch.equal(shard, x) and torch.equal(gathered, before)
+        m.destroy()
+    finally:
+        comm.destroy()
+
+
 def test_graph_replay_matches_eager(dev):
     """md_model_enable_graph: first call eager, second captured, later calls replayed -- all bit-identical, and a
     change of buffers or a timing/tap request falls back to eager launches."""
@@ -856,6 +891,60 @@ def test_depth_anything3_non_square_inputs(diag, dev):
     assert len(diag.RESULTS) - start >= 15
 
 
+@pytest.mark.parametrize("variant", ["tiny", "tiny_dual"])
+def test_depth_anything3_accepts_any_multiple_of_14_at_call_time(dev, variant):
+    """`DepthAnything3::infer` only asserts divisibility by the patch size (depth_anything3/mod.rs:509-520); the per-shape
+    state is the reference's `PosEmbedCache` (dpt.rs:784-833) plus burn_dino's interpolated position embedding. ONE model
+    created at 70 x 70 runs 84 x 84, 70 x 98 and 112 x 84 against the oracle, returns to earlier sizes without host work
+    (`da3_shape_builds` / `allocs` do not move), and its replayed graphs survive the size changes."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from oracle import da3_ref as D3, depth_pro_ref as R
+    cfg = DepthAnything3Config.tiny_test() if variant == "tiny" else DepthAnything3Config.tiny_dual_test()
+    cfg.precision, cfg.max_batch = Precision.F32, 2
+    m = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+    g = torch.Generator().manual_seed(3)
+    frames = {}
+
+    def check(H, Wd, B):
+        if (H, Wd, B) not in frames:
+            x = torch.randn(B, 3, H, Wd, generator=g)
+            with torch.no_grad():
+                frames[(H, Wd, B)] = (x, D3.infer(x, W, cfg))
+        x, ref = frames[(H, Wd, B)]
+        out = m.infer(x.cuda())
+        rel = ((out.depth.cpu() - ref["depth"]).abs() / ref["depth"].abs()).max().item()
+        assert tuple(out.depth.shape) == (B, H, Wd) and rel < 1e-3, (H, Wd, B, rel)
+        if cfg.dual_head:
+            assert (out.aux.cpu() - ref["aux"]).abs().max().item() < 1e-3
+            assert (out.pose_encoding.cpu() - ref["pose_encoding"]).abs().max().item() < 2e-4
+            assert ((out.depth_confidence.cpu() - ref["depth_confidence"]).abs() / ref["depth_confidence"].abs()).max().item() < 1e-3
+        return out
+
+    for (H, Wd, B) in [(70, 70, 1), (84, 84, 2), (70, 98, 1), (112, 84, 1)]:
+        check(H, Wd, B)
+    builds, allocs = m.query("da3_shape_builds"), m.query("allocs")
+    for (H, Wd, B) in [(84, 84, 2), (70, 70, 1), (112, 84, 1), (70, 98, 1), (70, 98, 1)]:  # every size was seen: cached
+        check(H, Wd, B)
+    assert m.query("da3_shape_builds") == builds and m.query("allocs") == allocs
+    # graph replay (mono entry point): eager, capture, replay at one size; another size; back -- all equal to the eager results
+    xa, xb = frames[(84, 84, 2)][0][:1].contiguous().cuda(), frames[(70, 98, 1)][0].cuda()
+    wa, wb = m.infer(xa).depth.clone(), m.infer(xb).depth.clone()
+    da, db = torch.empty_like(wa), torch.empty_like(wb)
+    m.enable_graph(True)
+    for _ in range(3):
+        m.infer_into(xa, da)
+    for _ in range(3):
+        m.infer_into(xb, db)
+    da.zero_()
+    m.infer_into(xa, da)
+    torch.cuda.synchronize()
+    assert torch.equal(da, wa) and torch.equal(db, wb)
+    m.destroy()
+
+
 def test_depth_anything3_error_paths(dev):
     from burn_depth_amd import _lib
     from burn_depth_amd.config import DepthAnything3Config
@@ -865,9 +954,11 @@ def test_depth_anything3_error_paths(dev):
     with pytest.raises(_lib.MdError) as e:  # mod.rs:509-520: not divisible by the patch size
         m.infer(torch.zeros(1, 3, 71, 70, device="cuda"))
     assert e.value.code == _lib.MD_ERR_SHAPE
-    with pytest.raises(_lib.MdError) as e:  # other sizes need pos-embed interpolation: reported, not silently wrong
-        m.infer(torch.zeros(1, 3, 84, 84, device="cuda"))
-    assert e.value.code == _lib.MD_ERR_UNSUPPORTED
+    out = m.infer(torch.zeros(1, 3, 84, 84, device="cuda"))  # any multiple of 14 is accepted at call time (values: the test below)
+    assert tuple(out.depth.shape) == (1, 84, 84) and torch.isfinite(out.depth).all()
+    with pytest.raises(_lib.MdError) as e:
+        m.infer(torch.zeros(2, 3, 70, 70, device="cuda"))  # batch beyond max_batch
+    assert e.value.code == _lib.MD_ERR_SHAPE
     out = m.infer(torch.zeros(1, 3, 70, 70, device="cuda"))
     assert tuple(out.depth.shape) == (1, 70, 70) and torch.isfinite(out.depth).all()
     m.destroy()
