@@ -122,9 +122,7 @@ struct GemmParams {
   int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear, 3 exp + 1 (DA3 confidence, dpt.rs:497)
 };
 
-// TILE_4W: the 256x256 tile on FOUR waves (one per SIMD, 128x128 each, register-staged operands; gemm4w_impl.h): 2-byte operand
-// types, dense / indexed A
-enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_4W = 3, TILE_AUTO = 99 };
+enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_AUTO = 99 };
 
 // Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16), MD_PREC_F16 (T = f16), MD_PREC_F16X2 (T = f16s: split-half planes),
 // MD_PREC_F32 (T = float) or MD_PREC_FP8 (T = e4m3, dense only).

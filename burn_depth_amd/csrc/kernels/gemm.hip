@@ -89,7 +89,6 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     p.raster_gn = tn <= 12 ? 0 : 4;
   }
   if (p.epi == EPI_HEAD) tile = TILE_256x32;
-  if (tile == TILE_4W && (p.epi == EPI_HEAD_UP2 || amode == A_CONV3 || prec == MD_PREC_F32 || prec == MD_PREC_FP8)) tile = TILE_256x256;
   if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);
   if (prec == MD_PREC_FP8) {
     if (p.out_fp8 && !(p.epi == EPI_STORE && p.act == ACT_GELU)) MD_FAIL(MD_ERR_UNSUPPORTED, "fp8 output is built for the GELU store only");

@@ -1,4 +1,4 @@
-#include "gemm4w_impl.h"
+#include "gemm_impl.h"
 
 namespace md {
 int launch_gemm_bf16(GemmParams& p, int amode, int tile, hipStream_t stream) {

@@ -1,5 +1,5 @@
 // IEEE half operand instantiation of the MFMA GEMM family (v_mfma_f32_*_f16; outputs / residuals f16 or f32).
-#include "gemm4w_impl.h"
+#include "gemm_impl.h"
 
 namespace md {
 int launch_gemm_f16(GemmParams& p, int amode, int tile, hipStream_t stream) {

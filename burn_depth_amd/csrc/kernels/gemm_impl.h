@@ -1421,14 +1421,8 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
 }
 
 template <typename T, int AMODE>
-static int launch_4w(GemmParams& p, hipStream_t stream);  // gemm4w_impl.h (included by the 2-byte operand translation units)
-
-template <typename T, int AMODE>
 static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
   switch (tile) {
-    case TILE_4W:
-      if constexpr (sizeof(T) == 2 && (AMODE == A_DENSE || AMODE == A_INDEXED)) return launch_4w<T, AMODE>(p, stream);
-      MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the 4-wave tile takes 2-byte operands and dense / indexed A rows");
     case TILE_256x256:
       return launch_256<T, AMODE>(p, stream);
     case TILE_128x128:

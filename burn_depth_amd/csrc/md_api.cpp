@@ -632,7 +632,6 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
   GemmParams p;
   p.N = N; p.ngroups = 1; p.g_rows[0] = M; p.W[0] = w.p; p.A = a.p;
   p.epi = EPI_STORE; p.out = o.p; p.ldo = N; p.debug_flags = (dbg & 3) | ((dbg & 64) ? 4 : 0) | ((dbg & 128) ? 8 : 0);
-  if (tile == TILE_4W) p.debug_flags = (dbg >> 8) & 15;  // the 4-wave tile's own ablation ids (gemm4w_impl.h launch_4w)
   DevBuf bias;
   DevBuf xres, lsc;
   if (dbg & 16) {  // proj / fc2-style epilogue: x(f32) += scale * (acc + bias)

@@ -150,10 +150,7 @@ def check_linear(dev):
              (1160, 1024, 4096, _lib.TILE_AUTO), (64, 32, 192, _lib.TILE_256x32), (1000, 32, 128, _lib.TILE_256x32),
              (129, 132, 64, _lib.TILE_128x128), (513, 260, 320, _lib.TILE_256x256), (2000, 1024, 1024, _lib.TILE_256x256),
              (2000, 1024, 1024, _lib.TILE_128x128), (300, 256, 64, _lib.TILE_256x256), (300, 256, 128, _lib.TILE_256x256), (21349, 1024, 1024, _lib.TILE_256x256),
-             (700, 3072, 64, _lib.TILE_256x256), (700, 512, 128, _lib.TILE_256x256), (700, 512, 192, _lib.TILE_256x256),
-             # the 4-wave (one wave per SIMD, register-staged) long-K tile; fp32 mode runs these on the 8-wave kernel
-             (300, 256, 64, _lib.TILE_4W), (300, 256, 128, _lib.TILE_4W), (513, 260, 320, _lib.TILE_4W), (2000, 1024, 1024, _lib.TILE_4W),
-             (1160, 1024, 4096, _lib.TILE_4W), (700, 512, 192, _lib.TILE_4W)]
+             (700, 3072, 64, _lib.TILE_256x256), (700, 512, 128, _lib.TILE_256x256), (700, 512, 192, _lib.TILE_256x256)]
     for prec, pname in [(0, "bf16"), (1, "f32"), (3, "f16")]:
         rnd = ROUND[prec]
         for (M, N, K, tile) in cases:

@@ -35,8 +35,6 @@ def main():
     gemms += [("full_proj", 0, 16384, 1024, 1024, 0, 0), ("rem_proj", 0, 5076, 1024, 1024, 0, 0), ("full_fc2", 0, 16384, 1024, 4096, 0, 0),
               ("rem_fc2", 0, 5076, 1024, 4096, 0, 0)]
     tiles += [(1 + 16 * 256, "128v1_rmw"), (1 + 1024, "128v1_gelu")]
-    tiles += [(3, "4w"), (3 + 1024, "4w_gelu"), (3 + 16 * 256, "4w_rmw")]
-    tiles += [(3 + (i << 16), n) for i, n in ((1, "4w_noloads"), (2, "4w_noloads_nowrites"), (3, "4w_noloads_nowrites_nobarrier"), (4, "4w_mfma_only"), (5, "4w_nobarrier"))]  # the 4-wave register-staged tile (gemm4w_impl.h)
     prec = int(os.environ.get("PREC", "0"))
     only = os.environ.get("ONLY")
     if only:
