@@ -120,6 +120,17 @@ struct GemmParams {
   const float* head_w = nullptr;  // [32]
   float head_b = 0.f;
   int head_act = 0;             // 0 relu (Depth Pro, mod.rs:111), 1 exp (DA3, dpt.rs:700), 2 linear, 3 exp + 1 (DA3 confidence, dpt.rs:497)
+  // EPI_HEAD with several output channels in ONE launch (the DA3 heads: depth + confidence; 6 ray channels + confidence --
+  // dpt.rs:481-513 runs the same 3x3 `reduce` convolution for all of them): channel c = act_c(relu(conv + b1) . head_wc[c] + b_c),
+  // written to head_out[c][img * head_bstride[c] + pixel] with img = m / head_plane. head_nch == 0: the one-channel form above.
+  int head_nch = 0;
+  int head_plane = 0;           // pixels per image (rows m per image)
+  FastDiv fd_head_plane;
+  float* head_out[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const float* head_wc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [32] each
+  long head_bstride[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float head_bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int head_acts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_AUTO = 99 };

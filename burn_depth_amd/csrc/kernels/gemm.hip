@@ -47,6 +47,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   if (p.batch > 1 && (p.epi != EPI_STORE || p.res1 || p.res2 || p.batch > 65535 || p.batch_inner < 1))
     MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: batching supports the plain store epilogue only (batch=%d)", p.batch);
   if (p.epi == EPI_HEAD && p.N != 32) MD_FAIL(MD_ERR_UNSUPPORTED, "head epilogue needs N == 32");
+  if (p.epi == EPI_HEAD && p.head_nch == 0 && !p.head_w) MD_FAIL(MD_ERR_INVALID_ARG, "head epilogue: output weights missing");
   if (p.epi == EPI_HEAD_UP2) {
     if (p.N != 128 || amode != A_CONV3 || p.cstride != 1 || p.cOW > 0 || p.cOH > 0 || p.ngroups != 1 || !p.bias[0] || !p.head_w)
       MD_FAIL(MD_ERR_UNSUPPORTED, "composed head epilogue: a stride-1 3x3 convolution with N == 4 x 32 and the 9 x 32 bias table");
@@ -68,6 +69,12 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     for (int g = 0; g < p.ngroups; ++g) no_scale = no_scale && !p.wscale[g];
     p.ps_fast = prec != MD_PREC_F32 && !p.out_f32 && !p.out2 && !p.out_fp8 && no_scale && p.psC % 8 == 0 && p.N % 8 == 0 &&
                 p.ldo % 8 == 0 && p.ps_coff % 8 == 0 && out_elems < 4.0e9;
+  }
+  if (p.epi == EPI_HEAD && p.head_nch > 0) {
+    if (p.head_nch > 8 || p.head_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "head epilogue: %d channels / plane %d", p.head_nch, p.head_plane);
+    for (int c = 0; c < p.head_nch; ++c)
+      if (!p.head_out[c] || !p.head_wc[c]) MD_FAIL(MD_ERR_INVALID_ARG, "head epilogue: output %d missing", c);
+    p.fd_head_plane = make_fastdiv(p.head_plane);
   }
   p.fd_psW = make_fastdiv(p.psW);
   p.fd_psH = make_fastdiv(p.psH);

@@ -497,10 +497,43 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
       const float* bias = MD_SEL_G(p.bias, g);
       f32x4_t bv[TN], hw[TN];
 #pragma unroll
-      for (int a = 0; a < TN; ++a) {
-        bv[a] = *(const f32x4_t*)(bias + 16 * a + 4 * q16);
-        hw[a] = *(const f32x4_t*)(p.head_w + 16 * a + 4 * q16);
+      for (int a = 0; a < TN; ++a) bv[a] = *(const f32x4_t*)(bias + 16 * a + 4 * q16);
+      auto act_of = [&](int kind, float z) __attribute__((always_inline)) {
+        return kind == 1 ? expf(z) : (kind == 2 ? z : (kind == 3 ? expf(z) + 1.0f : fmaxf(z, 0.f)));
+      };
+      if (p.head_nch > 0) {
+        // several output channels from ONE pass over the 3x3 convolution: relu(conv + b1) is formed once per element and
+        // dotted with each channel's 32 weights (the same q16 reduction as the one-channel form)
+        f32x4_t rl[TN][TM];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rl[a][b][j] = fmaxf(acc[a][b][j] + bv[a][j], 0.f);
+        for (int ch = 0; ch < p.head_nch; ++ch) {
+#pragma unroll
+          for (int a = 0; a < TN; ++a) hw[a] = *(const f32x4_t*)(p.head_wc[ch] + 16 * a + 4 * q16);
+#pragma unroll
+          for (int b = 0; b < TM; ++b) {
+            float part = 0.f;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) part += rl[a][b][j] * hw[a][j];
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            const int m = m_base + wm * WTM + b * 16 + r16;
+            if (q16 == 0 && m < m_end) {
+              const int img = fdiv(m, p.fd_head_plane);
+              p.head_out[ch][(long)img * p.head_bstride[ch] + (m - img * p.head_plane)] = act_of(p.head_acts[ch], part + p.head_bs[ch]);
+            }
+          }
+        }
+        return;
       }
+#pragma unroll
+      for (int a = 0; a < TN; ++a) hw[a] = *(const f32x4_t*)(p.head_w + 16 * a + 4 * q16);
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
         float part = 0.f;

@@ -66,6 +66,14 @@ struct md_model_s::Da3State {
   float *cam_raw = nullptr, *cam_h1 = nullptr, *cam_h2 = nullptr, *pose = nullptr, *extr = nullptr, *intr = nullptr;
   float* pos_aux = nullptr;
   float *conf_stage = nullptr, *aux_stage = nullptr;  // device staging when the caller wants host outputs
+  // The dual head's three independent tails -- main pyramid (depth + confidence), aux pyramid (rays + confidence) and the
+  // camera decoder -- run as CONCURRENT branches: the aux branch and the camera decoder on side streams that fork from / join
+  // the caller's stream through events (inside a captured graph they become parallel branches). Config 2 is launch-bound
+  // (181 launches of ~14 us in 2.7 ms): two launch chains side by side hide each other's gaps and fill CUs the small head
+  // convolutions leave idle. The aux pyramid has its own scratch maps.
+  hipStream_t s_aux = nullptr, s_cam = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_cam_fork = nullptr, ev_aux = nullptr, ev_cam = nullptr;
+  void *t2 = nullptr, *x2 = nullptr, *xr2 = nullptr, *y2 = nullptr, *up2 = nullptr, *o2 = nullptr;
   std::vector<float> main_bias, aux_bias;             // output_conv2.conv2.bias, output_conv2_aux.<last>.project.bias
   // ---- MD_PREC_FP8: the four ViT linear layers on e4m3 operands (weights per output channel, static activation scales) ----
   bool fp8 = false;
@@ -258,6 +266,14 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   DA3_TAKE(y, void*, big / 4);
   DA3_TAKE(up, void*, big);
   DA3_TAKE(o, void*, big);
+  if (c.dual_head) {  // scratch maps of the concurrent aux pyramid
+    DA3_TAKE(t2, void*, big / 4);
+    DA3_TAKE(x2, void*, big / 4);
+    DA3_TAKE(xr2, void*, big / 4);
+    DA3_TAKE(y2, void*, big / 4);
+    DA3_TAKE(up2, void*, big);
+    DA3_TAKE(o2, void*, big);
+  }
   DA3_TAKE(c1, void*, (size_t)B * 64 * ph * pw * cp(F / 2) * esz);
   DA3_TAKE(c1r, void*, (size_t)B * SS2 * cp(F / 2) * esz);
 #undef DA3_TAKE
@@ -591,6 +607,14 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
 
   if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
   (void)hipMemset(m->zero_page, 0, 4096);
+  if (cfg.dual_head) {
+    if (hipStreamCreateWithFlags(&d->s_aux, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_cam, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_cam_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_aux, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_cam, hipEventDisableTiming) != hipSuccess) {
+      set_error("stream / event creation for the dual head's concurrent branches failed");
+      return fail(MD_ERR_HIP);
+    }
+  }
   // workspace for the configured size + its tables (PosEmbedCache, dpt.rs:784-833: built once per shape); other sizes get
   // theirs on their first infer call (da3_set_shape)
   {
@@ -612,6 +636,10 @@ void da3_destroy_state(md_model_t m) {
   if (!m || !m->da3) return;
   for (auto& kv : m->da3->shapes) da3_free_tables(kv.second);
   m->da3->shapes.clear();
+  if (m->da3->s_aux) (void)hipStreamDestroy(m->da3->s_aux);
+  if (m->da3->s_cam) (void)hipStreamDestroy(m->da3->s_cam);
+  for (hipEvent_t e : {m->da3->ev_fork, m->da3->ev_cam_fork, m->da3->ev_aux, m->da3->ev_cam})
+    if (e) (void)hipEventDestroy(e);
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
   delete m->da3;
   m->da3 = nullptr;
@@ -923,16 +951,33 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       MD_TRY(r.tap_nhwc(("layer" + std::to_string(s + 1) + "_rn").c_str(), d->rn[s], F, sh[s], sw[s], Fp));
     }
   }
+  // ---- the head's tails. Dual head: main pyramid (depth, confidence), aux pyramid (rays, confidence) and the camera decoder
+  //      are independent of each other; they run as concurrent branches (side streams forked from / joined to `st` by events)
+  //      unless the debug taps are on (the taps copy maps on `st`). ----
+  struct Bufs { void *t, *x, *xr, *y, *up, *o; };
+  Bufs main_bufs{d->t, d->x, d->xr, d->y, d->up, d->o};
+  const bool want_aux = c.dual_head && (outp.aux || outp.aux_confidence);
+  const bool want_cam = c.dual_head && (outp.pose_encoding || outp.extrinsics || outp.intrinsics);
+  const bool par = c.dual_head && !m->taps_enabled && d->s_aux != nullptr;
+  Run ra{m, par ? d->s_aux : st, B};   // aux branch
+  Run rc{m, par ? d->s_cam : st, B};   // camera decoder
+  Bufs aux_bufs = par ? Bufs{d->t2, d->x2, d->xr2, d->y2, d->up2, d->o2} : main_bufs;
+  if (par && (want_aux || want_cam)) {
+    MD_HIP(hipEventRecord(d->ev_fork, st));
+    if (want_aux) MD_HIP(hipStreamWaitEvent(d->s_aux, d->ev_fork, 0));
+    if (want_cam) MD_HIP(hipStreamWaitEvent(d->s_cam, d->ev_fork, 0));
+  }
   // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
-  auto rcu = [&](const std::string& name, int hh, int ww, const void* x, const void* xr, const void* extra, void* out, void* out_relu) -> int {
-    MD_TRY(conv3(r, "head_conv3x3", xr, hh, ww, Fp, Wk(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, d->t, Fp, ACT_RELU,
+  auto rcu = [&](Run& rr, Bufs& bf, const std::string& name, int hh, int ww, const void* x, const void* xr, const void* extra, void* out,
+                 void* out_relu) -> int {
+    MD_TRY(conv3(rr, "head_conv3x3", xr, hh, ww, Fp, Wk(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, bf.t, Fp, ACT_RELU,
                  nullptr, nullptr, nullptr));
-    return conv3(r, "head_conv3x3", d->t, hh, ww, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
+    return conv3(rr, "head_conv3x3", bf.t, hh, ww, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
                  extra, out_relu);
   };
-  // the four FeatureFusionBlocks (dpt.rs:1206-1222) from the coarsest stage up; result in d->o at 8ph x 8pw
+  // the four FeatureFusionBlocks (dpt.rs:1206-1222) from the coarsest stage up; result in bf.o at 8ph x 8pw
   const int target[4] = {8 * ph, 4 * ph, 2 * ph, ph}, targw[4] = {8 * pw, 4 * pw, 2 * pw, pw};  // output size of refinenet1..4
-  auto pyramid = [&](const std::string& suffix) -> int {
+  auto pyramid = [&](Run& rr, Bufs& bf, const std::string& suffix) -> int {
     const void* top = nullptr;
     for (int lvl = 3; lvl >= 0; --lvl) {
       const std::string rf = hp + ".scratch.refinenet" + std::to_string(lvl + 1) + suffix;
@@ -941,40 +986,137 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
         yx = d->rn[3];
         yxr = d->rnr[3];
       } else {
-        MD_TRY(rcu(rf + ".residual1", sh[lvl], sw[lvl], d->rn[lvl], d->rnr[lvl], top, d->x, d->xr));
-        yx = d->x;
-        yxr = d->xr;
+        MD_TRY(rcu(rr, bf, rf + ".residual1", sh[lvl], sw[lvl], d->rn[lvl], d->rnr[lvl], top, bf.x, bf.xr));
+        yx = bf.x;
+        yxr = bf.xr;
       }
-      MD_TRY(rcu(rf + ".residual2", sh[lvl], sw[lvl], yx, yxr, nullptr, d->y, nullptr));
-      r.begin("head_resize");
-      MD_TRY(launch_resize_nhwc(d->y, B, sh[lvl], sw[lvl], F, Fp, d->up, target[lvl], targw[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, st));
-      r.end();
-      MD_TRY(gemm_rows(r, "head_out_conv", d->up, Fp, nullptr, (long)B * target[lvl] * targw[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
-                       Bi(rf + ".out_conv.bias"), d->o, Fp));
-      top = d->o;
+      MD_TRY(rcu(rr, bf, rf + ".residual2", sh[lvl], sw[lvl], yx, yxr, nullptr, bf.y, nullptr));
+      rr.begin("head_resize");
+      MD_TRY(launch_resize_nhwc(bf.y, B, sh[lvl], sw[lvl], F, Fp, bf.up, target[lvl], targw[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, rr.st));
+      rr.end();
+      MD_TRY(gemm_rows(rr, "head_out_conv", bf.up, Fp, nullptr, (long)B * target[lvl] * targw[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
+                       Bi(rf + ".out_conv.bias"), bf.o, Fp));
+      top = bf.o;
       if (m->taps_enabled)  // FeatureFusionBlock outputs (dpt.rs:705-720), main and aux pyramids
-        MD_TRY(r.tap_nhwc(("refinenet" + std::to_string(lvl + 1) + suffix).c_str(), d->o, F, target[lvl], targw[lvl], Fp));
+        MD_TRY(rr.tap_nhwc(("refinenet" + std::to_string(lvl + 1) + suffix).c_str(), bf.o, F, target[lvl], targw[lvl], Fp));
     }
     return MD_OK;
   };
-  // fused tail: out[m] = act(w . relu(conv3x3(in) + b1) + b2) over a [B, hh, ww, 64-padded] map (ConvStack, dpt.rs:1287-1290)
-  auto tail = [&](const char* name, const void* in, int hh, int ww, const void* w1, const float* b1, const float* w2, float b2, int act,
-                  float* out) -> int {
+  // fused tail: out_c[img][pixel] = act_c(w_c . relu(conv3x3(in) + b1) + b_c) for `nch` channels in ONE launch over a
+  // [B, hh, ww, 64-padded] map (ConvStack / `reduce` + `project`, dpt.rs:481-513,1287-1290)
+  struct TailCh { const float* w; float b; int act; float* out; long bstride; };
+  auto tail = [&](Run& rr, const char* name, const void* in, int hh, int ww, const void* w1, const float* b1, const TailCh* chs, int nch) -> int {
+    if (nch <= 0) return MD_OK;
     GemmParams p;
     p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = B * hh * ww; p.W[0] = w1;
     p.A = in; p.cH = hh; p.cW = ww; p.cC = F2p; p.zero_page = m->zero_page;
-    p.epi = EPI_HEAD; p.bias[0] = b1; p.head_w = w2; p.head_b = b2; p.head_act = act; p.out = out;
-    r.begin(name);
-    int s2 = launch_gemm(p, A_CONV3, m->prec, TILE_256x32, st);
-    r.end();
+    p.epi = EPI_HEAD; p.bias[0] = b1; p.head_nch = nch; p.head_plane = hh * ww;
+    for (int i = 0; i < nch; ++i) {
+      p.head_wc[i] = chs[i].w; p.head_bs[i] = chs[i].b; p.head_acts[i] = chs[i].act; p.head_out[i] = chs[i].out; p.head_bstride[i] = chs[i].bstride;
+    }
+    rr.begin(name);
+    int s2 = launch_gemm(p, A_CONV3, m->prec, TILE_256x32, rr.st);
+    rr.end();
     return s2;
   };
-  auto host_out = [&](float* dst, const float* src, size_t n) -> int {
-    if (out_kind == MD_MEM_HOST && dst) MD_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToHost, st));
+  auto host_out = [&](hipStream_t hs, float* dst, const float* src, size_t n) -> int {
+    if (out_kind == MD_MEM_HOST && dst) MD_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToHost, hs));
     return MD_OK;
   };
+  const size_t out_elems = (size_t)B * IH * IW;
+  float* depth_dev = outp.depth;
+  if (out_kind == MD_MEM_HOST) {
+    if (d->depth_stage_elems < out_elems) {
+      if (d->depth_stage) (void)hipFree(d->depth_stage);
+      MD_HIP(hipMalloc((void**)&d->depth_stage, out_elems * 4));
+      m->alloc_count += 1;
+      d->depth_stage_elems = out_elems;
+    }
+    depth_dev = d->depth_stage;
+  }
+  // ---- aux branch (build_aux_logits, dpt.rs:356-441): aux fusion pyramid on the same layerN_rn maps -> last level's 5-conv
+  //      neck -> + 2 x 0.1 x UV -> reduce 3x3 -> ReLU -> project 1x1 (7 ch: 6 ray values + confidence) ----
+  if (want_aux) {
+    MD_TRY(pyramid(ra, aux_bufs, "_aux"));
+    const int ah = 8 * ph, aw = 8 * pw;
+    const std::string lv = std::to_string(c.aux_levels - 1);
+    const void* cur = aux_bufs.o;
+    void* pp[2] = {aux_bufs.up, aux_bufs.o};
+    int cin = F;
+    for (int j = 0; j < c.aux_out1_conv_num; ++j) {
+      const int cout = j % 2 == 0 ? F / 2 : F;
+      const std::string n = hp + ".scratch.output_conv1_aux." + lv + ".layers." + std::to_string(j);
+      MD_TRY(conv3(ra, "aux_conv3x3", cur, ah, aw, cpad(m, cin), Wk(n + ".weight"), Bi(n + ".bias"), cout, pp[j & 1], cpad(m, cout), ACT_NONE,
+                   nullptr, nullptr, nullptr));
+      cur = pp[j & 1];
+      cin = cout;
+    }
+    void* hin = cur == aux_bufs.up ? aux_bufs.o : aux_bufs.up;
+    ra.begin("head_resize");
+    MD_TRY(launch_resize_nhwc(cur, B, ah, aw, F2, F2p, hin, ah, aw, F2p, MD_INTERP_BURN, d->pos_aux, m->prec, ra.st));
+    ra.end();
+    if (m->taps_enabled) {  // DepthTrace::aux_stage_necks (last level) / aux_head_input (mod.rs:241-246)
+      MD_TRY(ra.tap_nhwc("aux_neck", cur, F2, ah, aw, F2p));
+      MD_TRY(ra.tap_nhwc("aux_head_input", hin, F2, ah, aw, F2p));
+    }
+    const std::string oh = hp + ".scratch.output_conv2_aux." + lv;
+    const size_t plane = (size_t)ah * aw;
+    const int K7 = c.aux_output_dim;
+    const float* pw_ = Bi(oh + ".project.weight");
+    TailCh chs[8];
+    int nch = 0;
+    for (int ch = 0; ch < K7; ++ch) {  // aux lands as [B, 6, h, w], the confidence as [B, h, w]; host outputs through [B, 7, h, w] staging
+      const bool conf = ch == K7 - 1;
+      float* user = conf ? outp.aux_confidence : outp.aux;
+      if (!user) continue;
+      TailCh t;
+      t.w = pw_ + 32 * ch; t.b = d->aux_bias[ch]; t.act = conf ? 3 : 2;
+      if (out_kind == MD_MEM_HOST) { t.out = d->aux_stage + (size_t)ch * plane; t.bstride = (long)K7 * plane; }
+      else if (conf) { t.out = user; t.bstride = (long)plane; }
+      else { t.out = user + (size_t)ch * plane; t.bstride = (long)(K7 - 1) * plane; }
+      chs[nch++] = t;
+    }
+    MD_TRY(tail(ra, "aux_tail_fused", hin, ah, aw, Wk(oh + ".reduce.weight"), Bi(oh + ".reduce.bias"), chs, nch));
+    if (out_kind == MD_MEM_HOST)
+      for (int ch = 0; ch < K7; ++ch) {
+        const bool conf = ch == K7 - 1;
+        float* user = conf ? outp.aux_confidence : outp.aux;
+        if (!user) continue;
+        for (int b = 0; b < B; ++b)
+          MD_TRY(host_out(ra.st, conf ? user + (size_t)b * plane : user + ((size_t)b * (K7 - 1) + ch) * plane,
+                          d->aux_stage + ((size_t)b * K7 + ch) * plane, plane));
+      }
+    if (par) MD_HIP(hipEventRecord(d->ev_aux, d->s_aux));
+  }
+  // ---- camera decoder (camera.rs:143-199) on the raw camera feature of the last hook, fp32 ----
+  if (want_cam) {
+    auto lin = [&](const char* n, const float* in, int cout, int relu, float* out) -> int {
+      const std::string q = std::string("camera_decoder.") + n;
+      rc.begin("camera_decoder");
+      int s2 = launch_conv_direct(in, MD_PREC_F32, nullptr, B, 1, 1, din, Bi(q + ".weight"), Bi(q + ".bias"), cout, 1, 1, 0, relu, out, rc.st);
+      rc.end();
+      return s2;
+    };
+    MD_TRY(lin("backbone_1", d->cam_raw, din, 1, d->cam_h1));
+    MD_TRY(lin("backbone_2", d->cam_h1, din, 1, d->cam_h2));
+    // pose = (t3 | quat4 | relu(fov2)), assembled through a [B,9] buffer with strided outputs
+    MD_TRY(lin("fc_t", d->cam_h2, 3, 0, d->cam_h1));
+    MD_TRY(lin("fc_qvec", d->cam_h2, 4, 0, d->cam_h1 + (size_t)B * 3));
+    MD_TRY(lin("fc_fov", d->cam_h2, 2, 1, d->cam_h1 + (size_t)B * 7));
+    for (int b = 0; b < B; ++b) {
+      MD_HIP(hipMemcpyAsync(d->pose + b * 9, d->cam_h1 + b * 3, 12, hipMemcpyDeviceToDevice, rc.st));
+      MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 3, d->cam_h1 + (size_t)B * 3 + b * 4, 16, hipMemcpyDeviceToDevice, rc.st));
+      MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 7, d->cam_h1 + (size_t)B * 7 + b * 2, 8, hipMemcpyDeviceToDevice, rc.st));
+    }
+    MD_TRY(launch_pose_to_camera(d->pose, B, H, W, d->extr, d->intr, rc.st));
+    const hipMemcpyKind kk = out_kind == MD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (outp.pose_encoding) MD_HIP(hipMemcpyAsync(outp.pose_encoding, d->pose, (size_t)B * 9 * 4, kk, rc.st));
+    if (outp.extrinsics) MD_HIP(hipMemcpyAsync(outp.extrinsics, d->extr, (size_t)B * 12 * 4, kk, rc.st));
+    if (outp.intrinsics) MD_HIP(hipMemcpyAsync(outp.intrinsics, d->intr, (size_t)B * 9 * 4, kk, rc.st));
+    if (par) MD_HIP(hipEventRecord(d->ev_cam, d->s_cam));
+  }
   // ---- main branch: output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + activation ----
-  MD_TRY(pyramid(""));
+  MD_TRY(pyramid(r, main_bufs, ""));
   MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk(hp + ".scratch.output_conv1.weight"),
                Bi(hp + ".scratch.output_conv1.bias"), F2, d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
   r.begin("head_resize");
@@ -984,102 +1126,25 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     MD_TRY(r.tap_nhwc("output_conv1", d->c1, F2, 8 * ph, 8 * pw, F2p));
     MD_TRY(r.tap_nhwc("head_input", d->c1r, F2, IH, IW, F2p));  // resized + UV table: the input of output_conv2
   }
-  const size_t out_elems = (size_t)B * IH * IW;
-  float* depth_dev = outp.depth;
-  if (out_kind == MD_MEM_HOST) {
-    if (d->depth_stage_elems < out_elems) {
-      if (d->depth_stage) (void)hipFree(d->depth_stage);
-      MD_HIP(hipMalloc((void**)&d->depth_stage, out_elems * 4));
-      d->depth_stage_elems = out_elems;
+  {
+    const void* w1 = Wk(hp + ".scratch.output_conv2.conv1.weight");
+    const float* b1 = Bi(hp + ".scratch.output_conv2.conv1.bias");
+    const float* w2 = Bi(hp + ".scratch.output_conv2.conv2.weight");
+    TailCh chs[2];
+    int nch = 0;
+    chs[nch++] = TailCh{w2, d->main_bias[0], 1, depth_dev, (long)IH * IW};  // depth = exp(ch 0)
+    float* cd = nullptr;
+    if (c.dual_head && outp.depth_confidence) {  // confidence = exp(last channel) + 1 (select_conf_channel, ExpP1)
+      cd = out_kind == MD_MEM_HOST ? d->conf_stage : outp.depth_confidence;
+      chs[nch++] = TailCh{w2 + 32 * (c.output_dim - 1), d->main_bias[c.output_dim - 1], 3, cd, (long)IH * IW};
     }
-    depth_dev = d->depth_stage;
+    MD_TRY(tail(r, "head_tail_fused", d->c1r, IH, IW, w1, b1, chs, nch));
+    MD_TRY(host_out(st, outp.depth, depth_dev, out_elems));
+    if (cd) MD_TRY(host_out(st, outp.depth_confidence, cd, out_elems));
   }
-  const void* w1 = Wk(hp + ".scratch.output_conv2.conv1.weight");
-  const float* b1 = Bi(hp + ".scratch.output_conv2.conv1.bias");
-  const float* w2 = Bi(hp + ".scratch.output_conv2.conv2.weight");
-  MD_TRY(tail("head_tail_fused", d->c1r, IH, IW, w1, b1, w2, d->main_bias[0], 1, depth_dev));  // depth = exp(ch 0)
-  MD_TRY(host_out(outp.depth, depth_dev, out_elems));
-  if (c.dual_head) {
-    if (outp.depth_confidence) {  // confidence = exp(last channel) + 1 (select_conf_channel, ExpP1)
-      float* cd = out_kind == MD_MEM_HOST ? d->conf_stage : outp.depth_confidence;
-      MD_TRY(tail("head_tail_fused", d->c1r, IH, IW, w1, b1, w2 + 32 * (c.output_dim - 1), d->main_bias[c.output_dim - 1], 3, cd));
-      MD_TRY(host_out(outp.depth_confidence, cd, out_elems));
-    }
-    if (outp.aux || outp.aux_confidence) {
-      // aux branch (build_aux_logits, dpt.rs:356-441): aux fusion pyramid on the same layerN_rn maps -> last
-      // level's 5-conv neck -> + 2 x 0.1 x UV -> reduce 3x3 -> ReLU -> project 1x1 (7 ch: 6 ray values + conf)
-      MD_TRY(pyramid("_aux"));
-      const int ah = 8 * ph, aw = 8 * pw;
-      const std::string lv = std::to_string(c.aux_levels - 1);
-      const void* cur = d->o;
-      void* pp[2] = {d->up, d->o};
-      int cin = F;
-      for (int j = 0; j < c.aux_out1_conv_num; ++j) {
-        const int cout = j % 2 == 0 ? F / 2 : F;
-        const std::string n = hp + ".scratch.output_conv1_aux." + lv + ".layers." + std::to_string(j);
-        MD_TRY(conv3(r, "aux_conv3x3", cur, ah, aw, cpad(m, cin), Wk(n + ".weight"), Bi(n + ".bias"), cout, pp[j & 1], cpad(m, cout), ACT_NONE,
-                     nullptr, nullptr, nullptr));
-        cur = pp[j & 1];
-        cin = cout;
-      }
-      void* hin = cur == d->up ? d->o : d->up;
-      r.begin("head_resize");
-      MD_TRY(launch_resize_nhwc(cur, B, ah, aw, F2, F2p, hin, ah, aw, F2p, MD_INTERP_BURN, d->pos_aux, m->prec, st));
-      r.end();
-      if (m->taps_enabled) {  // DepthTrace::aux_stage_necks (last level) / aux_head_input (mod.rs:241-246)
-        MD_TRY(r.tap_nhwc("aux_neck", cur, F2, ah, aw, F2p));
-        MD_TRY(r.tap_nhwc("aux_head_input", hin, F2, ah, aw, F2p));
-      }
-      const std::string oh = hp + ".scratch.output_conv2_aux." + lv;
-      const size_t plane = (size_t)ah * aw;
-      const int K7 = c.aux_output_dim;
-      for (int ch = 0; ch < K7; ++ch) {
-        const bool conf = ch == K7 - 1;
-        float* user = conf ? outp.aux_confidence : outp.aux;
-        if (!user) continue;
-        for (int b = 0; b < B; ++b) {
-          // planes are written per image so that aux lands as [B, 6, h, w] and the confidence as [B, h, w]
-          float* dst_user = conf ? user + (size_t)b * plane : user + ((size_t)b * (K7 - 1) + ch) * plane;
-          float* dst = out_kind == MD_MEM_HOST ? d->aux_stage + ((size_t)b * K7 + ch) * plane : dst_user;
-          GemmParams p;
-          p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = ah * aw; p.W[0] = Wk(oh + ".reduce.weight");
-          p.A = (const char*)hin + (size_t)b * plane * F2p * m->esz; p.cH = ah; p.cW = aw; p.cC = F2p; p.zero_page = m->zero_page;
-          p.epi = EPI_HEAD; p.bias[0] = Bi(oh + ".reduce.bias"); p.head_w = Bi(oh + ".project.weight") + 32 * ch;
-          p.head_b = d->aux_bias[ch]; p.head_act = conf ? 3 : 2; p.out = dst;
-          r.begin("aux_tail_fused");
-          MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_256x32, st));
-          r.end();
-          MD_TRY(host_out(dst_user, dst, plane));
-        }
-      }
-    }
-    if (outp.pose_encoding || outp.extrinsics || outp.intrinsics) {
-      // CameraDecoder (camera.rs:143-199) on the raw camera feature of the last hook, fp32
-      auto lin = [&](const char* n, const float* in, int cout, int relu, float* out) -> int {
-        const std::string q = std::string("camera_decoder.") + n;
-        r.begin("camera_decoder");
-        int s2 = launch_conv_direct(in, MD_PREC_F32, nullptr, B, 1, 1, din, Bi(q + ".weight"), Bi(q + ".bias"), cout, 1, 1, 0, relu, out, st);
-        r.end();
-        return s2;
-      };
-      MD_TRY(lin("backbone_1", d->cam_raw, din, 1, d->cam_h1));
-      MD_TRY(lin("backbone_2", d->cam_h1, din, 1, d->cam_h2));
-      // pose = (t3 | quat4 | relu(fov2)), assembled through a [B,9] buffer with strided outputs
-      MD_TRY(lin("fc_t", d->cam_h2, 3, 0, d->cam_h1));
-      MD_TRY(lin("fc_qvec", d->cam_h2, 4, 0, d->cam_h1 + (size_t)B * 3));
-      MD_TRY(lin("fc_fov", d->cam_h2, 2, 1, d->cam_h1 + (size_t)B * 7));
-      for (int b = 0; b < B; ++b) {
-        MD_HIP(hipMemcpyAsync(d->pose + b * 9, d->cam_h1 + b * 3, 12, hipMemcpyDeviceToDevice, st));
-        MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 3, d->cam_h1 + (size_t)B * 3 + b * 4, 16, hipMemcpyDeviceToDevice, st));
-        MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 7, d->cam_h1 + (size_t)B * 7 + b * 2, 8, hipMemcpyDeviceToDevice, st));
-      }
-      MD_TRY(launch_pose_to_camera(d->pose, B, H, W, d->extr, d->intr, st));
-      const hipMemcpyKind kk = out_kind == MD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-      if (outp.pose_encoding) MD_HIP(hipMemcpyAsync(outp.pose_encoding, d->pose, (size_t)B * 9 * 4, kk, st));
-      if (outp.extrinsics) MD_HIP(hipMemcpyAsync(outp.extrinsics, d->extr, (size_t)B * 12 * 4, kk, st));
-      if (outp.intrinsics) MD_HIP(hipMemcpyAsync(outp.intrinsics, d->intr, (size_t)B * 9 * 4, kk, st));
-    }
-  }
+  // ---- join the side branches ----
+  if (par && want_aux) MD_HIP(hipStreamWaitEvent(st, d->ev_aux, 0));
+  if (par && want_cam) MD_HIP(hipStreamWaitEvent(st, d->ev_cam, 0));
   if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }

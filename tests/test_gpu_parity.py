@@ -731,7 +731,15 @@ def test_check_parity_cli_against_an_oracle_made_reference_dump(dev, tmp_path):
     spec.loader.exec_module(mod)
     args = ["--weights", wpath, "--image", str(tmp_path / "img.npy"), "--reference", str(tmp_path / "ref.safetensors"), "--preset", "tiny"]
     assert mod.main(args) == 0                      # fp32 parity mode passes the reference's own thresholds
-    assert mod.main(args + ["--precision", "bf16"]) in (0, 1)  # throughput mode: reported, may exceed 5e-3
+    rc, rep = mod.run(args + ["--precision", "f16x2"])  # so does the accurate fast mode (fp32-valued weights: three MFMA terms)
+    assert rc == 0 and rep.ok and rep.depth.max_rel <= 1e-3 and rep.depth.max_abs <= 1e-3
+    # throughput mode: it may exceed the reference's 5e-3 bar, but the harness's VALUES stay inside the bf16 bounds of this
+    # preset (tools/gpu_diag.py E2E_TOL: max-rel 8e-2; mean |depth| is ~0.6) and the verdict follows from them
+    rc, rep = mod.run(args + ["--precision", "bf16"])
+    assert rep is not None and rep.depth.max_rel <= 8e-2 and rep.depth.mean_abs <= 1e-2 and rep.fovx_diff <= 0.05 and rep.fovy_diff <= 0.05
+    assert rep.depth.max_rel > 1e-5, "a bf16 run cannot be fp32-exact: the precision switch did not reach the engine"
+    assert rc == (0 if (rep.depth.max_abs <= 5e-3 and rep.depth.mean_abs <= 1e-3 and rep.depth.max_rel <= 5e-3 and rep.fovx_diff <= 1e-3
+                        and rep.fovy_diff <= 1e-3) else 1)
 
 
 def test_infer_cli_writes_a_depth_png_for_both_model_kinds(dev, tmp_path):
@@ -759,6 +767,22 @@ def test_infer_cli_writes_a_depth_png_for_both_model_kinds(dev, tmp_path):
     assert cli.main(["--model", "depth-anything-3", "--checkpoint", ck, "--image", img, "--output", out]) == 0
     px = P.read_gray_png(out)
     assert px.shape == (120, 180) and px.min() == 0 and px.max() == 255
+    # VALUES: the same flow on the CPU oracle (prepare -> rgb_to_input_tensor -> DepthAnything3::infer -> crop / restore /
+    # min-max normalise, example/inference.rs:103-199) gives the same 8-bit pixels as the CLI in the parity mode (f32), up to
+    # one grey level where a value sits on a rounding boundary
+    from oracle import da3_ref as D3, depth_pro_ref as R
+    out32 = str(tmp_path / "depth_da3_f32.png")
+    assert cli.main(["--model", "depth-anything-3", "--checkpoint", ck, "--image", img, "--output", out32, "--precision", "f32"]) == 0
+    W = {k: R.f16_round(v) for k, v in R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY)).items()}  # the F16 container
+    prep = P.prepare_depth_anything3_image(rgb, cfg.image_size)
+    with torch.no_grad():
+        ref = D3.infer(R.rgb_to_input_tensor(prep.rgb.tobytes(), prep.width, prep.height), W, cfg)["depth"].numpy()
+    want = P.depth_to_u8(ref, prep.crop, (180, 120))
+    got = P.read_gray_png(out32).astype(np.int32)
+    diff = np.abs(got - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (int(diff.max()), float((diff > 0).mean()))
+    d16 = np.abs(px.astype(np.int32) - want.astype(np.int32))  # the default (bf16) run of the same image: a few grey levels
+    assert d16.mean() < 2.0 and d16.max() <= 24, (float(d16.mean()), int(d16.max()))
     # the same file under a neutral name: metric_large is tried first and rejected (shape mismatch), then small loads
     ck2 = str(tmp_path / "weights.safetensors")
     os.replace(ck, ck2)

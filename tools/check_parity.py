@@ -5,7 +5,8 @@ PyTorch-side dump (`tool/correctness_depth_pro.py` output, safetensors) using th
 
 `--image`: uint8 RGB array [H,W,3] as .npy (JPEG decoding is out of scope). The image goes through
 `infer_from_rgb` exactly like `example/inference.rs` (normalise -> resize to 1536^2 -> infer -> resize back).
-`--precision f32` (default) is the parity mode; bf16 reports the throughput mode's error against the same dump."""
+`--precision f32` (default) is the parity mode, `f16x2` the accurate fast mode (activations as hi + lo half planes; both are
+held to the reference's thresholds); bf16 / f16 report the throughput modes' error against the same dump."""
 import argparse
 import math
 import os
@@ -16,12 +17,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main(argv=None) -> int:
+def run(argv=None):
+    """Returns (exit code, burn_depth_amd.parity.Report or None)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--weights", required=True)
     ap.add_argument("--image", required=True)
     ap.add_argument("--reference", required=True)
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "f16x2", "f16", "bf16"], default="f32")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full", help="reduced presets are for the test-suite")
     a = ap.parse_args(argv)
     import torch
@@ -34,11 +36,11 @@ def main(argv=None) -> int:
     rgb = np.load(a.image)
     if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[2] != 3:
         print(f"--image must be uint8 [H,W,3], got {rgb.dtype} {rgb.shape}", file=sys.stderr)
-        return 2
+        return 2, None
     h, w = rgb.shape[:2]
     dev = Device(0)
     cfg = {"full": DepthProConfig, "small": DepthProConfig.small_test, "tiny": DepthProConfig.tiny_test}[a.preset]()
-    cfg.precision = Precision.F32 if a.precision == "f32" else Precision.BF16
+    cfg.precision = {"f32": Precision.F32, "f16x2": Precision.F16X2, "f16": Precision.F16, "bf16": Precision.BF16}[a.precision]
     model = DepthPro.load_with_config(dev, cfg, a.weights)
     model.enable_taps(True)
     out = model.infer(rgb_to_input_tensor(rgb.tobytes(), w, h, dev))
@@ -52,7 +54,12 @@ def main(argv=None) -> int:
             pass
     rep = parity.compare(ref, out.depth[0].cpu().numpy(), float(out.fovx_deg[0]), math.degrees(float(out.fovy_rad[0])), taps)
     print("\n".join(rep.lines))
-    return 0 if rep.ok else 1
+    model.destroy()
+    return (0 if rep.ok else 1), rep
+
+
+def main(argv=None) -> int:
+    return run(argv)[0]
 
 
 if __name__ == "__main__":
