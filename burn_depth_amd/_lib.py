@@ -16,7 +16,7 @@ MD_ERR_INVALID_ARG, MD_ERR_SHAPE, MD_ERR_IO, MD_ERR_FORMAT, MD_ERR_HIP = -1, -2,
 MD_ERR_UNSUPPORTED, MD_ERR_NO_FOV, MD_ERR_OOM, MD_ERR_LEVELS = -6, -7, -8, -9
 MD_MEM_HOST, MD_MEM_DEVICE = 0, 1
 MD_COMM_ID_BYTES = 128
-TILE_256x256, TILE_128x128, TILE_256x32, TILE_AUTO = 0, 1, 2, 99
+TILE_256x256, TILE_128x128, TILE_256x32, TILE_128x64, TILE_64x64, TILE_AUTO = 0, 1, 2, 3, 4, 99
 
 
 class MdError(RuntimeError):

@@ -133,7 +133,7 @@ struct GemmParams {
   int head_acts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_AUTO = 99 };
+enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_128x64 = 3, TILE_64x64 = 4, TILE_AUTO = 99 };
 
 // Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16), MD_PREC_F16 (T = f16), MD_PREC_F16X2 (T = f16s: split-half planes),
 // MD_PREC_F32 (T = float) or MD_PREC_FP8 (T = e4m3, dense only).

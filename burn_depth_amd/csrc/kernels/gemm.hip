@@ -11,24 +11,49 @@ int launch_gemm_f16(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_fp8(GemmParams& p, int amode, int tile, hipStream_t stream);
 int launch_gemm_f16x2(GemmParams& p, int amode, int tile, hipStream_t stream);
 
-static int pick_tile(const GemmParams& p) {
+// Tile choice = a small cost model of one launch, fitted on MI355X (tools/kernel_bench.py, profiles/r03_tile_model.txt):
+// the tiles of a launch are spread over the 256 CUs, a CU works through its n = ceil(tiles / 256) tiles in batches of `cap`
+// co-resident workgroups, and a batch of w workgroups advances one 128-byte k-tile in max(lat, w * thr) microseconds -- `lat`
+// is the latency-bound time of a lone workgroup (two-stage ring: one memory round trip per k-tile), `thr` the CU's
+// throughput-bound time per workgroup and k-tile. t0 = dispatch + first-tile latency + epilogue. The fit reproduces the
+// measured times of 24 shapes x 4 tiles to about 10 % (Depth Pro proj / fc2 at B = 1, the Depth-Anything-v3 small / base /
+// large linears at 518^2 and 1036^2, the 64- and 256-feature DPT-head convolutions at 37^2 .. 296^2). What it encodes:
+// large launches belong on the 256^2 kernel (1.38 us per 256^2 x 64 step against 2.1 - 3.5 for the same area on the smaller
+// tiles), launches of less than a round or two belong on the tile that fills the CUs (the 1370-token linears of
+// Depth-Anything-v3 small: 99 tiles of 128^2 = 13.6 us, 396 tiles of 64^2 = 7.7 us).
+struct TileModel {
+  int id, bm, bn, cap;
+  double lat, thr, t0;
+};
+static const TileModel kTileModel[] = {{TILE_256x256, 256, 256, 1, 1.38, 1.38, 5.6},
+                                       {TILE_128x128, 128, 128, 2, 0.75, 0.52, 9.0},
+                                       {TILE_128x64, 128, 64, 3, 0.42, 0.32, 7.0},
+                                       {TILE_64x64, 64, 64, 4, 0.24, 0.22, 5.0}};
+
+static int pick_tile(const GemmParams& p, int prec) {
   if (p.epi == EPI_HEAD || p.N <= 32) return TILE_256x32;
+  const int ke = prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64);
+  const double kt = (double)(p.K / ke);
+  const double slow = prec == MD_PREC_F32 ? 8.0 : 1.0;  // fp32 MFMA: 1/16 of the FLOPs per clock on half the k per tile
   long rows = 0;
-  int t256 = 0, t128 = 0;
-  for (int g = 0; g < p.ngroups; ++g) {
-    rows += p.g_rows[g];
-    t256 += cdiv(p.g_rows[g], 256);
-    t128 += cdiv(p.g_rows[g], 128);
+  for (int g = 0; g < p.ngroups; ++g) rows += p.g_rows[g];
+  int best = TILE_128x128;
+  double best_cost = 1e30;
+  for (const TileModel& t : kTileModel) {
+    if (t.id == TILE_256x256 && (p.N < 256 || rows < 256)) continue;
+    long wgs = 0;
+    for (int g = 0; g < p.ngroups; ++g) wgs += cdiv(p.g_rows[g], t.bm);
+    wgs *= cdiv(p.N, t.bn) * (long)(p.batch > 1 ? p.batch : 1);
+    const long n = (wgs + 255) / 256, nb = n / t.cap, r = n % t.cap;
+    const double thr = t.thr * slow;
+    const double per_k = nb * std::max(t.lat, t.cap * thr) + (r ? std::max(t.lat, r * thr) : 0.0);
+    const double cost = t.t0 + kt * per_k;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = t.id;
+    }
   }
-  if (p.N < 256 || rows < 256) return TILE_128x128;
-  // Wave quantisation decides between the two: a launch takes whole rounds (256 CUs x one 256^2 tile, or x two 128^2
-  // tiles), and a 128^2 round costs 0.78 of a 256^2 round -- measured on the Depth-Anything-v3 1036^2 shapes (M = 5477,
-  // tools/kernel_bench.py da3_*): qkv 2 rounds of 256^2 54 us against 3 rounds of 128^2 64 us, fc2 1 round 81 us against
-  // 1 round 74 us; the same ratio holds for the e4m3 operands. Large M always lands on 256^2 (half the rounds).
-  const long b256 = (long)t256 * cdiv(p.N, 256), b128 = (long)t128 * cdiv(p.N, 128);
-  const double c256 = (double)cdiv(b256, 256);
-  const double c128 = (double)cdiv(b128, 512) * 0.78;
-  return c256 <= c128 ? TILE_256x256 : TILE_128x128;
+  return best;
 }
 
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream) {
@@ -86,9 +111,9 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     for (int g = 0; g < p.ngroups; ++g) rows = std::max<long>(rows, (long)p.g_arow0[g] + p.g_rows[g]);
     if (rows >= (1L << 31)) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: more than 2^31 rows");
   }
-  if (tile == TILE_AUTO) tile = pick_tile(p);
+  if (tile == TILE_AUTO) tile = pick_tile(p, prec);
   {
-    const int bn = (tile == TILE_128x128) ? 128 : (tile == TILE_256x32 ? 32 : 256);
+    const int bn = (tile == TILE_128x128) ? 128 : (tile == TILE_256x32 ? 32 : ((tile == TILE_128x64 || tile == TILE_64x64) ? 64 : 256));
     const int tn = cdiv(p.N, bn);
     // raster group width, from a sweep on the Depth Pro step (B = 8): up to 12 n-tiles (qkv) plain n-fastest order is
     // best (qkv 24.3 -> 23.3 ms per step against groups of 4); the 16 n-tiles of fc1 run the same in groups of 4 or 8 and

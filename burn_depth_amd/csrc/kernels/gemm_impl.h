@@ -1462,6 +1462,10 @@ static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
       return launch_cfg<T, 128, 128, 2, 2, AMODE>(p, stream);
     case TILE_256x32:
       return launch_cfg<T, 256, 32, 8, 1, AMODE>(p, stream);
+    case TILE_128x64:  // N <= 64 (the 64-feature DPT head) and launches that leave CUs idle on 128^2 tiles
+      return launch_cfg<T, 128, 64, 2, 2, AMODE>(p, stream);
+    case TILE_64x64:
+      return launch_cfg<T, 64, 64, 2, 2, AMODE>(p, stream);
     default:
       MD_FAIL(MD_ERR_INVALID_ARG, "gemm: unknown tile config %d", tile);
   }

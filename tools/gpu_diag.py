@@ -150,7 +150,9 @@ def check_linear(dev):
              (1160, 1024, 4096, _lib.TILE_AUTO), (64, 32, 192, _lib.TILE_256x32), (1000, 32, 128, _lib.TILE_256x32),
              (129, 132, 64, _lib.TILE_128x128), (513, 260, 320, _lib.TILE_256x256), (2000, 1024, 1024, _lib.TILE_256x256),
              (2000, 1024, 1024, _lib.TILE_128x128), (300, 256, 64, _lib.TILE_256x256), (300, 256, 128, _lib.TILE_256x256), (21349, 1024, 1024, _lib.TILE_256x256),
-             (700, 3072, 64, _lib.TILE_256x256), (700, 512, 128, _lib.TILE_256x256), (700, 512, 192, _lib.TILE_256x256)]
+             (700, 3072, 64, _lib.TILE_256x256), (700, 512, 128, _lib.TILE_256x256), (700, 512, 192, _lib.TILE_256x256),
+             (300, 256, 128, _lib.TILE_128x64), (129, 132, 192, _lib.TILE_128x64), (1370, 384, 1536, _lib.TILE_64x64), (65, 68, 64, _lib.TILE_64x64),
+             (1370, 384, 384, _lib.TILE_AUTO), (1370, 64, 576, _lib.TILE_AUTO)]
     for prec, pname in [(0, "bf16"), (1, "f32"), (3, "f16")]:
         rnd = ROUND[prec]
         for (M, N, K, tile) in cases:
@@ -223,7 +225,8 @@ def check_linear_fp8(dev):
     g = torch.Generator().manual_seed(5)
     xs = torch.tensor(FP8_ACT_SCALE, dtype=torch.float32)
     for (M, N, K, tile, act) in [(300, 256, 128, _lib.TILE_128x128, 0), (300, 256, 256, _lib.TILE_256x256, 0), (1370, 3072, 1024, _lib.TILE_AUTO, 0),
-                                 (2740, 4096, 1024, _lib.TILE_256x256, 2), (2740, 1024, 4096, _lib.TILE_256x256, 0), (513, 260, 384, _lib.TILE_AUTO, 0)]:
+                                 (2740, 4096, 1024, _lib.TILE_256x256, 2), (2740, 1024, 4096, _lib.TILE_256x256, 0), (513, 260, 384, _lib.TILE_AUTO, 0),
+                                 (300, 256, 256, _lib.TILE_128x64, 0), (1370, 384, 1536, _lib.TILE_64x64, 2), (5477, 1024, 1024, _lib.TILE_AUTO, 0)]:
         x = torch.randn(M, K, generator=g) * 1.5
         w = torch.randn(N, K, generator=g) / math.sqrt(K)
         b = torch.randn(N, generator=g)
@@ -353,7 +356,7 @@ def check_split_ops(dev):
     P = 4
     for wexact in (True, False):
         wl = "w16" if wexact else "w32"
-        for (M, N, K, tile) in [(300, 256, 128, _lib.TILE_128x128), (300, 256, 128, _lib.TILE_256x256), (577, 3072, 1024, _lib.TILE_AUTO),
+        for (M, N, K, tile) in [(300, 256, 128, _lib.TILE_128x128), (300, 256, 128, _lib.TILE_256x256), (577, 3072, 1024, _lib.TILE_AUTO), (300, 256, 128, _lib.TILE_128x64), (300, 132, 192, _lib.TILE_64x64),
                                 (1160, 1024, 4096, _lib.TILE_AUTO), (64, 32, 192, _lib.TILE_256x32), (129, 132, 64, _lib.TILE_128x128),
                                 (513, 260, 320, _lib.TILE_256x256), (2000, 1024, 1024, _lib.TILE_256x256), (700, 512, 192, _lib.TILE_256x256)]:
             x = torch.randn(M, K, generator=g) * 1.7
@@ -700,6 +703,9 @@ def main():
         check_attention(dev)
         check_convs(dev)
         check_storage_epilogues(dev)
+    if want("linear") and only is not None:
+        check_linear(dev)
+        check_linear_fp8(dev)
     if want("tiny"):
         guarded("tiny f32")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f32", 1, (512, 512), Precision.F32)
         guarded("tiny bf16")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/bf16", 1, (512, 512), Precision.BF16)

@@ -34,7 +34,11 @@ def main():
     # tiles against the remaining rows on 128^2 tiles
     gemms += [("full_proj", 0, 16384, 1024, 1024, 0, 0), ("rem_proj", 0, 5076, 1024, 1024, 0, 0), ("full_fc2", 0, 16384, 1024, 4096, 0, 0),
               ("rem_fc2", 0, 5076, 1024, 4096, 0, 0)]
-    tiles += [(1 + 16 * 256, "128v1_rmw"), (1 + 1024, "128v1_gelu")]
+    tiles += [(1 + 16 * 256, "128v1_rmw"), (1 + 1024, "128v1_gelu"), (3, "128x64"), (4, "64x64")]
+    gemms += [("s_conv296", 1, 296 * 296, 64, 64, 296, 296), ("s_conv37", 1, 37 * 37, 64, 64, 37, 37), ("s_conv296_32", 1, 296 * 296, 32, 64, 296, 296),
+              ("l_conv148", 1, 148 * 148, 256, 256, 148, 148), ("l_conv74", 1, 74 * 74, 256, 256, 74, 74), ("l_conv37", 1, 37 * 37, 256, 256, 37, 37),
+              ("b_qkv", 0, ns, 2304, 768, 0, 0), ("b_proj", 0, ns, 768, 768, 0, 0), ("b_fc2", 0, ns, 768, 3072, 0, 0),
+              ("L_qkv", 0, ns, 3072, 1024, 0, 0), ("L_proj", 0, ns, 1024, 1024, 0, 0), ("L_fc1", 0, ns, 4096, 1024, 0, 0), ("L_fc2", 0, ns, 1024, 4096, 0, 0)]
     prec = int(os.environ.get("PREC", "0"))
     only = os.environ.get("ONLY")
     if only:
