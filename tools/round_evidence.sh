@@ -13,6 +13,8 @@ timeout -k 10 200 python bench.py --model da3_large --image-size 1036 --precisio
 timeout -k 10 200 python bench.py --model da3_small --graph --no-cpu-baseline --no-extras --steps 50 2>>gpurun_out/cfg5.err > gpurun_out/r03_cfg2_small_graph.json
 timeout -k 10 300 python bench.py --no-cpu-baseline --precision f16 --accuracy 2>gpurun_out/f16.err > gpurun_out/r03_bench_f16.json
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --precision f32 --steps 3 --warmup 1 2>gpurun_out/f32.err > gpurun_out/r03_bench_f32_full.json
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras --precision f16x2 --steps 5 --warmup 2 2>gpurun_out/f16x2.err > gpurun_out/r03_bench_f16x2.json
+timeout -k 10 200 python bench.py --model da3_small --no-cpu-baseline --no-extras --steps 50 2>>gpurun_out/cfg5.err > gpurun_out/r03_cfg2_small_eager.json
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r03_*.json")):
