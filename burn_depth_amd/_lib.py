@@ -108,6 +108,7 @@ SYMBOLS = {
     "md_op_conv2d_direct": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "md_op_fov_to_focal": (_I, [C.c_float, _I, _I, _F, _F]),
     "md_bench_gemm": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F]),
+    "md_gemm_pick_tile": (_I, [_I, _I, _I, _I]),
     "md_bench_attention": (_I, [_P, _I, _I, _I, _I, _F]),
     "md_bench_attention_ex": (_I, [_P, _I, _I, _I, _I, C.c_float, _I, _F]),
     "md_comm_unique_id": (_I, [_P]),

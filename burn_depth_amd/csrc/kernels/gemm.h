@@ -138,5 +138,7 @@ enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_
 // Launches the kernel. `prec`: MD_PREC_BF16 (T = bf16), MD_PREC_F16 (T = f16), MD_PREC_F16X2 (T = f16s: split-half planes),
 // MD_PREC_F32 (T = float) or MD_PREC_FP8 (T = e4m3, dense only).
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream);
+// The tile TILE_AUTO resolves to for these parameters (host-only).
+int gemm_pick_tile(const GemmParams& p, int prec);
 
 }  // namespace md

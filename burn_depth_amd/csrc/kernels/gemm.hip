@@ -56,6 +56,8 @@ static int pick_tile(const GemmParams& p, int prec) {
   return best;
 }
 
+int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
+
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream) {
   const int ke = prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64);
   if (p.ngroups < 1 || p.ngroups > kMaxGroups) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: ngroups %d", p.ngroups);

@@ -613,6 +613,13 @@ __attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, 
 }
 }  // namespace
 
+int md_gemm_pick_tile(int M, int N, int K, int precision) {
+  if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "md_gemm_pick_tile: M=%d N=%d K=%d", M, N, K);
+  md::GemmParams p;
+  p.N = N; p.K = K; p.ngroups = 1; p.g_rows[0] = M;
+  return md::gemm_pick_tile(p, precision);
+}
+
 int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int aux1, int precision, int tile, int iters,
                   float* avg_ms) {
   const int dbg = tile >> 8;  // timing-only ablation flags ride in the upper bits of `tile`

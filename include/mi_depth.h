@@ -289,6 +289,9 @@ int md_op_fov_to_focal(float fovx_deg, int H, int W, float* focal_px, float* fov
  * 64 no global stores, 128 no staging writes. tools/kernel_bench.py names the combinations. */
 int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int aux1, int precision, int tile, int iters,
                   float* avg_ms);
+/* Host-only diagnostic (no GPU work): the tile the engine's launch cost model picks for a dense [M,K] x [N,K]^T GEMM in
+ * `precision` -- 0 = 256x256, 1 = 128x128, 2 = 256x32 (N <= 32), 3 = 128x64, 4 = 64x64. */
+int md_gemm_pick_tile(int M, int N, int K, int precision);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
 /* The same with the operand type (MD_PREC_BF16 | MD_PREC_F16) and the range of the random q / k values, uniform in

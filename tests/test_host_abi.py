@@ -148,3 +148,28 @@ def test_container_roundtrip(tmp_path):
         k = "encoder.patch_encoder.blocks.0.attn.qkv.weight"
         assert W2[k].shape == W[k].shape
         assert np.abs(W2[k] - W[k]).max() <= tol * np.abs(W[k]).max() + (0 if tol else 0)
+
+
+def test_tile_cost_model_choices(lib):
+    """Host logic of the GEMM launch (gemm.hip::pick_tile, DESIGN.md section 5.1): large launches go to the 256^2 kernel,
+    launches of less than a round or two to the tile that fills the 256 CUs -- the measured best tiles of
+    profiles/r03_tile_model.txt."""
+    T256, T128, T256x32, T128x64, T64 = _lib.TILE_256x256, _lib.TILE_128x128, _lib.TILE_256x32, _lib.TILE_128x64, _lib.TILE_64x64
+    bf16 = 0
+    rows8 = 37 * 8 * 580   # Depth Pro at B = 8: 37 sequences of 580 rows per image
+    rows1 = 37 * 580
+    for (M, N, K) in [(rows8, 3072, 1024), (rows8, 4096, 1024), (rows8, 1024, 4096), (rows8, 1024, 1024),
+                      (rows1, 3072, 1024), (rows1, 1024, 4096), (rows1, 1024, 1024), (8192, 8192, 8192),
+                      (5477, 3072, 1024), (5477, 4096, 1024)]:
+        assert lib.md_gemm_pick_tile(M, N, K, bf16) == T256, (M, N, K)
+    # Depth-Anything-v3 small at 518^2 (1370 tokens, D = 384): 99 tiles of 128^2 would leave 157 CUs idle
+    for (M, N, K) in [(1370, 1152, 384), (1370, 384, 384), (1370, 1536, 384), (1370, 384, 1536)]:
+        assert lib.md_gemm_pick_tile(M, N, K, bf16) == T64, (M, N, K)
+    # Depth-Anything-v3 large at 1036^2: proj / fc2 on 128x64 (measured 21.8 / 62.0 us against 25.2 / 68.2 on 128^2)
+    for (M, N, K) in [(5477, 1024, 1024), (5477, 1024, 4096)]:
+        assert lib.md_gemm_pick_tile(M, N, K, bf16) == T128x64, (M, N, K)
+    assert lib.md_gemm_pick_tile(296 * 296, 64, 576, bf16) == T128x64   # 64-feature head convolution at 296^2 (as a dense shape)
+    assert lib.md_gemm_pick_tile(1000, 32, 128, bf16) == T256x32
+    assert lib.md_gemm_pick_tile(0, 32, 128, bf16) < 0                   # checked precondition, not a crash
+    for prec in (0, 1, 2, 3, 4):                                          # every precision resolves to a tile that exists
+        assert lib.md_gemm_pick_tile(700, 512, 256, prec) in (T256, T128, T128x64, T64)
