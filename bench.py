@@ -149,6 +149,9 @@ def parse_args(argv=None):
     ap.add_argument("--native-comm", action="store_true",
                     help="N > 1: weight broadcast, image scatter and depth gather through the library's own RCCL entry points (md_comm_*, grouped "
                          "ncclSend / ncclRecv on a side HIP stream) instead of torch.distributed; torch.distributed only carries the rendezvous id")
+    ap.add_argument("--tile-parallel", action="store_true",
+                    help="SURVEY 8(e) second mode: ONE image per step, its 37 ViT sequences split over the N ranks (md_comm_depth_pro_infer_tiles); "
+                         "the line reports single-image throughput = 1 / latency, scaling 'strong'")
     ap.add_argument("--no-extras", action="store_true",
                     help="default N = 1 Depth Pro bf16 run only: skip the objects measured after the timed region (`configs`: the other BASELINE "
                          "configurations; `accurate_mode` / `fp32_mode_fps`; `accuracy` at 1536^2 against the CPU-baseline frame; `host_io`)")
@@ -192,6 +195,8 @@ def main(argv=None) -> int:
     tdev = torch.device("cuda", local_rank)
     if args.model in ("da3_large", "da3_small"):
         return bench_da3(args, dev, tdev, world, rank)
+    if args.tile_parallel:
+        return bench_tile_parallel(args, dev, tdev, world, rank)
     if args.precision == "fp8":
         print("fp8 operands are built for the Depth-Anything-v3 models only (BASELINE config 5); the Depth Pro headline is bf16",
               file=sys.stderr)
@@ -626,6 +631,27 @@ def extra_measurements(dev, tdev, model, cfg, B, ref_frame):
     dt1, step1 = rate(model, 1, 10)
     configs = [{"name": "config 3: Depth Pro [1,3,1536,1536], bf16, B = 1", "value": round(1.0 / dt1, 3), "unit": "frames/s", "ms_per_step": round(dt1 * 1e3, 3),
                 "dtype": "bf16", "roofline": _dominant(model, step1, fl1, PEAK_BF16_TFLOPS)}]
+    # tile-parallel single-image mode (second mode): the device time of one frame on `parts` GPUs, measured window
+    # by window on THIS GPU (md_depth_pro_infer_windows issues the launches of each rank in turn) -- a projection, not a
+    # multi-GPU measurement: the exchange (100 MB of bf16 tokens + hooks to the root, 1/parts of it per xGMI link) is an estimate
+    try:
+        x1 = ((torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(1234)) - mean) / std).to(tdev)
+        proj = []
+        for parts in (2, 4, 8):
+            best = None
+            for _ in range(3):
+                _o, wms, tms = model.infer_windows(x1, parts, timings=True)
+                if best is None or max(wms) + tms < best[0]:
+                    best = (max(wms) + tms, wms, tms)
+            exch_ms = 100e6 / parts / 50e9 * 1e3 + 0.03  # every peer's shard (100 MB / parts) on its own xGMI link at ~50 GB/s + group latency
+            proj.append({"parts": parts, "max_window_ms": round(max(best[1]), 3), "tail_ms": round(best[2], 3), "exchange_ms_estimate": round(exch_ms, 3),
+                         "ms_per_frame": round(best[0] + exch_ms, 3), "vs_one_gpu": round(dt1 * 1e3 / (best[0] + exch_ms), 3)})
+        out["tile_parallel_projection"] = {
+            "what": "DepthPro::infer [1,3,1536,1536] with the 37 ViT sequences split over N GPUs (md_comm_depth_pro_infer_tiles): per-window and "
+                    "tail device times measured on ONE GPU, exchange estimated -- NOT a multi-GPU measurement",
+            "one_gpu_ms_per_frame": round(dt1 * 1e3, 3), "projection": proj}
+    except Exception as ex:  # noqa: BLE001 -- an extra must never lose the headline line
+        out["tile_parallel_projection"] = {"error": f"{type(ex).__name__}: {ex}"}
     # the accurate fast mode at the headline batch, and the fp32 parity mode
     c2 = DepthProConfig()
     c2.precision, c2.max_batch = Precision.F16X2, B
@@ -660,6 +686,73 @@ def extra_measurements(dev, tdev, model, cfg, B, ref_frame):
         configs.append(e)
     out["configs"] = configs
     return out
+
+
+def bench_tile_parallel(args, dev, tdev, world: int, rank: int) -> int:
+    """Single-image latency with the ViT stage sharded over the ranks (second mode): every step is ONE
+    `DepthPro::infer([B,3,1536,1536])` (B = --batch, default 1) whose input lives on rank 0 and whose outputs arrive on rank 0;
+    broadcast of the image, the ranks' windows, the token / hook exchange and the root's decoder are all inside the timed region."""
+    import torch
+    import torch.distributed as dist
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    from burn_depth_amd.parallel import NativeComm
+    cfg = {"full": DepthProConfig(), "small": DepthProConfig.small_test(), "tiny": DepthProConfig.tiny_test()}[args.preset]
+    cfg.precision = {"bf16": Precision.BF16, "f16": Precision.F16, "f32": Precision.F32, "f16x2": Precision.F16X2}[args.precision]
+    B = args.batch if args.batch and args.batch != 8 else 1
+    cfg.max_batch = B
+    S = cfg.img_size()
+    model = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
+    ncomm = NativeComm.from_torch_distributed(dev) if world > 1 else NativeComm(dev, NativeComm.unique_id(), 1, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ncomm.broadcast_weights(model, root=0)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    model.round_weights_to_f16()
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    x = ((torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1234)) - mean) / std).to(tdev) if rank == 0 else None
+    last = {}
+
+    def step():
+        last["out"] = ncomm.infer_tiles(model, x, (B, S, S), root=0)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ok = bool(torch.isfinite(last["out"].depth).all().item())
+        print(json.dumps({
+            "metric": "frames/sec Depth Pro @1536^2 bf16" if args.preset == "full" and args.precision == "bf16" else f"frames/sec Depth Pro preset={args.preset} {args.precision}",
+            "value": round(args.steps * B / elapsed, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic (seeded U[0,1) image, ImageNet-normalised; random-init weights rounded to f16)",
+            "config": {"workload": f"DepthPro::infer [{B},3,{S},{S}], ONE call per step sharded over the ranks", "global_batch": B,
+                       "parallelism": f"tile-parallel x{world}: the 37 B ViT sequences split over the ranks, token + hook exchange to rank 0, decoder on rank 0",
+                       "comm": "native md_comm_* (ncclBroadcast of the image, grouped ncclSend / ncclRecv of tokens and hooks)"},
+            "finite_output": ok, "weight_broadcast_s": round(t_bcast, 4), "roofline": None, "cpu_baseline": None}), flush=True)
+    model.destroy()
+    ncomm.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def bench_dry(args, world: int, rank: int) -> int:

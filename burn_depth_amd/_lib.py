@@ -77,6 +77,7 @@ SYMBOLS = {
     "md_model_destroy": (_I, [_P]),
     "md_model_fork": (_I, [_P, C.POINTER(_P)]),
     "md_depth_pro_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "md_depth_pro_infer_windows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "md_infer_from_rgb": (_I, [_P, _P, C.c_size_t, _I, _I, _I, _P, _P, _P, _I, _P]),
     "md_da3_cfg_default": (None, [C.POINTER(MdDa3Cfg)]),
     "md_da3_create": (_I, [_P, C.POINTER(MdDa3Cfg), C.c_uint64, _I, C.POINTER(_P)]),
@@ -118,6 +119,7 @@ SYMBOLS = {
     "md_comm_broadcast_weights": (_I, [_P, _P, _I]),
     "md_comm_scatter_images": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),
     "md_comm_gather_depth": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),
+    "md_comm_depth_pro_infer_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "md_param_inventory": (_I, [C.POINTER(MdDepthProCfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_uniform_stream": (_I, [C.c_char_p, C.c_uint64, C.c_size_t, C.c_float, C.c_float, _P]),
     "md_split_geometry": (_I, [_I, _I, C.c_float, C.POINTER(_I), C.POINTER(_I)]),

@@ -185,6 +185,19 @@ __device__ __forceinline__ f32x4_t relu4(f32x4_t v) {
 // ------------------------------------------------------------------------------------------------
 // Epilogue for 4 consecutive columns n..n+3 of row m (all bounds already checked by the caller).
 // ------------------------------------------------------------------------------------------------
+// x + s * v with ONE rounding per element, spelled as an fma so that every kernel of the family (the 256^2 kernel's
+// read-modify-write epilogue and the per-vector epilogue of the small tiles) produces the same bits for the same operands:
+// the tile choice -- and with it a tile-parallel split of the sequence range -- must not change the residual stream.
+__device__ __forceinline__ f32x4_t resid_ls4(f32x4_t x, f32x4_t s, f32x4_t v) {
+  return (f32x4_t){__builtin_fmaf(s[0], v[0], x[0]), __builtin_fmaf(s[1], v[1], x[1]), __builtin_fmaf(s[2], v[2], x[2]),
+                   __builtin_fmaf(s[3], v[3], x[3])};
+}
+// a * b + c, one rounding per element (the same reason: q = acc * qscale + bias * qscale in every kernel of the family)
+__device__ __forceinline__ f32x4_t fma4(f32x4_t a, f32x4_t b, f32x4_t c) {
+  return (f32x4_t){__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]),
+                   __builtin_fmaf(a[3], b[3], c[3])};
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int n, f32x4_t v, long boff) {
   const float* bias = MD_SEL_G(p.bias, g);
@@ -213,8 +226,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       f32x4_t r = *(const f32x4_t*)x;
       v += *(const f32x4_t*)(bias + n);
       f32x4_t s = *(const f32x4_t*)(sc + n);
-      r += s * v;
-      *(f32x4_t*)x = r;
+      *(f32x4_t*)x = resid_ls4(r, s, v);
       break;
     }
     case EPI_PATCH_EMBED: {
@@ -228,9 +240,15 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       break;
     }
     case EPI_QKV: {
-      v += *(const f32x4_t*)(bias + n);
+      // q columns: acc * qscale + bias * qscale (the 256^2 kernel folds the scale into its bias / scale vectors; the same
+      // two roundings here keep q independent of the tile). embed % 4 == 0: a 4-column vector never straddles q | k
+      if (n < p.embed) {
+        const f32x4_t qs = {p.qscale, p.qscale, p.qscale, p.qscale};
+        v = fma4(v, qs, *(const f32x4_t*)(bias + n) * p.qscale);
+      } else {
+        v += *(const f32x4_t*)(bias + n);
+      }
       const int two_d = 2 * p.embed;
-      if (n < p.embed) v *= p.qscale;  // embed % 4 == 0: a 4-column vector never straddles q | k
       if constexpr (is_split<T>::value) {
         // split-half rows [q_hi | q_lo | k_hi | k_lo], each `embed` wide; V^T lo plane v_plane elements behind the hi plane
         if (n < two_d) {
@@ -1126,7 +1144,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         asm volatile("" ::: "memory");
         if (!(DIAG && (p.debug_flags & 8)))  // timing-only ablation: skip the staging writes
           stage_half_2b(half, [&](int a, f32x4_t v) {
-            v = v * wq[a] + bq[a];
+            v = fma4(v, wq[a], bq[a]);
             if constexpr (EK == 4) {
               v = gelu4<TO>(v);
             } else if (relu) {
@@ -1299,7 +1317,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
         if (interior || (m < m_end && nvalid))
-          *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = pre2[half][it] + scale4 * (v * ws4 + bias4);
+          *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = resid_ls4(pre2[half][it], scale4, v * ws4 + bias4);
         if (half == 0 && it == 7) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) prefetch(1, j);

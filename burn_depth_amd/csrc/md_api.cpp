@@ -188,6 +188,20 @@ int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int
                      nullptr, 0);
 }
 
+int md_depth_pro_infer_windows(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
+                               float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, int parts,
+                               float* window_ms, float* tail_ms, void* stream) {
+  if (!nchw) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");
+  if (m && m->kind != 0) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth Pro model");
+  if (parts < 1 || parts > 64) MD_FAIL(MD_ERR_INVALID_ARG, "parts = %d (1 .. 64)", parts);
+  ShardPlan sp;
+  sp.parts = parts;
+  sp.part = -1;
+  sp.window_ms = window_ms;
+  sp.tail_ms = tail_ms;
+  return model_infer_sharded(m, nchw, B, H, W, in_kind, depth, focallength_px, fovx_deg, fovy_rad, out_kind, (hipStream_t)stream, sp);
+}
+
 int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, int h, int in_kind, float* depth,
                       float* focallength_px, float* fovy_rad, int out_kind, void* stream) {
   if (!rgb) MD_FAIL(MD_ERR_INVALID_ARG, "rgb pointer is null");

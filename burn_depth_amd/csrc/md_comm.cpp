@@ -132,4 +132,55 @@ int md_comm_gather_depth(md_comm_t c, const float* shard_dev, float* all_dev, si
   return MD_OK;
 }
 
+namespace {
+struct TileExchange {
+  md_comm_s* c;
+  int root;
+};
+// Behind a rank's ViT window: every part but the root's sends its three row ranges to the root; the root posts the matching
+// receives. Both sides walk the same table in the same order, so the k-th send of a peer meets the root's k-th receive for it.
+int tile_exchange(void* ctx, int parts, const ShardSegment (*seg)[3], hipStream_t st) {
+  TileExchange* x = (TileExchange*)ctx;
+  md_comm_s* c = x->c;
+  MD_NCCL(ncclGroupStart());
+  if (c->rank == x->root) {
+    for (int p = 0; p < parts; ++p)
+      if (p != x->root)
+        for (int k = 0; k < 3; ++k)
+          if (seg[p][k].bytes) MD_NCCL(ncclRecv(seg[p][k].ptr, seg[p][k].bytes, ncclInt8, p, c->comm, st));
+  } else {
+    for (int k = 0; k < 3; ++k)
+      if (seg[c->rank][k].bytes) MD_NCCL(ncclSend(seg[c->rank][k].ptr, seg[c->rank][k].bytes, ncclInt8, x->root, c->comm, st));
+  }
+  MD_NCCL(ncclGroupEnd());
+  return MD_OK;
+}
+}  // namespace
+
+int md_comm_depth_pro_infer_tiles(md_comm_t c, md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
+                                  float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, int root, void* stream) {
+  if (!c || !m) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (m->kind != 0) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth Pro model");
+  if (root < 0 || root >= c->world) MD_FAIL(MD_ERR_INVALID_ARG, "root %d of %d", root, c->world);
+  if (c->rank == root && !nchw) MD_FAIL(MD_ERR_INVALID_ARG, "the root rank needs the input");
+  if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
+  if (m->dev != c->dev) MD_FAIL(MD_ERR_INVALID_ARG, "model and communicator live on different devices");
+  MD_HIP(hipSetDevice(c->dev->ordinal));
+  hipStream_t st = stream ? (hipStream_t)stream : (m->own_stream ? m->own_stream : m->dev->stream);
+  // 1. the root's image reaches every rank's staging buffer (28 MB per 1536^2 frame)
+  const size_t elems = (size_t)B * 3 * H * W;
+  float* x_dev = nullptr;
+  MD_TRY(model_stage_input(m, c->rank == root ? nchw : nullptr, elems, in_kind, st, &x_dev));
+  if (c->world > 1) MD_NCCL(ncclBroadcast(x_dev, x_dev, elems, ncclFloat, root, c->comm, st));
+  // 2. - 4. this rank's window, the exchange, and on the root the rest of the network
+  TileExchange x{c, root};
+  ShardPlan sp;
+  sp.parts = c->world;
+  sp.part = c->rank;
+  sp.root = root;
+  sp.exchange = tile_exchange;
+  sp.ctx = &x;
+  return model_infer_sharded(m, x_dev, B, H, W, MD_MEM_DEVICE, depth, focallength_px, fovx_deg, fovy_rad, out_kind, st, sp);
+}
+
 }  // extern "C"

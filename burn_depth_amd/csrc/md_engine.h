@@ -165,6 +165,27 @@ int model_fork(md_model_t src, md_model_t* out);
 inline md_model_s* model_root(md_model_s* m) { return m->parent ? m->parent : m; }
 int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
+// Tile-parallel mode (SURVEY 8(e) "optional second mode": the 35 + 2 ViT sequences of one image never interact before
+// `merge`, layers/encoder.rs:329-348, 379-390): the ViT stage of ONE call is split into `parts` windows of the sequence
+// range; a rank runs its window, every other part's final tokens and hook rows travel to the root, the root runs the rest.
+struct ShardSegment {
+  void* ptr;
+  size_t bytes;
+};
+struct ShardPlan {
+  int parts = 1;
+  int part = 0;  // this rank's window; -1 = every window one after the other on this device (diagnostic / single-GPU test)
+  int root = 0;  // the part whose rank runs encoder tail, decoder, head and FOV and owns the outputs
+  // called once behind this rank's window, on the engine's stream: seg[p] = {final tokens, hook 0, hook 1} rows of part p
+  int (*exchange)(void* ctx, int parts, const ShardSegment (*seg)[3], hipStream_t st) = nullptr;
+  void* ctx = nullptr;
+  float* window_ms = nullptr;  // part == -1: GPU milliseconds of each window [parts] ...
+  float* tail_ms = nullptr;    // ... and of everything behind the ViT stage
+};
+int model_infer_sharded(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
+                        float* fovx, float* fovy, int out_kind, hipStream_t stream, const ShardPlan& sp);
+// the model's grow-only input staging buffer, holding `elems` floats: filled from `nchw` (host or device) when it is given
+int model_stage_input(md_model_t m, const float* nchw, size_t elems, int in_kind, hipStream_t stream, float** dev);
 int pack_weight(const float* src, const PackEntry& e, int prec, hipStream_t s);
 // number of values of w[0..n) that are not exactly representable as an IEEE half (synchronises the stream)
 int count_inexact_f16(const float* w, long n, hipStream_t s, unsigned* out);

@@ -912,25 +912,41 @@ static int get_index_set(md_model_s* m, int B, md_model_s::IndexSet* out) {
 // ------------------------------------------------------------------------------------------------
 // forward schedule
 // ------------------------------------------------------------------------------------------------
-static int run_vit(Run& r, int nseq_p, int nseq) {
+// The ViT stage over the sequences [s_lo, s_hi) of the 37 B (patch tiles, image, fov): the whole range in the ordinary
+// call; one rank's share in the tile-parallel mode (SURVEY 8(e) second mode -- the tiles of encoder.rs:329-348 never
+// interact before `merge`, so any split of the sequence range is exact). Every launch addresses absolute rows of the
+// workspace, so the windows of different ranks (or of successive calls) fill disjoint row ranges of the same buffers.
+static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
   md_model_s* m = r.m;
   md_model_s::Buffers* b = m->buf;
   const ModelCfg& c = m->cfg;
-  const int B = r.B, D = c.pv.D, P = m->P, SS = m->SS, NT = m->NT, heads = c.pv.heads, G = m->ngroups;
+  const int B = r.B, D = c.pv.D, P = m->P, SS = m->SS, NT = m->NT, heads = c.pv.heads;
   const int n0 = m->steps0 * m->steps0 * B, n1 = m->steps1 * m->steps1 * B;
   const int Kpe = 3 * c.pv.ps * c.pv.ps;
   const int gseq0[3] = {0, nseq_p, nseq_p + B};
   const int gnseq[3] = {nseq_p, B, B};
+  if (s_lo < 0 || s_hi > nseq || s_lo > s_hi) MD_FAIL(MD_ERR_INVALID_ARG, "sequence window [%d, %d) of %d", s_lo, s_hi, nseq);
+  const int WS = s_hi - s_lo;  // sequences of this window
+  if (WS == 0) return MD_OK;
+  // encoder groups clipped to the window: slot g of the launches is encoder gi[g] on sequences [glo[g], glo[g] + gcnt[g])
+  int G = 0, gi[3], glo[3], gcnt[3];
+  for (int g = 0; g < m->ngroups; ++g) {
+    const int lo = std::max(gseq0[g], s_lo), hi = std::min(gseq0[g] + gnseq[g], s_hi);
+    if (hi > lo) { gi[G] = g; glo[G] = lo; gcnt[G] = hi - lo; ++G; }
+  }
+  const size_t esz = (size_t)m->esz * m->xm;  // bytes per logical element of a T tensor
+  auto trow = [&](void* base, int width) { return (void*)((char*)base + (size_t)s_lo * SS * width * esz); };
+  float* xres_w = b->xres + (size_t)s_lo * SS * D;
 
-  SeqGroups sg;
+  SeqGroups sg;  // sequence numbers relative to the window
   sg.ngroups = G;
   for (int g = 0; g < 4; ++g) { sg.seq0[g] = 0; sg.nseq[g] = 0; sg.a[g] = nullptr; sg.b[g] = nullptr; }
-  for (int g = 0; g < G; ++g) { sg.seq0[g] = gseq0[g]; sg.nseq[g] = gnseq[g]; }
+  for (int g = 0; g < G; ++g) { sg.seq0[g] = glo[g] - s_lo; sg.nseq[g] = gcnt[g]; }
 
   // cls + pos[0], padding rows
-  for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].cls; sg.b[g] = m->vit[g].pos; }
+  for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].cls; sg.b[g] = m->vit[gi[g]].pos; }
   r.begin("cls_init");
-  MD_TRY(launch_cls_init(b->xres, nseq, SS, NT, D, sg, r.st));
+  MD_TRY(launch_cls_init(xres_w, WS, SS, NT, D, sg, r.st));
   r.end();
 
   // patch embed (conv 16x16 s16 as GEMM, + bias + pos_embed)
@@ -938,12 +954,13 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     GemmParams p;
     p.N = D; p.K = Kpe; p.ngroups = G;
     for (int g = 0; g < G; ++g) {
-      p.g_row0[g] = gseq0[g] * P;
-      p.g_rows[g] = gnseq[g] * P;
-      p.g_arow0[g] = g == 0 ? 0 : (n0 + n1) * P;  // image/fov encoders read the x2 tiles (encoder.rs:409, fov.rs:202)
-      p.W[g] = m->vit[g].pe_w;
-      p.bias[g] = m->vit[g].pe_b;
-      p.pos[g] = m->vit[g].pos;
+      p.g_row0[g] = glo[g] * P;
+      p.g_rows[g] = gcnt[g] * P;
+      // image/fov encoders read the x2 tiles (encoder.rs:409, fov.rs:202)
+      p.g_arow0[g] = gi[g] == 0 ? glo[g] * P : (n0 + n1 + (glo[g] - gseq0[gi[g]])) * P;
+      p.W[g] = m->vit[gi[g]].pe_w;
+      p.bias[g] = m->vit[gi[g]].pe_b;
+      p.pos[g] = m->vit[gi[g]].pos;
     }
     p.A = b->patches;
     split_dense_a(m, p, Kpe, Kpe, 0);
@@ -952,24 +969,25 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
     MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
     r.end();
   }
-  const long rows = (long)nseq * SS;
+  const long rows = (long)WS * SS;
   auto group_rows = [&](GemmParams& p) {
     p.ngroups = G;
     for (int g = 0; g < G; ++g) {
-      p.g_row0[g] = gseq0[g] * SS;
-      p.g_arow0[g] = gseq0[g] * SS;
-      p.g_rows[g] = gnseq[g] * SS;
+      p.g_row0[g] = glo[g] * SS;
+      p.g_arow0[g] = glo[g] * SS;
+      p.g_rows[g] = gcnt[g] * SS;
     }
   };
+  const size_t vt_seq = (size_t)heads * 64 * m->kpad * m->esz;  // bytes of one sequence in a V^T plane
   for (int i = 0; i < c.pv.depth; ++i) {
-    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].blk[i].n1g; sg.b[g] = m->vit[g].blk[i].n1b; }
+    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n1g; sg.b[g] = m->vit[gi[g]].blk[i].n1b; }
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(b->xres, b->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+    MD_TRY(launch_layernorm(xres_w, trow(b->xn, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
     r.end();
     {
       GemmParams p;
       p.N = 3 * D; group_rows(p);
-      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].qkv_w; p.bias[g] = m->vit[g].blk[i].qkv_b; }
+      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[gi[g]].blk[i].qkv_w; p.bias[g] = m->vit[gi[g]].blk[i].qkv_b; }
       p.A = b->xn;
       split_dense_a(m, p, D, D, 0);
       p.v_plane = (long)m->vt_plane;
@@ -978,31 +996,33 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
     }
+    void* vT_w = (char*)b->vT + (size_t)s_lo * vt_seq;
     if (m->prec != MD_PREC_F32) {
       r.begin("attention");
-      MD_TRY(launch_attention(b->qk, b->vT, b->ao, nseq, SS, NT, heads, D, m->kpad, m->prec, r.st, 0.f, (long)m->vt_plane));
+      MD_TRY(launch_attention(trow(b->qk, 2 * D), vT_w, trow(b->ao, D), WS, SS, NT, heads, D, m->kpad, m->prec, r.st, 0.f, (long)m->vt_plane));
       r.end();
     } else {
       // fp32: scores = q k^T (batched GEMM) -> row softmax -> P V^T^T (batched GEMM)
+      const float* qk_w = (const float*)trow(b->qk, 2 * D);
       GemmParams p;
       p.N = SS; p.K = 64; p.ngroups = 1; p.g_rows[0] = NT;
-      p.batch = nseq * heads; p.batch_inner = heads;
-      p.A = b->qk; p.lda = 2 * D; p.a_bs[0] = (long)SS * 2 * D; p.a_bs[1] = 64;
-      p.W[0] = (const float*)b->qk + D; p.ldw = 2 * D; p.w_bs[0] = (long)SS * 2 * D; p.w_bs[1] = 64;
+      p.batch = WS * heads; p.batch_inner = heads;
+      p.A = qk_w; p.lda = 2 * D; p.a_bs[0] = (long)SS * 2 * D; p.a_bs[1] = 64;
+      p.W[0] = qk_w + D; p.ldw = 2 * D; p.w_bs[0] = (long)SS * 2 * D; p.w_bs[1] = 64;
       p.epi = EPI_STORE; p.out_f32 = 1; p.out = b->scores; p.ldo = m->kpad;
       p.o_bs[0] = (long)heads * SS * m->kpad; p.o_bs[1] = (long)SS * m->kpad;
       r.begin("attn_scores_f32");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_128x128, r.st));
       r.end();
       r.begin("attn_softmax_f32");
-      MD_TRY(launch_softmax_rows(b->scores, (long)nseq * heads * SS, NT, m->kpad, 0.125f, r.st));
+      MD_TRY(launch_softmax_rows(b->scores, (long)WS * heads * SS, NT, m->kpad, 0.125f, r.st));
       r.end();
       GemmParams q;
       q.N = 64; q.K = m->kpad; q.ngroups = 1; q.g_rows[0] = NT;
-      q.batch = nseq * heads; q.batch_inner = heads;
+      q.batch = WS * heads; q.batch_inner = heads;
       q.A = b->scores; q.lda = m->kpad; q.a_bs[0] = (long)heads * SS * m->kpad; q.a_bs[1] = (long)SS * m->kpad;
-      q.W[0] = b->vT; q.ldw = m->kpad; q.w_bs[0] = (long)heads * 64 * m->kpad; q.w_bs[1] = 64L * m->kpad;
-      q.epi = EPI_STORE; q.out = b->ao; q.ldo = D; q.o_bs[0] = (long)SS * D; q.o_bs[1] = 64;
+      q.W[0] = vT_w; q.ldw = m->kpad; q.w_bs[0] = (long)heads * 64 * m->kpad; q.w_bs[1] = 64L * m->kpad;
+      q.epi = EPI_STORE; q.out = trow(b->ao, D); q.ldo = D; q.o_bs[0] = (long)SS * D; q.o_bs[1] = 64;
       r.begin("attn_pv_f32");
       MD_TRY(launch_gemm(q, A_DENSE, m->prec, TILE_128x128, r.st));
       r.end();
@@ -1011,7 +1031,7 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       GemmParams p;
       p.N = D; group_rows(p);
       for (int g = 0; g < G; ++g) {
-        p.W[g] = m->vit[g].blk[i].proj_w; p.bias[g] = m->vit[g].blk[i].proj_b; p.scale[g] = m->vit[g].blk[i].ls1;
+        p.W[g] = m->vit[gi[g]].blk[i].proj_w; p.bias[g] = m->vit[gi[g]].blk[i].proj_b; p.scale[g] = m->vit[gi[g]].blk[i].ls1;
       }
       p.A = b->ao;
       split_dense_a(m, p, D, D, 0);
@@ -1020,14 +1040,14 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
     }
-    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].blk[i].n2g; sg.b[g] = m->vit[g].blk[i].n2b; }
+    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n2g; sg.b[g] = m->vit[gi[g]].blk[i].n2b; }
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(b->xres, b->xn, rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+    MD_TRY(launch_layernorm(xres_w, trow(b->xn, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
     r.end();
     {
       GemmParams p;
       p.N = 4 * D; group_rows(p);
-      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[g].blk[i].fc1_w; p.bias[g] = m->vit[g].blk[i].fc1_b; }
+      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[gi[g]].blk[i].fc1_w; p.bias[g] = m->vit[gi[g]].blk[i].fc1_b; }
       p.A = b->xn;
       split_dense_a(m, p, D, D, 0);
       p.epi = EPI_STORE; p.act = ACT_GELU; p.out = b->hbuf;
@@ -1040,7 +1060,7 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       GemmParams p;
       p.N = D; group_rows(p);
       for (int g = 0; g < G; ++g) {
-        p.W[g] = m->vit[g].blk[i].fc2_w; p.bias[g] = m->vit[g].blk[i].fc2_b; p.scale[g] = m->vit[g].blk[i].ls2;
+        p.W[g] = m->vit[gi[g]].blk[i].fc2_w; p.bias[g] = m->vit[gi[g]].blk[i].fc2_b; p.scale[g] = m->vit[gi[g]].blk[i].ls2;
       }
       p.A = b->hbuf;
       split_dense_a(m, p, 4 * D, 4 * D, 0);
@@ -1049,17 +1069,22 @@ static int run_vit(Run& r, int nseq_p, int nseq) {
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
       r.end();
     }
-    // hooks: un-normalised tokens incl. cls after blocks hook_ids[0], hook_ids[1] (vit.rs:30,63)
+    // hooks: un-normalised tokens incl. cls after blocks hook_ids[0], hook_ids[1] (vit.rs:30,63): the first n0 sequences
+    // (the 5 x 5 high-resolution tiles, encoder.rs:379-390)
     for (int hk = 0; hk < 2; ++hk)
       if (c.pv.hook_ids[hk] == i) {
-        r.begin("hook_copy");
-        MD_TRY(launch_convert_rows(b->xres, b->hook[hk], (long)n0 * SS * D, m->prec, r.st, D));
-        r.end();
+        const int h_lo = std::min(s_lo, n0), h_hi = std::min(s_hi, n0);
+        if (h_hi > h_lo) {
+          r.begin("hook_copy");
+          MD_TRY(launch_convert_rows(b->xres + (size_t)h_lo * SS * D, (char*)b->hook[hk] + (size_t)h_lo * SS * D * esz,
+                                     (long)(h_hi - h_lo) * SS * D, m->prec, r.st, D));
+          r.end();
+        }
       }
   }
-  for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[g].norm_g; sg.b[g] = m->vit[g].norm_b; }
+  for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].norm_g; sg.b[g] = m->vit[gi[g]].norm_b; }
   r.begin("layernorm");
-  MD_TRY(launch_layernorm(b->xres, b->tok, rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+  MD_TRY(launch_layernorm(xres_w, trow(b->tok, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
   r.end();
   return MD_OK;
 }
@@ -1321,7 +1346,8 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
 }
 
 static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
-                             float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
+                             float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len,
+                             const ShardPlan* sp = nullptr);
 
 // Grow-only staging: (re)allocates only when `need` exceeds the capacity. hipFree is a device-wide synchronisation and
 // hipMalloc takes the allocator lock, so a caller that feeds host pointers or a fixed non-native size (the reference's
@@ -1375,8 +1401,33 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
   return run_with_graph(m, st, key, eligible, body);
 }
 
+int model_stage_input(md_model_t m, const float* nchw, size_t elems, int in_kind, hipStream_t stream, float** dev) {
+  if (!m || !dev || elems == 0) MD_FAIL(MD_ERR_INVALID_ARG, "model_stage_input: null argument");
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : (m->own_stream ? m->own_stream : m->dev->stream);
+  md_model_s::Buffers* b = m->buf;
+  if (b->xraw_cap < elems * 4) MD_HIP(hipStreamSynchronize(st));  // nothing may still read the buffer being replaced
+  MD_TRY(ensure_device(m, (void**)&b->xraw, &b->xraw_cap, elems * 4));
+  if (nchw) {
+    if (in_kind == MD_MEM_HOST) MD_TRY(stage_host_to_device(m, b->xraw, nchw, elems * 4, st));
+    else MD_HIP(hipMemcpyAsync(b->xraw, nchw, elems * 4, hipMemcpyDeviceToDevice, st));
+  }
+  *dev = b->xraw;
+  return MD_OK;
+}
+
+int model_infer_sharded(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
+                        float* fovx, float* fovy, int out_kind, hipStream_t stream, const ShardPlan& sp) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  if (sp.parts < 1 || sp.part < -1 || sp.part >= sp.parts || sp.root < 0 || sp.root >= sp.parts)
+    MD_FAIL(MD_ERR_INVALID_ARG, "tile-parallel plan: part %d of %d, root %d", sp.part, sp.parts, sp.root);
+  if (sp.part >= 0 && sp.parts > 1 && !sp.exchange) MD_FAIL(MD_ERR_INVALID_ARG, "tile-parallel plan: no exchange function");
+  return model_infer_eager(m, nchw, B, H, W, in_kind, depth, focal, fovx, fovy, out_kind, stream, nullptr, 0, &sp);
+}
+
 static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
-                             float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len) {
+                             float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len,
+                             const ShardPlan* sp) {
   if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
   if (!model_root(m)->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
   if (!nchw && !rgb) MD_FAIL(MD_ERR_INVALID_ARG, "input pointer is null");
@@ -1436,7 +1487,46 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
   r.end();
   md_model_s::IndexSet ix;
   MD_TRY(get_index_set(m, B, &ix));
-  MD_TRY(run_vit(r, nseq_p, nseq));
+  hipEvent_t ev_w[66] = {};  // diagnostic timing of the windowed pass (sp->part == -1)
+  const bool time_windows = sp && sp->part < 0 && (sp->window_ms || sp->tail_ms) && sp->parts <= 64;
+  if (!sp) {
+    MD_TRY(run_vit(r, nseq_p, nseq, 0, nseq));
+  } else {
+    auto lo_of = [&](int p) { return (int)((long)nseq * p / sp->parts); };
+    if (sp->part < 0) {  // every window in turn on this device: the same launches a rank of each part would issue
+      for (int p = 0; p < sp->parts; ++p) {
+        if (time_windows) { MD_HIP(hipEventCreate(&ev_w[p])); MD_HIP(hipEventRecord(ev_w[p], st)); }
+        MD_TRY(run_vit(r, nseq_p, nseq, lo_of(p), lo_of(p + 1)));
+      }
+      if (time_windows) { MD_HIP(hipEventCreate(&ev_w[sp->parts])); MD_HIP(hipEventRecord(ev_w[sp->parts], st)); }
+    } else {
+      MD_TRY(run_vit(r, nseq_p, nseq, lo_of(sp->part), lo_of(sp->part + 1)));
+      if (sp->parts > 1) {
+        const size_t rowb = (size_t)m->SS * m->cfg.pv.D * m->esz * m->xm;  // bytes of one sequence of a [rows, D] T tensor
+        std::vector<ShardSegment> segs((size_t)sp->parts * 3);
+        for (int p = 0; p < sp->parts; ++p) {
+          const int lo = lo_of(p), hi = lo_of(p + 1), hlo = std::min(lo, n0), hhi = std::min(hi, n0);
+          segs[3 * p + 0] = {(char*)b->tok + (size_t)lo * rowb, (size_t)(hi - lo) * rowb};
+          segs[3 * p + 1] = {(char*)b->hook[0] + (size_t)hlo * rowb, (size_t)(hhi - hlo) * rowb};
+          segs[3 * p + 2] = {(char*)b->hook[1] + (size_t)hlo * rowb, (size_t)(hhi - hlo) * rowb};
+        }
+        MD_TRY(sp->exchange(sp->ctx, sp->parts, (const ShardSegment(*)[3])segs.data(), st));
+      }
+      if (sp->part != sp->root) return MD_OK;  // this rank's share ends here: the root owns the rest and the outputs
+    }
+  }
+  auto finish_timing = [&]() -> int {
+    if (!time_windows) return MD_OK;
+    const int np = sp->parts;
+    MD_HIP(hipEventCreate(&ev_w[np + 1]));
+    MD_HIP(hipEventRecord(ev_w[np + 1], st));
+    MD_HIP(hipEventSynchronize(ev_w[np + 1]));
+    for (int p = 0; p < np; ++p)
+      if (sp->window_ms) MD_HIP(hipEventElapsedTime(&sp->window_ms[p], ev_w[p], ev_w[p + 1]));
+    if (sp->tail_ms) MD_HIP(hipEventElapsedTime(sp->tail_ms, ev_w[np], ev_w[np + 1]));
+    for (int p = 0; p <= np + 1; ++p) (void)hipEventDestroy(ev_w[p]);
+    return MD_OK;
+  };
   MD_TRY(run_encoder_tail(r, ix));
   MD_TRY(run_decoder_head(r));
   MD_TRY(run_fov(r, ix));
@@ -1482,7 +1572,7 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
     if (depth) memcpy(depth, ph, dbytes);
     for (int i = 0; i < 3; ++i)
       if (dsts[i]) memcpy(dsts[i], ph + dbytes + (size_t)i * B * 4, (size_t)B * 4);
-    return MD_OK;
+    return finish_timing();
   }
   auto copy_out = [&](float* dst, const float* src, size_t n) -> int {
     if (!dst) return MD_OK;
@@ -1492,7 +1582,7 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
   MD_TRY(copy_out(focal, b->focal, B));
   MD_TRY(copy_out(fovx, b->fov_deg, B));
   MD_TRY(copy_out(fovy, b->fovy, B));
-  return MD_OK;
+  return finish_timing();
 }
 
 }  // namespace md

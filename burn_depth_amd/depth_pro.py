@@ -219,6 +219,29 @@ class DepthPro:
                                                 C.c_void_p(fovx.data_ptr()), C.c_void_p(fovy.data_ptr()),
                                                 _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
 
+    def infer_windows(self, x: torch.Tensor, parts: int, timings: bool = False):
+        """`infer` with the ViT stage run as `parts` consecutive windows of its 37 B sequences on this GPU -- the launches the
+        ranks of the tile-parallel mode (`NativeComm.infer_tiles`) issue, without the exchange. Bit-identical to `infer`.
+        With `timings`, also returns (window_ms list, tail_ms): GPU milliseconds of each window and of everything behind the
+        ViT stage."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
+        x = x.contiguous().to(torch.float32)
+        B, _, H, W = x.shape
+        dev = torch.device("cuda", self.device.ordinal)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        focal, fovx, fovy = (torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(3))
+        wms = (C.c_float * max(int(parts), 1))()
+        tms = C.c_float()
+        in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_depth_pro_infer_windows(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind,
+                                                        C.c_void_p(depth.data_ptr()), C.c_void_p(focal.data_ptr()),
+                                                        C.c_void_p(fovx.data_ptr()), C.c_void_p(fovy.data_ptr()), _lib.MD_MEM_DEVICE,
+                                                        int(parts), wms if timings else None, C.byref(tms) if timings else None,
+                                                        _stream_ptr(self.device.ordinal)))
+        out = DepthProInference(depth, focal, fovx, fovy)
+        return (out, [float(v) for v in wms], float(tms.value)) if timings else out
+
     def infer_from_rgb(self, rgb: bytes, width: int, height: int) -> DepthProInference:
         """`infer_from_rgb` (src/inference.rs:128-137); raises MdError(MD_ERR_SHAPE) on a bad length."""
         dev = torch.device("cuda", self.device.ordinal)

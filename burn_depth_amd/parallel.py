@@ -102,6 +102,29 @@ class NativeComm:
         p = C.c_void_p(all_depth.data_ptr()) if all_depth is not None else None
         self._L.check(self._lib.md_comm_gather_depth(self._h, C.c_void_p(shard.data_ptr()), p, shard.numel(), int(root), C.c_void_p(stream)))
 
+    def infer_tiles(self, model, x: Optional[torch.Tensor], shape, root: int = 0, stream: int = 0):
+        """Tile-parallel `DepthPro::infer` of ONE call (md_comm_depth_pro_infer_tiles): every rank calls it with its replica of
+        the same weights; `x` [B,3,H,W] (host or device) on the root, None elsewhere; `shape` = (B, H, W) on every rank. The
+        root returns a DepthProInference (bit-identical to `model.infer(x)` on one GPU), the other ranks None."""
+        from .depth_pro import DepthProInference
+        B, H, W = (int(v) for v in shape)
+        stream = stream or torch.cuda.current_stream(torch.device("cuda", model.device.ordinal)).cuda_stream  # like model.infer
+        if self.rank == root:
+            x = x.contiguous().to(torch.float32)
+            assert tuple(x.shape) == (B, 3, H, W)
+            dev = torch.device("cuda", model.device.ordinal)
+            depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            focal, fovx, fovy = (torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(3))
+            in_kind = self._L.MD_MEM_DEVICE if x.is_cuda else self._L.MD_MEM_HOST
+            self._L.check(self._lib.md_comm_depth_pro_infer_tiles(self._h, model._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind,
+                                                                  C.c_void_p(depth.data_ptr()), C.c_void_p(focal.data_ptr()),
+                                                                  C.c_void_p(fovx.data_ptr()), C.c_void_p(fovy.data_ptr()),
+                                                                  self._L.MD_MEM_DEVICE, int(root), C.c_void_p(stream)))
+            return DepthProInference(depth, focal, fovx, fovy)
+        self._L.check(self._lib.md_comm_depth_pro_infer_tiles(self._h, model._h, None, B, H, W, self._L.MD_MEM_DEVICE, None, None, None, None,
+                                                              self._L.MD_MEM_DEVICE, int(root), C.c_void_p(stream)))
+        return None
+
     def destroy(self) -> None:
         if self._h:
             self._lib.md_comm_destroy(self._h)

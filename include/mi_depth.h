@@ -137,6 +137,17 @@ int md_model_fork(md_model_t m, md_model_t* out);
 int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                        float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream);
 
+/* The same call with the ViT stage run as `parts` consecutive windows of its 37 B sequences (35 B patch tiles + B image +
+ * B fov, layers/encoder.rs:329-348, 409; fov.rs:203) on THIS device: the launches the `parts` ranks of
+ * md_comm_depth_pro_infer_tiles issue, one rank after the other, without the exchange. Results are bit-identical to
+ * md_depth_pro_infer (the tiles never interact before `merge`). Single-GPU test and projection tool of the tile-parallel
+ * mode: window_ms[parts] / tail_ms (either may be NULL) receive the GPU milliseconds of each window and of everything
+ * behind the ViT stage, so max(window_ms) + tail_ms is the device time of one frame on `parts` GPUs before the exchange.
+ * 1 <= parts <= 64; synchronises the stream when timings are requested. */
+int md_depth_pro_infer_windows(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
+                               float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, int parts,
+                               float* window_ms, float* tail_ms, void* stream);
+
 /* `infer_from_rgb` + `rgb_to_input_tensor` (src/inference.rs:79-137): packed RGB bytes,
  * row-major, `rgb_len` must equal w*h*3 (else MD_ERR_SHAPE, as the reference's Err). B = 1. */
 int md_infer_from_rgb(md_model_t m, const uint8_t* rgb, size_t rgb_len, int w, int h, int in_kind,
@@ -325,6 +336,20 @@ int md_comm_broadcast_weights(md_comm_t c, md_model_t m, int root);
 int md_comm_scatter_images(md_comm_t c, const float* all_dev, float* shard_dev, size_t elems_per_rank, int root, void* stream);
 /* Collective: the inverse for the results (depth [B,H,W] per rank -> [world*B,H,W] on the root). */
 int md_comm_gather_depth(md_comm_t c, const float* shard_dev, float* all_dev, size_t elems_per_rank, int root, void* stream);
+
+/* Tile-parallel `DepthPro::infer` for ONE call (second mode: the only way more GPUs shorten the latency of a
+ * single image). Every rank of `comm` calls it with its replica of the same committed weights (md_comm_broadcast_weights):
+ *   1. the root's input [B,3,H,W] (host or device pointer; NULL on the other ranks) is broadcast to every rank's staging buffer;
+ *   2. rank r runs pyramid + patchify (0.02 ms) and the three ViT encoders on sequences [37B*r/n, 37B*(r+1)/n) of the 37 B
+ *      (the sliding-window tiles of layers/encoder.rs:329-348 and the image / fov sequences never interact before `merge`);
+ *   3. the final tokens of every window and the two hook outputs of its high-resolution tiles (encoder.rs:375-390) go to the
+ *      root as ONE group of ncclSend / ncclRecv (B = 1, bf16: 100 MB in total, 1/n of it per link);
+ *   4. the root runs merge, encoder tail, decoder, head and FOV network and fills the outputs; the other ranks return after
+ *      their send (their output pointers are ignored and may be NULL).
+ * The result on the root is bit-identical to md_depth_pro_infer on one GPU. Eager only (no graph replay). */
+int md_comm_depth_pro_infer_tiles(md_comm_t comm, md_model_t model, const float* nchw, int B, int H, int W, int in_kind,
+                                  float* depth, float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind,
+                                  int root, void* stream);
 
 /* ---- host-only utilities (no GPU needed) ---------------------------------------------------- */
 /* The parameter inventory of `DepthPro::new` for a config: returns the number of parameters; for

@@ -853,9 +853,71 @@ def test_native_rccl_entry_points_one_rank(dev):
         comm.gather_depth(d, gathered, root=0, stream=st)
         torch.cuda.synchronize()
         assert torch.equal(shard, x) and torch.equal(gathered, before)
+        # tile-parallel entry point on the 1-rank group: stage + (no) broadcast, the whole sequence range, no exchange
+        t = comm.infer_tiles(m, x, (2, 512, 512), root=0)
+        th = comm.infer_tiles(m, x.cpu(), (2, 512, 512), root=0)  # host input on the root
+        torch.cuda.synchronize()
+        assert torch.equal(t.depth, before) and torch.equal(th.depth, before)
         m.destroy()
     finally:
         comm.destroy()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16x2"])
+def test_tile_parallel_windows_are_bit_identical(dev, precision):
+    """SURVEY 8(e), second mode: the ViT stage of one call split over sequence windows (the sliding-window tiles of
+    layers/encoder.rs:329-348 plus the image / fov sequences never interact before `merge`). `infer_windows` issues, on ONE
+    GPU and one window after the other, exactly the launches the ranks of md_comm_depth_pro_infer_tiles issue -- the result
+    must not depend on the split: equal parts, ragged parts, one sequence per part, more parts than sequences (empty windows),
+    windows that straddle the patch / image / fov encoders, a non-native input size."""
+    from burn_depth_amd import _lib
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = {"f32": Precision.F32, "bf16": Precision.BF16, "f16x2": Precision.F16X2}[precision]
+    cfg.max_batch = 2
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    torch.manual_seed(11)
+    x = torch.randn(2, 3, 512, 512, device="cuda")
+    want = m.infer(x)
+    nseq = 37 * 2
+    for parts in (1, 2, 3, 8, 37, 64):
+        got = m.infer_windows(x, parts)
+        for a, b in ((got.depth, want.depth), (got.fovx_deg, want.fovx_deg), (got.focallength_px, want.focallength_px)):
+            assert torch.equal(a, b), (precision, parts)
+    assert nseq > 64  # so parts = 64 is "nearly one sequence per part"; B = 1 below has 37 < 64: empty windows
+    x1 = torch.randn(1, 3, 360, 540, device="cuda")  # resize in and out (mod.rs:317-325, 348-354)
+    w1 = m.infer(x1)
+    for parts in (5, 40, 64):
+        assert torch.equal(m.infer_windows(x1, parts).depth, w1.depth), (precision, parts)
+    got, wms, tms = m.infer_windows(x, 8, timings=True)
+    assert torch.equal(got.depth, want.depth) and len(wms) == 8 and all(v > 0 for v in wms) and tms > 0
+    for bad in (0, 65):
+        with pytest.raises(_lib.MdError) as e:
+            m.infer_windows(x, bad)
+        assert e.value.code == _lib.MD_ERR_INVALID_ARG
+    m.destroy()
+
+
+def test_tile_parallel_full_size_projection(dev):
+    """The default model at [1,3,1536,1536] in bf16: 8 windows of the 37 sequences equal the one-pass result bit for bit, and
+    the per-window / tail device times give the projected latency of the 8-GPU tile-parallel call (before the exchange)."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig()
+    cfg.precision, cfg.max_batch = Precision.BF16, 1
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    torch.manual_seed(2)
+    x = torch.randn(1, 3, 1536, 1536, device="cuda")
+    want = m.infer(x)
+    for parts in (2, 4, 8):
+        got, wms, tms = m.infer_windows(x, parts, timings=True)
+        assert torch.equal(got.depth, want.depth) and torch.equal(got.fovx_deg, want.fovx_deg), parts
+        print(f"tile-parallel projection, {parts} parts: windows {[round(v, 2) for v in wms]} ms, tail {tms:.2f} ms -> "
+              f"{max(wms) + tms:.2f} ms per frame before the exchange")
+    m.destroy()
 
 
 def test_graph_replay_matches_eager(dev):
