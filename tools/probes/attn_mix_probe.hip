@@ -1,0 +1,127 @@
+// Ceiling probe for the fused attention kernel (gfx950): the per-tile INSTRUCTION MIX of attention_kernel's fast body --
+// 8 + 8 v_mfma_f32_32x32x16_bf16 (S^T = K.Q^T over 4 k-steps for two 32-key blocks; O^T += V^T.P^T for 2 x 2 x 2 steps),
+// 32 v_exp_f32, 32 + 3 row-sum adds, 16 v_cvt_pk_bf16_f32 -- with the kernel's data dependencies (the S chain of four MFMAs per
+// block, exponentials on its accumulator, the packed exponentials as the B operand of the P.V MFMAs) but WITHOUT any memory
+// traffic: the K / V^T fragments are loop-invariant registers, there is no LDS read, no LDS-DMA, no barrier.
+// What it measures: the rate this mix reaches under the hardware's issue rules and hipcc's schedule at 1 .. 4 waves per SIMD.
+// attention_kernel cannot be faster than this; the distance between the two is what LDS fragment reads, LDS-DMA issue and the
+// tile barrier cost. Variants: 0 full mix, 1 MFMAs only (the matrix-pipe bound of the dependency structure), 2 no exponentials
+// (adds + packs stay), 3 no row sums.
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o tools/probes/build/attn_mix_probe tools/probes/attn_mix_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(4))) int i4;
+typedef __attribute__((ext_vector_type(16))) float f16v;
+
+__device__ __forceinline__ f16v mma(const i4& a, const i4& b, const f16v& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int pack2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  return __builtin_bit_cast(int, __builtin_convertvector((f2){a, b}, bf2));
+}
+
+template <int VARIANT, int WPS>
+__global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ seed, float* __restrict__ out, int tiles) {
+  const int lane = threadIdx.x & 63;
+  // loop-invariant "fragments" (opaque to the compiler: loaded from memory once)
+  // (one K fragment per 32-key block and one V^T fragment per d-tile, reused over the k-steps: the real kernel reads them from
+  // LDS just in time, so they must not occupy 64 registers here -- the probe has to fit four waves per SIMD like the kernel)
+  i4 kf[2], vf[2], qf[4];
+  for (int s = 0; s < 4; ++s) qf[s] = *(const i4*)(seed + ((lane + s * 64) & 1023) * 4);
+  for (int sub = 0; sub < 2; ++sub) kf[sub] = *(const i4*)(seed + ((lane + 256 + sub * 64) & 1023) * 4);
+  for (int dt = 0; dt < 2; ++dt) vf[dt] = *(const i4*)(seed + ((lane + 512 + dt * 64) & 1023) * 4);
+  f16v o[2] = {{0.f}, {0.f}};
+  float l_run = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    f16v st[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) st[sub] = mma(kf[sub], qf[s], s == 0 ? (f16v){0.f} : st[sub]);
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      i4 pf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sv = st[sub][8 * s2 + j];
+          p[j] = (VARIANT == 1 || VARIANT == 2) ? sv : __builtin_amdgcn_exp2f(sv);
+          if (VARIANT != 1 && VARIANT != 3) ps[j & 3] += p[j];
+        }
+        if (VARIANT != 1) {
+          pf[s2][0] = pack2(p[0], p[1]);
+          pf[s2][1] = pack2(p[2], p[3]);
+          pf[s2][2] = pack2(p[4], p[5]);
+          pf[s2][3] = pack2(p[6], p[7]);
+        } else {  // MFMAs only: the accumulator's raw bits are the next B operand (keeps the S -> P.V dependency)
+          pf[s2][0] = __builtin_bit_cast(int, p[0]);
+          pf[s2][1] = __builtin_bit_cast(int, p[2]);
+          pf[s2][2] = __builtin_bit_cast(int, p[4]);
+          pf[s2][3] = __builtin_bit_cast(int, p[6]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mma(vf[dt], pf[s2], o[dt]);
+    }
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    // keep the next tile's scores finite and data-dependent without extra vector work: rotate the q fragments (scalar-free moves
+    // are folded by the compiler into operand choice)
+    const i4 q0 = qf[0];
+    qf[0] = qf[1]; qf[1] = qf[2]; qf[2] = qf[3]; qf[3] = q0;
+  }
+  float acc = l_run;
+  for (int r = 0; r < 16; ++r) acc += o[0][r] + o[1][r];
+  if (acc == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = acc;  // never true: keeps everything alive
+}
+
+template <int VARIANT, int WPS>
+static double run(const int* seed, float* out, int tiles) {
+  // WPS waves per SIMD = WPS workgroups of 4 waves per CU; 256 CUs
+  const int blocks = 256 * WPS;
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipLaunchKernelGGL((mix_kernel<VARIANT, WPS>), dim3(blocks), dim3(256), 0, 0, seed, out, tiles);  // warm-up
+  float best = 1e30f;
+  for (int it = 0; it < 5; ++it) {
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL((mix_kernel<VARIANT, WPS>), dim3(blocks), dim3(256), 0, 0, seed, out, tiles);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    if (ms < best) best = ms;
+  }
+  const double flops = 16.0 * 2.0 * 32 * 32 * 16 * (double)tiles * 4.0 * blocks;  // 16 MFMAs per wave and tile
+  return flops / (best * 1e-3) / 1e12;
+}
+
+int main() {
+  int* seed;
+  float* out;
+  hipMalloc(&seed, 4096 * 4);
+  hipMalloc(&out, 256 * 4 * 256 * 4);
+  int h[4096];
+  for (int i = 0; i < 4096; ++i) h[i] = 0x3c003c00 + (i * 2654435761u >> 20 & 0x00ff00ff);  // bf16 pairs near 0.008: scores stay small
+  hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
+  const int tiles = 2000;
+  const char* names[4] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums"};
+  printf("attention instruction-mix ceiling, no memory traffic, 256 CUs, TFLOP/s of the 16 MFMAs per tile (peak 2500):\n");
+#define ROW(V)                                                                                                              \
+  printf("  %-50s 1 wave/SIMD %7.0f   2 %7.0f   3 %7.0f   4 %7.0f\n", names[V], run<V, 1>(seed, out, tiles), run<V, 2>(seed, out, tiles), \
+         run<V, 3>(seed, out, tiles), run<V, 4>(seed, out, tiles));
+  ROW(0) ROW(1) ROW(2) ROW(3)
+  return 0;
+}
