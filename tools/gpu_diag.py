@@ -703,6 +703,8 @@ def main():
         check_attention(dev)
         check_convs(dev)
         check_storage_epilogues(dev)
+    if want("attention") and only is not None:
+        check_attention(dev)
     if want("linear") and only is not None:
         check_linear(dev)
         check_linear_fp8(dev)
