@@ -637,14 +637,17 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY, taps=False):
     if precision == Precision.FP8:
         # e4m3 operands in the four ViT linear layers: compared with the oracle running the SAME quantisation
         # (bf16 operand rounding elsewhere), and reported against the fp32 oracle
-        with torch.no_grad():
-            refq = D3.infer(x, W, cfg, q=R.bf16_round, fp8=True)
-        rq = refq["depth"]
-        relq = (d - rq).abs() / rq.abs()
-        record(f"{label} depth max-rel vs fp8-emulating oracle", relq.max().item(), 1.5e-1, f"mean-rel={relq.mean().item():.2e}")
-        record(f"{label} depth mean-rel vs fp8-emulating oracle", relq.mean().item(), 1.5e-2)
         record(f"{label} depth mean-rel vs fp32 oracle (quantisation error)", rel.mean().item(), 6e-2, f"max-rel={rel.max().item():.2e}")
-        record(f"{label} oracle: fp8 emulation vs fp32 mean-rel (informative)", ((rq - rd).abs() / rd.abs()).mean().item(), 6e-2)
+        # the second CPU frame (the oracle with the engine's quantisation) only below 3000 tokens: at 1036^2 it costs 80 s of the
+        # GPU suite for bounds no tighter than the fp32 comparison above; the 518^2 tests carry it
+        if (cfg.image_size // 14) * ((getattr(cfg, "image_width", 0) or cfg.image_size) // 14) < 3000:
+            with torch.no_grad():
+                refq = D3.infer(x, W, cfg, q=R.bf16_round, fp8=True)
+            rq = refq["depth"]
+            relq = (d - rq).abs() / rq.abs()
+            record(f"{label} depth max-rel vs fp8-emulating oracle", relq.max().item(), 1.5e-1, f"mean-rel={relq.mean().item():.2e}")
+            record(f"{label} depth mean-rel vs fp8-emulating oracle", relq.mean().item(), 1.5e-2)
+            record(f"{label} oracle: fp8 emulation vs fp32 mean-rel (informative)", ((rq - rd).abs() / rd.abs()).mean().item(), 6e-2)
         model.enable_timing(True)
         model.infer(x.cuda())
         tm = model.read_timing()

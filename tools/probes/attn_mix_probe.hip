@@ -29,6 +29,22 @@ __device__ __forceinline__ int pack2(float a, float b) {
 template <int VARIANT, int WPS>
 __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ seed, float* __restrict__ out, int tiles) {
   const int lane = threadIdx.x & 63;
+  // variants 4 / 5: the sixteen fragments of a tile come from a 16-KB LDS image (conflict-free ds_read_b128, the kernel's
+  // swizzle), still without LDS-DMA and barrier: 4 = each group of four reads right before its MFMAs (what the kernel's source
+  // says), 5 = the eight K reads before the S MFMAs and the eight V^T reads behind them (whole tile in flight)
+  constexpr bool LDSV = VARIANT >= 4;
+  __shared__ __attribute__((aligned(16))) char tile_img[LDSV ? 16384 : 16];
+  if (LDSV) {
+    for (int i = threadIdx.x; i < 1024; i += 256) ((i4*)tile_img)[i] = *(const i4*)(seed + (i & 1023) * 4);
+    __syncthreads();
+  }
+  const int hh = lane >> 5, cc = lane & 31;
+  int koffp[2], voffp[2];
+  for (int sub = 0; sub < 2; ++sub) {
+    const int R = sub * 32 + cc;
+    koffp[sub] = R * 128 + ((((R >> 1) & 7) ^ hh) << 4);
+    voffp[sub] = 8192 + R * 128 + ((((R >> 1) & 7) ^ hh) << 4);
+  }
   // loop-invariant "fragments" (opaque to the compiler: loaded from memory once)
   // (one K fragment per 32-key block and one V^T fragment per d-tile, reused over the k-steps: the real kernel reads them from
   // LDS just in time, so they must not occupy 64 registers here -- the probe has to fit four waves per SIMD like the kernel)
@@ -39,11 +55,34 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
   f16v o[2] = {{0.f}, {0.f}};
   float l_run = 0.f;
   for (int t = 0; t < tiles; ++t) {
+    if (LDSV) asm volatile("" ::: "memory");  // the image counts as rewritten every tile: no hoisting of the fragment reads
     f16v st[2];
+    i4 kfr[2][4], vfr[2][2][2];
+    if constexpr (VARIANT == 5) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kfr[sub][s] = *(const i4*)(tile_img + (koffp[sub] ^ (s << 5)));
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) st[sub] = mma(kf[sub], qf[s], s == 0 ? (f16v){0.f} : st[sub]);
+      for (int s = 0; s < 4; ++s) {
+        i4 a = kf[sub];
+        if constexpr (VARIANT == 4) a = *(const i4*)(tile_img + (koffp[sub] ^ (s << 5)));
+        if constexpr (VARIANT == 5) a = kfr[sub][s];
+        st[sub] = mma(a, qf[s], s == 0 ? (f16v){0.f} : st[sub]);
+      }
+    }
+    if constexpr (VARIANT == 5) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vfr[sub][s2][dt] = *(const i4*)(tile_img + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+      __builtin_amdgcn_sched_barrier(0);
     }
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -55,7 +94,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float sv = st[sub][8 * s2 + j];
-          p[j] = (VARIANT == 1 || VARIANT == 2) ? sv : __builtin_amdgcn_exp2f(sv);
+          p[j] = (VARIANT == 1 || VARIANT == 2) ? sv : __builtin_amdgcn_exp2f(sv);  // variants 0, 3, 4, 5 exponentiate
           if (VARIANT != 1 && VARIANT != 3) ps[j & 3] += p[j];
         }
         if (VARIANT != 1) {
@@ -73,7 +112,12 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = mma(vf[dt], pf[s2], o[dt]);
+        for (int dt = 0; dt < 2; ++dt) {
+          i4 a = vf[dt];
+          if constexpr (VARIANT == 4) a = *(const i4*)(tile_img + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+          if constexpr (VARIANT == 5) a = vfr[sub][s2][dt];
+          o[dt] = mma(a, pf[s2], o[dt]);
+        }
     }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
     // keep the next tile's scores finite and data-dependent without extra vector work: rotate the q fragments (scalar-free moves
@@ -117,11 +161,12 @@ int main() {
   for (int i = 0; i < 4096; ++i) h[i] = 0x3c003c00 + (i * 2654435761u >> 20 & 0x00ff00ff);  // bf16 pairs near 0.008: scores stay small
   hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
   const int tiles = 2000;
-  const char* names[4] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums"};
+  const char* names[6] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums",
+                          "full mix + 16 ds_read_b128, read before use", "full mix + 16 ds_read_b128, whole tile in flight"};
   printf("attention instruction-mix ceiling, no memory traffic, 256 CUs, TFLOP/s of the 16 MFMAs per tile (peak 2500):\n");
 #define ROW(V)                                                                                                              \
   printf("  %-50s 1 wave/SIMD %7.0f   2 %7.0f   3 %7.0f   4 %7.0f\n", names[V], run<V, 1>(seed, out, tiles), run<V, 2>(seed, out, tiles), \
          run<V, 3>(seed, out, tiles), run<V, 4>(seed, out, tiles));
-  ROW(0) ROW(1) ROW(2) ROW(3)
+  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5)
   return 0;
 }
