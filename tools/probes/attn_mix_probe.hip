@@ -32,8 +32,12 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
   // variants 4 / 5: the sixteen fragments of a tile come from a 16-KB LDS image (conflict-free ds_read_b128, the kernel's
   // swizzle), still without LDS-DMA and barrier: 4 = each group of four reads right before its MFMAs (what the kernel's source
   // says), 5 = the eight K reads before the S MFMAs and the eight V^T reads behind them (whole tile in flight)
+  // variants 6 / 7: variant 4 + the kernel's streaming -- a two-stage ring, four LDS-DMA wave-instructions per wave and tile
+  // (buffer_load ... lds, 1 KB each) from a 1-MB global table: 6 = issue only (no wait: what the issue itself costs), 7 = with
+  // s_waitcnt vmcnt(0) + s_barrier at the top of every tile (the kernel's `top`)
   constexpr bool LDSV = VARIANT >= 4;
-  __shared__ __attribute__((aligned(16))) char tile_img[LDSV ? 16384 : 16];
+  constexpr bool STREAM = VARIANT >= 6;
+  __shared__ __attribute__((aligned(16))) char tile_img[LDSV ? (STREAM ? 32768 : 16384) : 16];
   if (LDSV) {
     for (int i = threadIdx.x; i < 1024; i += 256) ((i4*)tile_img)[i] = *(const i4*)(seed + (i & 1023) * 4);
     __syncthreads();
@@ -54,8 +58,20 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
   for (int dt = 0; dt < 2; ++dt) vf[dt] = *(const i4*)(seed + ((lane + 512 + dt * 64) & 1023) * 4);
   f16v o[2] = {{0.f}, {0.f}};
   float l_run = 0.f;
+  const int wave = threadIdx.x >> 6;
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)seed, 0, 1 << 20, 0x00020000);
+  const int voff_dma = ((lane >> 3) * 128 + (lane & 7) * 16) + wave * 1024 + (blockIdx.x & 15) * 16384;
   for (int t = 0; t < tiles; ++t) {
     if (LDSV) asm volatile("" ::: "memory");  // the image counts as rewritten every tile: no hoisting of the fragment reads
+    if constexpr (STREAM) {
+      if constexpr (VARIANT == 7) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(tile_img + ((t + 1) & 1) * 16384 + wave * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, voff_dma, ((t & 31) * 16384 + i * 4096) & 0xfffff, 0, 0);
+    }
     f16v st[2];
     i4 kfr[2][4], vfr[2][2][2];
     if constexpr (VARIANT == 5) {
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         i4 a = kf[sub];
-        if constexpr (VARIANT == 4) a = *(const i4*)(tile_img + (koffp[sub] ^ (s << 5)));
+        if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t & 1) * 16384 : 0) + (koffp[sub] ^ (s << 5)));
         if constexpr (VARIANT == 5) a = kfr[sub][s];
         st[sub] = mma(a, qf[s], s == 0 ? (f16v){0.f} : st[sub]);
       }
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           i4 a = vf[dt];
-          if constexpr (VARIANT == 4) a = *(const i4*)(tile_img + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+          if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t & 1) * 16384 : 0) + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
           if constexpr (VARIANT == 5) a = vfr[sub][s2][dt];
           o[dt] = mma(a, pf[s2], o[dt]);
         }
@@ -155,18 +171,20 @@ static double run(const int* seed, float* out, int tiles) {
 int main() {
   int* seed;
   float* out;
-  hipMalloc(&seed, 4096 * 4);
+  hipMalloc(&seed, 1 << 20);
+  hipMemset(seed, 0x3c, 1 << 20);
   hipMalloc(&out, 256 * 4 * 256 * 4);
   int h[4096];
   for (int i = 0; i < 4096; ++i) h[i] = 0x3c003c00 + (i * 2654435761u >> 20 & 0x00ff00ff);  // bf16 pairs near 0.008: scores stay small
   hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
   const int tiles = 2000;
-  const char* names[6] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums",
-                          "full mix + 16 ds_read_b128, read before use", "full mix + 16 ds_read_b128, whole tile in flight"};
+  const char* names[8] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums",
+                          "full mix + 16 ds_read_b128, read before use", "full mix + 16 ds_read_b128, whole tile in flight",
+                          "... + 4 LDS-DMA per wave and tile, issue only", "... + 4 LDS-DMA + vmcnt(0) + barrier per tile (= the kernel)"};
   printf("attention instruction-mix ceiling, no memory traffic, 256 CUs, TFLOP/s of the 16 MFMAs per tile (peak 2500):\n");
 #define ROW(V)                                                                                                              \
   printf("  %-50s 1 wave/SIMD %7.0f   2 %7.0f   3 %7.0f   4 %7.0f\n", names[V], run<V, 1>(seed, out, tiles), run<V, 2>(seed, out, tiles), \
          run<V, 3>(seed, out, tiles), run<V, 4>(seed, out, tiles));
-  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5)
+  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7)
   return 0;
 }
