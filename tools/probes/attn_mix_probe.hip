@@ -27,7 +27,7 @@ __device__ __forceinline__ int pack2(float a, float b) {
 }
 
 template <int VARIANT, int WPS>
-__global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ seed, float* __restrict__ out, int tiles) {
+__global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ seed, float* __restrict__ out, int tiles, const char* __restrict__ big) {
   const int lane = threadIdx.x & 63;
   // variants 4 / 5: the sixteen fragments of a tile come from a 16-KB LDS image (conflict-free ds_read_b128, the kernel's
   // swizzle), still without LDS-DMA and barrier: 4 = each group of four reads right before its MFMAs (what the kernel's source
@@ -37,7 +37,14 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
   // s_waitcnt vmcnt(0) + s_barrier at the top of every tile (the kernel's `top`)
   constexpr bool LDSV = VARIANT >= 4;
   constexpr bool STREAM = VARIANT >= 6;
-  __shared__ __attribute__((aligned(16))) char tile_img[LDSV ? (STREAM ? 32768 : 16384) : 16];
+  constexpr bool FARSRC = VARIANT >= 8;  // 8: the kernel's strided rows from a 512-MB buffer; 9: contiguous tiles from it
+  // variants 10 / 11: the kernel's sharing -- five consecutive workgroups are the q blocks of ONE (sequence, head) unit and stream the
+  // same K / V^T tiles (N = 4096 keys, q|k rows of 4096 B with the head's 128 B inside, V^T rows of 8192 B), every tile new to the L2
+  // the first time one of the five asks for it: 10 = two stages (tile t+1 requested at the top of tile t: the kernel), 11 = three
+  // stages (tile t+2 requested at the top of tile t, s_waitcnt vmcnt(4))
+  constexpr bool SHARED = VARIANT >= 10;
+  constexpr int NST = VARIANT == 11 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char tile_img[LDSV ? (STREAM ? NST * 16384 : 16384) : 16];
   if (LDSV) {
     for (int i = threadIdx.x; i < 1024; i += 256) ((i4*)tile_img)[i] = *(const i4*)(seed + (i & 1023) * 4);
     __syncthreads();
@@ -59,18 +66,54 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
   f16v o[2] = {{0.f}, {0.f}};
   float l_run = 0.f;
   const int wave = threadIdx.x >> 6;
-  const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)seed, 0, 1 << 20, 0x00020000);
+  const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)(FARSRC ? (const void*)big : (const void*)seed), 0, FARSRC ? (1 << 29) : (1 << 20), 0x00020000);
+  // 8: lane (r = lane >> 3, chunk = lane & 7) of DMA i reads 16 B of K row (8 wave + r + 32 i) at a 4096-B row stride (i < 2) or of
+  //    V^T row at a 1280-B stride (i >= 2); a tile advances K by 64 rows, V^T by 128 B; each workgroup has its own 2-MB region
+  const int wg_base = (int)((blockIdx.x * 2654435761u) & 0xff) * (1 << 21);
+  const int kv_k = wg_base + ((wave * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16);
+  const int kv_v = wg_base + (1 << 20) + ((wave * 8 + (lane >> 3)) * 1280 + (lane & 7) * 16);
+  // the kernel's XCD-aware id map: blocks b and b + 8 share an XCD, each XCD walks a contiguous id range -- the five sharers of a
+  // unit run on ONE XCD (one L2) at about the same time
+  int lid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int unit = lid / 5, useq = unit >> 4, uhead = unit & 15;
+  const int sh_k = useq * (24 << 20) + 2048 + uhead * 128 + (wave * 8 + (lane >> 3)) * 4096 + (lane & 7) * 16;
+  const int sh_v = useq * (24 << 20) + (16 << 20) + uhead * (512 << 10) + (wave * 8 + (lane >> 3)) * 8192 + (lane & 7) * 16;
   const int voff_dma = ((lane >> 3) * 128 + (lane & 7) * 16) + wave * 1024 + (blockIdx.x & 15) * 16384;
   for (int t = 0; t < tiles; ++t) {
     if (LDSV) asm volatile("" ::: "memory");  // the image counts as rewritten every tile: no hoisting of the fragment reads
     if constexpr (STREAM) {
-      if constexpr (VARIANT == 7) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      constexpr int DIST = NST - 1;  // tiles of prefetch distance
+      auto dma = [&](int tt) __attribute__((always_inline)) {  // requests tile tt into its ring slot
+        __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(tile_img + (tt % NST) * 16384 + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (SHARED) {
+            const int t6 = tt & 63;
+            if (i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, sh_k, (t6 * 64 + i * 32) * 4096, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, sh_v, t6 * 128 + (i - 2) * 32 * 8192, 0, 0);
+          } else if constexpr (VARIANT == 8) {
+            const int t4 = tt & 3;  // four tiles per region, then again (L2 hits after the first pass)
+            if (i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, kv_k, (t4 * 64 + i * 32) * 4096, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, kv_v, t4 * 128 + (i - 2) * 32 * 1280, 0, 0);
+          } else if constexpr (VARIANT == 9) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, voff_dma + wg_base, ((tt & 63) * 16384 + i * 4096), 0, 0);
+          } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, voff_dma, ((tt & 31) * 16384 + i * 4096) & 0xfffff, 0, 0);
+          }
+        }
+      };
+      if (t == 0 && DIST == 2) dma(1);
+      if constexpr (VARIANT >= 7) {
+        if constexpr (DIST == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-      __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(tile_img + ((t + 1) & 1) * 16384 + wave * 1024);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, sb + i * 4096, 16, voff_dma, ((t & 31) * 16384 + i * 4096) & 0xfffff, 0, 0);
+      dma(t + DIST);
     }
     f16v st[2];
     i4 kfr[2][4], vfr[2][2][2];
@@ -86,7 +129,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         i4 a = kf[sub];
-        if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t & 1) * 16384 : 0) + (koffp[sub] ^ (s << 5)));
+        if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t % NST) * 16384 : 0) + (koffp[sub] ^ (s << 5)));
         if constexpr (VARIANT == 5) a = kfr[sub][s];
         st[sub] = mma(a, qf[s], s == 0 ? (f16v){0.f} : st[sub]);
       }
@@ -130,7 +173,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           i4 a = vf[dt];
-          if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t & 1) * 16384 : 0) + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+          if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t % NST) * 16384 : 0) + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
           if constexpr (VARIANT == 5) a = vfr[sub][s2][dt];
           o[dt] = mma(a, pf[s2], o[dt]);
         }
@@ -146,6 +189,8 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
   if (acc == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = acc;  // never true: keeps everything alive
 }
 
+static const char* g_big = nullptr;
+
 template <int VARIANT, int WPS>
 static double run(const int* seed, float* out, int tiles) {
   // WPS waves per SIMD = WPS workgroups of 4 waves per CU; 256 CUs
@@ -153,11 +198,11 @@ static double run(const int* seed, float* out, int tiles) {
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  hipLaunchKernelGGL((mix_kernel<VARIANT, WPS>), dim3(blocks), dim3(256), 0, 0, seed, out, tiles);  // warm-up
+  hipLaunchKernelGGL((mix_kernel<VARIANT, WPS>), dim3(blocks), dim3(256), 0, 0, seed, out, tiles, g_big);  // warm-up
   float best = 1e30f;
   for (int it = 0; it < 5; ++it) {
     hipEventRecord(a, 0);
-    hipLaunchKernelGGL((mix_kernel<VARIANT, WPS>), dim3(blocks), dim3(256), 0, 0, seed, out, tiles);
+    hipLaunchKernelGGL((mix_kernel<VARIANT, WPS>), dim3(blocks), dim3(256), 0, 0, seed, out, tiles, g_big);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
     float ms;
@@ -172,19 +217,35 @@ int main() {
   int* seed;
   float* out;
   hipMalloc(&seed, 1 << 20);
-  hipMemset(seed, 0x3c, 1 << 20);
+  char* big;
+  hipMalloc(&big, (size_t)1 << 29);
+  g_big = big;
   hipMalloc(&out, 256 * 4 * 256 * 4);
-  int h[4096];
-  for (int i = 0; i < 4096; ++i) h[i] = 0x3c003c00 + (i * 2654435761u >> 20 & 0x00ff00ff);  // bf16 pairs near 0.008: scores stay small
-  hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
+  // RANDOM bf16 operands (sign and mantissa random, magnitude 2^-7 .. 2^-5: scores stay small): the clock the chip holds under MFMA
+  // load depends on operand toggling (MI355X_MICROARCH.md, DVFS give-back) -- constant data would flatter every row
+  auto fill = [](void* dev, size_t bytes) {
+    unsigned short* h = (unsigned short*)malloc(bytes);
+    unsigned x = 12345u;
+    for (size_t i = 0; i < bytes / 2; ++i) {
+      x = x * 1664525u + 1013904223u;
+      const unsigned r = x >> 8;
+      h[i] = (unsigned short)(((r & 1) << 15) | ((0x78 + (r >> 1) % 3) << 7) | ((r >> 4) & 0x7f));
+    }
+    hipMemcpy(dev, h, bytes, hipMemcpyHostToDevice);
+    free(h);
+  };
+  fill(seed, 1 << 20);
+  fill(big, (size_t)1 << 29);
   const int tiles = 2000;
-  const char* names[8] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums",
+  const char* names[12] = {"full mix (16 MFMA + 32 exp + 35 add + 16 pack)", "MFMAs only", "no exponentials", "no row sums",
                           "full mix + 16 ds_read_b128, read before use", "full mix + 16 ds_read_b128, whole tile in flight",
-                          "... + 4 LDS-DMA per wave and tile, issue only", "... + 4 LDS-DMA + vmcnt(0) + barrier per tile (= the kernel)"};
+                          "... + 4 LDS-DMA per wave and tile, issue only", "... + 4 LDS-DMA + vmcnt(0) + barrier per tile (L2-resident source)",
+                          "... the same, strided K / V^T rows, L2-resident after the first pass", "... the same, contiguous tiles streamed from HBM by EVERY workgroup (HBM-bound)",
+                          "... the same, 5 workgroups share a (sequence, head): tiles new to L2, two stages (= the kernel)", "... the same with three stages (tile t+2 requested at tile t)"};
   printf("attention instruction-mix ceiling, no memory traffic, 256 CUs, TFLOP/s of the 16 MFMAs per tile (peak 2500):\n");
 #define ROW(V)                                                                                                              \
-  printf("  %-50s 1 wave/SIMD %7.0f   2 %7.0f   3 %7.0f   4 %7.0f\n", names[V], run<V, 1>(seed, out, tiles), run<V, 2>(seed, out, tiles), \
+  printf("  %-98s 1 wave/SIMD %7.0f   2 %7.0f   3 %7.0f   4 %7.0f\n", names[V], run<V, 1>(seed, out, tiles), run<V, 2>(seed, out, tiles), \
          run<V, 3>(seed, out, tiles), run<V, 4>(seed, out, tiles));
-  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7)
+  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11)
   return 0;
 }
