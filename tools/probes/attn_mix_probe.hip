@@ -1,12 +1,15 @@
 // Ceiling probe for the fused attention kernel (gfx950): the per-tile INSTRUCTION MIX of attention_kernel's fast body --
 // 8 + 8 v_mfma_f32_32x32x16_bf16 (S^T = K.Q^T over 4 k-steps for two 32-key blocks; O^T += V^T.P^T for 2 x 2 x 2 steps),
 // 32 v_exp_f32, 32 + 3 row-sum adds, 16 v_cvt_pk_bf16_f32 -- with the kernel's data dependencies (the S chain of four MFMAs per
-// block, exponentials on its accumulator, the packed exponentials as the B operand of the P.V MFMAs) but WITHOUT any memory
-// traffic: the K / V^T fragments are loop-invariant registers, there is no LDS read, no LDS-DMA, no barrier.
-// What it measures: the rate this mix reaches under the hardware's issue rules and hipcc's schedule at 1 .. 4 waves per SIMD.
-// attention_kernel cannot be faster than this; the distance between the two is what LDS fragment reads, LDS-DMA issue and the
-// tile barrier cost. Variants: 0 full mix, 1 MFMAs only (the matrix-pipe bound of the dependency structure), 2 no exponentials
-// (adds + packs stay), 3 no row sums.
+// block, exponentials on its accumulator, the packed exponentials as the B operand of the P.V MFMAs), on random bf16 operands,
+// with the kernel's memory side added one piece at a time:
+//   0 full mix, fragments in registers      1 MFMAs only      2 no exponentials      3 no row sums
+//   4 + 16 ds_read_b128 fragment reads per tile from a static LDS image (read before use)      5 the same, whole tile in flight
+//   6 + 4 LDS-DMA per wave and tile (issue only)      7 + s_waitcnt vmcnt(0) + s_barrier per tile, L2-resident source
+//   8 strided K / V^T rows (L2 hits after the first pass)      9 every workgroup streams its own tiles from HBM (HBM-bound)
+//   10 five workgroups share a (sequence, head): the kernel's traffic      11 the same with a three-stage ring
+// each at 1 .. 4 workgroups of 4 waves per CU. What it measures: the rate hipcc's schedule of this structure reaches; the shipped
+// kernel sits at row 10's rate (profiles/r03_attention_mix_ceiling.txt).
 // build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o tools/probes/build/attn_mix_probe tools/probes/attn_mix_probe.hip
 #include <hip/hip_runtime.h>
 
@@ -242,7 +245,7 @@ int main() {
                           "... + 4 LDS-DMA per wave and tile, issue only", "... + 4 LDS-DMA + vmcnt(0) + barrier per tile (L2-resident source)",
                           "... the same, strided K / V^T rows, L2-resident after the first pass", "... the same, contiguous tiles streamed from HBM by EVERY workgroup (HBM-bound)",
                           "... the same, 5 workgroups share a (sequence, head): tiles new to L2, two stages (= the kernel)", "... the same with three stages (tile t+2 requested at tile t)"};
-  printf("attention instruction-mix ceiling, no memory traffic, 256 CUs, TFLOP/s of the 16 MFMAs per tile (peak 2500):\n");
+  printf("attention structure probe, random bf16 operands, 256 CUs, TFLOP/s of the 16 MFMAs per tile (nominal peak 2500):\n");
 #define ROW(V)                                                                                                              \
   printf("  %-98s 1 wave/SIMD %7.0f   2 %7.0f   3 %7.0f   4 %7.0f\n", names[V], run<V, 1>(seed, out, tiles), run<V, 2>(seed, out, tiles), \
          run<V, 3>(seed, out, tiles), run<V, 4>(seed, out, tiles));
