@@ -10,7 +10,8 @@
 //   10 five workgroups share a (sequence, head): the kernel's traffic      11 the same with a three-stage ring
 // each at 1 .. 4 workgroups of 4 waves per CU. What it measures: the rate hipcc's schedule of this structure reaches; the shipped
 // kernel sits at row 10's rate (profiles/r03_attention_mix_ceiling.txt).
-// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o tools/probes/build/attn_mix_probe tools/probes/attn_mix_probe.hip
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize [-DM16=1] -o /tmp/attn_mix_probe tools/probes/attn_mix_probe.hip
+//        (-DM16=1: the same FLOPs on v_mfma_f32_16x16x32_bf16, two per 32x32x16, one A fragment per two B fragments)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -19,9 +20,30 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(4))) int i4;
 typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(4))) float f4v;
+#ifndef M16
+#define M16 0
+#endif
 
-__device__ __forceinline__ f16v mma(const i4& a, const i4& b, const f16v& c) {
+// M16 = 1: the FLOPs of one 32x32x16 as two v_mfma_f32_16x16x32_bf16 on two of the four 4-register quarters of the accumulator
+// (pair `h` = quarters 2h, 2h+1): a 16 x 16 tiling of the same S^T / O^T blocks -- every K / V^T fragment feeds the two 16-query
+// tiles, an S quarter sees two dependent MFMAs per tile instead of four on the whole block. Layout-agnostic (a timing probe); the
+// chip holds a higher clock on this shape (MI355X_MICROARCH.md).
+__device__ __forceinline__ f16v mma(const i4& a, const i4& b, const f16v& c, int h = 0, const i4* b2p = nullptr) {
+#if M16
+  const i4 b2 = b2p ? *b2p : b;  // the second 16-query tile has its own B fragment (otherwise the two MFMAs are one expression)
+  f16v r = c;
+#pragma unroll
+  for (int qd = 0; qd < 2; ++qd) {
+    const int o = 8 * h + 4 * qd;
+    f4v t = {r[o], r[o + 1], r[o + 2], r[o + 3]};
+    t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, qd ? b2 : b), t, 0, 0, 0);
+    r[o] = t[0]; r[o + 1] = t[1]; r[o + 2] = t[2]; r[o + 3] = t[3];
+  }
+  return r;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ int pack2(float a, float b) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
         i4 a = kf[sub];
         if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t % NST) * 16384 : 0) + (koffp[sub] ^ (s << 5)));
         if constexpr (VARIANT == 5) a = kfr[sub][s];
-        st[sub] = mma(a, qf[s], s == 0 ? (f16v){0.f} : st[sub]);
+        st[sub] = mma(a, qf[s], (M16 ? s < 2 : s == 0) ? (s == 0 ? (f16v){0.f} : st[sub]) : st[sub], s & 1, &qf[(s + 2) & 3]);
       }
     }
     if constexpr (VARIANT == 5) {
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
           i4 a = vf[dt];
           if constexpr (VARIANT == 4 || STREAM) a = *(const i4*)(tile_img + (STREAM ? (t % NST) * 16384 : 0) + (voffp[dt] ^ ((sub * 4 + 2 * s2) << 4)));
           if constexpr (VARIANT == 5) a = vfr[sub][s2][dt];
-          o[dt] = mma(a, pf[s2], o[dt]);
+          o[dt] = mma(a, pf[s2], o[dt], s2, &pf[s2 ^ 1]);
         }
     }
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
