@@ -159,6 +159,27 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+_JSON_OUT = None
+
+
+def _claim_stdout() -> None:
+    """The contract is ONE JSON line on stdout. Libraries under this process write to file descriptor 1 on their own (RCCL prints
+    a five-line version banner at communicator creation, ROCm tools their notices), so a worker keeps the original descriptor for
+    the JSON line and points fd 1 at stderr for everything else."""
+    global _JSON_OUT
+    if _JSON_OUT is not None:
+        return
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
+def emit(obj) -> None:
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -169,6 +190,7 @@ def main(argv=None) -> int:
         return 2
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus, argv)  # before any torch / HIP import in this process
+    _claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -481,7 +503,7 @@ def main(argv=None) -> int:
                 e[0].destroy()
             extra = []
             out.update(extra_measurements(dev, tdev, model, cfg, B, ref_frame))
-        print(json.dumps(out), flush=True)
+        emit(out)
     for e in extra:
         e[0].destroy()
     model.destroy()
@@ -739,7 +761,7 @@ def bench_tile_parallel(args, dev, tdev, world: int, rank: int) -> int:
         elapsed = float(t.item())
     if rank == 0:
         ok = bool(torch.isfinite(last["out"].depth).all().item())
-        print(json.dumps({
+        emit(({
             "metric": "frames/sec Depth Pro @1536^2 bf16" if args.preset == "full" and args.precision == "bf16" else f"frames/sec Depth Pro preset={args.preset} {args.precision}",
             "value": round(args.steps * B / elapsed, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -747,7 +769,7 @@ def bench_tile_parallel(args, dev, tdev, world: int, rank: int) -> int:
             "config": {"workload": f"DepthPro::infer [{B},3,{S},{S}], ONE call per step sharded over the ranks", "global_batch": B,
                        "parallelism": f"tile-parallel x{world}: the 37 B ViT sequences split over the ranks, token + hook exchange to rank 0, decoder on rank 0",
                        "comm": "native md_comm_* (ncclBroadcast of the image, grouped ncclSend / ncclRecv of tokens and hooks)"},
-            "finite_output": ok, "weight_broadcast_s": round(t_bcast, 4), "roofline": None, "cpu_baseline": None}), flush=True)
+            "finite_output": ok, "weight_broadcast_s": round(t_bcast, 4), "roofline": None, "cpu_baseline": None}))
     model.destroy()
     ncomm.destroy()
     if world > 1:
@@ -802,12 +824,12 @@ def bench_dry(args, world: int, rank: int) -> int:
     if rank == 0 and world > 1:
         ok = ok and torch.equal(torch.cat(gathered, 0), full.sum(1) + 1.0)
     if rank == 0:
-        print(json.dumps({"metric": "frames/sec dry run (CPU stand-in, gloo)", "value": round(args.steps * B * world / elapsed, 3), "unit": "frames/s",
+        emit(({"metric": "frames/sec dry run (CPU stand-in, gloo)", "value": round(args.steps * B * world / elapsed, 3), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"dry run [{B},3,{S},{S}] per rank", "batch_per_gpu": B, "global_batch": B * world,
                                      "parallelism": f"dp{world}", "scatter_inputs_from_rank0": world > 1, "gather_depth_to_rank0": world > 1},
-                          "finite_output": bool(ok), "dry_run": True}), flush=True)
+                          "finite_output": bool(ok), "dry_run": True}))
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -884,7 +906,7 @@ def bench_da3(args, dev, tdev, world, rank) -> int:
                "backbone_tflops_algorithmic": round(vit_flops / B / 1e12, 3),
                "attention_tflops": round(4.0 * B * v.num_heads * NT * NT * 64 * depth_n / (attn_ms * 1e-3) / 1e12, 1) if attn_ms else None,
                "kernels": kernels}
-        print(json.dumps(out), flush=True)
+        emit(out)
     model.destroy()
     if world > 1:
         dist.destroy_process_group()
