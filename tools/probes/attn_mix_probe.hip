@@ -24,6 +24,9 @@ typedef __attribute__((ext_vector_type(4))) float f4v;
 #ifndef M16
 #define M16 0
 #endif
+#ifndef DOT2
+#define DOT2 0  // 1: row sums as 16 v_dot2c_f32_bf16 on the packed P words (sums the ROUNDED p) instead of 32 v_add_f32
+#endif
 
 // M16 = 1: the FLOPs of one 32x32x16 as two v_mfma_f32_16x16x32_bf16 on two of the four 4-register quarters of the accumulator
 // (pair `h` = quarters 2h, 2h+1): a 16 x 16 tiling of the same S^T / O^T blocks -- every K / V^T fragment feeds the two 16-query
@@ -179,13 +182,19 @@ __global__ __launch_bounds__(256, WPS) void mix_kernel(const int* __restrict__ s
         for (int j = 0; j < 8; ++j) {
           const float sv = st[sub][8 * s2 + j];
           p[j] = (VARIANT == 1 || VARIANT == 2) ? sv : __builtin_amdgcn_exp2f(sv);  // variants 0, 3, 4, 5 exponentiate
-          if (VARIANT != 1 && VARIANT != 3) ps[j & 3] += p[j];
+          if (VARIANT != 1 && VARIANT != 3 && !DOT2) ps[j & 3] += p[j];
         }
         if (VARIANT != 1) {
           pf[s2][0] = pack2(p[0], p[1]);
           pf[s2][1] = pack2(p[2], p[3]);
           pf[s2][2] = pack2(p[4], p[5]);
           pf[s2][3] = pack2(p[6], p[7]);
+          if (DOT2 && VARIANT != 3) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            const bf2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) ps[w] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pf[s2][w]), one, ps[w], false);
+          }
         } else {  // MFMAs only: the accumulator's raw bits are the next B operand (keeps the S -> P.V dependency)
           pf[s2][0] = __builtin_bit_cast(int, p[0]);
           pf[s2][1] = __builtin_bit_cast(int, p[2]);
