@@ -63,12 +63,13 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 //    some row of the wave saw a score more than 2^kDefer above it); p <= 2^kDefer fits f16.
 // Either way the result is softmax(q k^T / 8) v; which body ran only changes rounding.
 //
-// What bounds it (MI355X, T x N = 296 x 577, profiles/r02_attention_*.json and DESIGN.md section 5.2): the first form of
-// this round (running maximum, scale multiply) spent 75 % of the SIMD cycles issuing vector instructions; the fast body
-// issues 34 % fewer and runs 14-16 % faster, after which neither pipe is saturated (vector issue 59 %, matrix 42 %) and
-// the time is the waves' dependent chains: ablations of this kernel -- no exponentials / sums +12 %, no in-loop LDS-DMA
-// +20 %, no barrier 0 %, all three +48 % (837 TFLOP/s) -- and instruction-order experiments (softmax of one key half
-// pinned beside the MFMAs of the other, batched fragment reads, 8-wave workgroups) that all measured within +-4 %.
+// What bounds it (MI355X; DESIGN.md section 5.2, tools/probes/attn_mix_probe.hip, profiles/r03_attention_mix_ceiling.txt): on random
+// operands the bare MFMA sequence of a tile sustains 1703 TFLOP/s (the clock under load), with the softmax's vector work 1394,
+// with the sixteen fragment reads 1250, with LDS-DMA + vmcnt(0) + barrier per tile from an L2-resident source 1056-1107, with the
+// kernel's real traffic (five workgroups share the tiles of a (sequence, head)) 876-1077 -- the kernel executes 820-920: it sits at
+// the rate of its own structure under hipcc. Variants that measured slower (each correct): deeper rings, an intra-wave software
+// pipeline, a two-group schedule, 64 queries per wave, one or five waves per SIMD, row sums on the matrix pipe or on v_dot2c,
+// 8-wave workgroups, whole-tile fragment prefetch at three waves per SIMD, register-staged K / V^T tiles.
 //
 // Split-half operands (T = f16s_t, MD_PREC_F16X2): q, k and v arrive as hi + lo planes -- qk rows are
 // [q_hi | q_lo | k_hi | k_lo] (each D wide), V^T has its lo plane `v_plane` elements behind the hi plane. The scores run on
