@@ -219,6 +219,29 @@ __device__ __forceinline__ f32x4_t load4p(const T* p, long plane) {
   else return load4<T>(p);
 }
 
+// eight consecutive elements <-> fp32, plane-aware
+template <typename T>
+__device__ __forceinline__ void load8fp(const T* p, long plane, float* v) {
+  load8f<T>(p, v);
+  if constexpr (is_split<T>::value) {
+    float l[8];
+    load8f<T>(p + plane, l);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += l[i];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8p(T* p, long plane, const float* v) {
+  if constexpr (is_split<T>::value) {
+    i32x4_t hi, lo;
+    split8<T>((f32x4_t){v[0], v[1], v[2], v[3]}, (f32x4_t){v[4], v[5], v[6], v[7]}, hi, lo);
+    *(i32x4_t*)p = hi;
+    *(i32x4_t*)(p + plane) = lo;
+  } else {
+    store8<T>(p, v);
+  }
+}
+
 // Host-side dispatch over the storage type of a precision mode: `T` is float, f16_t or bf16_t inside STMT.
 // (MD_PREC_FP8 models store everything but the four ViT linear operands as bf16.)
 #define MD_BY_PREC(prec, STMT)             \

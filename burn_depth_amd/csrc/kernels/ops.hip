@@ -339,7 +339,7 @@ __global__ void patchify_kernel(const float* __restrict__ x, int B, int H, int W
       const int b = (int)(t / ph);
       v = x[(((long)b * 3 + c) * H + py * ps + ky) * W + px * ps + kx];
     }
-    st1<T>(out + e, v);
+    st1p<T>(out + row * ((long)Kp * kPlanes<T>) + col, Kp, v);  // split-half rows: [hi: Kp | lo: Kp]
   }
 }
 
@@ -362,9 +362,11 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* __restrict__ 
   const int row = blockIdx.x;
   const int b = row / OH, oy = row - b * OH;
   const AxisTap ty = axis_tap_s(oy, H, sy, method);
-  const T* r0 = in + ((long)b * H + ty.i0) * W * ld_in;
-  const T* r1 = in + ((long)b * H + ty.i1) * W * ld_in;
-  T* orow = out + (long)row * OW * ld_out;
+  constexpr int PL = kPlanes<T>;  // split-half pixels: [hi: ld | lo: ld]
+  const long pin = ld_in * PL, pout = ld_out * PL;
+  const T* r0 = in + ((long)b * H + ty.i0) * W * pin;
+  const T* r1 = in + ((long)b * H + ty.i1) * W * pin;
+  T* orow = out + (long)row * OW * pout;
   const float* arow = addend ? addend + (long)oy * OW * C : nullptr;
   const int n = OW * C8;
   for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += gridDim.y * 256) {
@@ -372,11 +374,11 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* __restrict__ 
     const int c = (e - ox * C8) * 8;
     const AxisTap tx = axis_tap_s(ox, W, sx, method);
     float tl[8], tr[8], bl[8], br[8], o[8];
-    load8f<T>(r0 + (long)tx.i0 * ld_in + c, tl);
-    load8f<T>(r0 + (long)tx.i1 * ld_in + c, tr);
-    load8f<T>(r1 + (long)tx.i0 * ld_in + c, bl);
-    load8f<T>(r1 + (long)tx.i1 * ld_in + c, br);
-    if constexpr (sizeof(T) == 4) {  // fp32 parity mode: the reference's separate multiplies and adds (interpolate.rs:78-89)
+    load8fp<T>(r0 + (long)tx.i0 * pin + c, ld_in, tl);
+    load8fp<T>(r0 + (long)tx.i1 * pin + c, ld_in, tr);
+    load8fp<T>(r1 + (long)tx.i0 * pin + c, ld_in, bl);
+    load8fp<T>(r1 + (long)tx.i1 * pin + c, ld_in, br);
+    if constexpr (sizeof(T) == 4 || is_split<T>::value) {  // fp32 parity mode and the split-half accurate mode: the reference's separate multiplies and adds (interpolate.rs:78-89)
 #pragma clang fp contract(off)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const T* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] += arow[(long)ox * C + c + i];
     }
-    store8<T>(orow + (long)ox * ld_out + c, o);
+    store8p<T>(orow + (long)ox * pout + c, ld_out, o);
   }
 }
 
@@ -909,8 +911,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, l
     const long row = (e >> 1) / heads;
     const int t = (int)(row % S);
     if (t >= NT) continue;  // wave-uniform
-    T* p = qk + row * 2L * D + (long)which * D + hd * 64 + lane;
-    const float v = ld1<T>(p);
+    T* p = qk + (row * 2L * D + (long)which * D) * kPlanes<T> + hd * 64 + lane;  // split-half rows: [q_hi | q_lo | k_hi | k_lo]
+    const float v = ld1p<T>(p, D);
     const float mean = wave_sum(v) * (1.0f / 64.0f);
     const float c = v - mean;
     const float rstd = 1.0f / sqrtf(wave_sum(c * c) * (1.0f / 64.0f) + eps);
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(T* __restrict__ qk, l
     const float partner = __shfl_xor(y, 16);
     float o = jj < 16 ? y * cs - partner * sn : y * cs + partner * sn;
     if (!which) o *= q_scale;  // the softmax scale rides on q (see GemmParams::qscale); the LayerNorm above removed the epilogue's
-    st1<T>(p, o);
+    st1p<T>(p, D, o);
   }
 }
 
@@ -1018,8 +1020,9 @@ __global__ __launch_bounds__(256) void hook_cat_ln_kernel(const float* __restric
         const int i = lane + 64 * k;
         const float y1 = (a[k] - mean) * rstd * hg[i] + hb[i];
         const float y2 = (b[k] - mean) * rstd * hg[D + i] + hb[D + i];
-        st1<TO>(out + row * 2 * D + i, y1);
-        st1<TO>(out + row * 2 * D + D + i, y2);
+        TO* orow = out + row * (2L * D * kPlanes<TO>);  // split-half rows: [hi: 2D | lo: 2D]
+        st1p<TO>(orow + i, 2L * D, y1);
+        st1p<TO>(orow + D + i, 2L * D, y2);
       }
   }
 }

@@ -794,9 +794,7 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
   d.precision = c->precision;
   d.max_batch = c->max_batch > 0 ? c->max_batch : 1;
   d.ln_eps = c->ln_eps > 0.f ? c->ln_eps : 1e-6f;
-  if (d.precision == MD_PREC_F16X2)
-    MD_FAIL(MD_ERR_UNSUPPORTED, "MD_PREC_F16X2 (split-half operands) is built for Depth Pro; Depth-Anything-v3 has MD_PREC_F32 as its accurate mode");
-  if (d.precision != MD_PREC_BF16 && d.precision != MD_PREC_F32 && d.precision != MD_PREC_FP8 && d.precision != MD_PREC_F16)
+  if (d.precision != MD_PREC_BF16 && d.precision != MD_PREC_F32 && d.precision != MD_PREC_FP8 && d.precision != MD_PREC_F16 && d.precision != MD_PREC_F16X2)
     MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", d.precision);
   *out = d;
   return MD_OK;

@@ -209,7 +209,8 @@ int da3_on_commit(md_model_t m) {
 static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   md_model_s::Da3State* d = m->da3;
   const Da3Cfg& c = d->cfg;
-  const int B = c.max_batch, D = c.vit.D, F = c.features, esz = m->esz;
+  const int B = c.max_batch, D = c.vit.D, F = c.features;
+  const int esz = m->esz * m->xm;  // bytes per LOGICAL element of a T tensor (MD_PREC_F16X2: two half planes)
   const size_t SS2 = (size_t)d->ih * d->iw;  // pixels of one input image
   const int* oc = c.out_channels;
   size_t total = 0;
@@ -237,6 +238,7 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
   DA3_TAKE(xn, void*, rows * D * esz);
   DA3_TAKE(qk, void*, rows * 2 * D * esz);
   DA3_TAKE(vT, void*, (size_t)B * c.vit.heads * 64 * d->kpad * esz);
+  m->vt_plane = m->xm == 2 ? (size_t)B * c.vit.heads * 64 * d->kpad : 0;
   DA3_TAKE(ao, void*, rows * D * esz);
   DA3_TAKE(hbuf, void*, rows * 4 * D * esz);
   if (m->prec == MD_PREC_F32) DA3_TAKE(scores, float*, (size_t)B * c.vit.heads * d->SS * d->kpad * 4);
@@ -342,9 +344,9 @@ static int da3_build_tables(md_model_s* m, md_model_s::Da3State::ShapeTables& t)
     const int ld = round_up(oc[s], m->ke);
     std::vector<float> padded((size_t)d->P * ld, 0.f);
     for (int p = 0; p < d->P; ++p) memcpy(&padded[(size_t)p * ld], &tab[(size_t)p * oc[s]], (size_t)oc[s] * 4);
-    MD_HIP(hipMalloc(&t.pos_stage[s], padded.size() * m->esz + 256));
+    MD_HIP(hipMalloc(&t.pos_stage[s], padded.size() * m->esz * m->xm + 256));
     MD_HIP(hipMemcpy(tmp, padded.data(), padded.size() * 4, hipMemcpyHostToDevice));
-    MD_TRY(launch_f32_to_rows(tmp, (long)padded.size(), t.pos_stage[s], m->prec, st));
+    MD_TRY(launch_f32_to_rows(tmp, (long)padded.size(), t.pos_stage[s], m->prec, st, ld));
     MD_HIP(hipStreamSynchronize(st));
   }
   MD_HIP(hipFree(tmp));
@@ -480,6 +482,8 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   m->prec = fp8 ? MD_PREC_BF16 : cfg.precision;
   m->esz = m->prec == MD_PREC_F32 ? 4 : 2;
   m->ke = 128 / m->esz;
+  m->xm = m->prec == MD_PREC_F16X2 ? 2 : 1;  // split-half operands: activation rows are [hi | lo]
+  m->wterms = m->xm == 2 ? 3 : 1;            // decided by model_commit: 2 when every plain weight is an exact half (an f16 record)
   m->cfg.max_batch = cfg.max_batch;
   m->cfg.precision = m->prec;
   m->da3 = new md_model_s::Da3State();
@@ -748,8 +752,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   r.end();
   {
     GemmParams p;
-    p.N = D; p.K = d->Kp; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = d->vit.pe_w; p.bias[0] = d->vit.pe_b; p.pos[0] = d->vit.pos;
-    p.A = d->patches; p.lda = d->Kp;
+    p.N = D; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = d->vit.pe_w; p.bias[0] = d->vit.pe_b; p.pos[0] = d->vit.pos;
+    p.A = d->patches;
+    split_dense_a(m, p, d->Kp, d->Kp, 0);
     p.epi = EPI_PATCH_EMBED; p.out = d->xres; p.ldo = D; p.seq_stride = SS; p.seq_patches = P; p.embed = D;
     r.begin("patch_embed");
     MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
@@ -778,7 +783,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     r.end();
     {
       GemmParams p;
-      p.N = 3 * D; p.K = D; dense(p); p.W[0] = k.qkv_w; p.bias[0] = k.qkv_b; p.A = d->xn; p.lda = D;
+      p.N = 3 * D; dense(p); p.W[0] = k.qkv_w; p.bias[0] = k.qkv_b; p.A = d->xn;
+      if (f8) { p.K = D; p.lda = D; } else split_dense_a(m, p, D, D, 0);
+      p.v_plane = (long)m->vt_plane;
       p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad; p.qscale = attn_qscale(m->prec);
       if (f8) { p.W[0] = d->w8[i].w[0]; p.wscale[0] = d->w8[i].s[0]; p.ascale = md_model_s::Da3State::kActScale; }
       r.begin("qkv_gemm");
@@ -795,7 +802,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
     if (m->prec != MD_PREC_F32) {
       r.begin("attention");
-      MD_TRY(launch_attention(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, m->prec, st, f8 ? a_inv : 0.f));
+      MD_TRY(launch_attention(d->qk, d->vT, d->ao, B, SS, NT, heads, D, d->kpad, m->prec, st, f8 ? a_inv : 0.f, (long)m->vt_plane));
       r.end();
     } else {
       GemmParams p;
@@ -821,8 +828,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
     {
       GemmParams p;
-      p.N = D; p.K = D; dense(p); p.W[0] = k.proj_w; p.bias[0] = k.proj_b; p.scale[0] = k.ls1;
-      p.A = d->ao; p.lda = D; p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      p.N = D; dense(p); p.W[0] = k.proj_w; p.bias[0] = k.proj_b; p.scale[0] = k.ls1;
+      p.A = d->ao;
+      if (f8) { p.K = D; p.lda = D; } else split_dense_a(m, p, D, D, 0);
+      p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
       if (f8) { p.W[0] = d->w8[i].w[1]; p.wscale[0] = d->w8[i].s[1]; p.ascale = md_model_s::Da3State::kActScale; }
       r.begin("proj_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
@@ -834,8 +843,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     r.end();
     {
       GemmParams p;
-      p.N = 4 * D; p.K = D; dense(p); p.W[0] = k.fc1_w; p.bias[0] = k.fc1_b; p.A = d->xn; p.lda = D;
-      p.epi = EPI_STORE; p.act = ACT_GELU; p.out = d->hbuf; p.ldo = 4 * D;
+      p.N = 4 * D; dense(p); p.W[0] = k.fc1_w; p.bias[0] = k.fc1_b; p.A = d->xn;
+      if (f8) { p.K = D; p.lda = D; } else split_dense_a(m, p, D, D, 0);
+      p.epi = EPI_STORE; p.act = ACT_GELU; p.out = d->hbuf;
+      split_out(m, p, 4 * D, true);
       if (f8) {
         p.W[0] = d->w8[i].w[2]; p.wscale[0] = d->w8[i].s[2]; p.ascale = md_model_s::Da3State::kActScale;
         p.out_fp8 = 1; p.out_inv_scale = h_inv;
@@ -846,8 +857,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
     {
       GemmParams p;
-      p.N = D; p.K = 4 * D; dense(p); p.W[0] = k.fc2_w; p.bias[0] = k.fc2_b; p.scale[0] = k.ls2;
-      p.A = d->hbuf; p.lda = 4 * D; p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      p.N = D; dense(p); p.W[0] = k.fc2_w; p.bias[0] = k.fc2_b; p.scale[0] = k.ls2;
+      p.A = d->hbuf;
+      if (f8) { p.K = 4 * D; p.lda = 4 * D; } else split_dense_a(m, p, 4 * D, 4 * D, 0);
+      p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
       if (f8) { p.W[0] = d->w8[i].w[3]; p.wscale[0] = d->w8[i].s[3]; p.ascale = md_model_s::Da3State::kHidScale; }
       r.begin("fc2_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
@@ -913,9 +926,12 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     const std::string ps = hp + ".projects." + std::to_string(s);
     {  // 1x1 projection over gathered patch tokens + 0.1 * UV position table
       GemmParams p;
-      p.N = oc[s]; p.K = din; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(ps + ".weight"); p.bias[0] = Bi(ps + ".bias");
-      p.A = d->hookn[s]; p.lda = din; p.a_index = tok_idx;
-      p.epi = EPI_STORE; p.out = d->sp[s]; p.ldo = ocp; p.res1 = d->pos_stage[s]; p.ldr = ocp; p.res_mod = P;
+      p.N = oc[s]; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(ps + ".weight"); p.bias[0] = Bi(ps + ".bias");
+      p.A = d->hookn[s]; p.a_index = tok_idx;
+      split_dense_a(m, p, din, din, 0);
+      p.epi = EPI_STORE; p.out = d->sp[s];
+      split_out(m, p, ocp, true);
+      p.res1 = d->pos_stage[s]; p.ldr = p.ldo; p.r_plane = p.o_plane; p.res_mod = P;
       r.begin("head_proj");
       MD_TRY(launch_gemm(p, A_INDEXED, m->prec, TILE_AUTO, st));
       r.end();
@@ -925,19 +941,24 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       const int f = s == 0 ? 4 : 2;
       const std::string rl = hp + ".resize_layers." + std::to_string(s) + ".conv_t";
       GemmParams p;
-      p.N = f * f * oc[s]; p.K = ocp; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(rl + ".weight"); p.bias[0] = Bi(rl + ".bias");
-      p.A = d->sp[s]; p.lda = ocp;
-      p.epi = EPI_PIXSHUF; p.out = d->sr[s]; p.ldo = ocp; p.psH = ph; p.psW = pw; p.psC = oc[s]; p.ps_f = f;
+      p.N = f * f * oc[s]; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = Wk(rl + ".weight"); p.bias[0] = Bi(rl + ".bias");
+      p.A = d->sp[s];
+      split_dense_a(m, p, ocp, ocp, 0);
+      p.epi = EPI_PIXSHUF; p.out = d->sr[s];
+      split_out(m, p, ocp, true);
+      p.psH = ph; p.psW = pw; p.psC = oc[s]; p.ps_f = f;
       r.begin("head_deconv");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, st));
       r.end();
       feat = d->sr[s];
     } else if (s == 3) {  // Conv2d 3x3 stride 2 pad 1 (+bias)
       GemmParams p;
-      p.N = oc[3]; p.K = 9 * ocp; p.ngroups = 1; p.g_rows[0] = B * d->h3h * d->h3w;
+      p.N = oc[3]; p.ngroups = 1; p.g_rows[0] = B * d->h3h * d->h3w;
       p.W[0] = Wk(hp + ".resize_layers.3.conv.weight"); p.bias[0] = Bi(hp + ".resize_layers.3.conv.bias");
-      p.A = d->sp[3]; p.cH = ph; p.cW = pw; p.cC = ocp; p.cOH = d->h3h; p.cOW = d->h3w; p.cstride = 2; p.zero_page = m->zero_page;
-      p.epi = EPI_STORE; p.out = d->sr[3]; p.ldo = ocp;
+      p.A = d->sp[3]; p.cH = ph; p.cW = pw; p.cOH = d->h3h; p.cOW = d->h3w; p.cstride = 2; p.zero_page = m->zero_page;
+      split_conv_a(m, p, ocp, 0);
+      p.epi = EPI_STORE; p.out = d->sr[3];
+      split_out(m, p, ocp, true);
       r.begin("head_conv_s2");
       MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_AUTO, st));
       r.end();
@@ -1008,8 +1029,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   auto tail = [&](Run& rr, const char* name, const void* in, int hh, int ww, const void* w1, const float* b1, const TailCh* chs, int nch) -> int {
     if (nch <= 0) return MD_OK;
     GemmParams p;
-    p.N = 32; p.K = 9 * F2p; p.ngroups = 1; p.g_rows[0] = B * hh * ww; p.W[0] = w1;
-    p.A = in; p.cH = hh; p.cW = ww; p.cC = F2p; p.zero_page = m->zero_page;
+    p.N = 32; p.ngroups = 1; p.g_rows[0] = B * hh * ww; p.W[0] = w1;
+    p.A = in; p.cH = hh; p.cW = ww; p.zero_page = m->zero_page;
+    split_conv_a(m, p, F2p, 0);
     p.epi = EPI_HEAD; p.bias[0] = b1; p.head_nch = nch; p.head_plane = hh * ww;
     for (int i = 0; i < nch; ++i) {
       p.head_wc[i] = chs[i].w; p.head_bs[i] = chs[i].b; p.head_acts[i] = chs[i].act; p.head_out[i] = chs[i].out; p.head_bstride[i] = chs[i].bstride;

@@ -245,7 +245,9 @@ inline int cpad(const md_model_s* m, int ch) { return (ch + m->ke - 1) / m->ke *
 // Callers pass LOGICAL padded channel counts (row widths, K); an activation row is physically [hi | lo] and a weight row
 // `terms` copies of its contraction (2: [W | W], 3: [Wh | Wh | Wl]). terms == 0 = the model's plain-weight form
 // (md_model_s::wterms); the products composed at commit are never f16-exact and pass 3.
-inline int split_terms(const md_model_s* m, int terms) { return m->xm == 1 ? 1 : (terms > 0 ? terms : m->wterms); }
+// (a fork reads its ROOT's term count: a re-commit on the root may change it while the fork lives, and the packed rows the
+// fork's launches read are the root's)
+inline int split_terms(const md_model_s* m, int terms) { return m->xm == 1 ? 1 : (terms > 0 ? terms : (m->parent ? m->parent : m)->wterms); }
 // dense / indexed A operand of `kp` logical channels per row
 inline void split_dense_a(const md_model_s* m, GemmParams& p, int kp, long lda, int terms) {
   const int t = split_terms(m, terms);

@@ -282,13 +282,19 @@ def test_full_size_default_config_against_the_oracle(diag, dev):
       * fp32 (the parity mode) and f16x2 (the accurate FAST mode: activations as hi + lo half planes on exact f16 weights):
         the reference's own bar max-rel <= 5e-3 (example/correctness.rs:887-897; held to 1e-3 / 5e-3) AND BASELINE's depth
         L_inf <= 1e-3 (tools/gpu_diag.py FULL_TOL / FULL_LINF; measured 2e-5 / 1.4e-4 for both);
-      * f16 and bf16 (the BASELINE throughput mode): the 99.9th percentile and the mean of the relative error."""
+      * f16 and bf16 (the BASELINE throughput mode): the 99.9th percentile and the mean of the relative error; bf16 also against
+        the oracle that rounds every MFMA operand to bf16 where the engine does (`q=bf16_round`);
+      * f16x2 / f16 / bf16: EVERY debug tap against the fp32 mode's tap of the same frame, rms-rel and max / peak (gpu_diag
+        FULL_TAP_TOL: twice what profiles/r03_stage_errors_*.txt measured) -- what catches a localised defect (one wrong halo
+        row of a 3x3 tile) that the percentile bounds on the depth would let through."""
     from burn_depth_amd.config import Precision
     start = len(diag.RESULTS)
     diag.guarded("full-size")(diag.run_full_size)(dev, (Precision.F32, Precision.F16X2, Precision.F16, Precision.BF16), f16_weights=True)
     _assert_new_results_ok(diag, start)
     names = [r[0] for r in diag.RESULTS[start:]]
     assert "full/f16x2/f16w depth L_inf vs fp32 oracle" in names and "full/f32/f16w depth L_inf vs fp32 oracle" in names
+    assert "full/bf16/f16w depth p99.9 rel vs bf16-operand-rounding oracle" in names
+    assert sum(1 for n in names if " tap " in n) == 3 * 13 * 2
     assert len(names) >= 26
 
 
@@ -343,15 +349,59 @@ def test_depth_pro_split_half_end_to_end(diag, dev, f16_weights):
     _assert_new_results_ok(diag, start)
 
 
-def test_split_half_is_rejected_for_depth_anything3(dev):
-    from burn_depth_amd import _lib
+@pytest.mark.parametrize("variant,f16_weights", [("tiny", False), ("tiny_dual", True)])
+def test_depth_anything3_split_half_reduced_variants(diag, dev, variant, f16_weights):
+    """MD_PREC_F16X2 for Depth-Anything-v3 (round 4; hi + lo half planes through the backbone extras -- q/k-norm + RoPE, the
+    concatenated hooks --, the UV-table addends and the align-corners resizes): every tap and every output field at the fp32
+    mode's bounds, and the depth inside the reference's own DA3 bar (example/correctness.rs:1109-1111). Seeded fp32 weights
+    run on three MFMA terms, an f16 record (example/correctness.rs:977) on two."""
     from burn_depth_amd.config import DepthAnything3Config, Precision
-    from burn_depth_amd.depth_anything3 import DepthAnything3
-    c = DepthAnything3Config.tiny_test()
-    c.precision = Precision.F16X2
-    with pytest.raises(_lib.MdError) as e:
-        DepthAnything3.new(dev, c, seed=0)
-    assert e.value.code == _lib.MD_ERR_UNSUPPORTED
+    cfg = DepthAnything3Config.tiny_test() if variant == "tiny" else DepthAnything3Config.tiny_dual_test()
+    start = len(diag.RESULTS)
+    diag.guarded("da3-f16x2")(diag.run_da3)(dev, cfg, f"da3-{variant}/f16x2", 2, Precision.F16X2, taps=True, f16_weights=f16_weights)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 12
+
+
+def test_depth_anything3_split_half_non_square(diag, dev):
+    # 112 x 84 on the 5 x 5 position table: the transposed UV pixel index (dpt.rs:879) and the bicubic pos-embed table in two planes
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    cnd = DepthAnything3Config.tiny_dual_test()
+    cnd.image_size, cnd.image_width = 112, 84
+    start = len(diag.RESULTS)
+    diag.guarded("da3-f16x2-ns")(diag.run_da3)(dev, cnd, "da3-tinydual112x84/f16x2", 1, Precision.F16X2, f16_weights=True)
+    _assert_new_results_ok(diag, start)
+
+
+def test_split_half_fork_follows_a_recommit_that_changes_the_term_count(dev):
+    """a fork must multiply with the ROOT's current weight form. Seeded fp32 weights pack as
+    [Wh | Wh | Wl] (three terms); rounding them to f16 and committing on the root re-packs every plain weight as [W | W]
+    (two terms) while the fork lives -- the fork's next call has to use K' = 2K rows, or it reads garbage."""
+    import numpy as np
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = Precision.F16X2
+    root = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    fork = root.fork()
+    assert root.query("weight_terms") == 3 and fork.query("weight_terms") == 3
+    torch.manual_seed(2)
+    x = torch.randn(1, 3, 512, 512, device="cuda")
+    before = fork.infer(x).depth.clone()
+    assert torch.equal(before, root.infer(x).depth)
+    for n, c in root.param_names():  # an f16 record of the same weights: every value an exact half
+        w = root.get_tensor(n, c)
+        root.set_tensor(n, w.astype(np.float16).astype(np.float32))
+    root.commit_weights()
+    assert root.query("weight_terms") == 2 and fork.query("weight_terms") == 2
+    want = root.infer(x).depth
+    got = fork.infer(x).depth
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)
+    assert not torch.equal(got, before)
+    fork.destroy()
+    root.destroy()
 
 
 def test_host_pointer_path_allocates_nothing_after_the_first_call(dev):
@@ -447,10 +497,12 @@ def test_config4_shard_of_eight_images_is_batch_independent(diag, dev):
     assert len(diag.RESULTS) - start >= 4
 
 
-@pytest.mark.parametrize("precision", [2, 0])
+@pytest.mark.parametrize("precision", [2, 0, 3, 4, 1])
 def test_config5_depth_anything3_large_1036(diag, dev, precision):
     """BASELINE config 5: Depth-Anything-v3 metric_large (ViT-L/14) on [1,3,1036,1036] (5477 tokens, position embedding
-    interpolated 37^2 -> 74^2): fp8 linear layers and bf16 against the fp32 oracle (the fp8-emulating oracle frame runs at 518^2 only: CPU time)."""
+    interpolated 37^2 -> 74^2): fp8 linear layers, bf16 and f16 against the fp32 oracle (the fp8-emulating oracle frame runs at
+    518^2 only: CPU time); the split-half and fp32 modes hold the 37^2 -> 74^2 bicubic table and everything behind it to the
+    fp32 bounds (max-rel 1e-3) and the reference's DA3 bar (example/correctness.rs:1109-1111)."""
     from burn_depth_amd.config import DepthAnything3Config
     cfg = DepthAnything3Config.metric_large()
     cfg.image_size = 1036
@@ -601,7 +653,7 @@ def test_full_size_properties(dev):
     model.destroy()
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 4, 3, 0])
 def test_depth_anything3_tiny_end_to_end(diag, dev, precision):
     # reference: DepthAnything3::infer (depth_anything3/mod.rs:288-291) on the reduced variant
     from burn_depth_amd.config import DepthAnything3Config
@@ -610,16 +662,16 @@ def test_depth_anything3_tiny_end_to_end(diag, dev, precision):
     _assert_new_results_ok(diag, start)
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 4, 3, 0])
 def test_depth_anything3_metric_large_end_to_end(diag, dev, precision):
     # BASELINE config shape for DA3: ViT-L/14, one 518x518 image (depth_anything3/mod.rs:634-642)
     from burn_depth_amd.config import DepthAnything3Config
     start = len(diag.RESULTS)
-    diag.guarded("da3-large")(diag.run_da3)(dev, DepthAnything3Config.metric_large(), f"da3-large/p{precision}", 1, precision)
+    diag.guarded("da3-large")(diag.run_da3)(dev, DepthAnything3Config.metric_large(), f"da3-large/p{precision}", 1, precision, f16_weights=precision == 4)
     _assert_new_results_ok(diag, start)
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 4, 3, 0])
 def test_depth_anything3_tiny_dual_end_to_end(diag, dev, precision):
     # the `small` topology (QK-norm + RoPE + camera token + concatenated hooks, dual head, camera decoder;
     # mod.rs:158-216, dpt.rs:153-513, camera.rs:113-199) on the reduced variant: every output field
@@ -630,12 +682,35 @@ def test_depth_anything3_tiny_dual_end_to_end(diag, dev, precision):
     assert len(diag.RESULTS) - start >= 12
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 4, 3, 0])
 def test_depth_anything3_small_end_to_end(diag, dev, precision):
     # BASELINE config 2: DA3-small, one 518x518 image
     from burn_depth_amd.config import DepthAnything3Config
     start = len(diag.RESULTS)
-    diag.guarded("da3-small")(diag.run_da3)(dev, DepthAnything3Config.small(), f"da3-small/p{precision}", 1, precision)
+    diag.guarded("da3-small")(diag.run_da3)(dev, DepthAnything3Config.small(), f"da3-small/p{precision}", 1, precision, f16_weights=precision == 4)
+    _assert_new_results_ok(diag, start)
+
+
+@pytest.mark.parametrize("precision", [1, 4, 0])
+def test_config2_test_jpg_through_prepare_depth_anything3_image(diag, dev, precision):
+    """BASELINE config 2's input as SURVEY 8(d) words it: the reference's assets/image/test.jpg (540 x 360; decoded pixels in
+    tests/golden/test_jpg_rgb.npy) through `prepare_depth_anything3_image` (shortest-side resize to 518 + centre crop,
+    src/model/mod.rs:162-210) and `infer_from_rgb` (src/inference.rs:128-137) into Depth-Anything-v3 small, against the
+    oracle on the same prepared pixels: every output field."""
+    import numpy as np
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.inference import rgb_to_input_tensor
+    from burn_depth_amd.pipeline import prepare_depth_anything3_image
+    from oracle import depth_pro_ref as R
+    rgb = np.load(os.path.join(ROOT, "tests", "golden", "test_jpg_rgb.npy"))
+    assert rgb.shape == (360, 540, 3)
+    prep = prepare_depth_anything3_image(rgb, 518)
+    assert (prep.width, prep.height) == (518, 518) and prep.rgb.shape == (518, 518, 3)
+    x = R.rgb_to_input_tensor(prep.rgb.tobytes(), 518, 518)
+    assert torch.equal(rgb_to_input_tensor(prep.rgb.tobytes(), 518, 518, dev).cpu(), x)  # the device normalisation is bit-exact
+    start = len(diag.RESULTS)
+    diag.guarded("da3-small-testjpg")(diag.run_da3)(dev, DepthAnything3Config.small(), f"da3-small/test_jpg/p{precision}", 1, precision,
+                                                    f16_weights=True, x=x)
     _assert_new_results_ok(diag, start)
 
 
