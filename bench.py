@@ -271,16 +271,17 @@ def main(argv=None) -> int:
     fovy = torch.empty((B,), dtype=torch.float32, device=tdev)
     gathered = [[torch.empty_like(depths[0]) for _ in range(world)] for _ in range(nbuf)] if (do_gather and rank == 0) else None
     scatter_chunks = list(global_in.split(B, 0)) if (do_scatter and rank == 0) else None
+    pipe = None
     if ncomm is not None:
         # native path: RCCL point-to-point groups on a side stream, ordered against the compute stream by events
-        cstream = torch.cuda.Stream(device=tdev)
-        ev_sc = [torch.cuda.Event() for _ in range(nbuf)]   # shard `slot` has arrived
-        ev_inf = [torch.cuda.Event() for _ in range(nbuf)]  # infer of buffer `slot` has finished (input + depth free / ready)
-        ev_ga = [torch.cuda.Event() for _ in range(nbuf)]   # depth buffer `slot` has been gathered
+        # (burn_depth_amd/parallel.py::NativePipeline; the same bookkeeping runs under `--dry-run --native-comm` on the CPU)
+        from burn_depth_amd.parallel import NativePipeline
         gathered_flat = [torch.empty((world * B, S, S), dtype=torch.float32, device=tdev) for _ in range(nbuf)] if (do_gather and rank == 0) else None
         if gathered_flat is not None:
             gathered = [list(g.split(B, 0)) for g in gathered_flat]
-        used = {"inf": [False] * nbuf, "ga": [False] * nbuf}
+        pipe = NativePipeline(ncomm, lambda slot, cur: model.infer_into(xs[slot], depths[slot], focal, fovx, fovy), nbuf, rank, 0, do_scatter, do_gather,
+                              global_in, xs, depths, gathered_flat, make_stream=lambda: torch.cuda.Stream(device=tdev), make_event=torch.cuda.Event,
+                              current_stream=torch.cuda.current_stream, stream_handle=lambda st: st.cuda_stream)
 
     extra = []  # additional in-flight batches: (forked model sharing the weights, stream, x, depth, focal, fovx, fovy)
     for si in range(1, args.streams):
@@ -294,40 +295,11 @@ def main(argv=None) -> int:
     def issue_scatter(slot):
         pending["scatter"] = dist.scatter(xs[slot], scatter_chunks, src=0, async_op=True)
 
-    def native_scatter(slot):
-        if used["inf"][slot]:
-            cstream.wait_event(ev_inf[slot])  # the previous infer on this input buffer has finished
-        ncomm.scatter_images(global_in if rank == 0 else None, xs[slot], root=0, stream=cstream.cuda_stream)
-        ev_sc[slot].record(cstream)
-        pending["scatter"] = slot
-
-    def native_step():
-        k = pending["k"]
-        slot = k % nbuf
-        cur = torch.cuda.current_stream()
-        if do_scatter:
-            if pending["scatter"] is None:
-                native_scatter(slot)
-            cur.wait_event(ev_sc[slot])
-            if nbuf > 1:
-                native_scatter((k + 1) % nbuf)  # the next step's shard travels while this step computes
-            else:
-                pending["scatter"] = None
-        if do_gather and used["ga"][slot]:
-            cur.wait_event(ev_ga[slot])  # depth buffer `slot` was handed to a gather nbuf steps ago
-        model.infer_into(xs[slot], depths[slot], focal, fovx, fovy)
-        ev_inf[slot].record(cur)
-        used["inf"][slot] = True
-        if do_gather:
-            cstream.wait_event(ev_inf[slot])
-            ncomm.gather_depth(depths[slot], gathered_flat[slot] if rank == 0 else None, root=0, stream=cstream.cuda_stream)
-            ev_ga[slot].record(cstream)
-            used["ga"][slot] = True
-        pending["k"] = k + 1
-
     def step():
-        if ncomm is not None:
-            return native_step()
+        if pipe is not None:
+            pipe.step()
+            pending["k"] = pipe.k
+            return
         k = pending["k"]
         slot = k % nbuf
         if do_scatter:
@@ -351,10 +323,8 @@ def main(argv=None) -> int:
         pending["k"] = k + 1
 
     def drain():
-        if ncomm is not None:
-            cstream.synchronize()
-            torch.cuda.synchronize()
-            pending["scatter"] = None  # a prefetched shard is dropped: the next step scatters its own
+        if pipe is not None:
+            pipe.drain(torch.cuda.synchronize)
             return
         if pending["scatter"] is not None:
             pending["scatter"].wait()
@@ -478,7 +448,9 @@ def main(argv=None) -> int:
                        "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
                        "parallelism": f"dp{world}",
                        "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather,
-                       "comm": "native md_comm_* (RCCL point-to-point groups on a side stream)" if ncomm is not None else ("torch.distributed (RCCL)" if world > 1 else None)},
+                       "comm": "native md_comm_* (RCCL point-to-point groups on a side stream)" if ncomm is not None else ("torch.distributed (RCCL)" if world > 1 else None),
+                       # what the communicator itself reports (ncclCommCount / the process group's size), beside WORLD_SIZE
+                       "ranks_seen": (ncomm.ranks_seen() if ncomm is not None else (dist.get_world_size() if world > 1 else 1))},
             "finite_output": ok,
             # FLOPs the schedule EXECUTES per frame (layers composed at commit count once); null when no per-family pass ran (--graph)
             "frame_tflops_executed": round(total_flops / B / 1e12, 3) if kernels else None,
@@ -842,7 +814,8 @@ def bench_tile_parallel(args, dev, tdev, world: int, rank: int) -> int:
             "dtype": args.precision, "data": "synthetic (seeded U[0,1) image, ImageNet-normalised; random-init weights rounded to f16)",
             "config": {"workload": f"DepthPro::infer [{B},3,{S},{S}], ONE call per step sharded over the ranks", "global_batch": B,
                        "parallelism": f"tile-parallel x{world}: the 37 B ViT sequences split over the ranks, token + hook exchange to rank 0, decoder on rank 0",
-                       "comm": "native md_comm_* (ncclBroadcast of the image, grouped ncclSend / ncclRecv of tokens and hooks)"},
+                       "comm": "native md_comm_* (ncclBroadcast of the image, grouped ncclSend / ncclRecv of tokens and hooks)",
+                       "ranks_seen": ncomm.ranks_seen()},
             "finite_output": ok, "weight_broadcast_s": round(t_bcast, 4), "roofline": None, "cpu_baseline": None}))
     model.destroy()
     ncomm.destroy()
@@ -879,8 +852,51 @@ def bench_dry(args, world: int, rank: int) -> int:
         if world > 1:
             dist.gather(depth, gathered, dst=0)
 
+    hb = None
+    if args.native_comm:
+        # `--native-comm`: the REAL double-buffer / event bookkeeping of the native path (parallel.NativePipeline) on CPU stand-ins:
+        # gloo moves the bytes synchronously, every buffer access is logged against the stream clocks of a happens-before
+        # checker -- a wait the GPU path would be missing shows up here as a race
+        from burn_depth_amd.parallel import HappensBefore, NativePipeline
+        hb = HappensBefore()
+        compute = hb.stream("compute")
+        nbuf = 2
+        xs = [torch.empty(B, 3, S, S) for _ in range(nbuf)]
+        depths = [torch.empty(B, S, S) for _ in range(nbuf)]
+        gflat = [torch.empty(B * world, S, S) for _ in range(nbuf)] if rank == 0 else None
+
+        class DryComm:
+            def scatter_images(self, all_images, shard, root, stream):
+                slot = [i for i, t in enumerate(xs) if t is shard][0]
+                hb.access(stream, f"scatter -> xs[{slot}]", reads=("global_in",) if rank == root else (), writes=(f"xs[{slot}]",))
+                if world > 1:
+                    dist.scatter(shard, list(all_images.split(B, 0)) if rank == root else None, src=root)
+                else:
+                    shard.copy_(all_images)
+
+            def gather_depth(self, shard, all_depth, root, stream):
+                slot = [i for i, t in enumerate(depths) if t is shard][0]
+                hb.access(stream, f"gather depths[{slot}]", reads=(f"depths[{slot}]",), writes=(f"gathered[{slot}]",) if rank == root else ())
+                if world > 1:
+                    dist.gather(shard, list(all_depth.split(B, 0)) if rank == root else None, dst=root)
+                else:
+                    all_depth.copy_(shard)
+
+        def dry_infer(slot, cur):
+            hb.access(cur, f"infer xs[{slot}] -> depths[{slot}]", reads=(f"xs[{slot}]",), writes=(f"depths[{slot}]",))
+            torch.sum(xs[slot], 1, out=depths[slot])
+            depths[slot].add_(1.0)
+
+        pipe = NativePipeline(DryComm(), dry_infer, nbuf, rank, 0, True, True, full if rank == 0 else None, xs, depths, gflat,
+                              make_stream=lambda: hb.stream("comm"), make_event=hb.event, current_stream=lambda: compute)
+
+        def step():  # noqa: F811
+            pipe.step()
+
     for _ in range(args.warmup):
         step()
+    if hb is not None:
+        pipe.drain(lambda: hb.host_join(compute))
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -894,16 +910,31 @@ def bench_dry(args, world: int, rank: int) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     b, e = shard_range(B * world, rank, world)
+    native = None
+    if hb is not None:
+        pipe.drain(lambda: hb.host_join(compute))
+        depth = depths[pipe.last_slot()]
+        if rank == 0:
+            gathered = [gflat[pipe.last_slot()]]
+        races = list(hb.races)
+        if world > 1:  # every rank's log counts
+            box = [None] * world
+            dist.all_gather_object(box, races)
+            races = [r for rr in box for r in rr]
+        native = {"pipeline": "burn_depth_amd.parallel.NativePipeline on CPU stand-ins (gloo transfers, happens-before checker)",
+                  "steps_walked": pipe.k, "races": races}
     ok = torch.equal(depth, full[b:e].sum(1) + 1.0)
-    if rank == 0 and world > 1:
+    if rank == 0 and (world > 1 or hb is not None):
         ok = ok and torch.equal(torch.cat(gathered, 0), full.sum(1) + 1.0)
+    if native is not None:
+        ok = ok and not native["races"]
     if rank == 0:
         emit(({"metric": "frames/sec dry run (CPU stand-in, gloo)", "value": round(args.steps * B * world / elapsed, 3), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"dry run [{B},3,{S},{S}] per rank", "batch_per_gpu": B, "global_batch": B * world,
                                      "parallelism": f"dp{world}", "scatter_inputs_from_rank0": world > 1, "gather_depth_to_rank0": world > 1},
-                          "finite_output": bool(ok), "dry_run": True}))
+                          "finite_output": bool(ok), "dry_run": True, "native_comm": native}))
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1

@@ -67,6 +67,8 @@ SYMBOLS = {
     "md_depth_pro_create": (_I, [_P, C.POINTER(MdDepthProCfg), C.c_uint64, _I, C.POINTER(_P)]),
     "md_depth_pro_load": (_I, [_P, C.c_char_p, C.POINTER(_P)]),
     "md_depth_pro_load_with_config": (_I, [_P, C.POINTER(MdDepthProCfg), C.c_char_p, C.POINTER(_P)]),
+    "md_checkpoint_info": (_I, [C.c_char_p, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(_I), C.POINTER(C.c_int64 * 8), C.POINTER(_I)]),
+    "md_checkpoint_read_tensor": (_I, [C.c_char_p, C.c_char_p, _P, C.c_size_t]),
     "md_model_set_tensor": (_I, [_P, C.c_char_p, _P, C.c_size_t]),
     "md_model_get_tensor": (_I, [_P, C.c_char_p, _P, C.c_size_t]),
     "md_model_param_count": (_I, [_P]),
@@ -115,6 +117,7 @@ SYMBOLS = {
     "md_comm_unique_id": (_I, [_P]),
     "md_comm_init_rank": (_I, [_P, _P, _I, _I, C.POINTER(_P)]),
     "md_comm_rank": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "md_comm_count": (_I, [_P, C.POINTER(_I)]),
     "md_comm_destroy": (_I, [_P]),
     "md_comm_broadcast_weights": (_I, [_P, _P, _I]),
     "md_comm_scatter_images": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),

@@ -127,6 +127,47 @@ int md_depth_pro_load(md_device_t dev, const char* path, md_model_t* out) {
   return md_depth_pro_load_with_config(dev, &c, path, out);
 }
 
+int md_checkpoint_info(const char* path, int index, const char** name, const char** dtype, int* rank, int64_t shape[8],
+                       int* is_burn_record) {
+  static thread_local Container c;
+  static thread_local std::string loaded;
+  static thread_local std::vector<std::string> names;
+  if (!path) MD_FAIL(MD_ERR_INVALID_ARG, "checkpoint path is null");
+  if (loaded != path || index < 0) {  // (re)read on a new path and on every count query
+    c = Container();
+    loaded.clear();
+    MD_TRY(read_container(path, &c));
+    loaded = path;
+    names.clear();
+    for (auto& kv : c.tensors) names.push_back(kv.first);
+    c.bytes.clear();  // only the directory is kept
+    c.bytes.shrink_to_fit();
+  }
+  if (is_burn_record) *is_burn_record = c.burn_record ? 1 : 0;
+  if (index >= 0 && index < (int)names.size()) {
+    const ContainerTensor& t = c.tensors[names[index]];
+    if (t.shape.size() > 8) MD_FAIL(MD_ERR_FORMAT, "tensor `%s` has rank %zu", names[index].c_str(), t.shape.size());
+    if (name) *name = names[index].c_str();
+    if (dtype) *dtype = t.dtype.c_str();
+    if (rank) *rank = (int)t.shape.size();
+    if (shape)
+      for (size_t i = 0; i < t.shape.size(); ++i) shape[i] = t.shape[i];
+  }
+  return (int)names.size();
+}
+
+int md_checkpoint_read_tensor(const char* path, const char* name, float* out_host, size_t count) {
+  if (!path || !name || !out_host) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  Container c;
+  MD_TRY(read_container(path, &c));
+  auto it = c.tensors.find(name);
+  if (it == c.tensors.end()) MD_FAIL(MD_ERR_INVALID_ARG, "checkpoint `%s` has no tensor `%s`", path, name);
+  size_t n = 1;
+  for (auto d : it->second.shape) n *= (size_t)d;
+  if (n != count) MD_FAIL(MD_ERR_SHAPE, "tensor `%s` has %zu elements, got %zu", name, n, count);
+  return container_tensor_to_f32(c, it->second, out_host, count);
+}
+
 int md_model_param_count(md_model_t m) { return m ? (int)m->params.size() : 0; }
 
 int md_model_param_info(md_model_t m, int index, const char** name, size_t* count) {

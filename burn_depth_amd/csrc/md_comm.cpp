@@ -30,6 +30,18 @@ struct md_comm_s {
     }                                                                                                   \
   } while (0)
 
+// Inside an ncclGroupStart / ncclGroupEnd pair: a failing call must not leave the group open (every later RCCL call of this
+// thread would be queued into it and never run) -- close it, then report the FIRST error.
+#define MD_NCCL_G(expr)                                                                                 \
+  do {                                                                                                  \
+    ncclResult_t _r = (expr);                                                                           \
+    if (_r != ncclSuccess) {                                                                            \
+      (void)ncclGroupEnd();                                                                             \
+      ::md::set_error("%s failed inside a group: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__); \
+      return MD_ERR_HIP;                                                                                \
+    }                                                                                                   \
+  } while (0)
+
 extern "C" {
 
 int md_comm_unique_id(uint8_t id[MD_COMM_ID_BYTES]) {
@@ -68,6 +80,15 @@ int md_comm_destroy(md_comm_t c) {
   return MD_OK;
 }
 
+// ranks RCCL itself reports for the communicator (ncclCommCount) -- what `bench.py` prints as `ranks_seen` for N > 1
+int md_comm_count(md_comm_t c, int* ranks_seen) {
+  if (!c || !ranks_seen) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  int n = 0;
+  MD_NCCL(ncclCommCount(c->comm, &n));
+  *ranks_seen = n;
+  return MD_OK;
+}
+
 int md_comm_rank(md_comm_t c, int* rank, int* world_size) {
   if (!c) MD_FAIL(MD_ERR_INVALID_ARG, "communicator is null");
   if (rank) *rank = c->rank;
@@ -102,9 +123,9 @@ int md_comm_scatter_images(md_comm_t c, const float* all_dev, float* shard_dev, 
   MD_NCCL(ncclGroupStart());
   if (c->rank == root) {
     for (int r = 0; r < c->world; ++r)
-      if (r != root) MD_NCCL(ncclSend(all_dev + (size_t)r * elems_per_rank, elems_per_rank, ncclFloat, r, c->comm, st));
+      if (r != root) MD_NCCL_G(ncclSend(all_dev + (size_t)r * elems_per_rank, elems_per_rank, ncclFloat, r, c->comm, st));
   } else {
-    MD_NCCL(ncclRecv(shard_dev, elems_per_rank, ncclFloat, root, c->comm, st));
+    MD_NCCL_G(ncclRecv(shard_dev, elems_per_rank, ncclFloat, root, c->comm, st));
   }
   MD_NCCL(ncclGroupEnd());
   if (c->rank == root && shard_dev != all_dev + (size_t)root * elems_per_rank)
@@ -122,9 +143,9 @@ int md_comm_gather_depth(md_comm_t c, const float* shard_dev, float* all_dev, si
   MD_NCCL(ncclGroupStart());
   if (c->rank == root) {
     for (int r = 0; r < c->world; ++r)
-      if (r != root) MD_NCCL(ncclRecv(all_dev + (size_t)r * elems_per_rank, elems_per_rank, ncclFloat, r, c->comm, st));
+      if (r != root) MD_NCCL_G(ncclRecv(all_dev + (size_t)r * elems_per_rank, elems_per_rank, ncclFloat, r, c->comm, st));
   } else {
-    MD_NCCL(ncclSend(shard_dev, elems_per_rank, ncclFloat, root, c->comm, st));
+    MD_NCCL_G(ncclSend(shard_dev, elems_per_rank, ncclFloat, root, c->comm, st));
   }
   MD_NCCL(ncclGroupEnd());
   if (c->rank == root && shard_dev != all_dev + (size_t)root * elems_per_rank)
@@ -147,10 +168,10 @@ int tile_exchange(void* ctx, int parts, const ShardSegment (*seg)[3], hipStream_
     for (int p = 0; p < parts; ++p)
       if (p != x->root)
         for (int k = 0; k < 3; ++k)
-          if (seg[p][k].bytes) MD_NCCL(ncclRecv(seg[p][k].ptr, seg[p][k].bytes, ncclInt8, p, c->comm, st));
+          if (seg[p][k].bytes) MD_NCCL_G(ncclRecv(seg[p][k].ptr, seg[p][k].bytes, ncclInt8, p, c->comm, st));
   } else {
     for (int k = 0; k < 3; ++k)
-      if (seg[c->rank][k].bytes) MD_NCCL(ncclSend(seg[c->rank][k].ptr, seg[c->rank][k].bytes, ncclInt8, x->root, c->comm, st));
+      if (seg[c->rank][k].bytes) MD_NCCL_G(ncclSend(seg[c->rank][k].ptr, seg[c->rank][k].bytes, ncclInt8, x->root, c->comm, st));
   }
   MD_NCCL(ncclGroupEnd());
   return MD_OK;
@@ -165,6 +186,12 @@ int md_comm_depth_pro_infer_tiles(md_comm_t c, md_model_t m, const float* nchw, 
   if (c->rank == root && !nchw) MD_FAIL(MD_ERR_INVALID_ARG, "the root rank needs the input");
   if (B <= 0 || H <= 0 || W <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid input shape [%d,3,%d,%d]", B, H, W);
   if (m->dev != c->dev) MD_FAIL(MD_ERR_INVALID_ARG, "model and communicator live on different devices");
+  // everything model_infer would refuse is refused HERE, before the first collective: these arguments are the same on every rank,
+  // so every rank returns the same error instead of some ranks waiting in a broadcast the root never joins
+  if (!model_root(m)->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
+  if (B > m->cfg.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d exceeds max_batch %d", B, m->cfg.max_batch);
+  if (!m->cfg.use_fov_head) MD_FAIL(MD_ERR_NO_FOV, "FOV head required for focal length");
+  if (in_kind != MD_MEM_HOST && in_kind != MD_MEM_DEVICE) MD_FAIL(MD_ERR_INVALID_ARG, "unknown memory kind %d", in_kind);
   MD_HIP(hipSetDevice(c->dev->ordinal));
   hipStream_t st = stream ? (hipStream_t)stream : (m->own_stream ? m->own_stream : m->dev->stream);
   // 1. the root's image reaches every rank's staging buffer (28 MB per 1536^2 frame)

@@ -136,6 +136,7 @@ struct md_model_s {
     hipGraphExec_t exec = nullptr;
   };
   std::map<std::vector<uintptr_t>, GraphEntry> graphs;  // key: stream, shapes and every in/out pointer
+  unsigned graphs_gen = 0;  // the root's commit_gen the entries of `graphs` were captured under (a fork drops them when it moves)
 
   // ---- md_model_fork: a fork shares the parameter / packed-weight arenas of its root model (never frees them) and
   //      owns its workspace, index tables, taps, timing, graphs and default stream ----

@@ -746,6 +746,15 @@ int model_load_params_from_container(md_model_t m, const char* path) {
     if (n != s.count()) {
       MD_FAIL(MD_ERR_FORMAT, "tensor `%s` has %zu elements, the model expects %zu", s.name.c_str(), n, s.count());
     }
+    // A Burn record stores `nn::Linear` weights [d_input, d_output] (Container::burn_record); the inventory -- and the
+    // MFMA pack -- hold them [out, in] like PyTorch. Every rank-2 parameter of the inventory is such a weight.
+    bool linear_t = false;
+    if (c.burn_record && s.shape.size() == 2 && it->second.shape.size() == 2) {
+      if (it->second.shape[0] != s.shape[1] || it->second.shape[1] != s.shape[0])
+        MD_FAIL(MD_ERR_FORMAT, "Burn record: linear weight `%s` has shape [%lld, %lld], expected [d_input = %lld, d_output = %lld]", s.name.c_str(),
+                (long long)it->second.shape[0], (long long)it->second.shape[1], (long long)s.shape[1], (long long)s.shape[0]);
+      linear_t = true;
+    }
     // ConvTranspose weights may arrive [out,in,..] (maybe_fix_conv_transpose2d, mod.rs:416-431)
     bool swap = false;
     if (s.shape.size() == 4 && it->second.shape.size() == 4 && s.shape[2] == 2 && s.shape[3] == 2 &&
@@ -753,6 +762,13 @@ int model_load_params_from_container(md_model_t m, const char* path) {
       swap = true;
     tmp.resize(n);
     MD_TRY(container_tensor_to_f32(c, it->second, tmp.data(), n));
+    if (linear_t) {  // [in, out] -> [out, in]
+      std::vector<float> t2(n);
+      const size_t no = (size_t)s.shape[0], ni = (size_t)s.shape[1];
+      for (size_t ii = 0; ii < ni; ++ii)
+        for (size_t o = 0; o < no; ++o) t2[o * ni + ii] = tmp[ii * no + o];
+      tmp.swap(t2);
+    }
     if (swap) {
       std::vector<float> t2(n);
       const size_t a = (size_t)s.shape[0], b2 = (size_t)s.shape[1];
@@ -1396,8 +1412,15 @@ int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kin
                         B <= m->cfg.max_batch && H == m->S && W == m->S;
   // the commit generation of the weights is part of the key: a graph bakes by-value launch parameters (the head's output
   // bias, the split-half term count), and a fork's graphs cannot be reached from the root's commit
+  const unsigned gen = model_root(m)->commit_gen;
+  if (m->graphs_gen != gen) {  // a fork's graphs of an older commit can never be replayed again (the root clears its own in model_commit)
+    for (auto& kv : m->graphs)
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    m->graphs.clear();
+    m->graphs_gen = gen;
+  }
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)depth,
-                                      (uintptr_t)focal, (uintptr_t)fovx, (uintptr_t)fovy, (uintptr_t)model_root(m)->commit_gen};
+                                      (uintptr_t)focal, (uintptr_t)fovx, (uintptr_t)fovy, (uintptr_t)gen};
   return run_with_graph(m, st, key, eligible, body);
 }
 
@@ -1487,7 +1510,15 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
   r.end();
   md_model_s::IndexSet ix;
   MD_TRY(get_index_set(m, B, &ix));
-  hipEvent_t ev_w[66] = {};  // diagnostic timing of the windowed pass (sp->part == -1)
+  // diagnostic timing of the windowed pass (sp->part == -1); destroyed on EVERY way out of this call, early error returns included
+  struct EventSet {
+    hipEvent_t e[66] = {};
+    ~EventSet() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+  } ev_set;
+  hipEvent_t* ev_w = ev_set.e;
   const bool time_windows = sp && sp->part < 0 && (sp->window_ms || sp->tail_ms) && sp->parts <= 64;
   if (!sp) {
     MD_TRY(run_vit(r, nseq_p, nseq, 0, nseq));
@@ -1524,7 +1555,6 @@ static int model_infer_eager(md_model_t m, const float* nchw, int B, int H, int 
     for (int p = 0; p < np; ++p)
       if (sp->window_ms) MD_HIP(hipEventElapsedTime(&sp->window_ms[p], ev_w[p], ev_w[p + 1]));
     if (sp->tail_ms) MD_HIP(hipEventElapsedTime(sp->tail_ms, ev_w[np], ev_w[np + 1]));
-    for (int p = 0; p <= np + 1; ++p) (void)hipEventDestroy(ev_w[p]);
     return MD_OK;
   };
   MD_TRY(run_encoder_tail(r, ix));

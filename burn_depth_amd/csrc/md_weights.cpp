@@ -3,6 +3,7 @@
 #include "md_weights.h"
 #include "md_engine.h"
 
+#include <cctype>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -351,6 +352,227 @@ struct Json {
 };
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Burn record reader: `NamedMpkFileRecorder<HalfPrecisionSettings>` files (`.mpk`), the argument of the reference's
+// `DepthPro::load(&device, path)` (depth_pro/mod.rs:193-208) and `DepthAnything3::load_file` (example/correctness.rs:977-982).
+// Format as published by Burn 0.19 (burn-core record/file.rs, record/tensor.rs; the crate is not vendored in the reference
+// tree and no `.mpk` exists there -- `.gitignore:8,17,32` --, so this reader is UNVALIDATED ON A REAL BURN RECORD): one
+// MessagePack map { "metadata": {...}, "item": <record> } where <record> nests maps by field name (rmp_serde::to_vec_named),
+// `Vec<Module>` as arrays, `Option::None` as nil, and every parameter as
+//   { "id": str, "param": { "bytes": bin, "shape": [..], "dtype": "F16" | "F32" | "BF16" } }.
+// The walker is tolerant: any map holding `bytes` + `shape` is a tensor; `param` / `item` wrappers and `id` entries do not
+// contribute to the dotted path; everything that is not a map or an array is skipped. The dotted paths are the Burn field
+// paths of the engine's parameter inventory.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct MsgPack {
+  const uint8_t* base;
+  const uint8_t* p;
+  const uint8_t* e;
+  bool ok = true;
+  int depth = 0;
+  bool need(size_t n) { if ((size_t)(e - p) < n) { ok = false; return false; } return true; }
+  uint64_t be(int n) {
+    if (!need((size_t)n)) return 0;
+    uint64_t v = 0;
+    for (int i = 0; i < n; ++i) v = (v << 8) | *p++;
+    return v;
+  }
+  // header of the next value: kind 'm' map, 'a' array, 's' str, 'b' bin, 'i' integer (value in `len`), 'x' anything else
+  // (already consumed); len = entries / elements / bytes
+  char head(uint64_t* len) {
+    *len = 0;
+    if (!need(1)) return 'x';
+    const uint8_t t = *p++;
+    if (t <= 0x7f) { *len = t; return 'i'; }
+    if (t >= 0x80 && t <= 0x8f) { *len = t & 0x0f; return 'm'; }
+    if (t >= 0x90 && t <= 0x9f) { *len = t & 0x0f; return 'a'; }
+    if (t >= 0xa0 && t <= 0xbf) { *len = t & 0x1f; return 's'; }
+    if (t >= 0xe0) { *len = (uint64_t)(int64_t)(int8_t)t; return 'i'; }
+    switch (t) {
+      case 0xc0: case 0xc2: case 0xc3: return 'x';                    // nil, false, true
+      case 0xc4: *len = be(1); return 'b';
+      case 0xc5: *len = be(2); return 'b';
+      case 0xc6: *len = be(4); return 'b';
+      case 0xc7: { const uint64_t n = be(1); if (need(n + 1)) p += n + 1; return 'x'; }  // ext 8 / 16 / 32: type byte + payload
+      case 0xc8: { const uint64_t n = be(2); if (need(n + 1)) p += n + 1; return 'x'; }
+      case 0xc9: { const uint64_t n = be(4); if (need(n + 1)) p += n + 1; return 'x'; }
+      case 0xca: if (need(4)) p += 4; return 'x';                     // float 32 / 64
+      case 0xcb: if (need(8)) p += 8; return 'x';
+      case 0xcc: *len = be(1); return 'i';
+      case 0xcd: *len = be(2); return 'i';
+      case 0xce: *len = be(4); return 'i';
+      case 0xcf: *len = be(8); return 'i';
+      case 0xd0: *len = (uint64_t)(int64_t)(int8_t)be(1); return 'i';
+      case 0xd1: *len = (uint64_t)(int64_t)(int16_t)be(2); return 'i';
+      case 0xd2: *len = (uint64_t)(int64_t)(int32_t)be(4); return 'i';
+      case 0xd3: *len = be(8); return 'i';
+      case 0xd4: if (need(2)) p += 2; return 'x';                     // fixext 1 / 2 / 4 / 8 / 16
+      case 0xd5: if (need(3)) p += 3; return 'x';
+      case 0xd6: if (need(5)) p += 5; return 'x';
+      case 0xd7: if (need(9)) p += 9; return 'x';
+      case 0xd8: if (need(17)) p += 17; return 'x';
+      case 0xd9: *len = be(1); return 's';
+      case 0xda: *len = be(2); return 's';
+      case 0xdb: *len = be(4); return 's';
+      case 0xdc: *len = be(2); return 'a';
+      case 0xdd: *len = be(4); return 'a';
+      case 0xde: *len = be(2); return 'm';
+      case 0xdf: *len = be(4); return 'm';
+      default: ok = false; return 'x';                                // 0xc1: never used
+    }
+  }
+  void skip() {  // any value
+    if (++depth > 64) { ok = false; --depth; return; }
+    uint64_t n;
+    const char k = head(&n);
+    if (k == 's' || k == 'b') { if (need(n)) p += n; }
+    else if (k == 'a') { for (uint64_t i = 0; ok && i < n; ++i) skip(); }
+    else if (k == 'm') { for (uint64_t i = 0; ok && i < 2 * n; ++i) skip(); }
+    --depth;
+  }
+  std::string key() {  // a map key: a string (integer keys are rendered as decimal text)
+    uint64_t n;
+    const char k = head(&n);
+    if (k == 's' && need(n)) { std::string s((const char*)p, (size_t)n); p += n; return s; }
+    if (k == 'i') return std::to_string((long long)n);
+    if (k == 'b' && need(n)) { std::string s((const char*)p, (size_t)n); p += n; return s; }
+    ok = false;
+    return std::string();
+  }
+};
+
+// tensor leaf: `p` stands behind the header of a map with `n` entries that holds `bytes` and `shape`
+int mpk_tensor(MsgPack& mp, uint64_t n, const std::string& name, Container* out) {
+  ContainerTensor t;
+  t.dtype = "F32";
+  bool have_bytes = false, have_shape = false;
+  for (uint64_t i = 0; mp.ok && i < n; ++i) {
+    const std::string k = mp.key();
+    if (!mp.ok) break;
+    if (k == "bytes") {
+      uint64_t len;
+      const char kind = mp.head(&len);
+      if (kind != 'b' || !mp.need(len)) MD_FAIL(MD_ERR_FORMAT, "Burn record: tensor `%s` does not hold its bytes as a MessagePack bin", name.c_str());
+      t.begin = (size_t)(mp.p - mp.base);
+      t.end = t.begin + (size_t)len;
+      mp.p += len;
+      have_bytes = true;
+    } else if (k == "shape") {
+      uint64_t len;
+      if (mp.head(&len) != 'a') MD_FAIL(MD_ERR_FORMAT, "Burn record: malformed shape of `%s`", name.c_str());
+      for (uint64_t j = 0; mp.ok && j < len; ++j) {
+        uint64_t d;
+        if (mp.head(&d) != 'i') MD_FAIL(MD_ERR_FORMAT, "Burn record: malformed shape of `%s`", name.c_str());
+        t.shape.push_back((int64_t)d);
+      }
+      have_shape = true;
+    } else if (k == "dtype") {
+      const uint8_t* save = mp.p;
+      uint64_t len;
+      const char kind = mp.head(&len);
+      if (kind == 's' && mp.need(len)) {
+        t.dtype.assign((const char*)mp.p, (size_t)len);
+        mp.p += len;
+      } else if (kind == 'm' && len == 1) {  // an externally tagged variant: {"F16": nil}
+        t.dtype = mp.key();
+        mp.skip();
+      } else {
+        mp.p = save;
+        mp.skip();
+      }
+    } else {
+      mp.skip();
+    }
+  }
+  if (!mp.ok || !have_bytes || !have_shape) MD_FAIL(MD_ERR_FORMAT, "Burn record: malformed tensor `%s`", name.c_str());
+  for (auto& ch : t.dtype) ch = (char)toupper((unsigned char)ch);
+  if (t.dtype != "F16" && t.dtype != "F32" && t.dtype != "BF16") MD_FAIL(MD_ERR_FORMAT, "Burn record: tensor `%s` has unsupported dtype `%s`", name.c_str(), t.dtype.c_str());
+  if (out->tensors.count(name)) MD_FAIL(MD_ERR_FORMAT, "Burn record: two tensors at `%s`", name.c_str());
+  out->tensors[name] = t;
+  return MD_OK;
+}
+
+int mpk_walk(MsgPack& mp, const std::string& path, Container* out) {
+  if (++mp.depth > 64) MD_FAIL(MD_ERR_FORMAT, "Burn record: nesting deeper than 64 levels");
+  const uint8_t* start = mp.p;
+  uint64_t n;
+  const char kind = mp.head(&n);
+  int rc = MD_OK;
+  if (kind == 'm') {
+    // first pass over the keys of this level: is it a tensor leaf?
+    const uint8_t* body = mp.p;
+    bool has_bytes = false, has_shape = false;
+    for (uint64_t i = 0; mp.ok && i < n; ++i) {
+      const std::string k = mp.key();
+      has_bytes |= k == "bytes";
+      has_shape |= k == "shape";
+      mp.skip();
+    }
+    if (!mp.ok) MD_FAIL(MD_ERR_FORMAT, "Burn record: truncated or malformed MessagePack near `%s`", path.c_str());
+    mp.p = body;
+    if (has_bytes && has_shape) {
+      rc = mpk_tensor(mp, n, path, out);
+    } else {
+      for (uint64_t i = 0; rc == MD_OK && mp.ok && i < n; ++i) {
+        const std::string k = mp.key();
+        if (!mp.ok) break;
+        if (k == "id") { mp.skip(); continue; }
+        const bool wrapper = k == "param" || k == "item";
+        rc = mpk_walk(mp, wrapper ? path : (path.empty() ? k : path + "." + k), out);
+      }
+    }
+  } else if (kind == 'a') {
+    for (uint64_t i = 0; rc == MD_OK && mp.ok && i < n; ++i) rc = mpk_walk(mp, path.empty() ? std::to_string(i) : path + "." + std::to_string(i), out);
+  } else if (kind == 's' || kind == 'b') {
+    if (mp.need(n)) mp.p += n;
+  }
+  (void)start;
+  --mp.depth;
+  if (rc == MD_OK && !mp.ok) MD_FAIL(MD_ERR_FORMAT, "Burn record: truncated or malformed MessagePack near `%s`", path.c_str());
+  return rc;
+}
+
+int read_burn_record(const char* path, Container* out) {
+  MsgPack mp{out->bytes.data(), out->bytes.data(), out->bytes.data() + out->bytes.size()};
+  uint64_t n;
+  if (mp.head(&n) != 'm') MD_FAIL(MD_ERR_FORMAT, "checkpoint `%s` is neither a safetensors container nor a Burn record", path);
+  bool found = false;
+  for (uint64_t i = 0; mp.ok && i < n; ++i) {
+    const std::string k = mp.key();
+    if (!mp.ok) break;
+    if (k == "item") {
+      MD_TRY(mpk_walk(mp, std::string(), out));
+      found = true;
+    } else if (k == "metadata") {
+      const uint8_t* save = mp.p;
+      uint64_t mlen;
+      if (mp.head(&mlen) == 'm') {  // {float, int, format, version, settings}: kept as strings where they are strings
+        for (uint64_t j = 0; mp.ok && j < mlen; ++j) {
+          const std::string mk = mp.key();
+          const uint8_t* vs = mp.p;
+          uint64_t vl;
+          if (mp.head(&vl) == 's' && mp.need(vl)) { out->metadata[mk].assign((const char*)mp.p, (size_t)vl); mp.p += vl; }
+          else { mp.p = vs; mp.skip(); }
+        }
+      } else {
+        mp.p = save;
+        mp.skip();
+      }
+    } else {
+      mp.skip();
+    }
+  }
+  if (!mp.ok) MD_FAIL(MD_ERR_FORMAT, "Burn record `%s`: truncated or malformed MessagePack", path);
+  if (!found) MD_FAIL(MD_ERR_FORMAT, "Burn record `%s`: no `item` entry", path);
+  if (out->tensors.empty()) MD_FAIL(MD_ERR_FORMAT, "Burn record `%s`: no tensors found", path);
+  out->data_off = 0;
+  out->burn_record = true;
+  out->metadata["container"] = "burn_mpk";
+  return MD_OK;
+}
+}  // namespace
+
 int read_container(const char* path, Container* out) {
   if (!path) MD_FAIL(MD_ERR_INVALID_ARG, "checkpoint path is null");
   std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -362,6 +584,11 @@ int read_container(const char* path, Container* out) {
   if (!f.read((char*)out->bytes.data(), sz)) MD_FAIL(MD_ERR_IO, "short read on `%s`", path);
   uint64_t hlen = 0;
   memcpy(&hlen, out->bytes.data(), 8);
+  // safetensors: 8-byte little-endian header length, then a JSON object. Anything else that opens with a MessagePack map
+  // (fixmap 0x80-0x8f, map16 0xde, map32 0xdf) is read as a Burn record (`DepthPro::load`'s argument, mod.rs:193-208).
+  const bool st_like = hlen <= (uint64_t)sz - 8 && hlen >= 2 && out->bytes[8] == '{';
+  const uint8_t b0 = out->bytes[0];
+  if (!st_like && ((b0 >= 0x80 && b0 <= 0x8f) || b0 == 0xde || b0 == 0xdf)) return read_burn_record(path, out);
   if (hlen > (uint64_t)sz - 8) MD_FAIL(MD_ERR_FORMAT, "container header length %llu exceeds file size", (unsigned long long)hlen);
   out->data_off = 8 + (size_t)hlen;
   const size_t data_len = (size_t)sz - out->data_off;

@@ -57,7 +57,7 @@ uint64_t fnv1a64(const std::string& s);
 // element i of the stream: lo + (hi-lo) * (top24(splitmix64(key + (i+1)*golden)) + 0.5) / 2^24
 void uniform_stream(const std::string& name, uint64_t seed, size_t count, float lo, float hi, float* out);
 
-// ---- safetensors subset ----
+// ---- checkpoint files: the engine's safetensors container, or a Burn record (`.mpk`) ----
 struct ContainerTensor {
   std::string dtype;  // F32 | F16 | BF16
   std::vector<int64_t> shape;
@@ -68,7 +68,12 @@ struct Container {
   size_t data_off = 0;
   std::map<std::string, ContainerTensor> tensors;
   std::map<std::string, std::string> metadata;
+  // true: the file is a Burn `NamedMpkFileRecorder` record (what `DepthPro::load` reads, depth_pro/mod.rs:193-208) -- tensor
+  // names are Burn field paths and `nn::Linear` weights are stored [d_input, d_output] (the records are written behind
+  // `PyTorchToBurnAdapter`, tool/import_da3.rs:199, which transposes PyTorch's [out, in]); the loader transposes them back
+  bool burn_record = false;
 };
+// Reads `path`, dispatching on its first bytes: a safetensors header (8-byte length + JSON object) or a MessagePack map.
 int read_container(const char* path, Container* out);
 // Convert tensor `t` to fp32 into dst (count elements).
 int container_tensor_to_f32(const Container& c, const ContainerTensor& t, float* dst, size_t count);

@@ -11,7 +11,14 @@ where <record> nests maps by field name (named = `rmp_serde::to_vec_named`), `Ve
 as nil, and every parameter as  { "id": str, "param": { "bytes": bin, "shape": [..], "dtype": "F16"|"F32"|"BF16" } }.
 The walker is tolerant: any map holding `bytes` + `shape` (+ `dtype`) is a tensor, `param` / `item` wrappers and
 `id` entries do not contribute to the dotted path. The resulting names are the Burn field paths the engine's
-container uses, so `mpk_to_container` only has to check them against the inventory."""
+container uses.
+
+Layout: a Burn record holds `nn::Linear` weights as `[d_input, d_output]` (the reference's importers write their records
+behind `PyTorchToBurnAdapter`, tool/import_da3.rs:199, which transposes PyTorch's `[out, in]`); the engine's inventory holds
+them `[out, in]`. Every rank-2 tensor of these models is such a weight, so `read_mpk` transposes rank-2 tensors on the way
+in and `write_mpk` on the way out (`burn_layout=True`, the default). The C ABI reads the same files natively
+(`md_depth_pro_load` / `md_da3_load` dispatch on the first bytes; csrc/md_weights.cpp): this module is the Python twin for the
+importer and the tests."""
 from __future__ import annotations
 
 from typing import Dict, List
@@ -61,8 +68,8 @@ def _walk(node, path: List[str], out: Dict[str, np.ndarray]) -> None:
             _walk(v, path + [str(i)], out)
 
 
-def read_mpk(path: str) -> Dict[str, np.ndarray]:
-    """All tensors of a Burn `.mpk` record as fp32 arrays keyed by dotted field path."""
+def read_mpk(path: str, burn_layout: bool = True) -> Dict[str, np.ndarray]:
+    """All tensors of a Burn `.mpk` record as fp32 arrays keyed by dotted field path, Linear weights as `[out, in]`."""
     import msgpack
     with open(path, "rb") as f:
         root = msgpack.unpackb(f.read(), raw=False, strict_map_key=False)
@@ -72,11 +79,14 @@ def read_mpk(path: str) -> Dict[str, np.ndarray]:
     _walk(root["item"], [], out)
     if not out:
         raise ValueError(f"{path}: no tensors found")
+    if burn_layout:
+        out = {k: (np.ascontiguousarray(v.T) if v.ndim == 2 else v) for k, v in out.items()}
     return out
 
 
-def write_mpk(path: str, tensors: Dict[str, np.ndarray], dtype: str = "F16") -> None:
-    """Writes the structure described above (used by the tests; mirrors `HalfPrecisionSettings` for dtype F16)."""
+def write_mpk(path: str, tensors: Dict[str, np.ndarray], dtype: str = "F16", burn_layout: bool = True) -> None:
+    """Writes the structure described above (used by the tests; mirrors `HalfPrecisionSettings` for dtype F16). `tensors` holds
+    Linear weights `[out, in]`; the file holds them `[d_input, d_output]` like a Burn record."""
     import msgpack
     root: dict = {}
     for name, arr in tensors.items():
@@ -84,7 +94,7 @@ def write_mpk(path: str, tensors: Dict[str, np.ndarray], dtype: str = "F16") -> 
         parts = name.split(".")
         for p in parts[:-1]:
             node = node.setdefault(p, {})
-        a = np.ascontiguousarray(arr, np.float32)
+        a = np.ascontiguousarray(arr.T if (burn_layout and np.ndim(arr) == 2) else arr, np.float32)
         raw = a.astype(np.float16).tobytes() if dtype == "F16" else a.tobytes()
         node[parts[-1]] = {"id": name, "param": {"bytes": raw, "shape": list(a.shape), "dtype": dtype}}
 

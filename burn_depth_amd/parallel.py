@@ -90,6 +90,12 @@ class NativeComm:
             dist.broadcast_object_list(box, src=0)
         return NativeComm(device, box[0], dist.get_world_size(), dist.get_rank())
 
+    def ranks_seen(self) -> int:
+        """`ncclCommCount` of the communicator: the ranks RCCL itself sees."""
+        n = C.c_int()
+        self._L.check(self._lib.md_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
     def broadcast_weights(self, model, root: int = 0) -> None:
         self._L.check(self._lib.md_comm_broadcast_weights(self._h, model._h, int(root)))
 
@@ -129,3 +135,146 @@ class NativeComm:
         if self._h:
             self._lib.md_comm_destroy(self._h)
             self._h = None
+
+
+class NativePipeline:
+    """The per-step data path of `bench.py --native-comm` (BASELINE config 4: "including scatter + gather"): the root scatters the
+    global batch, every rank infers its shard, the root gathers the depth maps -- scatter of step t+1 and gather of step t-1 on a
+    side HIP stream under step t's inference, ordered against the compute stream by events, over `nbuf` (2) input / depth buffers.
+
+    Everything it touches is injected, so the SAME bookkeeping runs on the GPU (torch.cuda streams / events, `NativeComm`,
+    `DepthPro.infer_into`) and in `bench.py --dry-run --native-comm` on CPU stand-ins that record every buffer access with the
+    stream clocks of `HappensBefore` below: a missing wait is a reported race there, not a once-in-a-while corrupted frame on 8 GPUs.
+
+      comm.scatter_images(all | None, shard, root, stream) / comm.gather_depth(shard, all | None, root, stream)
+      infer(slot, stream)               runs the model on xs[slot] -> depths[slot] on `stream`
+      make_stream() / make_event() / current_stream()
+      a stream has wait_event(ev) and synchronize(); an event has record(stream)
+    """
+
+    def __init__(self, comm, infer, nbuf, rank, root, do_scatter, do_gather, global_in, xs, depths, gathered_flat, make_stream, make_event,
+                 current_stream, stream_handle=lambda s: s):
+        self.comm, self.infer, self.nbuf, self.rank, self.root = comm, infer, nbuf, rank, root
+        self.do_scatter, self.do_gather = do_scatter, do_gather
+        self.global_in, self.xs, self.depths, self.gathered_flat = global_in, xs, depths, gathered_flat
+        self.current_stream, self.handle = current_stream, stream_handle
+        self.cstream = make_stream()
+        self.ev_sc = [make_event() for _ in range(nbuf)]   # shard `slot` has arrived
+        self.ev_inf = [make_event() for _ in range(nbuf)]  # infer of buffer `slot` has finished (input free, depth ready)
+        self.ev_ga = [make_event() for _ in range(nbuf)]   # depth buffer `slot` has been gathered
+        self.used_inf, self.used_ga = [False] * nbuf, [False] * nbuf
+        self.pending_scatter = None
+        self.k = 0
+
+    def _scatter(self, slot):
+        if self.used_inf[slot]:
+            self.cstream.wait_event(self.ev_inf[slot])  # the previous infer on this input buffer has finished
+        self.comm.scatter_images(self.global_in if self.rank == self.root else None, self.xs[slot], root=self.root, stream=self.handle(self.cstream))
+        self.ev_sc[slot].record(self.cstream)
+        self.pending_scatter = slot
+
+    def step(self):
+        k, nbuf = self.k, self.nbuf
+        slot = k % nbuf
+        cur = self.current_stream()
+        if self.do_scatter:
+            if self.pending_scatter is None:
+                self._scatter(slot)
+            cur.wait_event(self.ev_sc[slot])
+            if nbuf > 1:
+                self._scatter((k + 1) % nbuf)  # the next step's shard travels while this step computes
+            else:
+                self.pending_scatter = None
+        if self.do_gather and self.used_ga[slot]:
+            cur.wait_event(self.ev_ga[slot])  # depth buffer `slot` was handed to a gather nbuf steps ago
+        self.infer(slot, cur)
+        self.ev_inf[slot].record(cur)
+        self.used_inf[slot] = True
+        if self.do_gather:
+            self.cstream.wait_event(self.ev_inf[slot])
+            self.comm.gather_depth(self.depths[slot], self.gathered_flat[slot] if self.rank == self.root else None, root=self.root,
+                                   stream=self.handle(self.cstream))
+            self.ev_ga[slot].record(self.cstream)
+            self.used_ga[slot] = True
+        self.k = k + 1
+
+    def drain(self, device_synchronize):
+        self.cstream.synchronize()
+        device_synchronize()
+        self.pending_scatter = None  # a prefetched shard is dropped: the next step scatters its own
+
+    def last_slot(self):
+        return (self.k - 1) % self.nbuf
+
+
+class HappensBefore:
+    """Vector-clock race detector for the CPU stand-ins of `NativePipeline`: every stream carries a clock {stream: count},
+    recording an event copies it, waiting on an event joins it; an access to a buffer must happen-after the buffer's last
+    write (reads and writes) and after every read since (writes). `races` lists what did not."""
+
+    class Stream:
+        def __init__(self, hb, name):
+            self.hb, self.name, self.clock = hb, name, {name: 0}
+
+        def wait_event(self, ev):
+            if ev.clock is None:
+                self.hb.races.append(f"{self.name} waits on an event that was never recorded")
+                return
+            for k, v in ev.clock.items():
+                self.clock[k] = max(self.clock.get(k, 0), v)
+
+        def synchronize(self):  # the host has seen everything this stream did: later work on ANY stream happens after it
+            self.hb.host_join(self)
+
+        def tick(self):
+            self.clock[self.name] += 1
+            return (self.name, self.clock[self.name])
+
+    class Event:
+        def __init__(self):
+            self.clock = None
+
+        def record(self, stream):
+            self.clock = dict(stream.clock)
+
+    def __init__(self):
+        self.races, self.streams, self.host = [], [], {}
+        self.last_write, self.reads = {}, {}
+
+    def stream(self, name):
+        s = HappensBefore.Stream(self, name)
+        for k, v in self.host.items():
+            s.clock[k] = max(s.clock.get(k, 0), v)
+        self.streams.append(s)
+        return s
+
+    def event(self):
+        return HappensBefore.Event()
+
+    def host_join(self, stream):
+        for k, v in stream.clock.items():
+            self.host[k] = max(self.host.get(k, 0), v)
+        for s in self.streams:  # host-ordered: whatever is issued afterwards sees it
+            for k, v in self.host.items():
+                s.clock[k] = max(s.clock.get(k, 0), v)
+
+    def _after(self, stream, op):
+        return op is None or stream.clock.get(op[0], 0) >= op[1]
+
+    def access(self, stream, what, reads=(), writes=()):
+        for b in reads:
+            if not self._after(stream, self.last_write.get(b)):
+                self.races.append(f"{what} on {stream.name} reads {b} without waiting for its writer {self.last_write[b]}")
+        for b in writes:
+            if not self._after(stream, self.last_write.get(b)):
+                self.races.append(f"{what} on {stream.name} overwrites {b} without waiting for its writer {self.last_write[b]}")
+            for r in self.reads.get(b, []):
+                if not self._after(stream, r):
+                    self.races.append(f"{what} on {stream.name} overwrites {b} while reader {r} may still run")
+        op = stream.tick()
+        for b in reads:
+            self.reads.setdefault(b, []).append(op)
+        for b in writes:
+            self.last_write[b] = op
+            self.reads[b] = []
+        return op

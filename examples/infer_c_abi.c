@@ -3,14 +3,18 @@
  * length) and `bench/inference.rs:21-48` (zeros input). Build and run (tests/test_gpu_parity.py does both on the GPU box):
  *
  *   gcc -O2 -Iinclude examples/infer_c_abi.c -Lburn_depth_amd -lmi_depth -Wl,-rpath,$PWD/burn_depth_amd -lm -o /tmp/infer_c_abi
- *   /tmp/infer_c_abi [weights.safetensors]
+ *   /tmp/infer_c_abi [checkpoint [tiny]]
  *
+ * `checkpoint` is what the reference's `DepthPro::load(&device, path)` takes (depth_pro/mod.rs:193-208): a Burn `.mpk` record
+ * (NamedMpkFileRecorder<HalfPrecisionSettings>), read natively by the library, or the engine's safetensors container. A second
+ * argument `tiny` loads it with the reduced `tiny16_128` configuration (`DepthPro::load_with_config`, mod.rs:200-208).
  * Without a weight file it creates the reduced `tiny16_128` configuration with the seeded synthetic weights the parity
  * tests use and prints values the Python mirror must reproduce bit for bit (same library, same seed). */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "mi_depth.h"
 
@@ -31,9 +35,8 @@ int main(int argc, char** argv) {
   md_depth_pro_cfg cfg;
   md_depth_pro_cfg_default(&cfg);
   int S = 1536;
-  if (argc > 1) { /* DepthPro::load(&device, path): the default configuration */
-    CHECK(md_depth_pro_load(dev, argv[1], &model));
-  } else { /* DepthPro::new(&device, cfg) on the reduced configuration, seeded */
+  const int tiny = argc <= 1 || (argc > 2 && strcmp(argv[2], "tiny") == 0);
+  if (tiny) { /* the reduced configuration (the CI-size preset of the tests) */
     cfg.patch_encoder_preset = "tiny16_128";
     cfg.image_encoder_preset = "tiny16_128";
     cfg.fov_encoder_preset = "tiny16_128";
@@ -41,6 +44,12 @@ int main(int argc, char** argv) {
     cfg.precision = MD_PREC_F32;
     cfg.max_batch = 1;
     S = 512;
+  }
+  if (argc > 1 && tiny) { /* DepthPro::load_with_config(&device, path, cfg): a Burn .mpk record or a safetensors container */
+    CHECK(md_depth_pro_load_with_config(dev, &cfg, argv[1], &model));
+  } else if (argc > 1) { /* DepthPro::load(&device, path): the default configuration */
+    CHECK(md_depth_pro_load(dev, argv[1], &model));
+  } else { /* DepthPro::new(&device, cfg), seeded */
     CHECK(md_depth_pro_create(dev, &cfg, 0, MD_INIT_PARITY, &model));
   }
 

@@ -91,12 +91,24 @@ void md_depth_pro_cfg_default(md_depth_pro_cfg* cfg);
 /* `DepthPro::new(&device, cfg)` (depth_pro/mod.rs:145-191): seeded synthetic initialisation. */
 int md_depth_pro_create(md_device_t dev, const md_depth_pro_cfg* cfg, uint64_t seed, int init_scheme,
                         md_model_t* out);
-/* `DepthPro::load(&device, path)` (depth_pro/mod.rs:193-198): default config. The container is
- * safetensors keyed by the reference's Burn field paths. */
+/* `DepthPro::load(&device, path)` (depth_pro/mod.rs:193-198): default config. `path` is either
+ *  - the reference's own checkpoint: a Burn `NamedMpkFileRecorder<HalfPrecisionSettings>` record (`.mpk`, mod.rs:206) --
+ *    MessagePack, tensors keyed by Burn field path, `nn::Linear` weights [d_input, d_output] (transposed on load); the reader
+ *    follows Burn 0.19's published record layout and is UNVALIDATED ON A REAL BURN RECORD (none exists in the reference tree);
+ *  - or the engine's safetensors container keyed by the same field paths (tools/import_weights.py).
+ * The format is recognised from the first bytes of the file, not from its name. */
 int md_depth_pro_load(md_device_t dev, const char* path, md_model_t* out);
 /* `DepthPro::load_with_config` (depth_pro/mod.rs:200-208). */
 int md_depth_pro_load_with_config(md_device_t dev, const md_depth_pro_cfg* cfg, const char* path,
                                   md_model_t* out);
+/* Host-only view of a checkpoint file (either format above; no device needed): the number of tensors it holds, and for
+ * 0 <= index < that number the tensor's name (Burn field path), dtype ("F16" | "F32" | "BF16"), rank and shape as stored in
+ * the file (a Burn record's Linear weights read [d_input, d_output] here). `name` / `dtype` point into thread-local storage
+ * that lives until the next call on this thread. Returns the tensor count, or a negative MD_ERR_* code. */
+int md_checkpoint_info(const char* path, int index, const char** name, const char** dtype, int* rank, int64_t shape[8],
+                       int* is_burn_record);
+/* The values of one tensor of a checkpoint file widened to fp32, in the file's own element order (`count` must match). */
+int md_checkpoint_read_tensor(const char* path, const char* name, float* out_host, size_t count);
 /* `Module::load_record` / `into_record` (src/lib.rs:163-177): read or replace one named
  * parameter with host fp32 data. `count` = number of elements and must match. */
 int md_model_set_tensor(md_model_t m, const char* name, const float* host_data, size_t count);
@@ -174,7 +186,8 @@ typedef struct md_da3_cfg {
 void md_da3_cfg_default(md_da3_cfg* cfg);
 /* `DepthAnything3::new(&device, cfg)` (depth_anything3/mod.rs:253-286): seeded synthetic weights. */
 int md_da3_create(md_device_t dev, const md_da3_cfg* cfg, uint64_t seed, int init_scheme, md_model_t* out);
-/* `DepthAnything3::new(cfg).load_file(path, ..)` (example/correctness.rs:977-982), safetensors container. */
+/* `DepthAnything3::new(cfg).load_file(path, ..)` (example/correctness.rs:977-982): a Burn `.mpk` record or the engine's
+ * safetensors container, as md_depth_pro_load. */
 int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_model_t* out);
 /* `DepthAnything3::infer(&self, x)` (depth_anything3/mod.rs:288-291): NCHW fp32 in, depth [B*H*W] out.
  * H and W may be ANY multiples of the patch size (mod.rs:509-520 asserts only that; else MD_ERR_SHAPE). The model keeps
@@ -326,6 +339,8 @@ int md_comm_unique_id(uint8_t id[MD_COMM_ID_BYTES]);
 /* Collective over all ranks: joins the communicator of `world_size` ranks as `rank` on this device. */
 int md_comm_init_rank(md_device_t dev, const uint8_t id[MD_COMM_ID_BYTES], int world_size, int rank, md_comm_t* out);
 int md_comm_rank(md_comm_t c, int* rank, int* world_size);
+/* The number of ranks RCCL itself reports for the communicator (`ncclCommCount`). */
+int md_comm_count(md_comm_t c, int* ranks_seen);
 int md_comm_destroy(md_comm_t c);
 /* Collective: `DepthPro::load` happens on `root` only; its fp32 parameter arena is broadcast into every rank's model (same
  * config) in 1-GiB buckets and every rank commits (packs its own MFMA operand copies). Synchronises the device's stream. */

@@ -151,6 +151,64 @@ def test_load_container_matches_seeded_create(dev, tmp_path):
         m.destroy()
 
 
+def test_burn_mpk_record_loads_through_the_c_abi(dev, tmp_path):
+    """`DepthPro::load(&device, path)` takes the Burn record itself (depth_pro/mod.rs:193-208): md_depth_pro_load[_with_config] and
+    md_da3_load read a `.mpk` natively (csrc/md_weights.cpp; MessagePack walker + Linear [d_input, d_output] -> [out, in]). The
+    record is written by tests/mpk_fixture.py (byte-level, no code shared with the reader); the loaded model must equal the seeded
+    model with its weights rounded to f16 -- what an f16 record of them holds -- bit for bit, also from the plain-C caller.
+    (The record LAYOUT follows Burn 0.19's published format; it stays unvalidated on a real Burn record: none exists here.)"""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mpk_fixture
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, DepthProConfig, Precision
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = Precision.F32
+    cfg.max_batch = 1
+    path = str(tmp_path / "depth_pro.mpk")
+    mpk_fixture.write_record(path, Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
+    want_m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY).round_weights_to_f16()
+    got_m = DepthPro.load_with_config(dev, cfg, path)
+    for n, c in want_m.param_names():
+        assert (want_m.get_tensor(n, c) == got_m.get_tensor(n, c)).all(), n  # every parameter, Linear weights back in [out, in]
+    torch.manual_seed(5)
+    x = torch.randn(1, 3, 512, 512, device="cuda")
+    a, b = want_m.infer(x), got_m.infer(x)
+    assert torch.equal(a.depth, b.depth) and torch.equal(a.fovx_deg, b.fovx_deg)
+    # the plain-C program: `infer_c_abi depth_pro.mpk tiny` prints what the Python mirror gets from the rounded seeded model
+    exe = str(tmp_path / "infer_c_abi")
+    libdir = os.path.join(ROOT, "burn_depth_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "infer_c_abi.c"),
+                    "-L" + libdir, "-lmi_depth", "-Wl,-rpath," + libdir, "-lm", "-o", exe], check=True)
+    run = subprocess.run([exe, path, "tiny"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    m2 = re.search(r"zeros 512x512: depth\[0\]=([-+0-9.eE]+|inf|nan) focallength_px=([-+0-9.eE]+|inf|nan) fovx_deg=([-+0-9.eE]+|inf|nan)", run.stdout)
+    assert m2, run.stdout
+    import numpy as np
+    z = want_m.infer(torch.zeros(1, 3, 512, 512, device="cuda"))
+    f32 = lambda t: np.float32(torch.as_tensor(t).float().cpu().reshape(-1)[0].item())  # noqa: E731
+    assert np.float32(float(m2.group(1))) == f32(z.depth) and np.float32(float(m2.group(2))) == f32(z.focallength_px)
+    assert np.float32(float(m2.group(3))) == f32(z.fovx_deg)
+    want_m.destroy()
+    got_m.destroy()
+    # Depth-Anything-v3 (`DepthAnything3::new(cfg).load_file(path, ..)`, example/correctness.rs:977-982), dual head + camera decoder
+    dcfg = DepthAnything3Config.tiny_dual_test()
+    dcfg.precision = Precision.F32
+    dpath = str(tmp_path / "da3.mpk")
+    mpk_fixture.write_record(dpath, Wt.generate_da3_weights(dcfg, 0, Wt.INIT_PARITY))
+    dw = DepthAnything3.new(dev, dcfg, seed=0, init_scheme=Wt.INIT_PARITY).round_weights_to_f16()
+    dg = DepthAnything3.load_file(dev, dcfg, dpath)
+    xd = torch.randn(1, 3, 70, 70, device="cuda")
+    oa, ob = dw.infer(xd), dg.infer(xd)
+    for f in ("depth", "depth_confidence", "aux", "pose_encoding", "extrinsics"):
+        assert torch.equal(getattr(oa, f), getattr(ob, f)), f
+    dw.destroy()
+    dg.destroy()
+
+
 def test_imported_upstream_checkpoint_matches_the_oracle(dev, tmp_path):
     """SURVEY 8f rank 1 end to end: an upstream-style `depth_pro.pt` (timm / nn.Sequential key spellings, written out by
     the test-side inverse map of tests/test_importer.py) -> importer -> f16 container (the reference's
@@ -912,6 +970,7 @@ def test_native_rccl_entry_points_one_rank(dev):
     assert len(uid) == 128 and any(uid)
     comm = NativeComm(dev, uid, 1, 0)
     try:
+        assert comm.ranks_seen() == 1  # ncclCommCount: what bench.py reports as `ranks_seen` for N > 1
         cfg = DepthProConfig.tiny_test()
         cfg.max_batch = 2
         m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
