@@ -86,6 +86,7 @@ struct GemmParams {
   float out_inv_scale = 1.f;
   void* out = nullptr;
   long ldo = 0;
+  const float* resid_src = nullptr;  // EPI_RESID_LS: out = resid_src + scale * (acc + bias) instead of the in-place update (same ld as out)
   void* out2 = nullptr;         // optional relu(out) copy, element type T, same ld
   const void* res1 = nullptr;   // optional residual inputs, element type T
   const void* res2 = nullptr;

@@ -223,7 +223,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
     case EPI_RESID_LS: {
       const float* sc = MD_SEL_G(p.scale, g);
       float* x = (float*)p.out + (long)m * p.ldo + n;
-      f32x4_t r = *(const f32x4_t*)x;
+      f32x4_t r = p.resid_src ? *(const f32x4_t*)(p.resid_src + (long)m * p.ldo + n) : *(const f32x4_t*)x;
       v += *(const f32x4_t*)(bias + n);
       f32x4_t s = *(const f32x4_t*)(sc + n);
       *(f32x4_t*)x = resid_ls4(r, s, v);
@@ -1281,6 +1281,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   }
   // wave-uniform tile base + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
   char* out_b = (char*)p.out + (out_boff + (long)m_base * p.ldo + n0) * 4;
+  const char* rsrc_b = p.resid_src ? (const char*)p.resid_src + ((long)m_base * p.ldo + n0) * 4 : out_b;  // EPI_RESID_LS: x is read here
   const unsigned lcol = (unsigned)(wn * WTN + col);
   // The read-modify-write epilogue prefetches the fp32 x vectors of a half BEFORE its staging pass, so 16 loads per
   // lane are in flight at once instead of a dependent load -> store chain (that chain, not bandwidth, set the cost of
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if constexpr (rmw) {
       const int lrow_t = wm * WTM + half * 64 + (lane >> 4) + it * 4;
       const bool ok = interior || (m_base + lrow_t < m_end && nvalid);
-      pre2[half][it] = ok ? *(const f32x4_t*)(out_b + ((unsigned)lrow_t * (unsigned)p.ldo + lcol) * 4u) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      pre2[half][it] = ok ? *(const f32x4_t*)(rsrc_b + ((unsigned)lrow_t * (unsigned)p.ldo + lcol) * 4u) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
   };
 #pragma unroll

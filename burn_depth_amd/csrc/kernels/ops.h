@@ -78,8 +78,9 @@ int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStre
 // Small direct convolution, NHWC, fp32 accumulate (FOV head, fov.rs:16-49).
 // in: element type by in_prec (MD_PREC_BF16 -> bf16, MD_PREC_F32 -> float); w packed
 // [Cout][kh][kw][Cin] f32; add: optional f32 NHWC tensor added to the INPUT (fov.rs:185).
+// out_ld: elements between consecutive output pixels (0 = Cout): lets several small heads write the columns of one row.
 int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
-                       const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s);
+                       const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s, int out_ld = 0);
 
 // ---- fp8 (OCP e4m3) MFMA operands (MD_PREC_FP8) ----
 // out[i] = e4m3(clamp(in[i] * inv_scale, +-448)); n a multiple of 4.

@@ -752,7 +752,7 @@ template <typename TI, int CO, int VEC>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__ in, const float* __restrict__ add,
                                                           int B, int H, int W, int Cin, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int Cout, int k, int stride,
-                                                          int pad, int relu, float* __restrict__ out, int OH, int OW) {
+                                                          int pad, int relu, float* __restrict__ out, int OH, int OW, int out_ld) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__
       if (lane == 0 && co0 + c < Cout) {
         float r = sum + (bias ? bias[co0 + c] : 0.f);
         if (relu) r = fmaxf(r, 0.f);
-        out[(((long)b * OH + oy) * OW + ox) * Cout + co0 + c] = r;
+        out[(((long)b * OH + oy) * OW + ox) * out_ld + co0 + c] = r;
       }
     }
   }
@@ -816,14 +816,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const TI* __restrict__
 template <typename TI>
 static void conv_direct_dispatch(const TI* in, const float* add, int B, int H, int W, int Cin, const float* w,
                                  const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, int OH,
-                                 int OW, hipStream_t s) {
+                                 int OW, int out_ld, hipStream_t s) {
   const bool vec = Cin % 4 == 0;
   const int co = Cout >= 8 ? 8 : 1;
   const long total = (long)B * OH * OW * ((Cout + co - 1) / co);
   const int grid = grid_for(total * 64);
 #define MD_CD(CO, VEC)                                                                                               \
   hipLaunchKernelGGL((conv_direct_kernel<TI, CO, VEC>), dim3(grid), dim3(256), 0, s, in, add, B, H, W, Cin, w, bias, \
-                     Cout, k, stride, pad, relu, out, OH, OW)
+                     Cout, k, stride, pad, relu, out, OH, OW, out_ld)
   if (co == 8 && vec)
     MD_CD(8, 4);
   else if (co == 8)
@@ -836,10 +836,11 @@ static void conv_direct_dispatch(const TI* in, const float* add, int B, int H, i
 }
 
 int launch_conv_direct(const void* in, int in_prec, const float* add, int B, int H, int W, int Cin, const float* w,
-                       const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s) {
+                       const float* bias, int Cout, int k, int stride, int pad, int relu, float* out, hipStream_t s, int out_ld) {
   const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
   if (OH <= 0 || OW <= 0) MD_FAIL(MD_ERR_SHAPE, "conv_direct: input %dx%d smaller than kernel %d", H, W, k);
-  MD_BY_PREC(in_prec, conv_direct_dispatch<T>((const T*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW, s));
+  if (out_ld != 0 && out_ld < Cout) MD_FAIL(MD_ERR_INVALID_ARG, "conv_direct: output pixel stride %d below Cout %d", out_ld, Cout);
+  MD_BY_PREC(in_prec, conv_direct_dispatch<T>((const T*)in, add, B, H, W, Cin, w, bias, Cout, k, stride, pad, relu, out, OH, OW, out_ld ? out_ld : Cout, s));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

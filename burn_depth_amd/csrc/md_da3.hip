@@ -763,13 +763,17 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   const long rows = (long)B * SS;
   auto dense = [&](GemmParams& p) { p.ngroups = 1; p.g_rows[0] = (int)rows; };
   int hook_slot = 0;
+  // The residual stream lives in `xcur`. A GLOBAL block of the extended backbone needs the state behind the last LOCAL block
+  // for its hook (cat(x_local, LayerNorm(x))): its output projection therefore writes x + ls * (...) into the other buffer
+  // (GemmParams::resid_src) and the two swap -- the copy of the whole stream that used to precede every global block is gone.
+  float *xcur = d->xres, *xalt = d->xlocal;
   const int ext0 = c.dual_head ? c.ext_block_start : v.depth + 1;
   for (int i = 0; i < v.depth; ++i) {
     const VitBlockW& k = d->vit.blk[i];
     const bool ext = i >= ext0, is_global = ext && (i % 2 == 1);
     if (i == ext0) {  // the learned reference-view camera token takes the cls slot (single view)
       r.begin("camera_token");
-      MD_TRY(launch_set_token0(d->xres, B, SS, D, Bi(bp + ".camera_token"), st));
+      MD_TRY(launch_set_token0(xcur, B, SS, D, Bi(bp + ".camera_token"), st));
       r.end();
     }
     // MD_PREC_FP8: the operands of the four linear layers are e4m3 (LayerNorm / attention / GELU outputs are
@@ -779,7 +783,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     const float a_inv = 1.0f / md_model_s::Da3State::kActScale, h_inv = 1.0f / md_model_s::Da3State::kHidScale;
     sg.a[0] = k.n1g; sg.b[0] = k.n1b;
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
+    MD_TRY(launch_layernorm(xcur, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
     r.end();
     {
       GemmParams p;
@@ -831,7 +835,11 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       p.N = D; dense(p); p.W[0] = k.proj_w; p.bias[0] = k.proj_b; p.scale[0] = k.ls1;
       p.A = d->ao;
       if (f8) { p.K = D; p.lda = D; } else split_dense_a(m, p, D, D, 0);
-      p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      p.epi = EPI_RESID_LS; p.out = xcur; p.ldo = D;
+      if (is_global) {  // x_i = x_{i-1} + ...: read the last local state, write the other buffer, keep x_{i-1} for the hook
+        p.resid_src = xcur; p.out = xalt;
+        std::swap(xcur, xalt);
+      }
       if (f8) { p.W[0] = d->w8[i].w[1]; p.wscale[0] = d->w8[i].s[1]; p.ascale = md_model_s::Da3State::kActScale; }
       r.begin("proj_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
@@ -839,7 +847,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
     sg.a[0] = k.n2g; sg.b[0] = k.n2b;
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(d->xres, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
+    MD_TRY(launch_layernorm(xcur, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
     r.end();
     {
       GemmParams p;
@@ -860,7 +868,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       p.N = D; dense(p); p.W[0] = k.fc2_w; p.bias[0] = k.fc2_b; p.scale[0] = k.ls2;
       p.A = d->hbuf;
       if (f8) { p.K = 4 * D; p.lda = 4 * D; } else split_dense_a(m, p, 4 * D, 4 * D, 0);
-      p.epi = EPI_RESID_LS; p.out = d->xres; p.ldo = D;
+      p.epi = EPI_RESID_LS; p.out = xcur; p.ldo = D;
       if (f8) { p.W[0] = d->w8[i].w[3]; p.wscale[0] = d->w8[i].s[3]; p.ascale = md_model_s::Da3State::kHidScale; }
       r.begin("fc2_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
@@ -871,29 +879,23 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       // token 0 of the raw concat at the last hook
       bool hooked = false;
       for (int hk = 0; hk < 4; ++hk) hooked |= c.hook_ids[hk] == i;
-      const bool next_needs_local = !is_global && i + 1 < v.depth;
-      const float* xl = is_global ? d->xlocal : d->xres;  // a local block is its own "last local" state
+      const float* xl = is_global ? xalt : xcur;  // a local block is its own "last local" state; behind a global block the other buffer holds it
       for (int hk = 0; hk < 4; ++hk)
         if (c.hook_ids[hk] == i) {
           r.begin("hook_cat_ln");
-          MD_TRY(launch_hook_cat_ln(xl, d->xres, rows, SS, NT, D, d->vit.norm_g, d->vit.norm_b, c.ln_eps, Bi(hp + ".norm.gamma"),
+          MD_TRY(launch_hook_cat_ln(xl, xcur, rows, SS, NT, D, d->vit.norm_g, d->vit.norm_b, c.ln_eps, Bi(hp + ".norm.gamma"),
                                     Bi(hp + ".norm.beta"), 1e-5f, d->hookn[hk], hk == 3 ? d->cam_raw : nullptr, m->prec, st));
           r.end();
           if (m->taps_enabled) {  // DepthTrace::backbone_tokens (mod.rs:241-246,344-347): cat(x_local, LayerNorm_final(x)) patch rows
             const std::string tn = "backbone_tokens_" + std::to_string(hk);
             sg.a[0] = d->vit.norm_g; sg.b[0] = d->vit.norm_b;
-            MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
+            MD_TRY(launch_layernorm(xcur, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
             MD_TRY(r.tap_token_rows(tn.c_str(), xl, SS, 1, P, D, 2 * D, 0));
             MD_TRY(r.tap_token_rows(tn.c_str(), d->lnf, SS, 1, P, D, 2 * D, D));
           }
           ++hook_slot;
         }
       (void)hooked;
-      if (next_needs_local && i + 1 >= ext0 && ((i + 1) % 2 == 1)) {  // the next block is global: keep this x
-        r.begin("keep_local");
-        MD_HIP(hipMemcpyAsync(d->xlocal, d->xres, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st));
-        r.end();
-      }
     } else {
       // hooks (mod.rs:202-215): final LayerNorm of the block output, then the head's non-affine token
       // norm (apply_token_norm, dpt.rs:761-766: biased variance, eps 1e-5). A block may feed several hooks.
@@ -901,7 +903,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
         if (c.hook_ids[hk] == i) {
           sg.a[0] = d->vit.norm_g; sg.b[0] = d->vit.norm_b;
           r.begin("layernorm");
-          MD_TRY(launch_layernorm(d->xres, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
+          MD_TRY(launch_layernorm(xcur, d->lnf, rows, D, c.ln_eps, SS, sg, m->prec, 1, st));
           r.end();
           if (m->taps_enabled) {  // DepthTrace::backbone_tokens (mod.rs:241-246,344-347)
             const std::string tn = "backbone_tokens_" + std::to_string(hk);
@@ -1112,29 +1114,30 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   }
   // ---- camera decoder (camera.rs:143-199) on the raw camera feature of the last hook, fp32 ----
   if (want_cam) {
-    auto lin = [&](const char* n, const float* in, int cout, int relu, float* out) -> int {
+    auto lin = [&](const char* n, const float* in, int cout, int relu, float* out, int out_ld) -> int {
       const std::string q = std::string("camera_decoder.") + n;
       rc.begin("camera_decoder");
-      int s2 = launch_conv_direct(in, MD_PREC_F32, nullptr, B, 1, 1, din, Bi(q + ".weight"), Bi(q + ".bias"), cout, 1, 1, 0, relu, out, rc.st);
+      int s2 = launch_conv_direct(in, MD_PREC_F32, nullptr, B, 1, 1, din, Bi(q + ".weight"), Bi(q + ".bias"), cout, 1, 1, 0, relu, out, rc.st, out_ld);
       rc.end();
       return s2;
     };
-    MD_TRY(lin("backbone_1", d->cam_raw, din, 1, d->cam_h1));
-    MD_TRY(lin("backbone_2", d->cam_h1, din, 1, d->cam_h2));
-    // pose = (t3 | quat4 | relu(fov2)), assembled through a [B,9] buffer with strided outputs
-    MD_TRY(lin("fc_t", d->cam_h2, 3, 0, d->cam_h1));
-    MD_TRY(lin("fc_qvec", d->cam_h2, 4, 0, d->cam_h1 + (size_t)B * 3));
-    MD_TRY(lin("fc_fov", d->cam_h2, 2, 1, d->cam_h1 + (size_t)B * 7));
-    for (int b = 0; b < B; ++b) {
-      MD_HIP(hipMemcpyAsync(d->pose + b * 9, d->cam_h1 + b * 3, 12, hipMemcpyDeviceToDevice, rc.st));
-      MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 3, d->cam_h1 + (size_t)B * 3 + b * 4, 16, hipMemcpyDeviceToDevice, rc.st));
-      MD_HIP(hipMemcpyAsync(d->pose + b * 9 + 7, d->cam_h1 + (size_t)B * 7 + b * 2, 8, hipMemcpyDeviceToDevice, rc.st));
+    MD_TRY(lin("backbone_1", d->cam_raw, din, 1, d->cam_h1, 0));
+    MD_TRY(lin("backbone_2", d->cam_h1, din, 1, d->cam_h2, 0));
+    // pose = (t3 | quat4 | relu(fov2)): the three heads write their columns of the [B, 9] rows directly (device outputs: straight
+    // into the caller's buffers -- no staging copies on this branch)
+    const bool dev_out = out_kind == MD_MEM_DEVICE;
+    float* pose = (dev_out && outp.pose_encoding) ? outp.pose_encoding : d->pose;
+    MD_TRY(lin("fc_t", d->cam_h2, 3, 0, pose, 9));
+    MD_TRY(lin("fc_qvec", d->cam_h2, 4, 0, pose + 3, 9));
+    MD_TRY(lin("fc_fov", d->cam_h2, 2, 1, pose + 7, 9));
+    float* extr = (dev_out && outp.extrinsics) ? outp.extrinsics : d->extr;
+    float* intr = (dev_out && outp.intrinsics) ? outp.intrinsics : d->intr;
+    if (outp.extrinsics || outp.intrinsics) MD_TRY(launch_pose_to_camera(pose, B, H, W, extr, intr, rc.st));
+    if (!dev_out) {
+      if (outp.pose_encoding) MD_HIP(hipMemcpyAsync(outp.pose_encoding, pose, (size_t)B * 9 * 4, hipMemcpyDeviceToHost, rc.st));
+      if (outp.extrinsics) MD_HIP(hipMemcpyAsync(outp.extrinsics, extr, (size_t)B * 12 * 4, hipMemcpyDeviceToHost, rc.st));
+      if (outp.intrinsics) MD_HIP(hipMemcpyAsync(outp.intrinsics, intr, (size_t)B * 9 * 4, hipMemcpyDeviceToHost, rc.st));
     }
-    MD_TRY(launch_pose_to_camera(d->pose, B, H, W, d->extr, d->intr, rc.st));
-    const hipMemcpyKind kk = out_kind == MD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (outp.pose_encoding) MD_HIP(hipMemcpyAsync(outp.pose_encoding, d->pose, (size_t)B * 9 * 4, kk, rc.st));
-    if (outp.extrinsics) MD_HIP(hipMemcpyAsync(outp.extrinsics, d->extr, (size_t)B * 12 * 4, kk, rc.st));
-    if (outp.intrinsics) MD_HIP(hipMemcpyAsync(outp.intrinsics, d->intr, (size_t)B * 9 * 4, kk, rc.st));
     if (par) MD_HIP(hipEventRecord(d->ev_cam, d->s_cam));
   }
   // ---- main branch: output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + activation ----
