@@ -961,7 +961,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   };
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
-    if constexpr (sizeof(TO) == 2 && !is_split<TO>::value) {
+    if constexpr (sizeof(TO) == 2) {
       // V^T[seq][head][d][token] tiles: staged TRANSPOSED through the wave-private LDS area (64 n-rows x 64 tokens
       // per half) so that a lane stores 4 consecutive tokens of one (head, d) row -- 8-byte stores, 4 full 128-byte
       // row segments per instruction -- instead of 2-byte scatter stores (4x the store instructions). Needs whole
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             const int nl = it * 4 + nl0;
             f32x4_t v = *(const f32x4_t*)(stt + nl * SRT + (lane & 15) * 16);
             v = v * wsc[it] + bia[it];
-            if (ok) store4<TO>(vrow + (long)nl * p.kpad, v);
+            if (ok) store4p<TO>(vrow + (long)nl * p.kpad, p.v_plane, v);  // split-half: the lo plane v_plane elements behind
           }
           asm volatile("" ::: "memory");
         }
@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const bool interior = (m_base + BM <= m_end) && (n0 + BN <= p.N);  // wave-uniform: no per-row predicates needed
   // bf16 / f16 staging of a 64-row half: 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7): conflict-free for the
   // 8-byte writes from the accumulator layout and for the 16-byte reads (a lane then owns 8 consecutive columns)
+  // (split-half outputs: the hi plane's image at st, the lo plane's 8 KB behind it -- 16 of the wave's 17 KB)
   auto stage_half_2b = [&](int half, auto&& xform) __attribute__((always_inline)) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
@@ -1055,7 +1056,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const f32x4_t v = xform(a, (f32x4_t){c[0], c[1], c[2], c[3]});
         const int row = bb * 16 + r16;
         const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
-        *(i32x2_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = pack4<TO>(v);
+        if constexpr (is_split<TO>::value) {
+          i32x2_t hi, lo;
+          split4<TO>(v, hi, lo);
+          *(i32x2_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = hi;
+          *(i32x2_t*)(st + 8192 + row * 128 + chunk * 16 + (q16 & 1) * 8) = lo;
+        } else {
+          *(i32x2_t*)(st + row * 128 + chunk * 16 + (q16 & 1) * 8) = pack4<TO>(v);
+        }
       }
   };
   auto stage_half_f32 = [&](int half) __attribute__((always_inline)) {
@@ -1115,12 +1123,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     // ---- 2-byte store epilogue (EPI_STORE / q,k tiles of EPI_QKV; launcher guarantees N, ldo, ldr % 8 == 0) ----
     // A lane owns 8 consecutive columns of a row: per 64-row half 8 iterations of {LDS read, math, ONE 16-byte store};
     // runtime options are folded into wave-uniform flags once, and interior tiles run without per-row predicates.
-    const long ldo8 = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
+    constexpr int PLN = kPlanes<TO>;  // split-half rows: [hi | lo] per section
+    const long ldo8 = p.epi == EPI_QKV ? 2L * p.embed * PLN : p.ldo;
+    // element offset from a value's hi to its lo plane, and the tile's first column inside the physical row: q | k rows of the
+    // split-half form are [q_hi | q_lo | k_hi | k_lo], each `embed` wide (the launcher keeps a tile inside one section)
+    const long lo_off = PLN == 1 ? 0 : (p.epi == EPI_QKV ? (long)p.embed : p.o_plane);
+    const long n0p = (PLN == 2 && p.epi == EPI_QKV) ? (n0 >= p.embed ? n0 + p.embed : n0) : n0;
     const bool f32o = p.out_f32 != 0, relu = p.act == ACT_RELU, has_o2 = p.out2 != nullptr;
     const bool r1 = p.res1 != nullptr, r2 = p.res2 != nullptr, any_res = r1 || r2;
     const float* wsp = MD_SEL_G(p.wscale, g);  // fp8 operands: acc * (ascale * wscale[n]) before the bias
     const bool fp8o = p.out_fp8 != 0;
-    const long tb = (long)m_base * ldo8 + n0 + out_boff;
+    const long tb = (long)m_base * ldo8 + n0p + out_boff;
     char* ob = (char*)p.out + tb * (fp8o ? 1 : (f32o ? 4 : 2));
     char* o2b = (char*)p.out2 + tb * 2;
     const unsigned lc8 = (unsigned)(wn * WTN + c8);
@@ -1162,6 +1175,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             if (raw[0] == 0x12345678) *(i32x4_t*)(ob + ((unsigned)lrow_t * (unsigned)ldo8 + lc8) * 2u) = raw;
           } else if (interior || (m_base + lrow_t < m_end && nv8)) {
             *(i32x4_t*)(ob + ((unsigned)lrow_t * (unsigned)ldo8 + lc8) * 2u) = raw;
+            if constexpr (PLN == 2) {
+              const i32x4_t raw_lo = *(const i32x4_t*)(st + 8192 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+              *(i32x4_t*)(ob + ((unsigned)lrow_t * (unsigned)ldo8 + lc8 + (unsigned)lo_off) * 2u) = raw_lo;
+            }
           }
         }
         asm volatile("" ::: "memory");
@@ -1171,6 +1188,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
     // residual inputs / fp32, fp8 or second output: fp32 staging, the raw residual vectors of a half prefetched before
     // its staging pass (the dependent load -> store chain, not bandwidth, set the cost of the residual-conv epilogue)
+    // (one-plane outputs only: launch_256 sends split-half launches with residuals / second outputs to the generic kind)
+    if constexpr (is_split<TO>::value) return;
     f32x4_t bl = {0.f, 0.f, 0.f, 0.f}, bh = bl;
     if (biasp && nv8) {
       bl = *(const f32x4_t*)(biasp + n8);
@@ -1410,10 +1429,15 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   int ek = 0;
   if (p.epi == EPI_RESID_LS) ek = 1;
   else if (p.epi == EPI_PIXSHUF) ek = 3;
-  else if (sizeof(typename OutT<T>::type) == 2 && !is_split<T>::value) {
+  else if (sizeof(typename OutT<T>::type) == 2) {
     const long ldo_e = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
     const bool vec8 = p.N % 8 == 0 && ldo_e % 8 == 0 && (!(p.res1 || p.res2) || p.ldr % 8 == 0);
-    if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = 4;
+    // split-half outputs take the store kinds only for their lean sub-path (no residual inputs, no second / fp32 output) and,
+    // for q | k tiles, when a tile cannot straddle the q | k sections of the [q_hi | q_lo | k_hi | k_lo] rows
+    const bool split_ok = !is_split<T>::value || (!p.res1 && !p.res2 && !p.out2 && !p.out_f32 && !p.out_fp8 && p.o_plane % 8 == 0 &&
+                                                  (p.epi != EPI_QKV || p.embed % BN == 0));
+    if (!split_ok) ek = 0;
+    else if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = 4;
     else if (vec8 && ((p.epi == EPI_STORE && p.res_mod == 0 && p.act != ACT_GELU) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0))) ek = 2;
   }
   const bool diag = p.stamps != nullptr || p.debug_flags != 0;
@@ -1438,11 +1462,11 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
       if constexpr (!is_split<T>::value) return go(gemm256_kernel<T, AMODE, 3, false>, &set[3]);
       break;
     case 2:
-      if constexpr (sizeof(typename OutT<T>::type) == 2 && !is_split<T>::value) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);
+      if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);
       break;
     case 4:  // the GELU store kind is built for dense A only (the MLP's fc1); a GELU behind a gathered / convolution A operand
              // takes the store kind's runtime activation path of the generic epilogue
-      if constexpr (sizeof(typename OutT<T>::type) == 2 && AMODE == A_DENSE && !is_split<T>::value) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
+      if constexpr (sizeof(typename OutT<T>::type) == 2 && AMODE == A_DENSE) return go(gemm256_kernel<T, AMODE, 4, false>, &set[4]);
       break;
     default: break;
   }

@@ -58,6 +58,15 @@ def test_storage_epilogues_f16(diag, dev):
     _assert_new_results_ok(diag, start)
 
 
+def test_storage_epilogues_f16x2(diag, dev):
+    """The split-half store epilogues of the 256^2 kernel (round 4: hi and lo planes staged as two 2-byte images and stored with
+    16-byte vectors -- plain, ReLU, GELU, partial tiles -- instead of per-vector plane stores), the implicit 3x3 GEMM and the
+    generic pixel shuffle, against fp64 on operands that are exact in two half planes."""
+    start = len(diag.RESULTS)
+    diag.check_storage_epilogues(dev, 4)
+    _assert_new_results_ok(diag, start)
+
+
 @pytest.mark.parametrize("precision", [1, 0, 3])
 def test_depth_pro_tiny_end_to_end(diag, dev, precision):
     from burn_depth_amd.config import DepthProConfig

@@ -174,7 +174,7 @@ def check_storage_epilogues(dev, prec=0):
     """The store epilogues the ENGINE uses (2-byte output through the staged / pixel-shuffle paths of the 256x256
     kernel), at sizes that select that kernel and leave partial tiles. Tolerance = output rounding of the storage type."""
     g = torch.Generator().manual_seed(11)
-    tol = 6e-3 if prec == 0 else 8e-4
+    tol = {0: 6e-3, 4: 2e-5}.get(prec, 8e-4)  # f16x2: hi + lo planes carry 22 bits: fp32 accumulation order is what is left
     bf = ROUND[prec]  # noqa: F811 -- operands representable in the mode's storage type
     pn = PNAME[prec]
     for (M, N, K, act, has_bias) in [(2000, 1024, 1024, 0, True), (513, 264, 320, 0, True), (700, 512, 128, 2, True),
