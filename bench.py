@@ -1087,7 +1087,7 @@ def pmc_traffic(kernel: str, B: int, args):
     WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
     gfx950 corrections of MI355X_MICROARCH.md and writes profiles/rNN_traffic.json). None if the
     passes were made for another batch/precision."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
