@@ -165,6 +165,11 @@ class DepthAnything3Config:
     aux_output_dim: int = 7
     aux_levels: int = 4
     image_width: int = 0    # 0 = square; else input columns (multiple of 14): `infer` only asserts divisibility (mod.rs:509-520)
+    # `CameraEncoderConfig` (camera.rs:12-37; mod.rs:164-168 sets dim_out = embed_dim): only runs under `infer_with_camera`
+    camera_encoder: bool = False
+    cam_heads: int = 16
+    cam_trunk_depth: int = 4
+    cam_ln_eps: float = 1e-5   # token_norm / trunk_norm: Burn's `LayerNormConfig::new` default (camera.rs:84-85)
 
     @staticmethod
     def metric_large() -> "DepthAnything3Config":
@@ -178,12 +183,12 @@ class DepthAnything3Config:
     def small() -> "DepthAnything3Config":
         """`DepthAnything3Config::small()` (mod.rs:158-171) + `DepthAnything3HeadConfig::small()` (dpt.rs:60-79)."""
         return DepthAnything3Config("small", 518, 14, (5, 7, 9, 11), 768, 64, (48, 96, 192, 384), 2,
-                                    dual_head=True, ext_block_start=4)
+                                    dual_head=True, ext_block_start=4, camera_encoder=True)
 
     @staticmethod
     def tiny_dual_test() -> "DepthAnything3Config":
         return DepthAnything3Config("tiny_dual", 70, 14, (2, 3, 4, 5), 256, 64, (48, 96, 64, 128), 2,
-                                    dual_head=True, ext_block_start=2)
+                                    dual_head=True, ext_block_start=2, camera_encoder=True, cam_trunk_depth=2)
 
     def vit(self) -> ViTConfig:
         base = {"metric_large": DA3_VITL14, "small": DA3_VITS14, "tiny_dual": DA3_TINYDUAL14}.get(self.variant, DA3_TINY14)

@@ -95,8 +95,25 @@ int launch_pack_fp8_rows(const float* w, int N, int K, int Kp, void* out, float*
 int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int heads, int pw, const float* q_gamma,
                         const float* q_beta, const float* k_gamma, const float* k_beta, float eps, const float* rope_cos,
                         const float* rope_sin, int global_pos, float q_scale, int prec, hipStream_t s);
-// x[b*S + 0, :] = src[0:D] for every sequence (the learned camera token replaces the cls slot)
-int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s);
+// x[b*S + 0, :] = src[b*src_stride + 0:D] for every sequence (the camera token replaces the cls slot): src_stride 0 = the one
+// learned token for all, D = one encoded token per image (`infer_with_camera`)
+int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s, int src_stride = 0);
+
+// ---- Depth-Anything-v3 camera encoder (kernels/camera.hip; camera.rs:50-110) ----
+#define MD_CAM_MAX_VIEWS 16
+struct CamEncW {
+  static constexpr int kMaxDepth = 8;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;  // PoseBranch: [D/2, 9], [D, D/2]
+  const float *tn_g, *tn_b, *on_g, *on_b;      // token_norm, trunk_norm
+  struct Blk {
+    const float *n1g, *n1b, *n2g, *n2b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ls1, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ls2;
+  } blk[kMaxDepth];
+  int depth;
+};
+size_t camera_encoder_scratch_floats(int B, int V, int D);
+// extr [B, V, 3, 4] world-to-camera, intr [B, V, 3, 3] (device) -> out [B, D] (device); one workgroup per image
+int launch_camera_encoder(const float* extr, const float* intr, int B, int V, int D, int heads, int H, int W, float eps_tok, float eps_blk,
+                          const CamEncW& w, float* scratch, float* out, hipStream_t s);
 // hook = LayerNorm_head( cat( x_local, LayerNorm_final(x) ) ) -> T rows [rows, 2D]; optional raw token-0 concat
 // [nseq, 2D] f32 (the camera feature).
 int launch_hook_cat_ln(const float* x_local, const float* x, long rows, int S, int n_tokens, int D, const float* norm_g,

@@ -949,16 +949,16 @@ int launch_qk_norm_rope(void* qk, long rows, int S, int n_tokens, int D, int hea
   return MD_OK;
 }
 
-__global__ void set_token0_kernel(float* __restrict__ x, int nseq, int S, int D, const float* __restrict__ src) {
+__global__ void set_token0_kernel(float* __restrict__ x, int nseq, int S, int D, const float* __restrict__ src, int src_stride) {
   const long total = (long)nseq * D;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int b = (int)(i / D), d = (int)(i - (long)b * D);
-    x[(long)b * S * D + d] = src[d];
+    x[(long)b * S * D + d] = src[(long)b * src_stride + d];
   }
 }
 
-int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s) {
-  hipLaunchKernelGGL(set_token0_kernel, dim3(grid_for((long)nseq * D)), dim3(256), 0, s, x, nseq, S, D, src);
+int launch_set_token0(float* x, int nseq, int S, int D, const float* src, hipStream_t s, int src_stride) {
+  hipLaunchKernelGGL(set_token0_kernel, dim3(grid_for((long)nseq * D)), dim3(256), 0, s, x, nseq, S, D, src, src_stride);
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

@@ -812,11 +812,13 @@ int parse_da3_cfg(const md_da3_cfg* c, Da3Cfg* out) {
   } else if (d.variant == "small") {  // mod.rs:158-171,190-196; dpt.rs:60-79
     v.preset = "da3_vits14"; v.D = 384; v.depth = 12; v.heads = 6; v.img = 518;
     d.image_size = 518; d.features = 64; d.output_dim = 2; d.dual_head = true; d.ext_block_start = 4;
+    d.camera_encoder = true;
     const int oc[4] = {48, 96, 192, 384}, hk[4] = {5, 7, 9, 11};
     for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
   } else if (d.variant == "tiny_dual") {  // test-only: same topology, 6 blocks of width 128
     v.preset = "da3_tinydual14"; v.D = 128; v.depth = 6; v.heads = 2; v.img = 70;
     d.image_size = 70; d.features = 64; d.output_dim = 2; d.dual_head = true; d.ext_block_start = 2;
+    d.camera_encoder = true; d.cam_trunk_depth = 2;
     const int oc[4] = {48, 96, 64, 128}, hk[4] = {2, 3, 4, 5};
     for (int i = 0; i < 4; ++i) { d.out_channels[i] = oc[i]; d.hook_ids[i] = hk[i]; }
   } else {
@@ -896,6 +898,18 @@ int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in
   Da3Outputs o;
   o.depth = out->depth; o.depth_confidence = out->depth_confidence; o.aux = out->aux; o.aux_confidence = out->aux_confidence;
   o.pose_encoding = out->pose_encoding; o.extrinsics = out->extrinsics; o.intrinsics = out->intrinsics;
+  return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
+}
+
+int md_da3_infer_with_camera(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const float* extrinsics,
+                             const float* intrinsics, int views, const md_da3_outputs* out, int out_kind, void* stream) {
+  if (!out) MD_FAIL(MD_ERR_INVALID_ARG, "outputs struct is null");
+  if (!extrinsics || !intrinsics) MD_FAIL(MD_ERR_INVALID_ARG, "extrinsics/intrinsics is null (md_da3_infer_ex is the call without camera inputs)");
+  if (views < 1) MD_FAIL(MD_ERR_SHAPE, "camera inputs need at least one view, got %d", views);
+  Da3Outputs o;
+  o.depth = out->depth; o.depth_confidence = out->depth_confidence; o.aux = out->aux; o.aux_confidence = out->aux_confidence;
+  o.pose_encoding = out->pose_encoding; o.extrinsics = out->extrinsics; o.intrinsics = out->intrinsics;
+  o.cam_extrinsics = extrinsics; o.cam_intrinsics = intrinsics; o.cam_views = views;
   return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
 }
 

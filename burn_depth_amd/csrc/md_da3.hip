@@ -66,6 +66,9 @@ struct md_model_s::Da3State {
   float *cam_raw = nullptr, *cam_h1 = nullptr, *cam_h2 = nullptr, *pose = nullptr, *extr = nullptr, *intr = nullptr;
   float* pos_aux = nullptr;
   float *conf_stage = nullptr, *aux_stage = nullptr;  // device staging when the caller wants host outputs
+  // camera encoder (`infer_with_camera`): grow-only scratch = staged inputs [B*V*21] | encoded tokens [B*D] | kernel scratch
+  float* cam_enc_ws = nullptr;
+  size_t cam_enc_cap = 0;
   // The dual head's three independent tails -- main pyramid (depth + confidence), aux pyramid (rays + confidence) and the
   // camera decoder -- run as CONCURRENT branches: the aux branch and the camera decoder on side streams that fork from / join
   // the caller's stream through events (inside a captured graph they become parallel branches). Config 2 is launch-bound
@@ -645,6 +648,7 @@ void da3_destroy_state(md_model_t m) {
   for (hipEvent_t e : {m->da3->ev_fork, m->da3->ev_cam_fork, m->da3->ev_aux, m->da3->ev_cam})
     if (e) (void)hipEventDestroy(e);
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
+  if (m->da3->cam_enc_ws) (void)hipFree(m->da3->cam_enc_ws);
   delete m->da3;
   m->da3 = nullptr;
 }
@@ -702,7 +706,8 @@ int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_ki
                         B <= m->da3->cfg.max_batch && H == m->da3->ih && W == m->da3->iw;
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)outp.depth,
                                       (uintptr_t)outp.depth_confidence, (uintptr_t)outp.aux, (uintptr_t)outp.aux_confidence,
-                                      (uintptr_t)outp.pose_encoding, (uintptr_t)outp.extrinsics, (uintptr_t)outp.intrinsics};
+                                      (uintptr_t)outp.pose_encoding, (uintptr_t)outp.extrinsics, (uintptr_t)outp.intrinsics,
+                                      (uintptr_t)outp.cam_extrinsics, (uintptr_t)outp.cam_intrinsics, (uintptr_t)outp.cam_views};
   return run_with_graph(m, st, key, eligible, body);
 }
 
@@ -737,6 +742,53 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   }
   auto Wk = [&](const std::string& n) { return PK(m, n); };
   auto Bi = [&](const std::string& n) { return P32(m, n); };
+  // ---- camera encoder (`infer_with_camera`, mod.rs:522-527: a model without one ignores the camera inputs) ----
+  float* cam_tok = nullptr;
+  if (c.camera_encoder && c.dual_head && outp.cam_extrinsics && outp.cam_intrinsics) {
+    const int V = outp.cam_views;
+    if (V < 1 || V > MD_CAM_MAX_VIEWS) MD_FAIL(MD_ERR_SHAPE, "camera inputs with %d views (1..%d supported)", V, MD_CAM_MAX_VIEWS);
+    const size_t n_in = (size_t)B * V * 21, n_tok = align_up((size_t)B * D, 64);
+    const size_t need = align_up(n_in, 64) + n_tok + camera_encoder_scratch_floats(B, V, D);
+    if (need > d->cam_enc_cap) {
+      MD_HIP(hipStreamSynchronize(st));
+      if (d->cam_enc_ws) MD_HIP(hipFree(d->cam_enc_ws));
+      d->cam_enc_ws = nullptr; d->cam_enc_cap = 0;
+      MD_HIP(hipMalloc((void**)&d->cam_enc_ws, need * 4));
+      d->cam_enc_cap = need;
+      m->alloc_count += 1;
+    }
+    const float *e_dev = outp.cam_extrinsics, *k_dev = outp.cam_intrinsics;
+    if (in_kind == MD_MEM_HOST) {
+      MD_HIP(hipMemcpyAsync(d->cam_enc_ws, outp.cam_extrinsics, (size_t)B * V * 12 * 4, hipMemcpyHostToDevice, st));
+      MD_HIP(hipMemcpyAsync(d->cam_enc_ws + (size_t)B * V * 12, outp.cam_intrinsics, (size_t)B * V * 9 * 4, hipMemcpyHostToDevice, st));
+      e_dev = d->cam_enc_ws; k_dev = d->cam_enc_ws + (size_t)B * V * 12;
+    }
+    cam_tok = d->cam_enc_ws + align_up(n_in, 64);
+    CamEncW w;
+    memset(&w, 0, sizeof(w));
+    const std::string ce = "camera_encoder.";
+    w.fc1_w = Bi(ce + "pose_branch.fc1.weight"); w.fc1_b = Bi(ce + "pose_branch.fc1.bias");
+    w.fc2_w = Bi(ce + "pose_branch.fc2.weight"); w.fc2_b = Bi(ce + "pose_branch.fc2.bias");
+    w.tn_g = Bi(ce + "token_norm.gamma"); w.tn_b = Bi(ce + "token_norm.beta");
+    w.on_g = Bi(ce + "trunk_norm.gamma"); w.on_b = Bi(ce + "trunk_norm.beta");
+    w.depth = c.cam_trunk_depth;
+    if (w.depth > CamEncW::kMaxDepth) MD_FAIL(MD_ERR_UNSUPPORTED, "camera encoder trunk of %d blocks", w.depth);
+    for (int i = 0; i < w.depth; ++i) {
+      const std::string bk = ce + "trunk." + std::to_string(i) + ".";
+      CamEncW::Blk& k = w.blk[i];
+      k.n1g = Bi(bk + "norm1.gamma"); k.n1b = Bi(bk + "norm1.beta"); k.n2g = Bi(bk + "norm2.gamma"); k.n2b = Bi(bk + "norm2.beta");
+      k.qkv_w = Bi(bk + "attn.qkv.weight"); k.qkv_b = Bi(bk + "attn.qkv.bias");
+      k.proj_w = Bi(bk + "attn.proj.weight"); k.proj_b = Bi(bk + "attn.proj.bias"); k.ls1 = Bi(bk + "ls1.gamma");
+      k.fc1_w = Bi(bk + "mlp.fc1.weight"); k.fc1_b = Bi(bk + "mlp.fc1.bias");
+      k.fc2_w = Bi(bk + "mlp.fc2.weight"); k.fc2_b = Bi(bk + "mlp.fc2.bias"); k.ls2 = Bi(bk + "ls2.gamma");
+      if (!k.qkv_w || !k.ls2) MD_FAIL(MD_ERR_FORMAT, "camera encoder block %d is not in the inventory", i);
+    }
+    if (!w.fc1_w || !w.on_b) MD_FAIL(MD_ERR_FORMAT, "camera encoder is not in the inventory");
+    r.begin("camera_encoder");
+    MD_TRY(launch_camera_encoder(e_dev, k_dev, B, V, D, c.cam_heads, H, W, c.cam_ln_eps, c.ln_eps, w, cam_tok + n_tok, cam_tok, st));
+    r.end();
+    MD_TRY(r.tap_f32("camera_token", cam_tok, B, D, 0, 0));  // CameraEncoder::forward's result (camera.rs:89-110)
+  }
   // ---- backbone ----
   r.begin("patchify");
   MD_TRY(launch_patchify(x_dev, B, H, W, v.ps, d->Kp, d->patches, m->prec, st));
@@ -771,9 +823,12 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   for (int i = 0; i < v.depth; ++i) {
     const VitBlockW& k = d->vit.blk[i];
     const bool ext = i >= ext0, is_global = ext && (i % 2 == 1);
-    if (i == ext0) {  // the learned reference-view camera token takes the cls slot (single view)
+    if (i == ext0) {  // the camera token takes the cls slot: the encoder's (mod.rs:522-531) or the learned reference-view one
       r.begin("camera_token");
-      MD_TRY(launch_set_token0(xcur, B, SS, D, Bi(bp + ".camera_token"), st));
+      if (cam_tok)
+        MD_TRY(launch_set_token0(xcur, B, SS, D, cam_tok, st, D));
+      else
+        MD_TRY(launch_set_token0(xcur, B, SS, D, Bi(bp + ".camera_token"), st));
       r.end();
     }
     // MD_PREC_FP8: the operands of the four linear layers are e4m3 (LayerNorm / attention / GELU outputs are

@@ -205,6 +205,10 @@ struct Da3Cfg {
   bool dual_head = false;
   int ext_block_start = -1, aux_levels = 4, aux_out1_conv_num = 5, aux_output_dim = 7;
   float rope_frequency = 100.f, qk_norm_eps = 1e-5f;
+  // `CameraEncoderConfig` (camera.rs:12-37; mod.rs:164-168): only runs under `infer_with_camera`
+  bool camera_encoder = false;
+  int cam_heads = 16, cam_trunk_depth = 4;
+  float cam_ln_eps = 1e-5f;
 };
 std::vector<ParamSpec> da3_param_specs(const Da3Cfg& cfg, int scheme);
 int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out);
@@ -216,6 +220,10 @@ int da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind,
 struct Da3Outputs {
   float *depth = nullptr, *depth_confidence = nullptr, *aux = nullptr, *aux_confidence = nullptr;
   float *pose_encoding = nullptr, *extrinsics = nullptr, *intrinsics = nullptr;
+  // `infer_with_camera` (mod.rs:301-309): known world-to-camera extrinsics [B, views, 3, 4] and intrinsics [B, views, 3, 3], in the
+  // memory kind of the input image. Both set + a model with a camera encoder => the encoded token conditions the backbone.
+  const float *cam_extrinsics = nullptr, *cam_intrinsics = nullptr;
+  int cam_views = 0;
 };
 int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& out, int out_kind,
                  hipStream_t stream);

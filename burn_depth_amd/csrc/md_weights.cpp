@@ -265,6 +265,27 @@ std::vector<ParamSpec> da3_param_specs(const Da3Cfg& cfg, int scheme) {
     lin("camera_decoder.fc_qvec", 4, din, 1.0, false);
     lin("camera_decoder.fc_fov", 2, din, 0.25, true);
   }
+  if (cfg.camera_encoder) {  // CameraEncoder (camera.rs:50-87, 206-234): dim_in = target_dim = 9, dim_out = embed_dim
+    const std::string ce = "camera_encoder";
+    auto ls = [&](const std::string& name) {
+      if (par) sb.add(name, {D}, 0.05, 0.3); else sb.add(name, {D}, 1.0, 1.0);
+    };
+    lin(ce + ".pose_branch.fc1", D / 2, 9, 1.0, false);
+    lin(ce + ".pose_branch.fc2", D, D / 2, 1.0, false);
+    norm(ce + ".token_norm", D);
+    for (int i = 0; i < cfg.cam_trunk_depth; ++i) {
+      const std::string blk = ce + ".trunk." + std::to_string(i);
+      norm(blk + ".norm1", D);
+      norm(blk + ".norm2", D);
+      lin(blk + ".attn.qkv", 3 * D, D, 1.0, false);
+      lin(blk + ".attn.proj", D, D, 1.0, false);
+      ls(blk + ".ls1.gamma");
+      lin(blk + ".mlp.fc1", 4 * D, D, 1.0, false);
+      lin(blk + ".mlp.fc2", D, 4 * D, 1.0, false);
+      ls(blk + ".ls2.gamma");
+    }
+    norm(ce + ".trunk_norm", D);
+  }
   return specs;
 }
 

@@ -58,14 +58,26 @@ class DepthAnything3(DepthPro):
     def patch_size(self) -> int:
         return self.config.patch_size
 
-    def infer(self, x: torch.Tensor) -> DepthAnything3Inference:
+    def infer_with_camera(self, x: torch.Tensor, extrinsics: torch.Tensor, intrinsics: torch.Tensor) -> DepthAnything3Inference:
+        """`DepthAnything3::infer_with_camera` (mod.rs:301-309): extrinsics [B, V, 3, 4] (world-to-camera), intrinsics [B, V, 3, 3].
+        The camera encoder's token (camera.rs:89-110) conditions the backbone; a variant without an encoder ignores both
+        (mod.rs:522-527)."""
+        B = x.shape[0]
+        if extrinsics.dim() != 4 or tuple(extrinsics.shape[2:]) != (3, 4) or extrinsics.shape[0] != B:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected extrinsics [{B},V,3,4], got {tuple(extrinsics.shape)}")
+        V = extrinsics.shape[1]
+        if tuple(intrinsics.shape) != (B, V, 3, 3):
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected intrinsics [{B},{V},3,3], got {tuple(intrinsics.shape)}")
+        return self.infer(x, (extrinsics, intrinsics))
+
+    def infer(self, x: torch.Tensor, _camera=None) -> DepthAnything3Inference:
         if x.dim() != 4 or x.shape[1] != 3:
             raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
         x = x.contiguous().to(torch.float32)
         B, _, H, W = x.shape
         dev = torch.device("cuda", self.device.ordinal)
         depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-        if not self.config.dual_head:
+        if not self.config.dual_head:  # no camera encoder either: camera inputs are ignored (mod.rs:522-527)
             self.infer_into(x, depth)
             return DepthAnything3Inference(depth=depth)
         # dual head (`small`): every field of DepthAnything3Inference (mod.rs:231-239, 605-621)
@@ -78,6 +90,12 @@ class DepthAnything3(DepthPro):
         o = _lib.MdDa3Outputs(*(t.data_ptr() for t in (out.depth, out.depth_confidence, out.aux, out.aux_confidence,
                                                        out.pose_encoding, out.extrinsics, out.intrinsics)))
         in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        if _camera is not None:  # camera inputs travel in the memory kind of the image
+            e, k = (t.to(torch.float32).to(x.device).contiguous() for t in _camera)
+            _lib.check(self._lib.md_da3_infer_with_camera(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind, C.c_void_p(e.data_ptr()),
+                                                          C.c_void_p(k.data_ptr()), int(e.shape[1]), C.byref(o), _lib.MD_MEM_DEVICE,
+                                                          _stream_ptr(self.device.ordinal)))
+            return out
         _lib.check(self._lib.md_da3_infer_ex(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind, C.byref(o), _lib.MD_MEM_DEVICE,
                                              _stream_ptr(self.device.ordinal)))
         return out

@@ -89,11 +89,15 @@ def da3_rules(head_prefix: str = "head_mono") -> List[Rule]:
           (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.2\.weight$", r"\1.norm.layer_norm.gamma"),
           (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.2\.bias$", r"\1.norm.layer_norm.beta"),
           (rf"^({hp}\.scratch\.output_conv2_aux\.\d+)\.5\.(weight|bias)$", r"\1.project.\2")]
+    # camera encoder (import_da3.rs:184-195): trunk norm1/norm2, token_norm, trunk_norm
+    r += _norm_rules(r"camera_encoder\..*norm\d*")
     return r
 
 
-# the camera ENCODER only runs when extrinsics/intrinsics are passed in, which `infer` never does (mod.rs:288-291)
-DA3_IGNORED = (r"\.mask_token$", r"^camera_encoder\.")
+# a metric_large checkpoint has no camera encoder in the Burn module (mod.rs:139-156: `camera_encoder: None`); the importer
+# drops upstream `cam_enc.*` tensors there, like the reference's `allow_partial(true)` store (import_da3.rs:199-202)
+DA3_IGNORED = (r"\.mask_token$",)
+DA3_IGNORED_NO_ENCODER = DA3_IGNORED + (r"^camera_encoder\.",)
 
 
 class ImportError_(ValueError):
@@ -194,7 +198,8 @@ def import_da3(src: str, dst: str, cfg: DepthAnything3Config | None = None, dtyp
     by `DepthAnything3.load_file`."""
     cfg = cfg or DepthAnything3Config()
     specs = Wt.da3_param_specs(cfg, Wt.INIT_REFERENCE)
-    tensors = convert_state_dict(load_upstream(src), specs, da3_rules("head_dual" if cfg.dual_head else "head_mono"), DA3_IGNORED)
+    tensors = convert_state_dict(load_upstream(src), specs, da3_rules("head_dual" if cfg.dual_head else "head_mono"),
+                                 DA3_IGNORED if cfg.camera_encoder else DA3_IGNORED_NO_ENCODER)
     Wt.save_container(dst, tensors, metadata={"model": "depth_anything3", "variant": cfg.variant,
                                               "image_size": str(cfg.image_size)}, dtype=dtype)
     return tensors

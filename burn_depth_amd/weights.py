@@ -187,8 +187,9 @@ def depth_pro_param_specs(cfg: DepthProConfig, scheme: int = INIT_REFERENCE) -> 
 def da3_param_specs(cfg: DepthAnything3Config, scheme: int = INIT_REFERENCE) -> List[ParamSpec]:
     """Parameters of `DepthAnything3::new` (depth_anything3/mod.rs:253-286, dpt.rs:153-226,515-568,1002-1083,
     camera.rs:113-141), named as the importer maps them (tool/import_da3.rs:67-195): `backbone.pretrained.*`,
-    `head_mono.*` | `head_dual.*`, `camera_decoder.*`. The camera *encoder* (mod.rs:165-168) only runs when
-    extrinsics/intrinsics are passed in, which `infer` never does (mod.rs:288-291): not part of the inventory."""
+    `head_mono.*` | `head_dual.*`, `camera_decoder.*`, `camera_encoder.*` (camera.rs:50-87: PoseBranch, token_norm, a trunk of
+    burn_dino `Block`s, trunk_norm; it only runs under `infer_with_camera`, mod.rs:301-309,522-527). The camera-encoder entries come
+    last so that adding them left every earlier index where it was."""
     v = cfg.vit()
     par = scheme == INIT_PARITY
     bp = "backbone.pretrained"
@@ -273,6 +274,22 @@ def da3_param_specs(cfg: DepthAnything3Config, scheme: int = INIT_REFERENCE) -> 
         lin("camera_decoder.fc_t", 3, d)
         lin("camera_decoder.fc_qvec", 4, d)
         lin("camera_decoder.fc_fov", 2, d, gain=0.25, bias_range=(0.6, 1.2))  # parity init keeps relu(fov) > 0
+    if cfg.camera_encoder:  # CameraEncoder (camera.rs:50-87, 206-234): dim_in = target_dim = 9, dim_out = embed_dim
+        D, ce = v.embed_dim, "camera_encoder"
+        lin(f"{ce}.pose_branch.fc1", D // 2, 9)
+        lin(f"{ce}.pose_branch.fc2", D, D // 2)
+        norm(f"{ce}.token_norm", D)
+        for i in range(cfg.cam_trunk_depth):
+            blk = f"{ce}.trunk.{i}"
+            norm(f"{blk}.norm1", D)
+            norm(f"{blk}.norm2", D)
+            lin(f"{blk}.attn.qkv", 3 * D, D)
+            lin(f"{blk}.attn.proj", D, D)
+            specs.append(ParamSpec(f"{blk}.ls1.gamma", (D,), *((0.05, 0.3) if par else (1.0, 1.0))))
+            lin(f"{blk}.mlp.fc1", 4 * D, D)
+            lin(f"{blk}.mlp.fc2", D, 4 * D)
+            specs.append(ParamSpec(f"{blk}.ls2.gamma", (D,), *((0.05, 0.3) if par else (1.0, 1.0))))
+        norm(f"{ce}.trunk_norm", D)
     return specs
 
 

@@ -214,6 +214,14 @@ typedef struct md_da3_outputs {
 } md_da3_outputs;
 int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const md_da3_outputs* out,
                     int out_kind, void* stream);
+/* `DepthAnything3::infer_with_camera` (depth_anything3/mod.rs:301-309 -> 522-531): known cameras condition the backbone.
+ * extrinsics [B, views, 3, 4] (world-to-camera) and intrinsics [B, views, 3, 3], fp32, in the same memory kind as `nchw`;
+ * 1 <= views <= 16. The camera encoder (camera.rs:50-110: pose encoding of each view -> PoseBranch -> token_norm -> a trunk
+ * of transformer blocks over the view tokens -> trunk_norm -> mean over views) yields one token per image, which takes the
+ * place of the learned camera token in the backbone. A variant without a camera encoder (`metric_large`) ignores the
+ * camera inputs, as the reference's match does (mod.rs:522-527), and the call equals md_da3_infer_ex. */
+int md_da3_infer_with_camera(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const float* extrinsics,
+                             const float* intrinsics, int views, const md_da3_outputs* out, int out_kind, void* stream);
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,
                            float* lo, float* hi);
 
@@ -241,7 +249,8 @@ int md_model_query(md_model_t m, const char* key, int64_t* out);
  * Depth-Anything-v3 models (`DepthTrace` / `infer_with_trace`, depth_anything3/mod.rs:241-246,329-362, and the head's
  * stages, dpt.rs:587-731): backbone_tokens_{0..3} [B, P, D | 2D] (the hook patch tokens the head receives),
  * stage_{0..3} (prepare_stage outputs), layer{1..4}_rn, refinenet{4..1} (+ "_aux" for the dual head's second pyramid),
- * output_conv1, head_input (resized + UV table), aux_neck, aux_head_input. */
+ * output_conv1, head_input (resized + UV table), aux_neck, aux_head_input; camera_token [B, D] (the camera encoder's
+ * result, after md_da3_infer_with_camera). */
 int md_model_enable_taps(md_model_t m, int enable);
 int md_model_read_tap(md_model_t m, const char* name, float* host_data, size_t capacity, int64_t dims[4]);
 

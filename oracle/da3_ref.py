@@ -197,8 +197,9 @@ def rope2d(t: Tensor, pos: Tensor, base: float) -> Tensor:
     return torch.cat([_rope_half(t[..., :n], pos[:, 0], base), _rope_half(t[..., n:], pos[:, 1], base)], -1)
 
 
-def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8: bool = False):
-    """Returns (hooks: 4 x [B, P, 2D] with the second half final-norm'ed, camera feature [B, 2D] of the last hook)."""
+def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8: bool = False, camera_token=None):
+    """Returns (hooks: 4 x [B, P, 2D] with the second half final-norm'ed, camera feature [B, 2D] of the last hook).
+    `camera_token` [B, D]: the camera encoder's output (mod.rs:522-531); it takes the place of the learned reference token."""
     from oracle.depth_pro_ref import interpolate_pos_encoding, linear_quantisers, round_q_prescaled
     qn, qo, qh, qw = linear_quantisers(q, fp8)
     v = cfg.vit()
@@ -220,7 +221,8 @@ def backbone_hooks_ext(x: Tensor, W, cfg: DepthAnything3Config, q=identity, fp8:
         b = f"blocks.{i}"
         ext = start >= 0 and i >= start
         if ext and i == start:
-            xs = torch.cat([p("camera_token")[:, :1].expand(B, 1, D), xs[:, 1:]], 1)
+            cam_tok = p("camera_token")[:, :1].expand(B, 1, D) if camera_token is None else camera_token.reshape(B, 1, D)
+            xs = torch.cat([cam_tok, xs[:, 1:]], 1)
         is_global = ext and i % 2 == 1
         xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
         qkv = F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias"))
@@ -329,9 +331,80 @@ def camera_decode(cam: Tensor, W, height: int, width: int):
     return dict(pose_encoding=pose[:, None], extrinsics=extr[:, None], intrinsics=intr[:, None])
 
 
-def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False, fp8: bool = False):
+def matrix_to_quaternion(R: Tensor) -> Tensor:
+    """camera.rs:418-514: four candidate quaternions (x, y, z, w), one picked per matrix by the branch masks
+    (trace > 0; else m00 largest; else m11 > m22; else z). Clamps and the 1e-6 added to the divisors as in the reference."""
+    m = lambda i, j: R[:, i, j]
+    one, eps = torch.ones(R.shape[0]), 1e-6
+    trace = m(0, 0) + m(1, 1) + m(2, 2)
+    s = torch.sqrt(torch.clamp_min(trace + one, 1e-6)) * 2.0
+    q_t = torch.stack([(m(2, 1) - m(1, 2)) / s, (m(0, 2) - m(2, 0)) / s, (m(1, 0) - m(0, 1)) / s, 0.25 * s], 1)
+    s = torch.sqrt(torch.clamp_min(one + m(0, 0) - m(1, 1) - m(2, 2), 1e-6)) * 2.0
+    q_x = torch.stack([0.25 * s, (m(0, 1) + m(1, 0)) / (s + eps), (m(0, 2) + m(2, 0)) / (s + eps), (m(2, 1) - m(1, 2)) / (s + eps)], 1)
+    s = torch.sqrt(torch.clamp_min(one + m(1, 1) - m(0, 0) - m(2, 2), 1e-6)) * 2.0
+    q_y = torch.stack([(m(0, 1) + m(1, 0)) / (s + eps), 0.25 * s, (m(1, 2) + m(2, 1)) / (s + eps), (m(0, 2) - m(2, 0)) / (s + eps)], 1)
+    s = torch.sqrt(torch.clamp_min(one + m(2, 2) - m(0, 0) - m(1, 1), 1e-6)) * 2.0
+    q_z = torch.stack([(m(0, 2) + m(2, 0)) / (s + eps), (m(1, 2) + m(2, 1)) / (s + eps), 0.25 * s, (m(1, 0) - m(0, 1)) / (s + eps)], 1)
+    mk_t = (trace > 0).float()
+    mk_x = (one - mk_t) * (m(0, 0) > m(1, 1)).float() * (m(0, 0) > m(2, 2)).float()
+    mk_y = (one - mk_t - mk_x) * (m(1, 1) > m(2, 2)).float()
+    mk_z = one - mk_t - mk_x - mk_y
+    return q_t * mk_t[:, None] + q_x * mk_x[:, None] + q_y * mk_y[:, None] + q_z * mk_z[:, None]
+
+
+def approx_atan_positive(x: Tensor) -> Tensor:
+    """camera.rs:516-536: pi/4 v - v (v - 1)(0.2447 + 0.0663 v) for v <= 1, pi/2 - f(1/v) above."""
+    f = lambda v: np.float32(math.pi / 4) * v - v * (v - 1.0) * (0.2447 + 0.0663 * v)
+    small, large = f(x), np.float32(math.pi / 2) - f(1.0 / torch.clamp_min(x, 1e-6))
+    mk = (x <= 1.0).float()
+    return small * mk + large * (1.0 - mk)
+
+
+def pose_encoding(extrinsics: Tensor, intrinsics: Tensor, height: int, width: int) -> Tensor:
+    """extri_intri_to_pose_encoding (camera.rs:236-279): [B, V, 3, 4] world-to-camera + [B, V, 3, 3] ->
+    [B, V, 9] = (camera-to-world translation, quaternion xyzw of the camera-to-world rotation, fov_h, fov_w)."""
+    B, V = extrinsics.shape[:2]
+    w2c = extrinsics.reshape(B * V, 3, 4).float()
+    Rc2w = w2c[:, :, :3].transpose(1, 2)
+    t = -(Rc2w @ w2c[:, :, 3:4])[:, :, 0]
+    intr = intrinsics.reshape(B * V, 3, 3).float()
+    fov_w = approx_atan_positive(np.float32(width / 2.0) / intr[:, 0, 0]) * 2.0
+    fov_h = approx_atan_positive(np.float32(height / 2.0) / intr[:, 1, 1]) * 2.0
+    return torch.cat([t, matrix_to_quaternion(Rc2w), fov_h[:, None], fov_w[:, None]], 1).reshape(B, V, 9)
+
+
+def camera_encode(extrinsics: Tensor, intrinsics: Tensor, W, cfg: DepthAnything3Config, height: int, width: int, debug=None) -> Tensor:
+    """CameraEncoder::forward (camera.rs:89-110): pose encoding -> PoseBranch (fc1, erf-GELU, fc2; :206-234) -> token_norm ->
+    `trunk_depth` burn_dino Blocks over the V view tokens (qkv bias, LayerScale, plain softmax, no RoPE / qk-norm: :63-79) ->
+    trunk_norm -> mean over views. Returns [B, D]. fp32 throughout. The Block itself is burn_dino's (un-vendored): restated as the
+    standard pre-norm block the backbone uses, with the backbone's LayerNorm eps."""
+    v = cfg.vit()
+    D, Hn = v.embed_dim, cfg.cam_heads
+    hd = D // Hn
+    p = lambda n: W[f"camera_encoder.{n}"]
+    lin = lambda n, t: F.linear(t, p(f"{n}.weight"), p(f"{n}.bias"))
+    pe = pose_encoding(extrinsics, intrinsics, height, width)
+    B, V = pe.shape[:2]
+    x = lin("pose_branch.fc2", F.gelu(lin("pose_branch.fc1", pe)))
+    x = F.layer_norm(x, (D,), p("token_norm.gamma"), p("token_norm.beta"), cfg.cam_ln_eps)
+    if debug is not None:
+        debug["pose_encoding_in"], debug["cam_tokens0"] = pe, x
+    for i in range(cfg.cam_trunk_depth):
+        b = f"trunk.{i}"
+        qkv = lin(f"{b}.attn.qkv", F.layer_norm(x, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
+        qkv = qkv.reshape(B, V, 3, Hn, hd).permute(2, 0, 3, 1, 4)
+        a = torch.softmax((qkv[0] * hd ** -0.5) @ qkv[1].transpose(-1, -2), -1) @ qkv[2]
+        x = x + p(f"{b}.ls1.gamma") * lin(f"{b}.attn.proj", a.transpose(1, 2).reshape(B, V, D))
+        h = lin(f"{b}.mlp.fc2", F.gelu(lin(f"{b}.mlp.fc1", F.layer_norm(x, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))))
+        x = x + p(f"{b}.ls2.gamma") * h
+    x = F.layer_norm(x, (D,), p("trunk_norm.gamma"), p("trunk_norm.beta"), cfg.cam_ln_eps)
+    return x.mean(1)
+
+
+def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False, fp8: bool = False, extrinsics=None, intrinsics=None):
     """DepthAnything3::infer (mod.rs:288-291 -> 495-564 -> 587-624): depth [B,H,W] (+ confidence, aux rays,
-    aux confidence, pose encoding, extrinsics, intrinsics for the dual-head variant)."""
+    aux confidence, pose encoding, extrinsics, intrinsics for the dual-head variant). With `extrinsics` [B, V, 3, 4] and
+    `intrinsics` [B, V, 3, 3] it is `infer_with_camera` (mod.rs:301-309): the camera encoder's token conditions the backbone."""
     ref_config.check_da3(cfg)  # the product's variant tables against the oracle's own restatement of the reference's
     B, _, H, Wd = x.shape
     ps = cfg.patch_size
@@ -339,7 +412,12 @@ def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = Fal
         raise ValueError(f"Input {H}x{Wd} must be divisible by patch size {ps}")
     dbg = {} if debug else None
     if cfg.dual_head:
-        hooks, cam = backbone_hooks_ext(x, W, cfg, q, fp8)
+        cam_tok = None
+        if extrinsics is not None and intrinsics is not None and cfg.camera_encoder:  # mod.rs:522-527
+            cam_tok = camera_encode(extrinsics, intrinsics, W, cfg, H, Wd, dbg)
+            if debug:
+                dbg["camera_token"] = cam_tok
+        hooks, cam = backbone_hooks_ext(x, W, cfg, q, fp8, cam_tok)
         out = dual_head_forward(hooks, H, Wd, W, cfg, q, dbg)
         out.update(camera_decode(cam, W, H, Wd))
         if debug:

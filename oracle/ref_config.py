@@ -93,12 +93,14 @@ DA3_VARIANTS = {
     # DepthAnything3Config::default / metric_large (mod.rs:139-156) + DepthAnything3HeadConfig::metric_large (dpt.rs:41-58)
     "metric_large": dict(image_size=518, patch_size=14, hook_block_ids=(4, 11, 17, 23), dim_in=1024, features=256,
                          out_channels=(256, 512, 1024, 1024), output_dim=1, pos_embed=True, dual_head=False, aux_levels=4,
-                         aux_out1_conv_num=5, aux_output_dim=7, vit=VITL, ext_block_start=-1),
+                         aux_out1_conv_num=5, aux_output_dim=7, vit=VITL, ext_block_start=-1, camera_encoder=None),
     # DepthAnything3Config::small (mod.rs:158-171) + DepthAnything3HeadConfig::small (dpt.rs:60-79); the backbone extras start
     # at block 4 (alt / qk_norm / rope block_start, mod.rs:190-194)
     "small": dict(image_size=518, patch_size=14, hook_block_ids=(5, 7, 9, 11), dim_in=768, features=64,
                   out_channels=(48, 96, 192, 384), output_dim=2, pos_embed=True, dual_head=True, aux_levels=4,
-                  aux_out1_conv_num=5, aux_output_dim=7, vit=VITS, ext_block_start=4),
+                  aux_out1_conv_num=5, aux_output_dim=7, vit=VITS, ext_block_start=4,
+                  # CameraEncoderConfig { dim_out: 384, ..default } (mod.rs:164-167; camera.rs:25-37): trunk_depth 4, 16 heads, mlp 4
+                  camera_encoder=dict(heads=16, trunk_depth=4)),
 }
 
 
@@ -113,6 +115,7 @@ def check_da3(cfg) -> None:
                out_channels=tuple(cfg.out_channels), output_dim=cfg.output_dim, pos_embed=cfg.pos_embed, dual_head=cfg.dual_head,
                aux_levels=cfg.aux_levels, aux_out1_conv_num=cfg.aux_out1_conv_num, aux_output_dim=cfg.aux_output_dim,
                ext_block_start=cfg.ext_block_start,
+               camera_encoder=dict(heads=cfg.cam_heads, trunk_depth=cfg.cam_trunk_depth) if cfg.camera_encoder else None,
                vit=dict(embed_dim=v.embed_dim, depth=v.depth, num_heads=v.num_heads, mlp_ratio=v.mlp_ratio))
     for k, want in ref.items():
         if k == "image_size":

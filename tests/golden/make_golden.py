@@ -79,11 +79,52 @@ def da3_dual_case(B=1, seed=0):
     return out
 
 
+def camera_inputs(B, V, H, W):
+    """Fixed world-to-camera extrinsics [B, V, 3, 4] (rotations that take each of the four branches of the reference's
+    matrix_to_quaternion, camera.rs:418-514) and pinhole intrinsics [B, V, 3, 3] with fx, fy either side of W/2, H/2."""
+    import math
+
+    def rot(axis, ang):
+        a = np.asarray(axis, float)
+        a /= np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+    poses = [((1, 2, 3), 0.4), ((1, .1, .1), 3.0), ((.1, 1, .1), 3.0), ((.1, .1, 1), 3.0)]
+    E, I = np.zeros((B, V, 3, 4), np.float32), np.zeros((B, V, 3, 3), np.float32)
+    for b in range(B):
+        for v in range(V):
+            i = b * V + v
+            ax, ang = poses[i % 4]
+            E[b, v, :, :3] = rot(ax, ang + 0.01 * i)
+            E[b, v, :, 3] = [0.1 * (i + 1), -0.2, 0.05 * i - 0.3]
+            I[b, v] = [[W * (0.4 + 0.15 * (i % 4)), 0, W / 2], [0, H * (0.9 - 0.15 * (i % 4)), H / 2], [0, 0, 1]]
+    return torch.from_numpy(E), torch.from_numpy(I)
+
+
+def da3_camera_case(B=2, V=2, seed=0):
+    """`infer_with_camera` (depth_anything3/mod.rs:301-309) on the reduced dual-head variant: the camera encoder's token and the
+    outputs it conditions."""
+    cfg = DepthAnything3Config.tiny_dual_test()
+    S = cfg.image_size
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+    x = seeded_input(seed, B, S, S)
+    E, I = camera_inputs(B, V, S, S)
+    with torch.no_grad():
+        ref = D3.infer(x, W, cfg, debug=True, extrinsics=E, intrinsics=I)
+    out = dict(batch=np.int32(B), views=np.int32(V), seed=np.int32(seed), image_size=np.int32(S),
+               in_extrinsics=E.numpy(), in_intrinsics=I.numpy(), in_pose_encoding=ref["debug"]["pose_encoding_in"].numpy().astype(np.float32),
+               camera_token=ref["debug"]["camera_token"].numpy().astype(np.float32))
+    for k in ("depth", "depth_confidence", "aux_confidence", "pose_encoding", "extrinsics"):
+        out[k] = ref[k].numpy().astype(np.float32)
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "da3_tiny_dual_camera_f32.npz"), **da3_camera_case())
     np.savez_compressed(os.path.join(HERE, "depth_pro_tiny_f32.npz"), **depth_pro_case())
     np.savez_compressed(os.path.join(HERE, "da3_tiny_f32.npz"), **da3_case())
     np.savez_compressed(os.path.join(HERE, "da3_tiny_dual_f32.npz"), **da3_dual_case())
-    for f in ("depth_pro_tiny_f32.npz", "da3_tiny_f32.npz", "da3_tiny_dual_f32.npz"):
+    for f in ("depth_pro_tiny_f32.npz", "da3_tiny_f32.npz", "da3_tiny_dual_f32.npz", "da3_tiny_dual_camera_f32.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -441,6 +441,48 @@ def test_depth_anything3_split_half_non_square(diag, dev):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("precision,B,V,host", [(1, 2, 3, False), (4, 1, 1, True), (0, 2, 4, False), (3, 1, 16, False)])
+def test_depth_anything3_infer_with_camera_reduced_variant(diag, dev, precision, B, V, host):
+    # `DepthAnything3::infer_with_camera` (mod.rs:301-309): camera encoder (camera.rs:50-110) on the reduced dual-head variant
+    from burn_depth_amd.config import DepthAnything3Config
+    start = len(diag.RESULTS)
+    diag.guarded("da3-cam")(diag.run_da3_with_camera)(dev, DepthAnything3Config.tiny_dual_test(), f"da3-tinydual-camera/p{precision}", B, V,
+                                                      precision, host_inputs=host)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 7
+
+
+def test_depth_anything3_small_infer_with_camera(diag, dev):
+    # the reference's `small` preset: D = 384, 16 heads of 24, a trunk of 4 blocks (mod.rs:164-168; camera.rs:25-37)
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    start = len(diag.RESULTS)
+    diag.guarded("da3-small-cam")(diag.run_da3_with_camera)(dev, DepthAnything3Config.small(), "da3-small-camera/f32", 1, 2, Precision.F32)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 7
+
+
+def test_depth_anything3_mono_variant_ignores_camera_inputs(diag, dev):
+    # mod.rs:522-527: `(Some(encoder), Some(extr), Some(intr)) => ..., _ => None` -- no encoder, no conditioning
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    start = len(diag.RESULTS)
+    diag.guarded("da3-mono-cam")(diag.run_da3_with_camera)(dev, DepthAnything3Config.tiny_test(), "da3-tiny-camera/f32", 1, 2, Precision.F32)
+    _assert_new_results_ok(diag, start)
+
+
+def test_infer_with_camera_rejects_bad_views(dev):
+    import torch
+    from burn_depth_amd import _lib
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    m = DepthAnything3.new(dev, DepthAnything3Config.tiny_dual_test(), seed=0)
+    x = torch.zeros(1, 3, 70, 70, device="cuda")
+    with pytest.raises(_lib.MdError):  # 17 views: beyond the kernel's per-thread accumulators
+        m.infer_with_camera(x, torch.zeros(1, 17, 3, 4), torch.ones(1, 17, 3, 3))
+    with pytest.raises(_lib.MdError):  # intrinsics of another view count
+        m.infer_with_camera(x, torch.zeros(1, 2, 3, 4), torch.ones(1, 3, 3, 3))
+    m.destroy()
+
+
 def test_split_half_fork_follows_a_recommit_that_changes_the_term_count(dev):
     """a fork must multiply with the ROOT's current weight form. Seeded fp32 weights pack as
     [Wh | Wh | Wl] (three terms); rounding them to f16 and committing on the root re-packs every plain weight as [W | W]

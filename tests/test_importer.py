@@ -140,6 +140,7 @@ def test_da3_round_trip(tmp_path):
         return "model." + n
 
     upstream = {up(k): v for k, v in W.items()}
+    upstream["model.cam_enc.trunk.0.norm1.weight"] = np.zeros(4, np.float32)   # no camera encoder in this variant: dropped
     src, dst = str(tmp_path / "model.safetensors"), str(tmp_path / "da3.safetensors")
     Wt.save_container(src, upstream, dtype="F32")
     importer.import_da3(src, dst, cfg, dtype="F32")
@@ -168,12 +169,16 @@ def test_da3_small_round_trip(tmp_path):
         if n.startswith("camera_decoder."):
             n = "cam_dec." + n[len("camera_decoder."):]
             n = n.replace("backbone_1.", "backbone.0.").replace("backbone_2.", "backbone.2.").replace("fc_fov.", "fc_fov.0.")
+        if n.startswith("camera_encoder."):
+            n = "cam_enc." + n[len("camera_encoder."):]
         return "model." + n
 
     upstream = {up(k): v for k, v in W.items()}
     assert "model.cam_dec.backbone.2.weight" in upstream and "model.head.scratch.output_conv2_aux.0.2.weight" in upstream
     assert "model.backbone.pretrained.blocks.3.attn.q_norm.weight" in upstream and "model.head.norm.bias" in upstream
-    upstream["model.cam_enc.trunk.0.norm1.weight"] = np.zeros(4, np.float32)   # camera encoder: dropped
+    for k in ("trunk.1.norm2.bias", "token_norm.weight", "trunk_norm.bias", "pose_branch.fc1.weight", "trunk.0.ls1.gamma", "trunk.0.attn.qkv.bias"):
+        assert "model.cam_enc." + k in upstream, k     # the camera encoder (import_da3.rs:88,184-195)
+    upstream["model.backbone.pretrained.mask_token"] = np.zeros(4, np.float32)   # dropped
     src, dst = str(tmp_path / "model.safetensors"), str(tmp_path / "da3s.safetensors")
     Wt.save_container(src, upstream, dtype="F32")
     importer.import_da3(src, dst, cfg, dtype="F32")

@@ -758,6 +758,80 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY, taps=False, f1
     model.destroy()
 
 
+def camera_inputs(B, V, H, W, seed=3):
+    """Seeded world-to-camera extrinsics [B, V, 3, 4] whose rotations reach all four branches of the reference's matrix_to_quaternion
+    (camera.rs:418-514: trace > 0, and near-pi turns about x, y, z) and intrinsics [B, V, 3, 3] with fx, fy either side of W/2, H/2."""
+    import math
+    g = np.random.default_rng(seed)
+
+    def rot(axis, ang):
+        a = np.asarray(axis, float)
+        a /= np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+    axes = [(1, 2, 3), (1, .1, .1), (.1, 1, .1), (.1, .1, 1)]
+    E, I = np.zeros((B, V, 3, 4), np.float32), np.zeros((B, V, 3, 3), np.float32)
+    for b in range(B):
+        for v in range(V):
+            i = (b * V + v) % 4
+            ax = np.asarray(axes[i]) + 0.05 * g.standard_normal(3)
+            E[b, v, :, :3] = rot(ax, 0.3 + 0.4 * g.random() if i == 0 else 2.9 + 0.2 * g.random())
+            E[b, v, :, 3] = g.uniform(-0.5, 0.5, 3)
+            fx, fy = W * (0.35 + 0.5 * g.random()), H * (0.35 + 0.5 * g.random())
+            I[b, v] = [[fx, 0, W / 2], [0, fy, H / 2], [0, 0, 1]]
+    return torch.from_numpy(E), torch.from_numpy(I)
+
+
+def run_da3_with_camera(dev, cfg, label, B, V, precision, scheme=Wt.INIT_PARITY, host_inputs=False):
+    """`DepthAnything3::infer_with_camera` (mod.rs:301-309): the camera encoder's token against the oracle's, then every output of
+    the conditioned inference; the conditioning must move the depth away from the plain `infer` result."""
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from oracle import da3_ref as D3
+    cfg.precision = precision
+    cfg.max_batch = B
+    model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=scheme)
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, scheme))
+    torch.manual_seed(1)
+    S, Sw = cfg.image_size, cfg.image_width or cfg.image_size
+    x = torch.randn(B, 3, S, Sw)
+    E, I = camera_inputs(B, V, S, Sw)
+    with torch.no_grad():
+        ref = D3.infer(x, W, cfg, debug=True, extrinsics=E, intrinsics=I)
+        plain = cached(("da3", cfg_key(cfg), B, scheme, False, "seeded"), lambda: D3.infer(x, W, cfg))
+    model.enable_taps(True)
+    xin = x if host_inputs else x.cuda()
+    out = model.infer_with_camera(xin, E, I)
+    torch.cuda.synchronize()
+    if cfg.camera_encoder:
+        tok = torch.from_numpy(model.read_tap("camera_token"))
+        record(f"{label} camera_token vs oracle (rel)", rel_err(tok.reshape(ref["debug"]["camera_token"].shape), ref["debug"]["camera_token"]), 2e-5,
+               f"|token|max={ref['debug']['camera_token'].abs().max():.3f}")
+    model.enable_taps(False)
+    d, rd = out.depth.cpu(), ref["depth"]
+    rel = (d - rd).abs() / rd.abs()
+    tol = {Precision.BF16: (8e-2, 1e-2), Precision.F16: (1.2e-2, 1.5e-3)}.get(precision, (1e-3, 1e-4))
+    record(f"{label} depth max-rel vs fp32 oracle", rel.max().item(), tol[0], f"mean-rel={rel.mean().item():.2e}")
+    record(f"{label} depth mean-rel vs fp32 oracle", rel.mean().item(), tol[1])
+    moved = ((rd - plain["depth"]).abs() / plain["depth"].abs()).mean().item()
+    if cfg.camera_encoder:
+        got_moved = ((d - plain["depth"]).abs() / plain["depth"].abs()).mean().item()
+        record(f"{label} conditioning moves the depth (mean-rel vs plain infer, oracle {moved:.2e})", -got_moved, -0.25 * moved)
+        k = {Precision.BF16: 1.0, Precision.F16: 0.15}.get(precision, 0.0)
+        for name, at in (("pose_encoding", 3e-2 * k or 2e-4), ("extrinsics", 3e-2 * k or 2e-4), ("aux", 8e-2 * k or 1e-3)):
+            g, w = getattr(out, name).cpu(), ref[name]
+            record(f"{label} {name} max-abs", (g - w).abs().max().item(), at)
+    else:  # no camera encoder in this variant: the camera inputs are ignored (mod.rs:522-527)
+        record(f"{label} camera inputs ignored without an encoder (oracle)", moved, 0.0)
+        record(f"{label} camera inputs ignored without an encoder (engine)", (d - model.infer(x.cuda()).depth.cpu()).abs().max().item(), 0.0)
+    model.enable_timing(True)
+    model.infer_with_camera(x.cuda(), E.cuda(), I.cuda())
+    tm = model.read_timing()
+    if "camera_encoder" in tm:
+        print(f"      camera_encoder kernel: {tm['camera_encoder'][0] * 1e3:.0f} us of {sum(v[0] for v in tm.values()):.2f} ms (B={B}, views={V})", flush=True)
+    model.enable_timing(False)
+    model.destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-small", action="store_true")
