@@ -114,3 +114,36 @@ def test_python_twin_reads_the_fixture(tmp_path):
     assert set(got) == set(W)
     for k in ("encoder.patch_encoder.blocks.1.mlp.fc1.weight", "head.conv0.weight", "fov.encoder_proj.weight"):
         assert got[k].shape == W[k].shape and np.array_equal(got[k], W[k].astype(np.float16).astype(np.float32)), k
+
+
+def test_checkpoint_readers_survive_mutated_files_under_sanitizers(tmp_path):
+    """The two checkpoint parsers read untrusted files: build them for the host with AddressSanitizer + UBSan (GPU sanitizers do not
+    exist on the pool; these readers are plain C++) and feed them truncated and byte-flipped mutants of a valid record of each format
+    (tests/native/fuzz_checkpoint_readers.cpp). Every mutant must be parsed or refused -- no out-of-bounds access, no overflow."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "burn_depth_amd", "csrc")
+    exe = str(tmp_path / "fuzz_readers")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + csrc,
+                            os.path.join(root, "tests", "native", "fuzz_checkpoint_readers.cpp"), os.path.join(csrc, "md_weights.cpp"),
+                            os.path.join(csrc, "md_common.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    cfg = DepthAnything3Config.tiny_dual_test()
+    W = Wt.generate_da3_weights(cfg, 0)
+    keep = [k for k in W if k.startswith("camera_") or ".blocks.0." in k or "patch_embed" in k or k.endswith("cls_token")]
+    small = {k: W[k] for k in keep}
+    assert len(small) > 40
+    mpk, st = str(tmp_path / "r.mpk"), str(tmp_path / "r.safetensors")
+    mpk_fixture.write_record(mpk, small)
+    Wt.save_container(st, small, dtype="F16")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for path, seed in ((mpk, 11), (st, 12)):
+        run = subprocess.run([exe, path, "400", str(seed)], capture_output=True, text=True, timeout=900, env=env)
+        assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+        assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+        parsed, rejected = [int(run.stdout.split(w)[1].split()[0].strip("(),")) for w in ("parsed", "rejected")]
+        assert parsed > 20 and rejected > 20, run.stdout   # both outcomes are exercised
