@@ -913,6 +913,19 @@ int md_da3_infer_with_camera(md_model_t m, const float* nchw, int B, int H, int 
   return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
 }
 
+int md_da3_infer_from_tokens(md_model_t m, const float* const* tokens, int tokens_per_image, int B, int H, int W, int in_kind,
+                             const md_da3_outputs* out, int out_kind, void* stream) {
+  if (!out) MD_FAIL(MD_ERR_INVALID_ARG, "outputs struct is null");
+  if (!tokens) MD_FAIL(MD_ERR_INVALID_ARG, "tokens is null");
+  Da3Outputs o;
+  o.depth = out->depth; o.depth_confidence = out->depth_confidence; o.aux = out->aux; o.aux_confidence = out->aux_confidence;
+  o.pose_encoding = out->pose_encoding; o.extrinsics = out->extrinsics; o.intrinsics = out->intrinsics;
+  for (int i = 0; i < 4; ++i) o.tokens[i] = tokens[i];
+  if (!o.tokens[0]) MD_FAIL(MD_ERR_LEVELS, "Backbone returned fewer hooks (0) than requested (4)");
+  o.tokens_per_image = tokens_per_image;
+  return da3_infer_ex(m, nullptr, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
+}
+
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count, float* lo,
                            float* hi) {
   Da3Cfg dc;

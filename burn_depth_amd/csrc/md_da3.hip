@@ -69,6 +69,9 @@ struct md_model_s::Da3State {
   // camera encoder (`infer_with_camera`): grow-only scratch = staged inputs [B*V*21] | encoded tokens [B*D] | kernel scratch
   float* cam_enc_ws = nullptr;
   size_t cam_enc_cap = 0;
+  // `infer_from_tokens`: caller-supplied hook tokens staged as fp32 rows [max_batch * SS + 64, din] (grow-only, zero-filled once)
+  float* tok_stage = nullptr;
+  size_t tok_stage_cap = 0;
   // The dual head's three independent tails -- main pyramid (depth + confidence), aux pyramid (rays + confidence) and the
   // camera decoder -- run as CONCURRENT branches: the aux branch and the camera decoder on side streams that fork from / join
   // the caller's stream through events (inside a captured graph they become parallel branches). Config 2 is launch-bound
@@ -649,6 +652,7 @@ void da3_destroy_state(md_model_t m) {
     if (e) (void)hipEventDestroy(e);
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
   if (m->da3->cam_enc_ws) (void)hipFree(m->da3->cam_enc_ws);
+  if (m->da3->tok_stage) (void)hipFree(m->da3->tok_stage);
   delete m->da3;
   m->da3 = nullptr;
 }
@@ -702,7 +706,7 @@ int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_ki
   if (!m->graph_enabled) return body();
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t st = stream ? stream : m->dev->stream;
-  const bool eligible = nchw && outp.depth && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
+  const bool eligible = nchw && !outp.tokens[0] && outp.depth && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
                         B <= m->da3->cfg.max_batch && H == m->da3->ih && W == m->da3->iw;
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)outp.depth,
                                       (uintptr_t)outp.depth_confidence, (uintptr_t)outp.aux, (uintptr_t)outp.aux_confidence,
@@ -715,7 +719,8 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
                            hipStream_t stream) {
   if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
   if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
-  if (!nchw || !outp.depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
+  const bool from_tokens = outp.tokens[0] != nullptr;
+  if ((!nchw && !from_tokens) || !outp.depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
   md_model_s::Da3State* d = m->da3;
   const Da3Cfg& c = d->cfg;
   const ViTDims& v = c.vit;
@@ -736,12 +741,50 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   const int Fp = cpad(m, F), F2 = F / 2, F2p = cpad(m, F2);
   const std::string hp = d->hp, bp = "backbone.pretrained";
   const float* x_dev = nchw;
-  if (in_kind == MD_MEM_HOST) {
+  if (in_kind == MD_MEM_HOST && !from_tokens) {
     MD_HIP(hipMemcpyAsync(d->xin, nchw, (size_t)B * 3 * H * W * 4, hipMemcpyHostToDevice, st));
     x_dev = d->xin;
   }
   auto Wk = [&](const std::string& n) { return PK(m, n); };
   auto Bi = [&](const std::string& n) { return P32(m, n); };
+  if (from_tokens) {
+    // ---- `infer_from_tokens` (mod.rs:405-469): no backbone, no camera prediction; the head's token LayerNorm (mono: non-affine,
+    //      dpt.rs:761-766; dual: the affine `norm`, dpt.rs:308) on the caller's hook tokens, patch rows only ----
+    if (outp.pose_encoding || outp.extrinsics || outp.intrinsics)
+      MD_FAIL(MD_ERR_UNSUPPORTED, "infer_from_tokens has no camera prediction (finalize_inference(head_output, None), mod.rs:468)");
+    const int T = outp.tokens_per_image;
+    if (T != P && T != P + 1)  // mod.rs:419-424: tokens == expected -> patch_start 0, else patch_token_start = 1
+      MD_FAIL(MD_ERR_SHAPE, "%d tokens per image for a %dx%d input: expected %d patch rows (or %d with a leading cls row)", T, H, W, P, P + 1);
+    for (int hk = 0; hk < 4; ++hk)
+      if (!outp.tokens[hk]) MD_FAIL(MD_ERR_LEVELS, "Backbone returned fewer hooks (%d) than requested (4)", hk);
+    const int start = T == P ? 0 : 1;
+    const size_t need = ((size_t)c.max_batch * SS + 64) * din;
+    if (need > d->tok_stage_cap) {
+      MD_HIP(hipStreamSynchronize(st));
+      if (d->tok_stage) MD_HIP(hipFree(d->tok_stage));
+      d->tok_stage = nullptr; d->tok_stage_cap = 0;
+      MD_HIP(hipMalloc((void**)&d->tok_stage, need * 4));
+      MD_HIP(hipMemset(d->tok_stage, 0, need * 4));
+      d->tok_stage_cap = need;
+      m->alloc_count += 1;
+    }
+    SeqGroups tg;
+    memset(&tg, 0, sizeof(tg));
+    tg.ngroups = 1;
+    tg.nseq[0] = B;
+    tg.a[0] = c.dual_head ? Bi(hp + ".norm.gamma") : nullptr;
+    tg.b[0] = c.dual_head ? Bi(hp + ".norm.beta") : nullptr;
+    const hipMemcpyKind kind = in_kind == MD_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    for (int hk = 0; hk < 4; ++hk) {
+      for (int b = 0; b < B; ++b)  // patch rows of image b -> rows b*SS + 1 .. of the staging tensor (the layout the head gathers from)
+        MD_HIP(hipMemcpyAsync(d->tok_stage + ((size_t)b * SS + 1) * din, outp.tokens[hk] + ((size_t)b * T + start) * din, (size_t)P * din * 4,
+                              kind, st));
+      r.begin("layernorm");
+      MD_TRY(launch_layernorm(d->tok_stage, d->hookn[hk], (long)B * SS, din, 1e-5f, SS, tg, m->prec, 0, st));
+      r.end();
+      if (m->taps_enabled) MD_TRY(r.tap_token_rows(("backbone_tokens_" + std::to_string(hk)).c_str(), d->tok_stage, SS, 1, P, din, din, 0));
+    }
+  } else {
   // ---- camera encoder (`infer_with_camera`, mod.rs:522-527: a model without one ignores the camera inputs) ----
   float* cam_tok = nullptr;
   if (c.camera_encoder && c.dual_head && outp.cam_extrinsics && outp.cam_intrinsics) {
@@ -973,6 +1016,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
   }
   if (hook_slot < 4) MD_FAIL(MD_ERR_LEVELS, "Backbone returned fewer hooks (%d) than requested (4)", hook_slot);  // mod.rs:532-537
+  }  // !from_tokens
 
   // ---- DPT head: prepare_stage (dpt.rs:282-317 / 649-689) ----
   int* tok_idx = nullptr;
@@ -1035,7 +1079,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   struct Bufs { void *t, *x, *xr, *y, *up, *o; };
   Bufs main_bufs{d->t, d->x, d->xr, d->y, d->up, d->o};
   const bool want_aux = c.dual_head && (outp.aux || outp.aux_confidence);
-  const bool want_cam = c.dual_head && (outp.pose_encoding || outp.extrinsics || outp.intrinsics);
+  const bool want_cam = c.dual_head && !from_tokens && (outp.pose_encoding || outp.extrinsics || outp.intrinsics);
   const bool par = c.dual_head && !m->taps_enabled && d->s_aux != nullptr;
   Run ra{m, par ? d->s_aux : st, B};   // aux branch
   Run rc{m, par ? d->s_cam : st, B};   // camera decoder

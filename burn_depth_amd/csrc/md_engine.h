@@ -224,6 +224,10 @@ struct Da3Outputs {
   // memory kind of the input image. Both set + a model with a camera encoder => the encoded token conditions the backbone.
   const float *cam_extrinsics = nullptr, *cam_intrinsics = nullptr;
   int cam_views = 0;
+  // `infer_from_tokens` (mod.rs:389-469): the head alone on caller-supplied hook tokens. tokens[i] = [B, tokens_per_image, din] fp32
+  // in the memory kind `in_kind`; tokens_per_image = P (patch rows only) or P + 1 (a leading cls row is skipped, `patch_token_start`)
+  const float* tokens[4] = {nullptr, nullptr, nullptr, nullptr};
+  int tokens_per_image = 0;
 };
 int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& out, int out_kind,
                  hipStream_t stream);

@@ -70,6 +70,29 @@ class DepthAnything3(DepthPro):
             raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected intrinsics [{B},{V},3,3], got {tuple(intrinsics.shape)}")
         return self.infer(x, (extrinsics, intrinsics))
 
+    def infer_from_tokens(self, patches, height: int, width: int) -> DepthAnything3Inference:
+        """`DepthAnything3::infer_from_tokens` (mod.rs:389-469): the head alone on the four hooks' patch tokens, each
+        [B, P | P + 1, din]; no camera prediction. The aux trace is read through the taps (`aux_neck`, `aux_head_input`)."""
+        if len(patches) != 4:
+            raise _lib.MdError(_lib.MD_ERR_LEVELS, f"Backbone returned fewer hooks ({len(patches)}) than requested (4)")
+        toks = [t.contiguous().to(torch.float32) for t in patches]
+        B, T, din = toks[0].shape
+        if any(tuple(t.shape) != (B, T, din) or t.device != toks[0].device for t in toks):
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, "the four hook tensors must share one shape and device")
+        dev = torch.device("cuda", self.device.ordinal)
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        out = DepthAnything3Inference(depth=f(B, height, width))
+        if self.config.dual_head:
+            ah, aw = 8 * (height // self.config.patch_size), 8 * (width // self.config.patch_size)
+            out.depth_confidence, out.aux, out.aux_confidence = f(B, height, width), f(B, self.config.aux_output_dim - 1, ah, aw), f(B, ah, aw)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        o = _lib.MdDa3Outputs(ptr(out.depth), ptr(out.depth_confidence), ptr(out.aux), ptr(out.aux_confidence), None, None, None)
+        arr = (C.c_void_p * 4)(*(t.data_ptr() for t in toks))
+        in_kind = _lib.MD_MEM_DEVICE if toks[0].is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_da3_infer_from_tokens(self._h, arr, int(T), int(B), int(height), int(width), in_kind, C.byref(o),
+                                                      _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
+        return out
+
     def infer(self, x: torch.Tensor, _camera=None) -> DepthAnything3Inference:
         if x.dim() != 4 or x.shape[1] != 3:
             raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")

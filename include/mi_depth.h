@@ -222,6 +222,15 @@ int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in
  * camera inputs, as the reference's match does (mod.rs:522-527), and the call equals md_da3_infer_ex. */
 int md_da3_infer_with_camera(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const float* extrinsics,
                              const float* intrinsics, int views, const md_da3_outputs* out, int out_kind, void* stream);
+/* `DepthAnything3::infer_from_tokens(patches, height, width)` (depth_anything3/mod.rs:389-469; the head-only comparison of
+ * example/da3_small_correctness.rs:278-322): the DPT head alone on caller-supplied hook tokens. tokens[0..3]: the four hooks'
+ * `DinoIntermediate::patches`, each [B, tokens_per_image, din] fp32 in the memory kind `in_kind`; din = embed_dim (mono head) or
+ * 2 * embed_dim (dual head: cat(local, final-normed)); tokens_per_image = (H/14)*(W/14) patch rows, or one more with a leading row
+ * that is skipped (`patch_token_start`, mod.rs:419-424); anything else is MD_ERR_SHAPE. The head applies its own token LayerNorm.
+ * No camera prediction (mod.rs:468 passes None): pose_encoding / extrinsics / intrinsics must be NULL (MD_ERR_UNSUPPORTED).
+ * The trace the reference returns beside the inference (aux_stage_necks, aux_head_input) is read through the taps. */
+int md_da3_infer_from_tokens(md_model_t m, const float* const* tokens, int tokens_per_image, int B, int H, int W, int in_kind,
+                             const md_da3_outputs* out, int out_kind, void* stream);
 int md_da3_param_inventory(const md_da3_cfg* cfg, int init_scheme, int index, const char** name, size_t* count,
                            float* lo, float* hi);
 

@@ -401,6 +401,26 @@ def camera_encode(extrinsics: Tensor, intrinsics: Tensor, W, cfg: DepthAnything3
     return x.mean(1)
 
 
+def infer_from_tokens(patches: List[Tensor], W, cfg: DepthAnything3Config, height: int, width: int, q=identity, debug: bool = False):
+    """DepthAnything3::infer_from_tokens (mod.rs:389-469): the head on caller-supplied hook tokens [B, T, din]; rows before
+    `patch_start` are dropped (0 when T is the patch count, else `patch_token_start` = 1, mod.rs:419-424); no camera prediction."""
+    ref_config.check_da3(cfg)
+    ps = cfg.patch_size
+    expected = max(height // ps, 1) * max(width // ps, 1)
+    start = 0 if patches[0].shape[1] == expected else 1
+    hooks = [t[:, start:] for t in patches]
+    if any(h.shape[1] != expected for h in hooks):
+        raise ValueError(f"{patches[0].shape[1]} tokens per image for a {height}x{width} input")
+    dbg = {} if debug else None
+    if cfg.dual_head:
+        out = dual_head_forward(hooks, height, width, W, cfg, q, dbg)
+    else:
+        out = dict(depth=head_forward_raw(hooks, height, width, W, cfg, q, dbg)[:, 0])
+    if debug:
+        out["debug"] = dbg
+    return out
+
+
 def infer(x: Tensor, W, cfg: DepthAnything3Config, q=identity, debug: bool = False, fp8: bool = False, extrinsics=None, intrinsics=None):
     """DepthAnything3::infer (mod.rs:288-291 -> 495-564 -> 587-624): depth [B,H,W] (+ confidence, aux rays,
     aux confidence, pose encoding, extrinsics, intrinsics for the dual-head variant). With `extrinsics` [B, V, 3, 4] and

@@ -89,3 +89,49 @@ def test_fp8_mode_stays_close_to_fp32_on_the_oracle():
         b = D3.infer(x, W, cfg, q=R.bf16_round, fp8=True)["depth"]
     rel = ((a - b).abs() / a.abs())
     assert rel.mean() < 3e-2 and rel.max() < 0.3
+
+
+def test_infer_from_tokens_is_the_head_of_infer():
+    # reference: DepthAnything3::infer_from_tokens (mod.rs:389-469) = forward_raw / forward_dual on given hook tokens; a leading row
+    # (patch_token_start = 1) is dropped when the token count is not the patch count (mod.rs:419-424)
+    for cfg in (DepthAnything3Config.tiny_test(), DepthAnything3Config.tiny_dual_test()):
+        W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+        x = torch.randn(2, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(4))
+        full = D.infer(x, W, cfg, debug=True)
+        toks = full["debug"]["hooks"]
+        assert torch.equal(D.infer_from_tokens(toks, W, cfg, 70, 70)["depth"], full["depth"])
+        lead = [torch.cat([torch.full((2, 1, t.shape[2]), 7.0), t], 1) for t in toks]
+        out = D.infer_from_tokens(lead, W, cfg, 70, 70)
+        assert torch.equal(out["depth"], full["depth"]) and "pose_encoding" not in out
+        try:
+            D.infer_from_tokens([t[:, :-1] for t in toks], W, cfg, 70, 70)
+        except ValueError:
+            continue
+        raise AssertionError("expected an error")
+
+
+def test_camera_pose_encoding_round_trips_through_the_decoder_formulas():
+    # extri_intri_to_pose_encoding (camera.rs:236-279) followed by pose_encoding_to_extri_intri (camera.rs:281-358) returns the
+    # extrinsics (quaternion branches: trace > 0, x, y, z largest) and, up to the reference's polynomial atan, the focal lengths
+    import math
+
+    def rot(axis, ang):
+        a = np.asarray(axis, float)
+        a /= np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+    Rs = [rot((1, 2, 3), 0.4), rot((1, .1, .1), 3.0), rot((.1, 1, .1), 3.0), rot((.1, .1, 1), 3.0)]
+    E = torch.tensor(np.stack([np.concatenate([r, [[0.3], [-0.2], [0.5]]], 1) for r in Rs]), dtype=torch.float32).reshape(1, 4, 3, 4)
+    K = torch.tensor([[100.0, 0, 35], [0, 20.0, 35], [0, 0, 1]]).expand(1, 4, 3, 3)   # fx > W/2 (small branch), fy < H/2 (reciprocal branch)
+    pe = D.pose_encoding(E, K, 70, 70).reshape(4, 9)
+    assert [int(r.abs().argmax()) for r in pe[:, 3:7]] == [3, 0, 1, 2]
+    t, (qx, qy, qz, qw) = pe[:, :3], pe[:, 3:7].unbind(1)
+    Rm = torch.stack([torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)], 1),
+                      torch.stack([2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)], 1),
+                      torch.stack([2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)], 1)], 1)
+    Rt = Rm.transpose(1, 2)
+    back = torch.cat([Rt, -(Rt @ t[:, :, None])], 2)
+    assert (back - E[0]).abs().max() < 2e-5
+    fy = 35.0 / torch.tan(pe[:, 7] * 0.5)
+    fx = 35.0 / torch.tan(pe[:, 8] * 0.5)
+    assert ((fx - 100.0).abs() / 100.0).max() < 1e-2 and ((fy - 20.0).abs() / 20.0).max() < 1e-2   # approx_atan_positive, camera.rs:516-536

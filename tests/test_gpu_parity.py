@@ -469,6 +469,36 @@ def test_depth_anything3_mono_variant_ignores_camera_inputs(diag, dev):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("variant,precision,B,lead,host", [("tiny", 1, 2, False, False), ("tiny", 0, 1, True, True), ("tiny_dual", 1, 2, True, False),
+                                                          ("tiny_dual", 4, 1, False, True), ("tiny_dual", 3, 2, False, False)])
+def test_depth_anything3_infer_from_tokens(diag, dev, variant, precision, B, lead, host):
+    # `DepthAnything3::infer_from_tokens` (mod.rs:389-469): the head alone on the oracle's backbone tokens, mono and dual heads
+    from burn_depth_amd.config import DepthAnything3Config
+    cfg = DepthAnything3Config.tiny_test() if variant == "tiny" else DepthAnything3Config.tiny_dual_test()
+    start = len(diag.RESULTS)
+    diag.guarded("da3-tokens")(diag.run_da3_from_tokens)(dev, cfg, f"da3-{variant}-from-tokens/p{precision}", B, precision, lead_row=lead, host_inputs=host)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 4
+
+
+def test_infer_from_tokens_error_paths(dev):
+    import torch
+    from burn_depth_amd import _lib
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    m = DepthAnything3.new(dev, DepthAnything3Config.tiny_dual_test(), seed=0)
+    P, din = 25, 256
+    ok = [torch.zeros(1, P, din, device="cuda") for _ in range(4)]
+    m.infer_from_tokens(ok, 70, 70)
+    with pytest.raises(_lib.MdError):   # fewer hooks than requested (mod.rs:532-537)
+        m.infer_from_tokens(ok[:3], 70, 70)
+    with pytest.raises(_lib.MdError):   # a token count that is neither P nor P + 1
+        m.infer_from_tokens([torch.zeros(1, P + 2, din, device="cuda") for _ in range(4)], 70, 70)
+    with pytest.raises(_lib.MdError):   # size not divisible by the patch size (mod.rs:509-520)
+        m.infer_from_tokens(ok, 71, 70)
+    m.destroy()
+
+
 def test_infer_with_camera_rejects_bad_views(dev):
     import torch
     from burn_depth_amd import _lib

@@ -832,6 +832,50 @@ def run_da3_with_camera(dev, cfg, label, B, V, precision, scheme=Wt.INIT_PARITY,
     model.destroy()
 
 
+def run_da3_from_tokens(dev, cfg, label, B, precision, lead_row=False, host_inputs=False, scheme=Wt.INIT_PARITY):
+    """`DepthAnything3::infer_from_tokens` (mod.rs:389-469; the head-only comparison of example/da3_small_correctness.rs:278-322): the four
+    hooks' patch tokens of the ORACLE's backbone go into the engine's head; every head output against the oracle's head on the same
+    tokens. `lead_row`: tokens carry one leading row (patch_token_start = 1) that must be skipped."""
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from oracle import da3_ref as D3
+    cfg.precision = precision
+    cfg.max_batch = B
+    model = DepthAnything3.new(dev, cfg, seed=0, init_scheme=scheme)
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, scheme))
+    torch.manual_seed(1)
+    S, Sw = cfg.image_size, cfg.image_width or cfg.image_size
+    x = torch.randn(B, 3, S, Sw)
+    with torch.no_grad():
+        full = cached(("da3", cfg_key(cfg), B, scheme, True, "seeded"), lambda: D3.infer(x, W, cfg, debug=True))
+        toks = [t.clone() for t in full["debug"]["hooks"]]
+        if lead_row:  # a row the head must never read: make it poisonous
+            toks = [torch.cat([torch.full((B, 1, t.shape[2]), 1e30), t], 1) for t in toks]
+        ref = D3.infer_from_tokens(toks, W, cfg, S, Sw)
+    # the oracle's own two paths agree (the head sees the same tokens either way)
+    record(f"{label} oracle: from-tokens depth == infer depth", (ref["depth"] - full["depth"]).abs().max().item(), 0.0)
+    out = model.infer_from_tokens([t if host_inputs else t.cuda() for t in toks], S, Sw)
+    torch.cuda.synchronize()
+    d, rd = out.depth.cpu(), ref["depth"]
+    rel = (d - rd).abs() / rd.abs()
+    tol = {Precision.BF16: (8e-2, 1e-2), Precision.F16: (1.2e-2, 1.5e-3)}.get(precision, (1e-3, 1e-4))
+    record(f"{label} depth max-rel vs the oracle's head", rel.max().item(), tol[0], f"mean-rel={rel.mean().item():.2e}")
+    record(f"{label} depth mean-rel vs the oracle's head", rel.mean().item(), tol[1])
+    if cfg.dual_head:
+        k = {Precision.BF16: 1.0, Precision.F16: 0.15}.get(precision, 0.0)
+        for name, rt, at in (("depth_confidence", 8e-2 * k or 1e-3, 0.0), ("aux_confidence", 8e-2 * k or 1e-3, 0.0), ("aux", 0.0, 8e-2 * k or 1e-3)):
+            g, w = getattr(out, name).cpu(), ref[name]
+            if rt:
+                record(f"{label} {name} max-rel", ((g - w).abs() / w.abs()).max().item(), rt)
+            else:
+                record(f"{label} {name} max-abs", (g - w).abs().max().item(), at)
+        record(f"{label} no camera prediction (mod.rs:468)", float(out.pose_encoding is not None or out.extrinsics is not None), 0.0)
+    # the full path on the engine's own backbone stays what it was (the token staging does not leak into it)
+    e2e = model.infer(x.cuda()).depth.cpu()
+    relf = (e2e - full["depth"]).abs() / full["depth"].abs()
+    record(f"{label} infer() after infer_from_tokens max-rel", relf.max().item(), tol[0])
+    model.destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-small", action="store_true")
