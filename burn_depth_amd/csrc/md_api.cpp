@@ -913,6 +913,13 @@ int md_da3_infer_with_camera(md_model_t m, const float* nchw, int B, int H, int 
   return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
 }
 
+int md_da3_infer_raw(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* logits, int out_kind, void* stream) {
+  if (!logits) MD_FAIL(MD_ERR_INVALID_ARG, "logits is null");
+  Da3Outputs o;
+  o.raw_logits = logits;
+  return da3_infer_ex(m, nchw, B, H, W, in_kind, o, out_kind, (hipStream_t)stream);
+}
+
 int md_da3_infer_from_tokens(md_model_t m, const float* const* tokens, int tokens_per_image, int B, int H, int W, int in_kind,
                              const md_da3_outputs* out, int out_kind, void* stream) {
   if (!out) MD_FAIL(MD_ERR_INVALID_ARG, "outputs struct is null");

@@ -706,7 +706,7 @@ int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_ki
   if (!m->graph_enabled) return body();
   MD_HIP(hipSetDevice(m->dev->ordinal));
   hipStream_t st = stream ? stream : m->dev->stream;
-  const bool eligible = nchw && !outp.tokens[0] && outp.depth && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
+  const bool eligible = nchw && !outp.tokens[0] && outp.depth && !outp.raw_logits && in_kind == MD_MEM_DEVICE && out_kind == MD_MEM_DEVICE && m->committed && B > 0 &&
                         B <= m->da3->cfg.max_batch && H == m->da3->ih && W == m->da3->iw;
   const std::vector<uintptr_t> key = {(uintptr_t)st, (uintptr_t)B, (uintptr_t)H, (uintptr_t)W, (uintptr_t)nchw, (uintptr_t)outp.depth,
                                       (uintptr_t)outp.depth_confidence, (uintptr_t)outp.aux, (uintptr_t)outp.aux_confidence,
@@ -720,7 +720,9 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
   if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
   const bool from_tokens = outp.tokens[0] != nullptr;
-  if ((!nchw && !from_tokens) || !outp.depth) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
+  if ((!nchw && !from_tokens) || (!outp.depth && !outp.raw_logits)) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
+  if (outp.raw_logits && (outp.depth || outp.depth_confidence || outp.aux || outp.aux_confidence || outp.pose_encoding || outp.extrinsics || outp.intrinsics))
+    MD_FAIL(MD_ERR_INVALID_ARG, "infer_raw returns the main logits only");
   md_model_s::Da3State* d = m->da3;
   const Da3Cfg& c = d->cfg;
   const ViTDims& v = c.vit;
@@ -1147,13 +1149,15 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     return MD_OK;
   };
   const size_t out_elems = (size_t)B * IH * IW;
-  float* depth_dev = outp.depth;
+  const size_t stage_elems = out_elems * (outp.raw_logits ? c.output_dim : 1);
+  float* depth_dev = outp.raw_logits ? outp.raw_logits : outp.depth;
   if (out_kind == MD_MEM_HOST) {
-    if (d->depth_stage_elems < out_elems) {
+    if (d->depth_stage_elems < stage_elems) {
       if (d->depth_stage) (void)hipFree(d->depth_stage);
-      MD_HIP(hipMalloc((void**)&d->depth_stage, out_elems * 4));
+      d->depth_stage = nullptr; d->depth_stage_elems = 0;
+      MD_HIP(hipMalloc((void**)&d->depth_stage, stage_elems * 4));
       m->alloc_count += 1;
-      d->depth_stage_elems = out_elems;
+      d->depth_stage_elems = stage_elems;
     }
     depth_dev = d->depth_stage;
   }
@@ -1254,10 +1258,21 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     const void* w1 = Wk(hp + ".scratch.output_conv2.conv1.weight");
     const float* b1 = Bi(hp + ".scratch.output_conv2.conv1.bias");
     const float* w2 = Bi(hp + ".scratch.output_conv2.conv2.weight");
-    TailCh chs[2];
+    TailCh chs[8];
     int nch = 0;
-    chs[nch++] = TailCh{w2, d->main_bias[0], 1, depth_dev, (long)IH * IW};  // depth = exp(ch 0)
     float* cd = nullptr;
+    if (outp.raw_logits) {
+      // infer_raw (mod.rs:364-380): the dual head hands out `depth_logits` = output_conv2's result as it is (dpt.rs:337-354, 271);
+      // the mono head's `forward_raw` has its activation applied (dpt.rs:700)
+      if (c.output_dim > 8) MD_FAIL(MD_ERR_UNSUPPORTED, "infer_raw with %d channels", c.output_dim);
+      for (int ch = 0; ch < c.output_dim; ++ch)
+        chs[nch++] = TailCh{w2 + 32 * ch, d->main_bias[ch], c.dual_head ? 2 : 1, depth_dev + (size_t)ch * IH * IW, (long)c.output_dim * IH * IW};
+      MD_TRY(tail(r, "head_tail_fused", d->c1r, IH, IW, w1, b1, chs, nch));
+      MD_TRY(host_out(st, outp.raw_logits, depth_dev, stage_elems));
+      if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
+      return MD_OK;
+    }
+    chs[nch++] = TailCh{w2, d->main_bias[0], 1, depth_dev, (long)IH * IW};  // depth = exp(ch 0)
     if (c.dual_head && outp.depth_confidence) {  // confidence = exp(last channel) + 1 (select_conf_channel, ExpP1)
       cd = out_kind == MD_MEM_HOST ? d->conf_stage : outp.depth_confidence;
       chs[nch++] = TailCh{w2 + 32 * (c.output_dim - 1), d->main_bias[c.output_dim - 1], 3, cd, (long)IH * IW};

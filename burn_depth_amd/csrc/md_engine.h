@@ -228,6 +228,9 @@ struct Da3Outputs {
   // in the memory kind `in_kind`; tokens_per_image = P (patch rows only) or P + 1 (a leading cls row is skipped, `patch_token_start`)
   const float* tokens[4] = {nullptr, nullptr, nullptr, nullptr};
   int tokens_per_image = 0;
+  // `infer_raw` (mod.rs:364-380): [B, output_dim, H, W] -- the dual head's main logits before the activations, the mono head's
+  // `forward_raw` result. When set, `depth` may be NULL and nothing else is produced.
+  float* raw_logits = nullptr;
 };
 int da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const Da3Outputs& out, int out_kind,
                  hipStream_t stream);

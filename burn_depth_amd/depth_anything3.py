@@ -70,6 +70,19 @@ class DepthAnything3(DepthPro):
             raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected intrinsics [{B},{V},3,3], got {tuple(intrinsics.shape)}")
         return self.infer(x, (extrinsics, intrinsics))
 
+    def infer_raw(self, x: torch.Tensor) -> torch.Tensor:
+        """`DepthAnything3::infer_raw` (mod.rs:364-380): [B, C, H, W] -- the dual head's main logits (C = 2), the mono head's
+        `forward_raw` result (C = 1)."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
+        x = x.contiguous().to(torch.float32)
+        B, _, H, W = x.shape
+        out = torch.empty((B, self.config.output_dim, H, W), dtype=torch.float32, device=torch.device("cuda", self.device.ordinal))
+        in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_da3_infer_raw(self._h, C.c_void_p(x.data_ptr()), B, H, W, in_kind, C.c_void_p(out.data_ptr()),
+                                              _lib.MD_MEM_DEVICE, _stream_ptr(self.device.ordinal)))
+        return out
+
     def infer_from_tokens(self, patches, height: int, width: int) -> DepthAnything3Inference:
         """`DepthAnything3::infer_from_tokens` (mod.rs:389-469): the head alone on the four hooks' patch tokens, each
         [B, P | P + 1, din]; no camera prediction. The aux trace is read through the taps (`aux_neck`, `aux_head_input`)."""

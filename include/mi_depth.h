@@ -222,6 +222,10 @@ int md_da3_infer_ex(md_model_t m, const float* nchw, int B, int H, int W, int in
  * camera inputs, as the reference's match does (mod.rs:522-527), and the call equals md_da3_infer_ex. */
 int md_da3_infer_with_camera(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, const float* extrinsics,
                              const float* intrinsics, int views, const md_da3_outputs* out, int out_kind, void* stream);
+/* `DepthAnything3::infer_raw` (depth_anything3/mod.rs:364-380): logits [B, C, H, W] fp32. Dual head (`small`): C = 2, the main
+ * branch's `depth_logits` before the activations (depth = exp(ch 0), confidence = exp(ch 1) + 1; dpt.rs:271,337-354,443-469).
+ * Mono head (`metric_large`): C = 1, `forward_raw`'s result (its exp activation applied, dpt.rs:700). */
+int md_da3_infer_raw(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* logits, int out_kind, void* stream);
 /* `DepthAnything3::infer_from_tokens(patches, height, width)` (depth_anything3/mod.rs:389-469; the head-only comparison of
  * example/da3_small_correctness.rs:278-322): the DPT head alone on caller-supplied hook tokens. tokens[0..3]: the four hooks'
  * `DinoIntermediate::patches`, each [B, tokens_per_image, din] fp32 in the memory kind `in_kind`; din = embed_dim (mono head) or

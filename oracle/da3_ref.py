@@ -401,6 +401,19 @@ def camera_encode(extrinsics: Tensor, intrinsics: Tensor, W, cfg: DepthAnything3
     return x.mean(1)
 
 
+def infer_raw(x: Tensor, W, cfg: DepthAnything3Config, q=identity) -> Tensor:
+    """DepthAnything3::infer_raw (mod.rs:364-380): the dual head's `depth_logits` [B, 2, H, W] (output_conv2's result, dpt.rs:271,
+    337-354), the mono head's `forward_raw` result [B, 1, H, W] (activation applied, dpt.rs:700)."""
+    ref_config.check_da3(cfg)
+    H, Wd = x.shape[2:]
+    if cfg.dual_head:
+        hooks, _ = backbone_hooks_ext(x, W, cfg, q)
+        dbg = {}
+        dual_head_forward(hooks, H, Wd, W, cfg, q, dbg)
+        return dbg["main_logits"]
+    return head_forward_raw(backbone_hooks(x, W, cfg, q), H, Wd, W, cfg, q)
+
+
 def infer_from_tokens(patches: List[Tensor], W, cfg: DepthAnything3Config, height: int, width: int, q=identity, debug: bool = False):
     """DepthAnything3::infer_from_tokens (mod.rs:389-469): the head on caller-supplied hook tokens [B, T, din]; rows before
     `patch_start` are dropped (0 when T is the patch count, else `patch_token_start` = 1, mod.rs:419-424); no camera prediction."""

@@ -481,6 +481,35 @@ def test_depth_anything3_infer_from_tokens(diag, dev, variant, precision, B, lea
     assert len(diag.RESULTS) - start >= 4
 
 
+@pytest.mark.parametrize("variant,precision,host", [("tiny", 1, False), ("tiny_dual", 1, True), ("tiny_dual", 4, False), ("tiny_dual", 0, False)])
+def test_depth_anything3_infer_raw(dev, variant, precision, host):
+    """`DepthAnything3::infer_raw` (mod.rs:364-380): the dual head's main logits before the activations, the mono head's forward_raw
+    result; against the oracle, and consistent with `infer` of the same model (depth = exp(logit 0), confidence = exp(logit 1) + 1)."""
+    import torch
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from oracle import da3_ref as D3, depth_pro_ref as R
+    cfg = DepthAnything3Config.tiny_test() if variant == "tiny" else DepthAnything3Config.tiny_dual_test()
+    cfg.precision, cfg.max_batch = precision, 2
+    m = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
+    x = torch.randn(2, 3, 70, 70, generator=torch.Generator().manual_seed(5))
+    raw = m.infer_raw(x if host else x.cuda()).cpu()
+    with torch.no_grad():
+        want = D3.infer_raw(x, W, cfg)
+    assert raw.shape == want.shape == (2, cfg.output_dim, 70, 70)
+    tol = {0: 6e-2, 3: 1e-2}.get(precision, 2e-4)   # logits are O(1): absolute bounds
+    assert (raw - want).abs().max() < tol * max(1.0, float(want.abs().max()))
+    out = m.infer(x.cuda())
+    if cfg.dual_head:
+        assert torch.allclose(torch.exp(raw[:, 0]), out.depth.cpu(), rtol=2e-6, atol=0)
+        assert torch.allclose(torch.exp(raw[:, 1]) + 1.0, out.depth_confidence.cpu(), rtol=2e-6, atol=0)
+    else:
+        assert torch.equal(raw[:, 0], out.depth.cpu())
+    m.destroy()
+
+
 def test_infer_from_tokens_error_paths(dev):
     import torch
     from burn_depth_amd import _lib
