@@ -21,7 +21,7 @@ def main():
         fl = 4.0 * T * heads * N * N * 64
         print(f"T={T} N={N} heads={heads} prec={prec}: {ms.value:.4f} ms = {fl / ms.value / 1e9:.0f} TFLOP/s", flush=True)
         return
-    for (T, N, heads) in [(37, 577, 16), (296, 577, 16), (1, 1370, 16), (8, 1370, 16), (1, 5477, 16)]:
+    for (T, N, heads) in [(37, 577, 16), (296, 577, 16), (1, 1370, 6), (1, 1370, 16), (8, 1370, 16), (1, 2738, 16), (1, 5477, 16)]:
         fl = 4.0 * T * heads * N * N * 64
         row = []
         for name, prec, scale in [("bf16 fast", 0, 0.7), ("bf16 safe", 0, 4.0), ("f16", 3, 0.7)]:
