@@ -77,37 +77,20 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // to one half (PTERMS = 1: its rounding averages over the keys; tools/precision_study.py prices it) or as hi + lo as well
 // (PTERMS = 2: a third MFMA, P_lo.v_hi). A stage holds the four tiles (32 KB), two stages 64 KB: two workgroups per CU, so the
 // kernel is built for two waves per SIMD (256 registers) instead of four. Softmax, row sums and O stay fp32 as before.
-//
-// Key split inside the workgroup (KS = 4 for the one-plane types, 2 for split-half operands; launches of at most kKeySplitBlocks
-// workgroups over >= 1024 keys): a single image of a thousand-odd tokens gives fewer workgroups than the chip has CUs (DA3 `small`
-// at 518^2: 6 heads x 11 query blocks = 66), one wave per SIMD, and that wave runs its 22 key tiles' MFMAs and softmax one after the
-// other -- the launch is as long as that chain (16.5 us). With KS groups of four waves per workgroup, group g walks the g-th part of
-// the key tiles through its own two-stage ring for the SAME 128 queries, so every SIMD holds KS waves whose matrix and vector
-// work overlap; the fast body keeps no running maximum, so the partial (O, l) of the groups simply add (f16: after moving to a
-// common fixed offset), through the ring's LDS once the walks are done. Measured (profiles/r04_attention_key_split.txt): T = 1,
-// 1370 keys, 6 heads 16.8 -> 15.2 us stand-alone, 16.5 -> 10 us inside config 2's graph (2.016 -> 1.938 ms per frame); with more
-// workgroups than CUs the plain form is faster (8 images: 72 against 100 us), hence the launch-size rule -- which makes the LAST BITS
-// of a bf16 / f16 DA3 result depend on whether the launch was small (a different summation order of the same terms); Depth Pro's
-// 577-key sequences and the fp32 mode never take it. The rare safe pass runs un-split on group 0.
-template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1>
-__global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1>
+__global__ __launch_bounds__(256, is_split<T>::value ? 2 : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
                                                            int S, int n_tokens, int heads, int D, int kpad, int qblocks,
                                                            float out_fp8_inv, long v_plane) {
   constexpr bool SP = is_split<T>::value;
   constexpr int STAGE = SP ? 32768 : 16384;  // K tile 64x128B + V^T tile 64x128B (split-half: hi tiles, then the lo tiles 16 KB behind)
   constexpr int LO = 16384;                  // split-half: offset of a stage's lo tiles
   // one-plane types: static LDS (two stages | redo flag); split-half: 64 KB + flag as dynamic LDS (above the static limit)
-  constexpr bool DYN = SP || KS > 1;
-  static_assert(KS == 1 || (!FP8OUT && FAST && KS * 2 * STAGE <= 131072), "the key split is built for the fast body; the rings must fit the LDS");
-  __shared__ __attribute__((aligned(16))) char smem_static[DYN ? 16 : 2 * STAGE + 16];
+  __shared__ __attribute__((aligned(16))) char smem_static[SP ? 16 : 2 * STAGE + 16];
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  char* const smem = DYN ? smem_dyn : smem_static;
+  char* const smem = SP ? smem_dyn : smem_static;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = KS > 1 ? (wave_all & 3) : wave_all;  // the query wave: 32 queries
-  const int grp = KS > 1 ? (wave_all >> 2) : 0;         // the key group (own ring)
-  char* const ring = smem + grp * (2 * STAGE);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int id;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -155,7 +138,7 @@ __global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attentio
   const int vvoff = r0 * kpad * (int)sizeof(T) + lc0 * 16;
   const int NT = (n_tokens + 63) / 64;
   auto issue = [&](int t) __attribute__((always_inline)) {
-    __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(ring + (t & 1) * STAGE + wave * 1024);
+    __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(smem + (t & 1) * STAGE + wave * 1024);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, sb + i * 4096, 16, kvoff, (t * 64 + i * 32) * (int)krow_bytes, 0, 0);
@@ -199,7 +182,7 @@ __global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attentio
   };
   // S^T[sub] = K[sub] . Q^T (log2 units: q is pre-scaled); register r of lane half h holds local key (r&7) + 8h + 16(r>>3)
   auto scores_sub = [&](int t, int sub, f32x16_t& st) __attribute__((always_inline)) {
-    const char* sb = ring + (t & 1) * STAGE;
+    const char* sb = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
@@ -252,7 +235,7 @@ __global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attentio
   };
   // O^T[dt] += V^T[dt][keys of sub] . P^T[sub]: k-step s2 holds local keys 16 s2 .. 16 s2 + 15 of the 32-key block
   auto pv_sub = [&](int t, int sub, const i32x4_t (&pf)[2], const i32x4_t (&pfl)[2], int nsteps) __attribute__((always_inline)) {
-    const char* sb = ring + (t & 1) * STAGE;
+    const char* sb = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       if (s2 < nsteps) {
@@ -327,59 +310,24 @@ __global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attentio
       for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     m_run = SAFE ? -INFINITY : 0.f;  // safe: alpha = 2^-inf = 0 multiplies zeros at the first tile
     l_run = 0.f;
-    if constexpr (KS == 1) {
-      issue(0);
-      top(0);
-      if (active) {
-        if (NFULL == 0) tile(0, safe_c, std::true_type(), check_t());
-        else tile(0, safe_c, std::false_type(), check_t());
-      }
-      for (int t = 1; t < NFULL; ++t) {
-        top(t);
-        if (active) tile(t, safe_c, std::false_type(), std::false_type());
-      }
-      if (last_partial && NT > 1) {
-        top(NT - 1);
-        if (active) tile(NT - 1, safe_c, std::true_type(), std::false_type());
-      }
-    } else {
-      // this group's tiles [tb, te): a quarter of the keys in the fast pass; the safe pass runs on group 0 alone. Every wave of
-      // the workgroup meets the same `per` barriers (a group with fewer tiles idles through the rest).
-      const int per = SAFE ? NT : (NT + KS - 1) / KS;
-      const int tb = grp * per < NT ? grp * per : NT;
-      const int te = SAFE ? (grp == 0 ? NT : 0) : (tb + per < NT ? tb + per : NT);
-      const int n = te - tb;
-      const int nfull = (last_partial && te == NT) ? n - 1 : n;  // this group's tiles without masked keys
-      auto top_g = [&](int t) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < te) issue(t + 1);
-      };
-      if (n > 0) {
-        issue(tb);
-        top_g(tb);
-        if (active) {
-          if (nfull == 0) tile(tb, safe_c, std::true_type(), check_t());
-          else tile(tb, safe_c, std::false_type(), check_t());
-        }
-        for (int t = tb + 1; t < tb + nfull; ++t) {
-          top_g(t);
-          if (active) tile(t, safe_c, std::false_type(), std::false_type());
-        }
-        if (nfull < n && n > 1) {
-          top_g(te - 1);
-          if (active) tile(te - 1, safe_c, std::true_type(), std::false_type());
-        }
-      }
-      for (int i = n; i < per; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
+    issue(0);
+    top(0);
+    if (active) {
+      if (NFULL == 0) tile(0, safe_c, std::true_type(), check_t());
+      else tile(0, safe_c, std::false_type(), check_t());
+    }
+    for (int t = 1; t < NFULL; ++t) {
+      top(t);
+      if (active) tile(t, safe_c, std::false_type(), std::false_type());
+    }
+    if (last_partial && NT > 1) {
+      top(NT - 1);
+      if (active) tile(NT - 1, safe_c, std::true_type(), std::false_type());
     }
   };
   bool use_safe = !FAST;
   if constexpr (FAST) {
-    int* redo = (int*)(smem + KS * 2 * STAGE);  // behind the stages in either LDS form
+    int* redo = (int*)(smem + 2 * STAGE);  // behind the two stages in either LDS form
     if (tid == 0) *redo = 0;
     pass(std::false_type());
     if (active) bad = bad || __any(!(l_run < kFastSumMax));  // a tile row sum >= 2^100, inf or NaN shows in the total
@@ -389,45 +337,6 @@ __global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attentio
     if (use_safe) __syncthreads();        // everyone has read the flag and left the last tiles before stage 0 is reloaded
   }
   if (use_safe) pass(std::true_type());
-  if constexpr (KS > 1) {
-    if (use_safe) {
-      if (grp > 0) return;  // the safe pass ran on group 0
-    } else {
-      // the groups' partial sums meet in the (now idle) ring: 34 floats per lane and wave, lane-contiguous
-      float* const xch = (float*)smem;
-      __syncthreads();  // every group has left its last tile
-      if (grp > 0 && active) {
-        float* px = xch + ((grp - 1) * 4 + wave) * (34 * 64) + lane;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) px[(dt * 16 + r) * 64] = o[dt][r];
-        px[32 * 64] = l_run;
-        px[33 * 64] = m_run;
-      }
-      __syncthreads();
-      if (grp > 0) return;
-      if (active) {
-#pragma unroll
-        for (int g = 1; g < KS; ++g) {
-          const float* px = xch + ((g - 1) * 4 + wave) * (34 * 64) + lane;
-          float a = 1.f, b = 1.f;
-          if constexpr (kOffsetFast) {  // f16: each group ran on its own fixed offset (the row maximum of its first tile)
-            const float mg = px[33 * 64];
-            const float mn = fmaxf(m_run, mg);
-            a = __builtin_amdgcn_exp2f(m_run - mn);
-            b = __builtin_amdgcn_exp2f(mg - mn);
-            m_run = mn;
-          }
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] = kOffsetFast ? o[dt][r] * a + px[(dt * 16 + r) * 64] * b : o[dt][r] + px[(dt * 16 + r) * 64];
-          l_run = kOffsetFast ? l_run * a + px[32 * 64] * b : l_run + px[32 * 64];
-        }
-      }
-    }
-  }
 
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -472,19 +381,6 @@ static int attn_pterms() {
   return v;
 }
 
-// launches that take the key-split workgroups: sequences long enough for four groups of >= 4 tiles, and few enough workgroups that
-// CUs would idle (measured break-even between 176 and 352 workgroups)
-static int kKeySplitMin = 1024, kKeySplitBlocks = 192;
-// MD_ATTN_KEYSPLIT=0 turns the key split off (DEBUG-ONLY A/B knob, read once per process)
-static bool key_split_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MD_ATTN_KEYSPLIT");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
-
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
                      int kpad, int prec, hipStream_t s, float out_fp8_inv, long v_plane) {
   if (prec != MD_PREC_BF16 && prec != MD_PREC_F16 && prec != MD_PREC_F16X2) MD_FAIL(MD_ERR_UNSUPPORTED, "fused attention takes bf16, f16 or split-half operands (precision %d)", prec);
@@ -498,8 +394,8 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   const dim3 grid((unsigned)blocks), block(256);
   if (prec == MD_PREC_F16X2) {
     if (out_fp8_inv > 0.f || v_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "attention: split-half operands need the V^T plane offset and write split-half rows");
-    auto go = [&](auto kern, auto ks_c) -> int {
-      constexpr int KS = decltype(ks_c)::value, smem = KS * 2 * 32768 + 16;
+    constexpr int smem = 2 * 32768 + 16;
+    auto go = [&](auto kern) -> int {
       // the attribute is per DEVICE: it is set once per (kernel, device ordinal), not once per process
       static bool attr_set[64] = {};
       int ordinal = 0;
@@ -508,40 +404,15 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
         MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         if (ordinal >= 0 && ordinal < 64) attr_set[ordinal] = true;
       }
-      hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, (const f16s_t*)qk, (const f16s_t*)vT, (f16s_t*)out, S, n_tokens, heads, D, kpad, qblocks, 0.f, v_plane);
+      hipLaunchKernelGGL(kern, grid, block, smem, s, (const f16s_t*)qk, (const f16s_t*)vT, (f16s_t*)out, S, n_tokens, heads, D, kpad, qblocks, 0.f, v_plane);
       return MD_OK;
     };
-    typedef std::integral_constant<int, 1> ks1;
-    typedef std::integral_constant<int, 2> ks2;
-    const bool split = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && key_split_enabled();
-    if (attn_pterms() == 1) {
-      if (split) MD_TRY(go(attention_kernel<f16s_t, false, true, 1, 2>, ks2()));
-      else MD_TRY(go(attention_kernel<f16s_t, false, true, 1>, ks1()));
-    } else {
-      if (split) MD_TRY(go(attention_kernel<f16s_t, false, true, 2, 2>, ks2()));
-      else MD_TRY(go(attention_kernel<f16s_t, false, true, 2>, ks1()));
-    }
+    if (attn_pterms() == 1) MD_TRY(go(attention_kernel<f16s_t, false, true, 1>));
+    else MD_TRY(go(attention_kernel<f16s_t, false, true, 2>));
   } else if (out_fp8_inv > 0.f) {
     if (prec != MD_PREC_BF16) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: e4m3 output rows are built for bf16 operands");
     hipLaunchKernelGGL((attention_kernel<bf16_t, true, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
-  } else if (n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && key_split_enabled()) {
-    // key split inside the workgroup (see the kernel's header): chosen by the sequence length alone
-    constexpr int KS = 4, smem = KS * 2 * 16384 + 16;
-    auto go = [&](auto kern, auto tag) -> int {
-      typedef decltype(tag) TT;
-      static bool attr_set[64] = {};
-      int ordinal = 0;
-      MD_HIP(hipGetDevice(&ordinal));
-      if (ordinal < 0 || ordinal >= 64 || !attr_set[ordinal]) {
-        MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        if (ordinal >= 0 && ordinal < 64) attr_set[ordinal] = true;
-      }
-      hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, (const TT*)qk, (const TT*)vT, (TT*)out, S, n_tokens, heads, D, kpad, qblocks, 0.f, 0L);
-      return MD_OK;
-    };
-    if (prec == MD_PREC_F16) MD_TRY(go(attention_kernel<f16_t, false, true, 1, KS>, f16_t()));
-    else MD_TRY(go(attention_kernel<bf16_t, false, true, 1, KS>, bf16_t()));
   } else if (prec == MD_PREC_F16) {
     hipLaunchKernelGGL((attention_kernel<f16_t, false, true>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);

@@ -269,8 +269,7 @@ def check_attention(dev):
     g = torch.Generator().manual_seed(4)
     for prec, rnd, tol_max, tol_mean in [(0, bf, 8e-3, 2.5e-3), (3, h16, 1e-3, 4e-4)]:
         pn = PNAME[prec]
-        # 1024 <= N < 4096 run the key-split workgroups (four groups of key tiles per 128 queries, attention.hip): exact multiples
-        # of the tile, a one-key last tile, groups of unequal length, the upper end of the range
+        # longer sequences: exact multiples of the tile, a one-key last tile, 64 tiles
         for (T, N, heads) in [(2, 65, 4), (3, 577, 2), (1, 577, 16), (2, 64, 1), (1, 130, 3), (1, 1370, 2), (2, 1024, 2), (1, 1025, 1),
                               (1, 2000, 3), (1, 4095, 1), (1, 4096, 1)]:
             qkv = torch.randn(T, N, 3 * heads * 64, generator=g)
@@ -310,9 +309,8 @@ def check_attention(dev):
         spike("first tile", first_tile, [5, 6, 300])
         spike("all low", all_low, [9, 10, 576])
 
-        # the same hand-overs under the key split (N = 1370: 22 tiles, groups of 6 / 6 / 6 / 4): a range failure in the FIRST tile
-        # of group 1 (tokens 384..447), a row sum overflowing inside group 3, and the all-low row -- each must send the whole
-        # workgroup to the un-split running-maximum pass
+        # the same hand-overs on a 1370-key sequence (22 tiles): a range failure deep inside the walk, a row sum overflowing near
+        # its end, and the all-low row
         def first_tile_group1(qkv):
             qkv[0, 390, 64:128] = qkv[0, 5, :64] * 7.0
             qkv[0, 1200, 64:128] = qkv[0, 5, :64] * 12.0
@@ -322,9 +320,9 @@ def check_attention(dev):
             qkv[0, 1330, 64:128] = qkv[0, 3, :64] * 9.0
             qkv[0, 40, :64] *= 8.0
 
-        spike("key-split first tile of group 1", first_tile_group1, [5, 6, 300, 1369], N=1370)
-        spike("key-split late keys in group 3", late_keys_group3, [3, 40, 1000], N=1370)
-        spike("key-split all low", all_low, [9, 10, 1369], N=1370)
+        spike("1370 keys, out-of-range key at 390", first_tile_group1, [5, 6, 300, 1369], N=1370)
+        spike("1370 keys, late keys", late_keys_group3, [3, 40, 1000], N=1370)
+        spike("1370 keys, all low", all_low, [9, 10, 1369], N=1370)
     for (T, N, heads) in [(2, 65, 4), (3, 577, 2), (1, 130, 3), (1, 1370, 2)]:
         qkv = torch.randn(T, N, 3 * heads * 64, generator=g)
         qkv[..., :heads * 64] *= 2.0
@@ -414,7 +412,6 @@ def check_split_ops(dev):
     x = torch.randn(300, 256, generator=g) * 1e-3
     w = h16(torch.randn(128, 256, generator=g))
     record("linear f16x2 small activations (1e-3)", rel_err(ops.linear(dev, x.cuda(), w.cuda(), None, 0, P), F.linear(x.double(), w.double()).float()), 3e-4)
-    # (1, 1370, 2), (1, 1025, 1), (1, 2000, 3): small launches over >= 1024 keys run the key-split workgroups (two groups, attention.hip)
     for (T, N, heads) in [(2, 65, 4), (3, 577, 2), (1, 577, 16), (2, 64, 1), (1, 130, 3), (1, 1370, 2), (1, 1025, 1), (1, 2000, 3)]:
         qkv = torch.randn(T, N, 3 * heads * 64, generator=g)
         qkv[..., :heads * 64] *= 2.0
@@ -428,12 +425,12 @@ def check_split_ops(dev):
     qkv[0, 570, 64:128] = qkv[0, 3, :64] * 9.0
     qkv[0, 40, :64] *= 8.0
     record("attention f16x2 late keys max", rel_err(ops.attention(dev, qkv.cuda(), 1, P), attn_ref(qkv, 1, R.identity)), 5e-4)
-    # the same under the key split: the overflow sits in the second group's keys
+    # the same on a 1370-key sequence
     qkv = torch.randn(1, 1370, 3 * 64, generator=g)
     qkv[0, 1200, 64:128] = qkv[0, 3, :64] * 6.0
     qkv[0, 1330, 64:128] = qkv[0, 3, :64] * 9.0
     qkv[0, 40, :64] *= 8.0
-    record("attention f16x2 key-split late keys max", rel_err(ops.attention(dev, qkv.cuda(), 1, P), attn_ref(qkv, 1, R.identity)), 5e-4)
+    record("attention f16x2 1370 keys, late keys max", rel_err(ops.attention(dev, qkv.cuda(), 1, P), attn_ref(qkv, 1, R.identity)), 5e-4)
 
 
 # depth tolerances (max-rel, focal rel, mean-rel) and tap tolerance per precision mode, against the fp32 oracle.
