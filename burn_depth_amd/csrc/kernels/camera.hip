@@ -10,6 +10,7 @@
 // of the engine: the result is one token of the fp32 residual stream.
 #include <hip/hip_runtime.h>
 
+#include "camera_math.h"
 #include "ops.h"
 
 namespace md {
@@ -63,7 +64,7 @@ __device__ void pose_encode(const float* __restrict__ e, const float* __restrict
   out[8] = approx_atan_positive(half_w / k[0]) * 2.0f;  // fov_w from fx
 }
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RESID_LS = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RESID_LS = 2, ACT_RELU = 3 };
 
 // y[v][n] = act(bias[n] + sum_k x[v][k] * w[n][k]) for v < V. ACT_RESID_LS: y[v][n] += gamma[n] * (...)   (y is the residual stream)
 template <int ACT>
@@ -100,6 +101,7 @@ __device__ void wg_linear(const float* __restrict__ x, int ldx, const float* __r
         if (lane == 0) {
           t += bias[n];
           if (ACT == ACT_GELU) t = gelu_erf(t);
+          if (ACT == ACT_RELU) t = fmaxf(t, 0.f);
           if (ACT == ACT_RESID_LS) t = y[(long)v * ldy + n] + gamma[n] * t;
           y[(long)v * ldy + n] = t;
         }
@@ -201,7 +203,49 @@ __global__ __launch_bounds__(1024) void camera_encoder_kernel(const float* __res
   }
 }
 
+// ---- camera DECODER (`CameraDecoder::forward`, camera.rs:143-199): two din x din linears + ReLU on the [B, din] camera feature, then
+//      three small heads and the pose -> matrices tail. A din x din fp32 weight is 2.4 MB (din = 768): one workgroup streams it in
+//      ~20 us, 48 workgroups of 16 output columns each in ~2 -- so the two wide layers are one multi-workgroup launch each (every
+//      wave owns output columns, lanes stride K, the B rows ride in registers) and the heads + tail are one single-workgroup launch.
+template <int ACT>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int ldy, int N, int K, int B,
+                                                          int cols_per_wg) {
+  const int n0 = blockIdx.x * cols_per_wg;
+  const int n1 = n0 + cols_per_wg < N ? n0 + cols_per_wg : N;
+  for (int b0 = 0; b0 < B; b0 += kMaxViews) {
+    const int V = B - b0 < kMaxViews ? B - b0 : kMaxViews;
+    wg_linear<ACT>(x + (long)b0 * ldx, ldx, w + (long)n0 * K, bias + n0, y + (long)b0 * ldy + n0, ldy, n1 - n0, K, V, nullptr);
+  }
+}
+
+__global__ __launch_bounds__(256) void camera_heads_kernel(const float* __restrict__ h, int din, const float* __restrict__ wt,
+                                                           const float* __restrict__ bt, const float* __restrict__ wq, const float* __restrict__ bq,
+                                                           const float* __restrict__ wf, const float* __restrict__ bf, int H, int W,
+                                                           float* __restrict__ pose, float* __restrict__ extr, float* __restrict__ intr) {
+  // pose = (t3 | quat4 | relu(fov2)) of image blockIdx.x (camera.rs:171-181), then pose_encoding_to_extri_intri (camera.rs:281-358)
+  const int b = blockIdx.x;
+  const float* hb = h + (long)b * din;
+  float* pb = pose + b * 9;
+  wg_linear<ACT_NONE>(hb, din, wt, bt, pb, 9, 3, din, 1, nullptr);
+  wg_linear<ACT_NONE>(hb, din, wq, bq, pb + 3, 9, 4, din, 1, nullptr);
+  wg_linear<ACT_RELU>(hb, din, wf, bf, pb + 7, 9, 2, din, 1, nullptr);
+  __syncthreads();
+  if (threadIdx.x == 0 && (extr || intr)) pose_to_camera_one(pb, H, W, extr ? extr + b * 12 : nullptr, intr ? intr + b * 9 : nullptr);
+}
+
 }  // namespace
+
+int launch_camera_decoder(const float* cam, int B, int din, const CamDecW& w, int H, int W, float* h1, float* h2, float* pose, float* extr,
+                          float* intr, hipStream_t s) {
+  if (din % 4 != 0 || B < 1) MD_FAIL(MD_ERR_INVALID_ARG, "camera decoder: width %d, batch %d", din, B);
+  const int cols = 16, grid = (din + cols - 1) / cols;
+  hipLaunchKernelGGL(linear_rows_kernel<ACT_RELU>, dim3(grid), dim3(256), 0, s, cam, din, w.w1, w.b1, h1, din, din, din, B, cols);
+  hipLaunchKernelGGL(linear_rows_kernel<ACT_RELU>, dim3(grid), dim3(256), 0, s, (const float*)h1, din, w.w2, w.b2, h2, din, din, din, B, cols);
+  hipLaunchKernelGGL(camera_heads_kernel, dim3(B), dim3(256), 0, s, (const float*)h2, din, w.wt, w.bt, w.wq, w.bq, w.wf, w.bf, H, W, pose, extr, intr);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
 
 size_t camera_encoder_scratch_floats(int B, int V, int D) { return (size_t)B * V * (12 + 9 * (size_t)D); }
 

@@ -110,6 +110,13 @@ struct CamEncW {
   } blk[kMaxDepth];
   int depth;
 };
+// camera DECODER (camera.rs:143-199, 281-358): cam [B, din] fp32 -> pose [B, 9] (+ extrinsics [B, 12], intrinsics [B, 9], either may be
+// null); h1 / h2 = [B, din] scratch. Three launches: two multi-workgroup din x din linears (+ReLU), one heads + tail kernel.
+struct CamDecW {
+  const float *w1, *b1, *w2, *b2, *wt, *bt, *wq, *bq, *wf, *bf;
+};
+int launch_camera_decoder(const float* cam, int B, int din, const CamDecW& w, int H, int W, float* h1, float* h2, float* pose, float* extr,
+                          float* intr, hipStream_t s);
 size_t camera_encoder_scratch_floats(int B, int V, int D);
 // extr [B, V, 3, 4] world-to-camera, intr [B, V, 3, 3] (device) -> out [B, D] (device); one workgroup per image
 int launch_camera_encoder(const float* extr, const float* intr, int B, int V, int D, int heads, int H, int W, float eps_tok, float eps_blk,

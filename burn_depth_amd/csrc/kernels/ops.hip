@@ -2,6 +2,7 @@
 // where the layout allows it, blocks are 256 threads (4 waves of 64), grids are capped and
 // grid-strided (MI355X: 256 CUs x 8 blocks).
 #include "ops.h"
+#include "camera_math.h"
 #include "elem.h"
 
 namespace md {
@@ -1040,28 +1041,9 @@ int launch_hook_cat_ln(const float* x_local, const float* x, long rows, int S, i
 
 __global__ void pose_to_camera_kernel(const float* __restrict__ pose, int B, int H, int W, float* __restrict__ extr,
                                       float* __restrict__ intr) {
-#pragma clang fp contract(off)
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const float* p = pose + b * 9;
-  const float tx = p[0], ty = p[1], tz = p[2], x = p[3], y = p[4], z = p[5], w = p[6], fh = p[7], fw = p[8];
-  // quaternion_to_matrix (camera.rs:360-416), no normalisation, as in the reference
-  float R[3][3];
-  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - w * z); R[0][2] = 2.f * (x * z + w * y);
-  R[1][0] = 2.f * (x * y + w * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - w * x);
-  R[2][0] = 2.f * (x * z - w * y); R[2][1] = 2.f * (y * z + w * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
-  float* e = extr + b * 12;
-  for (int i = 0; i < 3; ++i) {  // [R^T | -R^T t]
-    const float r0 = R[0][i], r1 = R[1][i], r2 = R[2][i];
-    e[i * 4 + 0] = r0; e[i * 4 + 1] = r1; e[i * 4 + 2] = r2;
-    e[i * 4 + 3] = -(r0 * tx + r1 * ty + r2 * tz);
-  }
-  const float th = sinf(fh * 0.5f) / cosf(fh * 0.5f), tw = sinf(fw * 0.5f) / cosf(fw * 0.5f);
-  const float hh = (float)H / 2.0f, wh = (float)W / 2.0f;
-  float* k = intr + b * 9;
-  k[0] = wh / tw; k[1] = 0.f; k[2] = wh;
-  k[3] = 0.f; k[4] = hh / th; k[5] = hh;
-  k[6] = 0.f; k[7] = 0.f; k[8] = 1.f;
+  pose_to_camera_one(pose + b * 9, H, W, extr ? extr + b * 12 : nullptr, intr ? intr + b * 9 : nullptr);
 }
 
 int launch_pose_to_camera(const float* pose, int B, int H, int W, float* extrinsics, float* intrinsics, hipStream_t s) {

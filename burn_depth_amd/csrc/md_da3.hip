@@ -72,13 +72,13 @@ struct md_model_s::Da3State {
   // `infer_from_tokens`: caller-supplied hook tokens staged as fp32 rows [max_batch * SS + 64, din] (grow-only, zero-filled once)
   float* tok_stage = nullptr;
   size_t tok_stage_cap = 0;
-  // The dual head's three independent tails -- main pyramid (depth + confidence), aux pyramid (rays + confidence) and the
-  // camera decoder -- run as CONCURRENT branches: the aux branch and the camera decoder on side streams that fork from / join
-  // the caller's stream through events (inside a captured graph they become parallel branches). Config 2 is launch-bound
-  // (181 launches of ~14 us in 2.7 ms): two launch chains side by side hide each other's gaps and fill CUs the small head
-  // convolutions leave idle. The aux pyramid has its own scratch maps.
-  hipStream_t s_aux = nullptr, s_cam = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_cam_fork = nullptr, ev_aux = nullptr, ev_cam = nullptr;
+  // The dual head's aux pyramid (rays + confidence) runs as a CONCURRENT branch beside the main pyramid (depth + confidence): on a
+  // side stream that forks from / joins the caller's stream through events (inside a captured graph it becomes a parallel branch),
+  // with its own scratch maps. Config 2 is launch-bound: two launch chains side by side hide part of each other's gaps (measured:
+  // 1.76 ms serial, 1.68 ms concurrent, without the camera decoder). The camera decoder (a 40-us chain of six tiny launches) stays
+  // on the caller's stream: a second fork / join cost 0.26 ms more than it hid (round 4, profiles/r04_cfg2_branches.txt).
+  hipStream_t s_aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_aux = nullptr;
   void *t2 = nullptr, *x2 = nullptr, *xr2 = nullptr, *y2 = nullptr, *up2 = nullptr, *o2 = nullptr;
   std::vector<float> main_bias, aux_bias;             // output_conv2.conv2.bias, output_conv2_aux.<last>.project.bias
   // ---- MD_PREC_FP8: the four ViT linear layers on e4m3 operands (weights per output channel, static activation scales) ----
@@ -618,10 +618,9 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
   if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
   (void)hipMemset(m->zero_page, 0, 4096);
   if (cfg.dual_head) {
-    if (hipStreamCreateWithFlags(&d->s_aux, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_cam, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_cam_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d->ev_aux, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_cam, hipEventDisableTiming) != hipSuccess) {
-      set_error("stream / event creation for the dual head's concurrent branches failed");
+    if (hipStreamCreateWithFlags(&d->s_aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_aux, hipEventDisableTiming) != hipSuccess) {
+      set_error("stream / event creation for the dual head's concurrent branch failed");
       return fail(MD_ERR_HIP);
     }
   }
@@ -647,8 +646,7 @@ void da3_destroy_state(md_model_t m) {
   for (auto& kv : m->da3->shapes) da3_free_tables(kv.second);
   m->da3->shapes.clear();
   if (m->da3->s_aux) (void)hipStreamDestroy(m->da3->s_aux);
-  if (m->da3->s_cam) (void)hipStreamDestroy(m->da3->s_cam);
-  for (hipEvent_t e : {m->da3->ev_fork, m->da3->ev_cam_fork, m->da3->ev_aux, m->da3->ev_cam})
+  for (hipEvent_t e : {m->da3->ev_fork, m->da3->ev_aux})
     if (e) (void)hipEventDestroy(e);
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
   if (m->da3->cam_enc_ws) (void)hipFree(m->da3->cam_enc_ws);
@@ -1084,12 +1082,12 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   const bool want_cam = c.dual_head && !from_tokens && (outp.pose_encoding || outp.extrinsics || outp.intrinsics);
   const bool par = c.dual_head && !m->taps_enabled && d->s_aux != nullptr;
   Run ra{m, par ? d->s_aux : st, B};   // aux branch
-  Run rc{m, par ? d->s_cam : st, B};   // camera decoder
+  Run rc{m, st, B};                    // camera decoder: on the caller's stream (round 4: its own side stream cost more in fork / join than
+                                       // the 40 us chain it hid: config 2 1.97 -> 1.70 ms, profiles/r04_cfg2_branches.txt)
   Bufs aux_bufs = par ? Bufs{d->t2, d->x2, d->xr2, d->y2, d->up2, d->o2} : main_bufs;
-  if (par && (want_aux || want_cam)) {
+  if (par && want_aux) {
     MD_HIP(hipEventRecord(d->ev_fork, st));
-    if (want_aux) MD_HIP(hipStreamWaitEvent(d->s_aux, d->ev_fork, 0));
-    if (want_cam) MD_HIP(hipStreamWaitEvent(d->s_cam, d->ev_fork, 0));
+    MD_HIP(hipStreamWaitEvent(d->s_aux, d->ev_fork, 0));
   }
   // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
   auto rcu = [&](Run& rr, Bufs& bf, const std::string& name, int hh, int ww, const void* x, const void* xr, const void* extra, void* out,
@@ -1217,31 +1215,25 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   }
   // ---- camera decoder (camera.rs:143-199) on the raw camera feature of the last hook, fp32 ----
   if (want_cam) {
-    auto lin = [&](const char* n, const float* in, int cout, int relu, float* out, int out_ld) -> int {
-      const std::string q = std::string("camera_decoder.") + n;
-      rc.begin("camera_decoder");
-      int s2 = launch_conv_direct(in, MD_PREC_F32, nullptr, B, 1, 1, din, Bi(q + ".weight"), Bi(q + ".bias"), cout, 1, 1, 0, relu, out, rc.st, out_ld);
-      rc.end();
-      return s2;
-    };
-    MD_TRY(lin("backbone_1", d->cam_raw, din, 1, d->cam_h1, 0));
-    MD_TRY(lin("backbone_2", d->cam_h1, din, 1, d->cam_h2, 0));
-    // pose = (t3 | quat4 | relu(fov2)): the three heads write their columns of the [B, 9] rows directly (device outputs: straight
-    // into the caller's buffers -- no staging copies on this branch)
+    // pose = (t3 | quat4 | relu(fov2)) rows [B, 9]; device outputs are written straight into the caller's buffers
     const bool dev_out = out_kind == MD_MEM_DEVICE;
     float* pose = (dev_out && outp.pose_encoding) ? outp.pose_encoding : d->pose;
-    MD_TRY(lin("fc_t", d->cam_h2, 3, 0, pose, 9));
-    MD_TRY(lin("fc_qvec", d->cam_h2, 4, 0, pose + 3, 9));
-    MD_TRY(lin("fc_fov", d->cam_h2, 2, 1, pose + 7, 9));
     float* extr = (dev_out && outp.extrinsics) ? outp.extrinsics : d->extr;
     float* intr = (dev_out && outp.intrinsics) ? outp.intrinsics : d->intr;
-    if (outp.extrinsics || outp.intrinsics) MD_TRY(launch_pose_to_camera(pose, B, H, W, extr, intr, rc.st));
+    CamDecW w;
+    auto CW = [&](const char* n) { return Bi(std::string("camera_decoder.") + n); };
+    w.w1 = CW("backbone_1.weight"); w.b1 = CW("backbone_1.bias"); w.w2 = CW("backbone_2.weight"); w.b2 = CW("backbone_2.bias");
+    w.wt = CW("fc_t.weight"); w.bt = CW("fc_t.bias"); w.wq = CW("fc_qvec.weight"); w.bq = CW("fc_qvec.bias");
+    w.wf = CW("fc_fov.weight"); w.bf = CW("fc_fov.bias");
+    rc.begin("camera_decoder");
+    MD_TRY(launch_camera_decoder(d->cam_raw, B, din, w, H, W, d->cam_h1, d->cam_h2, pose, outp.extrinsics ? extr : nullptr,
+                                 outp.intrinsics ? intr : nullptr, rc.st));
+    rc.end();
     if (!dev_out) {
       if (outp.pose_encoding) MD_HIP(hipMemcpyAsync(outp.pose_encoding, pose, (size_t)B * 9 * 4, hipMemcpyDeviceToHost, rc.st));
       if (outp.extrinsics) MD_HIP(hipMemcpyAsync(outp.extrinsics, extr, (size_t)B * 12 * 4, hipMemcpyDeviceToHost, rc.st));
       if (outp.intrinsics) MD_HIP(hipMemcpyAsync(outp.intrinsics, intr, (size_t)B * 9 * 4, hipMemcpyDeviceToHost, rc.st));
     }
-    if (par) MD_HIP(hipEventRecord(d->ev_cam, d->s_cam));
   }
   // ---- main branch: output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + activation ----
   MD_TRY(pyramid(r, main_bufs, ""));
@@ -1283,7 +1275,6 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   }
   // ---- join the side branches ----
   if (par && want_aux) MD_HIP(hipStreamWaitEvent(st, d->ev_aux, 0));
-  if (par && want_cam) MD_HIP(hipStreamWaitEvent(st, d->ev_cam, 0));
   if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
