@@ -91,7 +91,7 @@ struct GemmParams {
   const void* res1 = nullptr;   // optional residual inputs, element type T
   const void* res2 = nullptr;
   long ldr = 0;
-  int res_mod = 0;              // > 0: residual row = m % res_mod (a per-image table shared by the batch)
+  int res_mod = 0;              // > 0: res1's row = m % res_mod (a per-image table shared by the batch, or an input two weight groups share); res2 is never wrapped
   // EPI_PATCH_EMBED / EPI_QKV
   int seq_stride = 0;           // rows per sequence in the token buffers (tokens padded to x4)
   int seq_patches = 0;          // patches per sequence (EPI_PATCH_EMBED input rows per sequence)

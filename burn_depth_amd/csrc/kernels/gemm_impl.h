@@ -207,7 +207,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
       if (bias) v += *(const f32x4_t*)(bias + n);
       const long rm = p.res_mod > 0 ? (long)(m - fdiv(m, p.fd_res_mod) * p.res_mod) : (long)m;
       if (p.res1) v += load4p<T>((const T*)p.res1 + rm * p.ldr + n, p.r_plane);
-      if (p.res2) v += load4p<T>((const T*)p.res2 + rm * p.ldr + n, p.r_plane);
+      if (p.res2) v += load4p<T>((const T*)p.res2 + (long)m * p.ldr + n, p.r_plane);  // res_mod wraps res1 only
       if (p.act == ACT_RELU) {
         v = relu4(v);
       } else if (p.act == ACT_GELU) {

@@ -72,14 +72,7 @@ struct md_model_s::Da3State {
   // `infer_from_tokens`: caller-supplied hook tokens staged as fp32 rows [max_batch * SS + 64, din] (grow-only, zero-filled once)
   float* tok_stage = nullptr;
   size_t tok_stage_cap = 0;
-  // The dual head's aux pyramid (rays + confidence) runs as a CONCURRENT branch beside the main pyramid (depth + confidence): on a
-  // side stream that forks from / joins the caller's stream through events (inside a captured graph it becomes a parallel branch),
-  // with its own scratch maps. Config 2 is launch-bound: two launch chains side by side hide part of each other's gaps (measured:
-  // 1.76 ms serial, 1.68 ms concurrent, without the camera decoder). The camera decoder (a 40-us chain of six tiny launches) stays
-  // on the caller's stream: a second fork / join cost 0.26 ms more than it hid (round 4, profiles/r04_cfg2_branches.txt).
-  hipStream_t s_aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_aux = nullptr;
-  void *t2 = nullptr, *x2 = nullptr, *xr2 = nullptr, *y2 = nullptr, *up2 = nullptr, *o2 = nullptr;
+  void *up2 = nullptr, *o2 = nullptr;
   std::vector<float> main_bias, aux_bias;             // output_conv2.conv2.bias, output_conv2_aux.<last>.project.bias
   // ---- MD_PREC_FP8: the four ViT linear layers on e4m3 operands (weights per output channel, static activation scales) ----
   bool fp8 = false;
@@ -268,17 +261,15 @@ static int da3_plan(md_model_s* m, bool dry, size_t* total_out) {
     DA3_TAKE(rnr[s], void*, (size_t)B * px[s] * cp(F) * esz);
   }
   const size_t big = (size_t)B * 64 * ph * pw * cp(F) * esz;  // 8ph x 8pw
-  DA3_TAKE(t, void*, big / 4);
-  DA3_TAKE(x, void*, big / 4);
-  DA3_TAKE(xr, void*, big / 4);
-  DA3_TAKE(y, void*, big / 4);
-  DA3_TAKE(up, void*, big);
-  DA3_TAKE(o, void*, big);
-  if (c.dual_head) {  // scratch maps of the concurrent aux pyramid
-    DA3_TAKE(t2, void*, big / 4);
-    DA3_TAKE(x2, void*, big / 4);
-    DA3_TAKE(xr2, void*, big / 4);
-    DA3_TAKE(y2, void*, big / 4);
+  // the dual head runs its two fusion pyramids in the same launches: every pyramid map holds 2B images (main | aux)
+  const size_t pg = c.dual_head ? 2 : 1;
+  DA3_TAKE(t, void*, pg * big / 4);
+  DA3_TAKE(x, void*, pg * big / 4);
+  DA3_TAKE(xr, void*, pg * big / 4);
+  DA3_TAKE(y, void*, pg * big / 4);
+  DA3_TAKE(up, void*, pg * big);
+  DA3_TAKE(o, void*, pg * big);
+  if (c.dual_head) {  // ping-pong maps of the aux neck (it runs beside the main tail, which reads `o`)
     DA3_TAKE(up2, void*, big);
     DA3_TAKE(o2, void*, big);
   }
@@ -617,13 +608,6 @@ int da3_create(md_device_t dev, const Da3Cfg& cfg, md_model_t* out) {
 
   if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
   (void)hipMemset(m->zero_page, 0, 4096);
-  if (cfg.dual_head) {
-    if (hipStreamCreateWithFlags(&d->s_aux, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_aux, hipEventDisableTiming) != hipSuccess) {
-      set_error("stream / event creation for the dual head's concurrent branch failed");
-      return fail(MD_ERR_HIP);
-    }
-  }
   // workspace for the configured size + its tables (PosEmbedCache, dpt.rs:784-833: built once per shape); other sizes get
   // theirs on their first infer call (da3_set_shape)
   {
@@ -645,9 +629,6 @@ void da3_destroy_state(md_model_t m) {
   if (!m || !m->da3) return;
   for (auto& kv : m->da3->shapes) da3_free_tables(kv.second);
   m->da3->shapes.clear();
-  if (m->da3->s_aux) (void)hipStreamDestroy(m->da3->s_aux);
-  for (hipEvent_t e : {m->da3->ev_fork, m->da3->ev_aux})
-    if (e) (void)hipEventDestroy(e);
   if (m->da3->depth_stage) (void)hipFree(m->da3->depth_stage);
   if (m->da3->cam_enc_ws) (void)hipFree(m->da3->cam_enc_ws);
   if (m->da3->tok_stage) (void)hipFree(m->da3->tok_stage);
@@ -1073,54 +1054,92 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       MD_TRY(r.tap_nhwc(("layer" + std::to_string(s + 1) + "_rn").c_str(), d->rn[s], F, sh[s], sw[s], Fp));
     }
   }
-  // ---- the head's tails. Dual head: main pyramid (depth, confidence), aux pyramid (rays, confidence) and the camera decoder
-  //      are independent of each other; they run as concurrent branches (side streams forked from / joined to `st` by events)
-  //      unless the debug taps are on (the taps copy maps on `st`). ----
+  // ---- the head's tails. Dual head: the main fusion pyramid (depth, confidence) and the aux fusion pyramid (rays, confidence) have
+  //      the same shapes and share their inputs (the layerN_rn maps): with the aux outputs wanted they run in the SAME launches as
+  //      two weight groups -- group 0 = main on images [0, B), group 1 = aux on images [B, 2B) of every pyramid map. A 64-feature
+  //      3x3 convolution costs ~11 us at 37^2 and ~14 us at 296^2 (launch floor + nine dependent k-tiles, not throughput), so the
+  //      second group is nearly free where a second chain of launches was not (round 4: 44 -> 22 pyramid launches; the side-stream
+  //      form overlapped only a third of the aux pyramid, profiles/r04_cfg2_branches.txt). ----
   struct Bufs { void *t, *x, *xr, *y, *up, *o; };
-  Bufs main_bufs{d->t, d->x, d->xr, d->y, d->up, d->o};
+  Bufs bf{d->t, d->x, d->xr, d->y, d->up, d->o};
   const bool want_aux = c.dual_head && (outp.aux || outp.aux_confidence);
   const bool want_cam = c.dual_head && !from_tokens && (outp.pose_encoding || outp.extrinsics || outp.intrinsics);
-  const bool par = c.dual_head && !m->taps_enabled && d->s_aux != nullptr;
-  Run ra{m, par ? d->s_aux : st, B};   // aux branch
-  Run rc{m, st, B};                    // camera decoder: on the caller's stream (round 4: its own side stream cost more in fork / join than
-                                       // the 40 us chain it hid: config 2 1.97 -> 1.70 ms, profiles/r04_cfg2_branches.txt)
-  Bufs aux_bufs = par ? Bufs{d->t2, d->x2, d->xr2, d->y2, d->up2, d->o2} : main_bufs;
-  if (par && want_aux) {
-    MD_HIP(hipEventRecord(d->ev_fork, st));
-    MD_HIP(hipStreamWaitEvent(d->s_aux, d->ev_fork, 0));
-  }
-  // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
-  auto rcu = [&](Run& rr, Bufs& bf, const std::string& name, int hh, int ww, const void* x, const void* xr, const void* extra, void* out,
-                 void* out_relu) -> int {
-    MD_TRY(conv3(rr, "head_conv3x3", xr, hh, ww, Fp, Wk(name + ".conv1.weight"), Bi(name + ".conv1.bias"), F, bf.t, Fp, ACT_RELU,
-                 nullptr, nullptr, nullptr));
-    return conv3(rr, "head_conv3x3", bf.t, hh, ww, Fp, Wk(name + ".conv2.weight"), Bi(name + ".conv2.bias"), F, out, Fp, ACT_NONE, x,
-                 extra, out_relu);
+  // Everything runs on the caller's stream. Rounds 3-4 ran the aux branch and the camera decoder on side streams (parallel branches of
+  // the captured graph): every fork / join cost more than the overlap gave back (config 2, all outputs: 1.97 ms with two side streams,
+  // 1.80 on one stream, 1.70 with the aux branch alone on a side stream; with the pyramids grouped 1.74 with a side stream for the aux
+  // tail against 1.63 without -- profiles/r04_cfg2_branches.txt).
+  Run& ra = r;  // aux neck + tail
+  Run& rc = r;  // camera decoder
+  const int G = want_aux ? 2 : 1;
+  const char* const sfx[2] = {"", "_aux"};
+  const size_t px_bytes = (size_t)Fp * m->esz * m->xm;  // one pixel of an F-channel map
+  // 3x3 convolution F -> F over [G*B, hh, ww] with one weight set per group; `in_shared`: both groups read images [0, B) of `in`;
+  // res1_shared: the same for the first residual input
+  auto conv3g = [&](Run& rr, const void* in, bool in_shared, int hh, int ww, const std::string& rfb, const std::string& unit, void* out, int act,
+                    const void* res1, bool res1_shared, const void* res2, void* out2) -> int {
+    GemmParams p;
+    const int M = B * hh * ww;
+    p.N = F; p.ngroups = G;
+    for (int g = 0; g < G; ++g) {
+      p.g_rows[g] = M; p.g_row0[g] = g * M; p.g_arow0[g] = in_shared ? 0 : g * M;
+      p.W[g] = Wk(rfb + sfx[g] + unit + ".weight"); p.bias[g] = Bi(rfb + sfx[g] + unit + ".bias");
+    }
+    p.A = in; p.cH = hh; p.cW = ww; p.zero_page = m->zero_page;
+    split_conv_a(m, p, Fp, 0);
+    p.epi = EPI_STORE; p.act = act; p.out = out; p.out2 = out2;
+    split_out(m, p, Fp, true);
+    p.res1 = res1; p.res2 = res2; p.ldr = p.ldo; p.r_plane = (res1 || res2) ? p.o_plane : 0;
+    if (res1 && res1_shared && G > 1) p.res_mod = M;
+    rr.begin("head_conv3x3");
+    int s2 = launch_gemm(p, A_CONV3, m->prec, TILE_AUTO, rr.st);
+    rr.end();
+    return s2;
   };
-  // the four FeatureFusionBlocks (dpt.rs:1206-1222) from the coarsest stage up; result in bf.o at 8ph x 8pw
+  // ResidualConvUnit (dpt.rs:1248-1252): out = x + conv2(relu(conv1(relu(x)))) [+ extra]
+  auto rcu = [&](Run& rr, const std::string& rfb, const std::string& unit, int hh, int ww, const void* x, const void* xr, bool x_shared,
+                 const void* extra, void* out, void* out_relu) -> int {
+    MD_TRY(conv3g(rr, xr, x_shared, hh, ww, rfb, unit + ".conv1", bf.t, ACT_RELU, nullptr, false, nullptr, nullptr));
+    return conv3g(rr, bf.t, false, hh, ww, rfb, unit + ".conv2", out, ACT_NONE, x, x_shared, extra, out_relu);
+  };
+  // the four FeatureFusionBlocks (dpt.rs:1206-1222) from the coarsest stage up; result in bf.o at 8ph x 8pw (G*B images)
   const int target[4] = {8 * ph, 4 * ph, 2 * ph, ph}, targw[4] = {8 * pw, 4 * pw, 2 * pw, pw};  // output size of refinenet1..4
-  auto pyramid = [&](Run& rr, Bufs& bf, const std::string& suffix) -> int {
+  auto pyramid = [&](Run& rr) -> int {
     const void* top = nullptr;
     for (int lvl = 3; lvl >= 0; --lvl) {
-      const std::string rf = hp + ".scratch.refinenet" + std::to_string(lvl + 1) + suffix;
+      const std::string rfb = hp + ".scratch.refinenet" + std::to_string(lvl + 1);
       const void *yx, *yxr;
+      bool y_shared;
       if (lvl == 3) {
-        yx = d->rn[3];
-        yxr = d->rnr[3];
+        yx = d->rn[3]; yxr = d->rnr[3]; y_shared = true;
       } else {
-        MD_TRY(rcu(rr, bf, rf + ".residual1", sh[lvl], sw[lvl], d->rn[lvl], d->rnr[lvl], top, bf.x, bf.xr));
-        yx = bf.x;
-        yxr = bf.xr;
+        MD_TRY(rcu(rr, rfb, ".residual1", sh[lvl], sw[lvl], d->rn[lvl], d->rnr[lvl], true, top, bf.x, bf.xr));
+        yx = bf.x; yxr = bf.xr; y_shared = false;
       }
-      MD_TRY(rcu(rr, bf, rf + ".residual2", sh[lvl], sw[lvl], yx, yxr, nullptr, bf.y, nullptr));
+      MD_TRY(rcu(rr, rfb, ".residual2", sh[lvl], sw[lvl], yx, yxr, y_shared, nullptr, bf.y, nullptr));
       rr.begin("head_resize");
-      MD_TRY(launch_resize_nhwc(bf.y, B, sh[lvl], sw[lvl], F, Fp, bf.up, target[lvl], targw[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, rr.st));
+      MD_TRY(launch_resize_nhwc(bf.y, G * B, sh[lvl], sw[lvl], F, Fp, bf.up, target[lvl], targw[lvl], Fp, MD_INTERP_BURN, nullptr, m->prec, rr.st));
       rr.end();
-      MD_TRY(gemm_rows(rr, "head_out_conv", bf.up, Fp, nullptr, (long)B * target[lvl] * targw[lvl], Wk(rf + ".out_conv.weight"), F, Fp,
-                       Bi(rf + ".out_conv.bias"), bf.o, Fp));
+      {  // out_conv 1x1 (+bias), one weight set per group
+        GemmParams p;
+        const int M2 = B * target[lvl] * targw[lvl];
+        p.N = F; p.ngroups = G;
+        for (int g = 0; g < G; ++g) {
+          p.g_rows[g] = M2; p.g_row0[g] = g * M2; p.g_arow0[g] = g * M2;
+          p.W[g] = Wk(rfb + sfx[g] + ".out_conv.weight"); p.bias[g] = Bi(rfb + sfx[g] + ".out_conv.bias");
+        }
+        p.A = bf.up;
+        split_dense_a(m, p, Fp, Fp, 0);
+        p.epi = EPI_STORE; p.out = bf.o;
+        split_out(m, p, Fp, true);
+        rr.begin("head_out_conv");
+        MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, rr.st));
+        rr.end();
+      }
       top = bf.o;
       if (m->taps_enabled)  // FeatureFusionBlock outputs (dpt.rs:705-720), main and aux pyramids
-        MD_TRY(rr.tap_nhwc(("refinenet" + std::to_string(lvl + 1) + suffix).c_str(), bf.o, F, target[lvl], targw[lvl], Fp));
+        for (int g = 0; g < G; ++g)
+          MD_TRY(rr.tap_nhwc(("refinenet" + std::to_string(lvl + 1) + sfx[g]).c_str(),
+                             (const char*)bf.o + (size_t)g * B * target[lvl] * targw[lvl] * px_bytes, F, target[lvl], targw[lvl], Fp));
     }
     return MD_OK;
   };
@@ -1161,14 +1180,39 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   }
   // ---- aux branch (build_aux_logits, dpt.rs:356-441): aux fusion pyramid on the same layerN_rn maps -> last level's 5-conv
   //      neck -> + 2 x 0.1 x UV -> reduce 3x3 -> ReLU -> project 1x1 (7 ch: 6 ray values + confidence) ----
+  MD_TRY(pyramid(r));  // both pyramids (two weight groups) when the aux outputs are wanted
+  // output_conv1 (main, dpt.rs:337-344) and the first convolution of the aux neck (dpt.rs:1085-1113) are both 3x3 F -> F/2 on the
+  // 8ph x 8pw results of their pyramids: one launch, two weight groups, into the (now free) `up` map -- main | aux
+  const void* c1_map = d->c1;
+  const void* aux_cur = nullptr;
+  const std::string lv = std::to_string(c.aux_levels - 1);
   if (want_aux) {
-    MD_TRY(pyramid(ra, aux_bufs, "_aux"));
+    GemmParams p;
+    const int M = B * 8 * ph * 8 * pw;
+    const std::string n0 = hp + ".scratch.output_conv1_aux." + lv + ".layers.0";
+    p.N = F2; p.ngroups = 2;
+    for (int g = 0; g < 2; ++g) { p.g_rows[g] = M; p.g_row0[g] = g * M; p.g_arow0[g] = g * M; }
+    p.W[0] = Wk(hp + ".scratch.output_conv1.weight"); p.bias[0] = Bi(hp + ".scratch.output_conv1.bias");
+    p.W[1] = Wk(n0 + ".weight"); p.bias[1] = Bi(n0 + ".bias");
+    p.A = bf.o; p.cH = 8 * ph; p.cW = 8 * pw; p.zero_page = m->zero_page;
+    split_conv_a(m, p, Fp, 0);
+    p.epi = EPI_STORE; p.out = bf.up;
+    split_out(m, p, F2p, true);
+    r.begin("head_conv3x3");
+    MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_AUTO, st));
+    r.end();
+    c1_map = bf.up;
+    aux_cur = (const char*)bf.up + (size_t)M * F2p * m->esz * m->xm;
+  } else {
+    MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk(hp + ".scratch.output_conv1.weight"), Bi(hp + ".scratch.output_conv1.bias"), F2,
+                 d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
+  }
+  if (want_aux) {
     const int ah = 8 * ph, aw = 8 * pw;
-    const std::string lv = std::to_string(c.aux_levels - 1);
-    const void* cur = aux_bufs.o;
-    void* pp[2] = {aux_bufs.up, aux_bufs.o};
-    int cin = F;
-    for (int j = 0; j < c.aux_out1_conv_num; ++j) {
+    const void* cur = aux_cur;  // the neck's first convolution ran beside output_conv1
+    void* pp[2] = {d->up2, d->o2};
+    int cin = F2;
+    for (int j = 1; j < c.aux_out1_conv_num; ++j) {
       const int cout = j % 2 == 0 ? F / 2 : F;
       const std::string n = hp + ".scratch.output_conv1_aux." + lv + ".layers." + std::to_string(j);
       MD_TRY(conv3(ra, "aux_conv3x3", cur, ah, aw, cpad(m, cin), Wk(n + ".weight"), Bi(n + ".bias"), cout, pp[j & 1], cpad(m, cout), ACT_NONE,
@@ -1176,7 +1220,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       cur = pp[j & 1];
       cin = cout;
     }
-    void* hin = cur == aux_bufs.up ? aux_bufs.o : aux_bufs.up;
+    void* hin = cur == d->up2 ? d->o2 : d->up2;
     ra.begin("head_resize");
     MD_TRY(launch_resize_nhwc(cur, B, ah, aw, F2, F2p, hin, ah, aw, F2p, MD_INTERP_BURN, d->pos_aux, m->prec, ra.st));
     ra.end();
@@ -1211,7 +1255,6 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
           MD_TRY(host_out(ra.st, conf ? user + (size_t)b * plane : user + ((size_t)b * (K7 - 1) + ch) * plane,
                           d->aux_stage + ((size_t)b * K7 + ch) * plane, plane));
       }
-    if (par) MD_HIP(hipEventRecord(d->ev_aux, d->s_aux));
   }
   // ---- camera decoder (camera.rs:143-199) on the raw camera feature of the last hook, fp32 ----
   if (want_cam) {
@@ -1236,14 +1279,11 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     }
   }
   // ---- main branch: output_conv1 -> resize to the image size (+ UV table) -> output_conv2 + activation ----
-  MD_TRY(pyramid(r, main_bufs, ""));
-  MD_TRY(conv3(r, "head_conv3x3", d->o, 8 * ph, 8 * pw, Fp, Wk(hp + ".scratch.output_conv1.weight"),
-               Bi(hp + ".scratch.output_conv1.bias"), F2, d->c1, F2p, ACT_NONE, nullptr, nullptr, nullptr));
   r.begin("head_resize");
-  MD_TRY(launch_resize_nhwc(d->c1, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, IH, IW, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
+  MD_TRY(launch_resize_nhwc(c1_map, B, 8 * ph, 8 * pw, F2, F2p, d->c1r, IH, IW, F2p, MD_INTERP_BURN, d->pos_final, m->prec, st));
   r.end();
   if (m->taps_enabled) {
-    MD_TRY(r.tap_nhwc("output_conv1", d->c1, F2, 8 * ph, 8 * pw, F2p));
+    MD_TRY(r.tap_nhwc("output_conv1", c1_map, F2, 8 * ph, 8 * pw, F2p));
     MD_TRY(r.tap_nhwc("head_input", d->c1r, F2, IH, IW, F2p));  // resized + UV table: the input of output_conv2
   }
   {
@@ -1273,8 +1313,6 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     MD_TRY(host_out(st, outp.depth, depth_dev, out_elems));
     if (cd) MD_TRY(host_out(st, outp.depth_confidence, cd, out_elems));
   }
-  // ---- join the side branches ----
-  if (par && want_aux) MD_HIP(hipStreamWaitEvent(st, d->ev_aux, 0));
   if (out_kind == MD_MEM_HOST) MD_HIP(hipStreamSynchronize(st));
   return MD_OK;
 }
