@@ -306,9 +306,14 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int g, int m, int
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WGM, int WGN, int AMODE>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p) {
-  constexpr int NW = WGM * WGN;
+// KSPLIT > 1 (launches that leave most CUs idle behind a long contraction: DA3 `small`'s fc2, K = 1536 on 132 workgroups; its stride-2
+// stage convolution, K = 3456 on 36): KSPLIT groups of WGM x WGN waves share the output tile, group g multiplies the g-th part of the
+// k-tiles through its own two-stage ring, the partial accumulators meet in LDS in a fixed order (group 0 + group 1 + ...) and group 0
+// runs the epilogue -- the dependent k-loop is KSPLIT times shorter, the result is deterministic, and it differs from the unsplit
+// kernel's in the last bits (another summation order of the same products).
+template <typename T, int BM, int BN, int WGM, int WGN, int AMODE, int KSPLIT = 1>
+__global__ __launch_bounds__(WGM* WGN * 64 * KSPLIT) void gemm_kernel(const GemmParams p) {
+  constexpr int NW = WGM * WGN;  // waves of one k-group
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 16, TN = WTN / 16;  // 16x16 MFMA tiles per wave tile
   constexpr int RG_A = BM / 8, RG_W = BN / 8;  // 8-row groups (one glds wave-instruction each)
@@ -320,12 +325,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
   constexpr int ESZ = (int)sizeof(T);
   constexpr int KE = 128 / ESZ;  // K elements per 128-byte LDS row
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KSPLIT > 1 ? wave_all / NW : 0;       // k-group
+  const int wave = KSPLIT > 1 ? wave_all % NW : wave_all;
   const int wm = wave / WGN, wn = wave % WGN;
+  char* const smem = smem_all + grp * (2 * STAGE_BYTES);  // this group's two-stage ring
 
   // ---- XCD-aware, bijective block -> logical tile id (blocks b and b+8 share an XCD) ----
   const int nwg = gridDim.x;
@@ -466,12 +474,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
   const int q16 = lane >> 4, r16 = lane & 15;
   const int lane_off = r16 * 128 + ((((r16 >> 1) & 7) ^ q16) << 4);  // logical chunk 4 ks + q16, swizzled by (row >> 1) & 7
 
-  issue(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
+  const int KTg = KT / KSPLIT, kt0 = grp * KTg;  // this group's k-tiles (the launcher splits only when KSPLIT divides KT)
+  issue(0, kt0);
+  for (int i = 0; i < KTg; ++i) {
+    const int kt = kt0 + i;
+    const int cur = i & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) issue(cur ^ 1, kt + 1);
+    if (i + 1 < KTg) issue(cur ^ 1, kt + 1);
     const char* As = smem + cur * STAGE_BYTES + wm * WTM * 128;
     const char* Ws = smem + cur * STAGE_BYTES + BM * 128 + wn * WTN * 128;
     if constexpr (std::is_same<T, fp8_t>::value) {  // block-scaled MFMA: both 16-byte halves of the k-tile per instruction
@@ -502,6 +512,33 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_kernel(const GemmParams p)
 #pragma unroll
           for (int b = 0; b < TM; ++b) Atom16<T>::mma(wf[a], af[b], acc[a][b]);
       }
+    }
+  }
+
+  if constexpr (KSPLIT > 1) {
+    // the groups' partial accumulators meet in the (now idle) rings: TN x TM vectors per lane, lane-contiguous; fixed order
+    f32x4_t* const xch = (f32x4_t*)smem_all;
+    __syncthreads();
+    if (grp > 0) {
+      f32x4_t* px = xch + ((grp - 1) * NW + wave) * (TN * TM * 64) + lane;
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) px[(a * TM + b) * 64] = (f32x4_t){acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g2 = 1; g2 < KSPLIT; ++g2) {
+      const f32x4_t* px = xch + ((g2 - 1) * NW + wave) * (TN * TM * 64) + lane;
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const f32x4_t o = px[(a * TM + b) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[a][b][j] += o[j];
+        }
     }
   }
 
@@ -1474,7 +1511,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WGM, int WGN, int AMODE>
+template <typename T, int BM, int BN, int WGM, int WGN, int AMODE, int KSPLIT = 1>
 static int launch_cfg(GemmParams& p, hipStream_t stream) {
   int tiles_m = 0;
   for (int g = 0; g < p.ngroups; ++g) {
@@ -1488,8 +1525,8 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
   if (blocks <= 0) return MD_OK;
   if (blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: too many tiles (%ld)", blocks);
   prep_tile_map(p, tiles_m, tiles_n);
-  constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = gemm_kernel<T, BM, BN, WGM, WGN, AMODE>;
+  constexpr int smem = 2 * (BM + BN) * 128 * KSPLIT;
+  auto kern = gemm_kernel<T, BM, BN, WGM, WGN, AMODE, KSPLIT>;
   static unsigned long attr_set = 0;  // one bit per device ordinal (the attribute is per device)
   {
     int ordinal = 0;
@@ -1500,9 +1537,25 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
       attr_set |= bit;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(WGM * WGN * 64), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(WGM * WGN * 64 * KSPLIT), smem, stream, p);
   MD_HIP(hipGetLastError());
   return MD_OK;
+}
+
+// k-groups for a 64 x 64 launch (gemm_kernel's KSPLIT): only launches that leave most CUs idle (<= kSplitBlocks workgroups) behind a
+// long dependent k-loop, only 16-bit operand types (the fp32 mode keeps one summation order for every launch size)
+constexpr int kSplitBlocks = 160;
+template <typename T>
+static int pick_ksplit(const GemmParams& p) {
+  if (std::is_same<T, float>::value || std::is_same<T, fp8_t>::value || p.batch > 1) return 1;
+  if (p.epi == EPI_HEAD || p.epi == EPI_HEAD_UP2) return 1;
+  long tiles_m = 0;
+  for (int g = 0; g < p.ngroups; ++g) tiles_m += cdiv(p.g_rows[g], 64);
+  if (tiles_m * cdiv(p.N, 64) > kSplitBlocks) return 1;
+  const int KT = p.K / (128 / (int)sizeof(T));
+  if (KT % 4 == 0 && KT / 4 >= 5) return 4;
+  if (KT % 2 == 0 && KT / 2 >= 8) return 2;
+  return 1;
 }
 
 template <typename T, int AMODE>
@@ -1517,6 +1570,11 @@ static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
     case TILE_128x64:  // N <= 64 (the 64-feature DPT head) and launches that leave CUs idle on 128^2 tiles
       return launch_cfg<T, 128, 64, 2, 2, AMODE>(p, stream);
     case TILE_64x64:
+      if constexpr (!std::is_same<T, float>::value && !std::is_same<T, fp8_t>::value) {
+        const int ks = pick_ksplit<T>(p);
+        if (ks == 4) return launch_cfg<T, 64, 64, 2, 2, AMODE, 4>(p, stream);
+        if (ks == 2) return launch_cfg<T, 64, 64, 2, 2, AMODE, 2>(p, stream);
+      }
       return launch_cfg<T, 64, 64, 2, 2, AMODE>(p, stream);
     default:
       MD_FAIL(MD_ERR_INVALID_ARG, "gemm: unknown tile config %d", tile);

@@ -40,6 +40,19 @@ def run(dev, iters=25, verbose=False):
                         bad.append((M, N, K, it, "tile", tile, "prec", prec, d))
         if verbose:
             print("shape", M, N, K, "ok" if not bad else "MISMATCH", flush=True)
+    # the 64 x 64 kernel with its contraction split over two / four wave groups of the workgroup (small launches behind a long k-loop:
+    # gemm_kernel's KSPLIT): the groups' partial accumulators are summed through LDS -- exact on small integers, bf16 and f16 operands
+    for (M, N, K) in [(1370, 384, 1536), (361, 384, 3456), (300, 128, 1024), (65, 68, 2048)]:
+        x = torch.randint(-3, 4, (M, K), generator=g).float()
+        w = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-5, 6, (N,), generator=g).float()
+        want = (x.double() @ w.double().t() + b.double()).float().cuda()
+        xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+        for it in range(max(1, iters // 4)):
+            for prec in (0, 3):
+                d = (ops.linear(dev, xc, wc, bc, 0, prec, _lib.TILE_64x64) - want).abs().max().item()
+                if d != 0.0:
+                    bad.append((M, N, K, it, "k-split", "prec", prec, d))
     # the implicit-GEMM convolution (tap masks, 32-bit pixel index) and the one-division pixel-shuffle epilogue
     import torch.nn.functional as F
     for (B, Cin, H, W, Cout) in [(2, 128, 160, 120, 256), (1, 64, 33, 17, 32)]:
