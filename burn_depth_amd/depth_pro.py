@@ -131,11 +131,10 @@ class DepthPro:
             for f in list(self._forks):  # only reachable at interpreter shutdown: a live fork holds a reference to its root
                 f.destroy()
             self.destroy()
-        except _lib.MdError as e:  # never silent: a failed destroy leaks the weight / workspace arenas
-            import warnings
-            warnings.warn(f"DepthPro.__del__: {e}", ResourceWarning)
-        except Exception:  # interpreter shutdown: the library may already be gone
-            pass
+        except Exception as e:  # noqa: BLE001 -- at interpreter shutdown module globals (even `_lib.MdError`) may already be None
+            if _lib is not None and getattr(_lib, "MdError", None) is not None and isinstance(e, _lib.MdError):
+                import warnings  # never silent: a failed destroy leaks the weight / workspace arenas
+                warnings.warn(f"DepthPro.__del__: {e}", ResourceWarning)
 
     # ---- introspection --------------------------------------------------------------------
     def query(self, key: str) -> int:
