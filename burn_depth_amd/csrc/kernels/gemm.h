@@ -102,6 +102,17 @@ struct GemmParams {
   float qscale = 1.f;           // EPI_QKV: the q columns (n < embed) are stored as (acc + bias) * qscale -- the softmax scale
                                 // head_dim^-0.5 * log2(e) folded into q BEFORE its one rounding to the operand type, so that the
                                 // attention kernel exponentiates the MFMA result directly (v_exp_f32 = 2^x)
+  // EPI_QKV with DA3's per-head q / k LayerNorm(64) + 2-D rotary embedding fused in (tiles with BN == 64 = one head of q or k per
+  // tile; set qkn_g[0] to ask for it -- the launcher then keeps to the 64-column tiles): q' = rope(LN_q(acc + bias)) * qscale,
+  // k' = rope(LN_k(acc + bias)). Token t = row % seq_stride sits at (0, 0) for t == 0 or t >= rope_ntok, else at patch
+  // (1 + (t-1) / rope_pw, 1 + (t-1) % rope_pw), or at (1, 1) when rope_global; the first half of the head rotates with the row
+  // position, the second with the column position, pairs (j, j + 16), angles from rope_cos / rope_sin [pos][16].
+  const float* qkn_g[2] = {nullptr, nullptr};  // q, k gamma [64]
+  const float* qkn_b[2] = {nullptr, nullptr};  // q, k beta [64]
+  float qkn_eps = 1e-5f;
+  const float *rope_cos = nullptr, *rope_sin = nullptr;
+  int rope_pw = 1, rope_global = 0, rope_ntok = 0;
+  FastDiv fd_rope_pw;
   // EPI_PIXSHUF: input pixel grid [B, psH, psW]; N = f*f*psC (f = ps_f, 2 or 4); out NHWC [B, f*psH, f*psW, ldo] at +ps_coff
   int psH = 0, psW = 0, psC = 0, ps_coff = 0, ps_f = 2;
   int ps_fast = 0;  // set by launch_gemm: bf16 out, no second output, 8-column groups inside one tap, 32-bit element offsets

@@ -87,6 +87,14 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   p.fd_res_mod = make_fastdiv(p.res_mod);
   p.fd_seq_patches = make_fastdiv(p.seq_patches);
   p.fd_seq_stride = make_fastdiv(p.seq_stride);
+  p.fd_rope_pw = make_fastdiv(p.rope_pw);
+  if (p.qkn_g[0]) {
+    if (p.epi != EPI_QKV || !p.qkn_g[1] || !p.qkn_b[0] || !p.qkn_b[1] || !p.rope_cos || !p.rope_sin || p.embed % 64 != 0 || p.seq_stride <= 0 ||
+        prec == MD_PREC_FP8)
+      MD_FAIL(MD_ERR_INVALID_ARG, "gemm: the fused q/k-norm + RoPE epilogue needs EPI_QKV, both norms, the angle tables and 64-wide heads");
+    if (tile != TILE_AUTO && tile != TILE_64x64 && tile != TILE_128x64)
+      MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the fused q/k-norm + RoPE epilogue lives in the 64-column tiles");
+  }
   p.fd_psC = make_fastdiv(p.psC);
   if (p.epi == EPI_PIXSHUF) {
     long px = 0;
@@ -114,6 +122,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     if (rows >= (1L << 31)) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: more than 2^31 rows");
   }
   if (tile == TILE_AUTO) tile = pick_tile(p, prec);
+  if (p.qkn_g[0] && tile != TILE_64x64 && tile != TILE_128x64) {  // one head per tile: the 64-column tiles only
+    long rows = 0;
+    for (int g = 0; g < p.ngroups; ++g) rows += p.g_rows[g];
+    tile = rows >= 4096 ? TILE_128x64 : TILE_64x64;
+  }
   {
     const int bn = (tile == TILE_128x128) ? 128 : (tile == TILE_256x32 ? 32 : ((tile == TILE_128x64 || tile == TILE_64x64) ? 64 : 256));
     const int tn = cdiv(p.N, bn);

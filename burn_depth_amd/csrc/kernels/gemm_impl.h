@@ -542,6 +542,95 @@ __global__ __launch_bounds__(WGM* WGN * 64 * KSPLIT) void gemm_kernel(const Gemm
     }
   }
 
+  if constexpr (BN == 64 && WGN == 2 && !std::is_same<T, fp8_t>::value) {
+    if (p.epi == EPI_QKV && p.qkn_g[0] != nullptr && n0 < 2 * p.embed) {
+      // ---- a q or k tile = one head: per-head LayerNorm(64) + 2-D RoPE on the accumulators (DA3's extended blocks; what
+      //      qk_norm_rope_kernel does on the stored rows, here before the one rounding to T). A row's 64 columns live in the two
+      //      waves wn = 0 | 1 of its wave row: the row statistics meet in the (idle) ring. ----
+      const int isk = n0 >= p.embed ? 1 : 0;
+      const float* bias = MD_SEL_G(p.bias, g);
+      const int c0 = wn * 32 + 4 * q16;  // this lane's first column inside the head, for a = 0 (a = 1: + 16)
+      f32x4_t y[TN][TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a) {
+        const f32x4_t bv = *(const f32x4_t*)(bias + n0 + c0 + 16 * a);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) y[a][b] = (f32x4_t){acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]} + bv;
+      }
+      float* const red = (float*)smem_all;  // [2 passes][wn][BM]
+      auto row_total = [&](float (&part)[TM], int pass) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          part[b] += __shfl_xor(part[b], 16);
+          part[b] += __shfl_xor(part[b], 32);
+          if (q16 == 0) red[(pass * 2 + wn) * BM + wm * WTM + b * 16 + r16] = part[b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TM; ++b) part[b] = red[(pass * 2) * BM + wm * WTM + b * 16 + r16] + red[(pass * 2 + 1) * BM + wm * WTM + b * 16 + r16];
+      };
+      float mean[TM], rstd[TM];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        mean[b] = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) mean[b] += (y[a][b][0] + y[a][b][1]) + (y[a][b][2] + y[a][b][3]);
+      }
+      __syncthreads();  // every wave has left the main loop's last k-tile: the ring is free
+      row_total(mean, 0);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        mean[b] *= (1.0f / 64.0f);
+        rstd[b] = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+          y[a][b] = y[a][b] - mean[b];
+          rstd[b] += (y[a][b][0] * y[a][b][0] + y[a][b][1] * y[a][b][1]) + (y[a][b][2] * y[a][b][2] + y[a][b][3] * y[a][b][3]);
+        }
+      }
+      row_total(rstd, 1);
+      const f32x4_t g0 = *(const f32x4_t*)(p.qkn_g[isk] + c0), g1 = *(const f32x4_t*)(p.qkn_g[isk] + c0 + 16);
+      const f32x4_t b0 = *(const f32x4_t*)(p.qkn_b[isk] + c0), b1 = *(const f32x4_t*)(p.qkn_b[isk] + c0 + 16);
+      const float qs = isk ? 1.0f : p.qscale;
+      const int two_d = 2 * p.embed;
+      static_assert(TN == 2, "two n16-tiles per wave: the RoPE pair (j, j + 16) sits in one lane");
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const float rs = 1.0f / sqrtf(rstd[b] * (1.0f / 64.0f) + p.qkn_eps);
+        const f32x4_t u0 = y[0][b] * rs * g0 + b0, u1 = y[1][b] * rs * g1 + b1;
+        const int m = m_base + wm * WTM + b * 16 + r16;
+        const int mc = m < m_end ? m : m_end - 1;
+        const int t = mc - fdiv(mc, p.fd_seq_stride) * p.seq_stride;
+        int py = 0, px = 0;
+        if (t > 0 && t < p.rope_ntok) {
+          if (p.rope_global) {
+            py = px = 1;
+          } else {
+            const int pi = t - 1;
+            py = fdiv(pi, p.fd_rope_pw);
+            px = pi - py * p.rope_pw + 1;
+            py += 1;
+          }
+        }
+        const int pos = wn ? px : py;  // first half of the head rotates with the row position, the second with the column position
+        const f32x4_t cs = *(const f32x4_t*)(p.rope_cos + pos * 16 + 4 * q16), sn = *(const f32x4_t*)(p.rope_sin + pos * 16 + 4 * q16);
+        const f32x4_t o0 = (u0 * cs - u1 * sn) * qs, o1 = (u1 * cs + u0 * sn) * qs;
+        if (m < m_end) {
+          const int n = n0 + c0;
+          if constexpr (is_split<TO>::value) {
+            TO* row = (TO*)p.out + (long)m * (2L * two_d) + isk * two_d + (n - isk * p.embed);
+            store4s<TO>(row, p.embed, o0);
+            store4s<TO>(row + 16, p.embed, o1);
+          } else {
+            store4<TO>((TO*)p.out + (long)m * two_d + n, o0);
+            store4<TO>((TO*)p.out + (long)m * two_d + n + 16, o1);
+          }
+        }
+      }
+      return;
+    }
+  }
+
   auto head_act = [&](float z) __attribute__((always_inline)) {
     return p.head_act == 1 ? expf(z) : (p.head_act == 2 ? z : (p.head_act == 3 ? expf(z) + 1.0f : fmaxf(z, 0.f)));
   };
@@ -1548,7 +1637,7 @@ constexpr int kSplitBlocks = 160;
 template <typename T>
 static int pick_ksplit(const GemmParams& p) {
   if (std::is_same<T, float>::value || std::is_same<T, fp8_t>::value || p.batch > 1) return 1;
-  if (p.epi == EPI_HEAD || p.epi == EPI_HEAD_UP2) return 1;
+  if (p.epi == EPI_HEAD || p.epi == EPI_HEAD_UP2 || p.qkn_g[0]) return 1;  // (the fused q/k-norm epilogue has workgroup barriers of its own)
   long tiles_m = 0;
   for (int g = 0; g < p.ngroups; ++g) tiles_m += cdiv(p.g_rows[g], 64);
   if (tiles_m * cdiv(p.N, 64) > kSplitBlocks) return 1;

@@ -28,7 +28,10 @@ int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches,
 
 // Generic ViT patch extraction (any patch size, e.g. 14 for DA3): fp32 NCHW [B,3,H,W] ->
 // A[(b*ph + py)*pw + px][c*ps*ps + ky*ps + kx], row length Kp >= 3*ps*ps (tail zero-filled).
-int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s);
+// cls_x != nullptr: the launch also writes the cls rows (cls + pos0) and zero padding rows of the fp32 residual stream cls_x
+// [B * S, D] (launch_cls_init's work for one sequence group)
+int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s, float* cls_x = nullptr,
+                    int S = 0, int n_tokens = 0, int D = 0, const float* cls = nullptr, const float* pos0 = nullptr);
 
 // Bilinear resize of an NHWC tensor (element type by prec), align_corners per `method`
 // (MD_INTERP_BURN = align_corners=True, depth_anything3/interpolate.rs:7-47), optional per-pixel
@@ -62,8 +65,10 @@ int launch_cls_init(float* x, int nseq_total, int S, int n_tokens, int D, const 
 // K3 LayerNorm over D (biased variance), fp32 rows -> T rows (bf16/f32) or fp32 (out_f32).
 // gamma/beta per group (a = gamma, b = beta); NULL gamma = non-affine. Rows grouped by sequence.
 // prec == MD_PREC_FP8 (and !out_f32): rows of OCP e4m3 bytes, value * fp8_inv_scale, saturating.
+// tok0 != nullptr: row 0 of every sequence is first replaced by tok0[seq * tok0_stride ..] (written back through x_rw == x)
 int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
-                     int out_f32, hipStream_t s, float fp8_inv_scale = 1.f);
+                     int out_f32, hipStream_t s, float fp8_inv_scale = 1.f, const float* tok0 = nullptr, int tok0_stride = 0,
+                     float* x_rw = nullptr);
 // fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width = 0);
 

@@ -323,10 +323,29 @@ int launch_pyramid_patchify(const float* x, const PyramidGeom& g, void* patches,
 // ------------------------------------------------------------------------------------------------
 // generic patch extraction + NHWC bilinear resize (Depth-Anything-v3 path)
 // ------------------------------------------------------------------------------------------------
+// `ci.x != nullptr`: the same launch also writes the cls rows (cls + pos[0]) and the zero padding rows of the fp32 residual
+// stream (what cls_init_kernel does; DA3 runs both at the start of every frame and each launch costs its ~4.5 us floor)
+struct PatchifyCls {
+  float* x;
+  int S, n_tokens, D;
+  const float *cls, *pos0;
+};
 template <typename T>
-__global__ void patchify_kernel(const float* __restrict__ x, int B, int H, int W, int ps, int Kp, T* __restrict__ out) {
+__global__ void patchify_kernel(const float* __restrict__ x, int B, int H, int W, int ps, int Kp, T* __restrict__ out, PatchifyCls ci) {
   const int ph = H / ps, pw = W / ps, K = 3 * ps * ps;
   const long total = (long)B * ph * pw * Kp;
+  if (ci.x) {
+    const int extra = 1 + (ci.S - ci.n_tokens);  // cls row + padding rows of every sequence
+    const long ctotal = (long)B * extra * ci.D;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < ctotal; e += (long)gridDim.x * blockDim.x) {
+      const int d = (int)(e % ci.D);
+      const long t = e / ci.D;
+      const int r = (int)(t % extra);
+      const int seq = (int)(t / extra);
+      if (r == 0) ci.x[((long)seq * ci.S) * ci.D + d] = ci.cls[d] + ci.pos0[d];
+      else ci.x[((long)seq * ci.S + ci.n_tokens + r - 1) * ci.D + d] = 0.f;
+    }
+  }
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int col = (int)(e % Kp);
     const long row = e / Kp;
@@ -344,10 +363,13 @@ __global__ void patchify_kernel(const float* __restrict__ x, int B, int H, int W
   }
 }
 
-int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s) {
+int launch_patchify(const float* x, int B, int H, int W, int ps, int Kp, void* out, int prec, hipStream_t s, float* cls_x, int S,
+                    int n_tokens, int D, const float* cls, const float* pos0) {
   if (ps <= 0 || H % ps || W % ps || Kp < 3 * ps * ps) MD_FAIL(MD_ERR_SHAPE, "patchify: %dx%d / patch %d / K %d", H, W, ps, Kp);
+  if (cls_x && (!cls || !pos0 || S < n_tokens || D <= 0)) MD_FAIL(MD_ERR_INVALID_ARG, "patchify: cls rows need the cls token and pos[0]");
   const long total = (long)B * (H / ps) * (W / ps) * Kp;
-  MD_BY_PREC(prec, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (T*)out));
+  const PatchifyCls ci{cls_x, S, n_tokens, D, cls, pos0};
+  MD_BY_PREC(prec, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, B, H, W, ps, Kp, (T*)out, ci));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
@@ -566,14 +588,19 @@ __device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
   return __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), w, true);
 }
 
+// `tok0` != nullptr: row 0 of every sequence is REPLACED first by tok0[seq * tok0_stride ..] (DA3: the camera token takes the cls
+// slot at the first extended block; this kernel is that block's first LayerNorm) -- the new row is normalised and written back to x
 template <typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, TO* __restrict__ out, long rows,
-                                                        int D, float eps, int S, SeqGroups g, float fp8_inv_scale) {
+                                                        int D, float eps, int S, SeqGroups g, float fp8_inv_scale,
+                                                        const float* __restrict__ tok0, int tok0_stride, float* __restrict__ x_rw) {
   const int lane = threadIdx.x & 63;
   const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   for (long row = wave_id; row < rows; row += nwaves) {
     const float* xr = x + row * D;
+    const bool repl = tok0 != nullptr && row % S == 0;  // wave-uniform
+    if (repl) xr = tok0 + (row / S) * tok0_stride;
     f32x4_t v[NV];
     float sum = 0.f;
 #pragma unroll
@@ -581,6 +608,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       const int i = lane * 4 + k * 256;
       if (i < D) {
         v[k] = *(const f32x4_t*)(xr + i);
+        if (repl) *(f32x4_t*)(x_rw + row * D + i) = v[k];
         sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
       } else {
         v[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -620,7 +648,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
-                     int out_f32, hipStream_t s, float fp8_inv_scale) {
+                     int out_f32, hipStream_t s, float fp8_inv_scale, const float* tok0, int tok0_stride, float* x_rw) {
+  if (tok0 && x_rw != x) MD_FAIL(MD_ERR_INVALID_ARG, "layernorm: the token-0 replacement writes back into the input rows");
   if (D % 4 != 0 || D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
   const int nv = (D + 255) / 256;
   const int grid = grid_for(rows * 64);
@@ -628,16 +657,16 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
   const bool fp8o = !out_f32 && prec == MD_PREC_FP8;
 #define MD_LN(NV)                                                                                                   \
   if (f32o)                                                                                                         \
-    hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3(grid), dim3(256), 0, s, x, (float*)out, rows, D, eps, S, g, 1.f); \
+    hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3(grid), dim3(256), 0, s, x, (float*)out, rows, D, eps, S, g, 1.f, tok0, tok0_stride, x_rw); \
   else if (fp8o)                                                                                                    \
     hipLaunchKernelGGL((layernorm_kernel<fp8_t, NV>), dim3(grid), dim3(256), 0, s, x, (fp8_t*)out, rows, D, eps, S, g, \
-                       fp8_inv_scale);                                                                              \
+                       fp8_inv_scale, tok0, tok0_stride, x_rw);                                                                              \
   else if (prec == MD_PREC_F16)                                                                                     \
-    hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16_t*)out, rows, D, eps, S, g, 1.f); \
+    hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16_t*)out, rows, D, eps, S, g, 1.f, tok0, tok0_stride, x_rw); \
   else if (prec == MD_PREC_F16X2)                                                                                   \
-    hipLaunchKernelGGL((layernorm_kernel<f16s_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16s_t*)out, rows, D, eps, S, g, 1.f); \
+    hipLaunchKernelGGL((layernorm_kernel<f16s_t, NV>), dim3(grid), dim3(256), 0, s, x, (f16s_t*)out, rows, D, eps, S, g, 1.f, tok0, tok0_stride, x_rw); \
   else                                                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g, 1.f);
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), dim3(grid), dim3(256), 0, s, x, (bf16_t*)out, rows, D, eps, S, g, 1.f, tok0, tok0_stride, x_rw);
   switch (nv) {
     case 1: MD_LN(1) break;
     case 2: MD_LN(2) break;

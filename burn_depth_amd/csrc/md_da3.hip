@@ -814,18 +814,13 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     MD_TRY(r.tap_f32("camera_token", cam_tok, B, D, 0, 0));  // CameraEncoder::forward's result (camera.rs:89-110)
   }
   // ---- backbone ----
-  r.begin("patchify");
-  MD_TRY(launch_patchify(x_dev, B, H, W, v.ps, d->Kp, d->patches, m->prec, st));
+  r.begin("patchify");  // + the cls rows (cls + pos[0]) and the zero padding rows of the residual stream, in the same launch
+  MD_TRY(launch_patchify(x_dev, B, H, W, v.ps, d->Kp, d->patches, m->prec, st, d->xres, SS, NT, D, d->vit.cls, d->vit.pos));
   r.end();
   SeqGroups sg;
   memset(&sg, 0, sizeof(sg));
   sg.ngroups = 1;
   sg.nseq[0] = B;
-  sg.a[0] = d->vit.cls;
-  sg.b[0] = d->vit.pos;
-  r.begin("cls_init");
-  MD_TRY(launch_cls_init(d->xres, B, SS, NT, D, sg, st));
-  r.end();
   {
     GemmParams p;
     p.N = D; p.ngroups = 1; p.g_rows[0] = B * P; p.W[0] = d->vit.pe_w; p.bias[0] = d->vit.pe_b; p.pos[0] = d->vit.pos;
@@ -847,14 +842,10 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
   for (int i = 0; i < v.depth; ++i) {
     const VitBlockW& k = d->vit.blk[i];
     const bool ext = i >= ext0, is_global = ext && (i % 2 == 1);
-    if (i == ext0) {  // the camera token takes the cls slot: the encoder's (mod.rs:522-531) or the learned reference-view one
-      r.begin("camera_token");
-      if (cam_tok)
-        MD_TRY(launch_set_token0(xcur, B, SS, D, cam_tok, st, D));
-      else
-        MD_TRY(launch_set_token0(xcur, B, SS, D, Bi(bp + ".camera_token"), st));
-      r.end();
-    }
+    // entering block ext0 the camera token takes the cls slot -- the encoder's (mod.rs:522-531) or the learned reference-view one:
+    // this block's first LayerNorm replaces row 0 of every sequence on its way in (and writes it back to the residual stream)
+    const float* tok0 = i == ext0 ? (cam_tok ? cam_tok : Bi(bp + ".camera_token")) : nullptr;
+    const int tok0_stride = (i == ext0 && cam_tok) ? D : 0;
     // MD_PREC_FP8: the operands of the four linear layers are e4m3 (LayerNorm / attention / GELU outputs are
     // written as e4m3 on static scales; weights were quantised per output channel at commit)
     const bool f8 = d->fp8;
@@ -862,7 +853,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     const float a_inv = 1.0f / md_model_s::Da3State::kActScale, h_inv = 1.0f / md_model_s::Da3State::kHidScale;
     sg.a[0] = k.n1g; sg.b[0] = k.n1b;
     r.begin("layernorm");
-    MD_TRY(launch_layernorm(xcur, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv));
+    MD_TRY(launch_layernorm(xcur, d->xn, rows, D, c.ln_eps, SS, sg, lin_prec, 0, st, a_inv, tok0, tok0_stride, tok0 ? xcur : nullptr));
     r.end();
     {
       GemmParams p;
@@ -871,11 +862,18 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
       p.v_plane = (long)m->vt_plane;
       p.epi = EPI_QKV; p.out = d->qk; p.vT = d->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = d->kpad; p.qscale = attn_qscale(m->prec);
       if (f8) { p.W[0] = d->w8[i].w[0]; p.wscale[0] = d->w8[i].s[0]; p.ascale = md_model_s::Da3State::kActScale; }
+      if (ext && !f8) {  // per-head q/k LayerNorm + 2-D RoPE in this GEMM's epilogue (global blocks: every patch at position (1, 1))
+        const std::string a = bp + ".blocks." + std::to_string(i) + ".attn.";
+        p.qkn_g[0] = Bi(a + "q_norm.gamma"); p.qkn_b[0] = Bi(a + "q_norm.beta");
+        p.qkn_g[1] = Bi(a + "k_norm.gamma"); p.qkn_b[1] = Bi(a + "k_norm.beta");
+        p.qkn_eps = c.qk_norm_eps; p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
+        p.rope_pw = pw; p.rope_global = is_global ? 1 : 0; p.rope_ntok = NT;
+      }
       r.begin("qkv_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, lin_prec, TILE_AUTO, st));
       r.end();
     }
-    if (ext) {  // per-head q/k LayerNorm + 2-D RoPE (global blocks: every patch at position (1,1))
+    if (ext && f8) {  // e4m3 operands: the separate kernel (the fused epilogue is not built for the block-scaled GEMM)
       const std::string a = bp + ".blocks." + std::to_string(i) + ".attn.";
       r.begin("qk_norm_rope");
       MD_TRY(launch_qk_norm_rope(d->qk, rows, SS, NT, D, heads, pw, Bi(a + "q_norm.gamma"), Bi(a + "q_norm.beta"),
