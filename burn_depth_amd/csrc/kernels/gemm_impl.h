@@ -1631,9 +1631,11 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
   return MD_OK;
 }
 
-// k-groups for a 64 x 64 launch (gemm_kernel's KSPLIT): only launches that leave most CUs idle (<= kSplitBlocks workgroups) behind a
-// long dependent k-loop, only 16-bit operand types (the fp32 mode keeps one summation order for every launch size)
-constexpr int kSplitBlocks = 160;
+// k-groups for a 64 x 64 launch (gemm_kernel's KSPLIT): only launches of at most kSplitBlocks workgroups (one or two four-wave
+// workgroups per CU: a wave or two per SIMD, each paying a full L2 round trip per k-tile) behind a long dependent k-loop, only
+// 16-bit operand types (the fp32 mode keeps one summation order for every launch size). 160 -> 512: DA3 metric_large at 518^2
+// (proj / fc2: 352 workgroups) 206 -> 221 frames/s, config 2 and config 5 unchanged.
+constexpr int kSplitBlocks = 512;
 template <typename T>
 static int pick_ksplit(const GemmParams& p) {
   if (std::is_same<T, float>::value || std::is_same<T, fp8_t>::value || p.batch > 1) return 1;
