@@ -91,6 +91,7 @@ struct GemmParams {
   const void* res1 = nullptr;   // optional residual inputs, element type T
   const void* res2 = nullptr;
   long ldr = 0;
+  int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)
   int res_mod = 0;              // > 0: res1's row = m % res_mod (a per-image table shared by the batch, or an input two weight groups share); res2 is never wrapped
   // EPI_PATCH_EMBED / EPI_QKV
   int seq_stride = 0;           // rows per sequence in the token buffers (tokens padded to x4)
@@ -143,6 +144,17 @@ struct GemmParams {
   long head_bstride[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float head_bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int head_acts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// The contraction split inside the workgroup (gemm_kernel's KSPLIT) changes the summation order of a launch that is small enough to
+// take it, so a result may differ in its last bits between batch sizes. Depth Pro promises (and tests) bit-identical images across batch
+// sizes: the split is off unless the calling thread turned it on -- the Depth-Anything-v3 engine does, around each of its calls.
+void gemm_allow_ksplit(int on);  // per host thread
+struct KsplitScope {
+  explicit KsplitScope(int on) { gemm_allow_ksplit(on); }
+  ~KsplitScope() { gemm_allow_ksplit(0); }
+  KsplitScope(const KsplitScope&) = delete;
+  KsplitScope& operator=(const KsplitScope&) = delete;
 };
 
 enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_128x64 = 3, TILE_64x64 = 4, TILE_AUTO = 99 };

@@ -58,8 +58,12 @@ static int pick_tile(const GemmParams& p, int prec) {
 
 int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
 
+static thread_local int g_ksplit_ok = 0;
+void gemm_allow_ksplit(int on) { g_ksplit_ok = on ? 1 : 0; }
+
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream) {
   const int ke = prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64);
+  p.ksplit_ok = g_ksplit_ok;
   if (p.ngroups < 1 || p.ngroups > kMaxGroups) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: ngroups %d", p.ngroups);
   if (p.N <= 0 || p.N % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: N=%d must be a positive multiple of 4", p.N);
   if (p.K <= 0 || p.K % ke != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", p.K, ke);

@@ -1638,7 +1638,7 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
 constexpr int kSplitBlocks = 512;
 template <typename T>
 static int pick_ksplit(const GemmParams& p) {
-  if (std::is_same<T, float>::value || std::is_same<T, fp8_t>::value || p.batch > 1) return 1;
+  if (!p.ksplit_ok || std::is_same<T, float>::value || std::is_same<T, fp8_t>::value || p.batch > 1) return 1;
   if (p.epi == EPI_HEAD || p.epi == EPI_HEAD_UP2 || p.qkn_g[0]) return 1;  // (the fused q/k-norm epilogue has workgroup barriers of its own)
   long tiles_m = 0;
   for (int g = 0; g < p.ngroups; ++g) tiles_m += cdiv(p.g_rows[g], 64);

@@ -467,6 +467,7 @@ int md_op_linear_tile(md_device_t dev, const float* x_dev, const float* w_dev, c
                       int act, int precision, int tile, float* out_dev, void* stream) {
   if (!dev || !x_dev || !w_dev || !out_dev) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
   if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_SHAPE, "invalid shape");
+  const KsplitScope ksplit(1);  // the stand-alone operator exercises the k-split form of the 64 x 64 kernel (what the DA3 engine runs)
   const bool storage_out = (precision & MD_OP_STORAGE_OUT) && (precision & 0xff) != MD_PREC_F32;
   precision &= 0xff;
   if (precision != MD_PREC_BF16 && precision != MD_PREC_F32 && precision != MD_PREC_FP8 && precision != MD_PREC_F16 && precision != MD_PREC_F16X2) MD_FAIL(MD_ERR_INVALID_ARG, "unknown precision %d", precision);
