@@ -150,6 +150,8 @@ struct GemmParams {
 // take it, so a result may differ in its last bits between batch sizes. Depth Pro promises (and tests) bit-identical images across batch
 // sizes: the split is off unless the calling thread turned it on -- the Depth-Anything-v3 engine does, around each of its calls.
 void gemm_allow_ksplit(int on);  // per host thread
+void gemm_count_ksplit_launch();   // diagnostics: md_gemm_ksplit_launches()
+long long gemm_ksplit_launches();
 struct KsplitScope {
   explicit KsplitScope(int on) { gemm_allow_ksplit(on); }
   ~KsplitScope() { gemm_allow_ksplit(0); }

@@ -1,3 +1,4 @@
+#include <atomic>
 // Host-side validation, tile selection and precision dispatch of the MFMA GEMM family.
 // The kernel template lives in gemm_impl.h and is instantiated per precision in
 // gemm_bf16.hip / gemm_f32.hip (separate translation units so they compile in parallel).
@@ -60,6 +61,9 @@ int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
 
 static thread_local int g_ksplit_ok = 0;
 void gemm_allow_ksplit(int on) { g_ksplit_ok = on ? 1 : 0; }
+static std::atomic<long long> g_ksplit_launches{0};
+void gemm_count_ksplit_launch() { g_ksplit_launches.fetch_add(1, std::memory_order_relaxed); }
+long long gemm_ksplit_launches() { return g_ksplit_launches.load(std::memory_order_relaxed); }
 
 int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream) {
   const int ke = prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64);

@@ -1626,6 +1626,7 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
       attr_set |= bit;
     }
   }
+  if (KSPLIT > 1) gemm_count_ksplit_launch();
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1)), dim3(WGM * WGN * 64 * KSPLIT), smem, stream, p);
   MD_HIP(hipGetLastError());
   return MD_OK;

@@ -669,6 +669,8 @@ __attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, 
 }
 }  // namespace
 
+int md_gemm_ksplit_launches(void) { return (int)(md::gemm_ksplit_launches() & 0x7fffffff); }
+
 int md_gemm_pick_tile(int M, int N, int K, int precision) {
   if (M <= 0 || N <= 0 || K <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "md_gemm_pick_tile: M=%d N=%d K=%d", M, N, K);
   md::GemmParams p;

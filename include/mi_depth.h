@@ -338,6 +338,10 @@ int md_bench_gemm(md_device_t dev, int mode, int M, int N, int K, int aux0, int 
 /* Host-only diagnostic (no GPU work): the tile the engine's launch cost model picks for a dense [M,K] x [N,K]^T GEMM in
  * `precision` -- 0 = 256x256, 1 = 128x128, 2 = 256x32 (N <= 32), 3 = 128x64, 4 = 64x64. */
 int md_gemm_pick_tile(int M, int N, int K, int precision);
+/* Host-only diagnostic: launches of the 64 x 64 GEMM kernel that split their contraction over wave groups inside the workgroup
+ * (gemm_kernel's KSPLIT) since the library was loaded (modulo 2^31) -- lets a test check that the form it
+ * means to exercise actually ran. */
+int md_gemm_ksplit_launches(void);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
 /* The same with the operand type (MD_PREC_BF16 | MD_PREC_F16) and the range of the random q / k values, uniform in
