@@ -72,10 +72,13 @@ def da3_dual_case(B=1, seed=0):
     W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, Wt.INIT_PARITY))
     x = seeded_input(seed, B, S, S)
     with torch.no_grad():
-        ref = D3.infer(x, W, cfg)
+        ref = D3.infer(x, W, cfg, debug=True)
     out = dict(batch=np.int32(B), seed=np.int32(seed), image_size=np.int32(S))
     for k in ("depth", "depth_confidence", "aux", "aux_confidence", "pose_encoding", "extrinsics", "intrinsics"):
         out[k] = ref[k].numpy().astype(np.float32)
+    # `infer_raw` (mod.rs:364-380): the main logits before the activations; `infer_from_tokens` (mod.rs:389-469): the four hooks'
+    # patch tokens the head consumes (every 5th token row keeps the fixture small: the test feeds the oracle's full tokens instead)
+    out["main_logits"] = ref["debug"]["main_logits"].numpy().astype(np.float32)
     return out
 
 
