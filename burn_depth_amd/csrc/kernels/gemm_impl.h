@@ -1645,8 +1645,8 @@ static int pick_ksplit(const GemmParams& p) {
   for (int g = 0; g < p.ngroups; ++g) tiles_m += cdiv(p.g_rows[g], 64);
   if (tiles_m * cdiv(p.N, 64) > kSplitBlocks) return 1;
   const int KT = p.K / (128 / (int)sizeof(T));
-  if (KT % 4 == 0 && KT / 4 >= 5) return 4;
-  if (KT % 2 == 0 && KT / 2 >= 8) return 2;
+  for (int ks = 4; ks >= 2; --ks)  // the most groups that divide the k-tiles and leave each at least five of them
+    if (KT % ks == 0 && KT / ks >= 5) return ks;
   return 1;
 }
 
@@ -1665,6 +1665,7 @@ static int launch_tile(GemmParams& p, int tile, hipStream_t stream) {
       if constexpr (!std::is_same<T, float>::value && !std::is_same<T, fp8_t>::value) {
         const int ks = pick_ksplit<T>(p);
         if (ks == 4) return launch_cfg<T, 64, 64, 2, 2, AMODE, 4>(p, stream);
+        if (ks == 3) return launch_cfg<T, 64, 64, 2, 2, AMODE, 3>(p, stream);
         if (ks == 2) return launch_cfg<T, 64, 64, 2, 2, AMODE, 2>(p, stream);
       }
       return launch_cfg<T, 64, 64, 2, 2, AMODE>(p, stream);

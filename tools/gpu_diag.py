@@ -154,7 +154,7 @@ def check_linear(dev):
              (300, 256, 128, _lib.TILE_128x64), (129, 132, 192, _lib.TILE_128x64), (1370, 384, 1536, _lib.TILE_64x64), (65, 68, 64, _lib.TILE_64x64),
              (1370, 384, 384, _lib.TILE_AUTO), (1370, 64, 576, _lib.TILE_AUTO),
              # small launches behind a long contraction: the 64 x 64 kernel splits K over two / four wave groups (gemm_kernel's KSPLIT)
-             (361, 384, 3456, _lib.TILE_64x64), (300, 128, 1024, _lib.TILE_64x64), (65, 68, 2048, _lib.TILE_AUTO), (1370, 384, 1536, _lib.TILE_AUTO)]
+             (361, 384, 3456, _lib.TILE_64x64), (300, 128, 1024, _lib.TILE_64x64), (1369, 64, 1728, _lib.TILE_64x64), (1370, 96, 768, _lib.TILE_64x64), (65, 68, 2048, _lib.TILE_AUTO), (1370, 384, 1536, _lib.TILE_AUTO)]
     for prec, pname in [(0, "bf16"), (1, "f32"), (3, "f16")]:
         rnd = ROUND[prec]
         for (M, N, K, tile) in cases:

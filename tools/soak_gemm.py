@@ -43,7 +43,7 @@ def run(dev, iters=25, verbose=False):
     # the 64 x 64 kernel with its contraction split over two / four wave groups of the workgroup (small launches behind a long k-loop:
     # gemm_kernel's KSPLIT): the groups' partial accumulators are summed through LDS -- exact on small integers, bf16 and f16 operands
     split_before = _lib.load().md_gemm_ksplit_launches()
-    for (M, N, K) in [(1370, 384, 1536), (361, 384, 3456), (300, 128, 1024), (65, 68, 2048)]:
+    for (M, N, K) in [(1370, 384, 1536), (361, 384, 3456), (300, 128, 1024), (65, 68, 2048), (1369, 64, 1728), (1370, 96, 768)]:
         x = torch.randint(-3, 4, (M, K), generator=g).float()
         w = torch.randint(-2, 3, (N, K), generator=g).float()
         b = torch.randint(-5, 6, (N,), generator=g).float()
@@ -54,7 +54,7 @@ def run(dev, iters=25, verbose=False):
                 d = (ops.linear(dev, xc, wc, bc, 0, prec, _lib.TILE_64x64) - want).abs().max().item()
                 if d != 0.0:
                     bad.append((M, N, K, it, "k-split", "prec", prec, d))
-    if _lib.load().md_gemm_ksplit_launches() - split_before < 8 * max(1, iters // 4):  # every launch above must have taken the split form
+    if _lib.load().md_gemm_ksplit_launches() - split_before < 12 * max(1, iters // 4):  # every launch above must have taken the split form
         bad.append(("k-split form did not run", _lib.load().md_gemm_ksplit_launches() - split_before))
     # the implicit-GEMM convolution (tap masks, 32-bit pixel index) and the one-division pixel-shuffle epilogue
     import torch.nn.functional as F
