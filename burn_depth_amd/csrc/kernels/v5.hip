@@ -78,19 +78,19 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // (PTERMS = 2: a third MFMA, P_lo.v_hi). A stage holds the four tiles (32 KB), two stages 64 KB: two workgroups per CU, so the
 // kernel is built for two waves per SIMD (256 registers) instead of four. Softmax, row sums and O stay fp32 as before.
 //
-// Small launches (KS = 2, QW = 2; one-plane types; >= 1024 keys and at most kKeySplitBlocks workgroups of the plain form): a single image
-// of a thousand-odd tokens gives far fewer workgroups than the chip has CUs (DA3 `small` at 518^2: 6 heads x 11 blocks of 128 queries =
-// 66), one wave per SIMD, and that wave runs the MFMAs and the softmax of its 22 key tiles one after the other (0.44 us per tile: the
-// launch is that chain plus ~7 us of floor, prologue and epilogue). Here a workgroup is QW = 2 query waves (64 queries: twice the
-// workgroups) x KS = 2 key groups: group g walks the g-th half of the key tiles through its own two-stage ring for the same queries;
-// the fast body keeps no running maximum, so the partial (O, l) of the groups simply add (f16: after moving to a common fixed offset),
-// through the idle rings once the walks are done -- each SIMD still holds one wave, with half the chain. (KS = 4 groups of four query
-// waves on the same 66 workgroups gained 9 % stand-alone and nothing in the model: profiles/r04_attention_key_split.txt -- the CU does
-// the same work either way; spreading it over twice the CUs is what shortens the chain.) The rule depends on the launch size, so the
-// last bits of a DA3 result may differ between one image and a batch; Depth Pro's 577-key sequences never take it. The rare safe pass
-// runs un-split on group 0.
-template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1, int QW = 4>
-__global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+// Key split inside the workgroup (KS = 4 for the one-plane types, 2 for split-half operands; launches of at most kKeySplitBlocks
+// workgroups over >= 1024 keys): a single image of a thousand-odd tokens gives fewer workgroups than the chip has CUs (DA3 `small`
+// at 518^2: 6 heads x 11 query blocks = 66), one wave per SIMD, and that wave runs its 22 key tiles' MFMAs and softmax one after the
+// other -- the launch is as long as that chain (16.5 us). With KS groups of four waves per workgroup, group g walks the g-th part of
+// the key tiles through its own two-stage ring for the SAME 128 queries, so every SIMD holds KS waves whose matrix and vector
+// work overlap; the fast body keeps no running maximum, so the partial (O, l) of the groups simply add (f16: after moving to a
+// common fixed offset), through the ring's LDS once the walks are done. Measured (profiles/r04_attention_key_split.txt): T = 1,
+// 1370 keys, 6 heads 16.8 -> 15.2 us stand-alone, 16.5 -> 10 us inside config 2's graph (2.016 -> 1.938 ms per frame); with more
+// workgroups than CUs the plain form is faster (8 images: 72 against 100 us), hence the launch-size rule -- which makes the LAST BITS
+// of a bf16 / f16 DA3 result depend on whether the launch was small (a different summation order of the same terms); Depth Pro's
+// 577-key sequences and the fp32 mode never take it. The rare safe pass runs un-split on group 0.
+template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1>
+__global__ __launch_bounds__(256 * KS, is_split<T>::value ? 2 : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
                                                            int S, int n_tokens, int heads, int D, int kpad, int qblocks,
                                                            float out_fp8_inv, long v_plane) {
   constexpr bool SP = is_split<T>::value;
@@ -99,16 +99,14 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   // one-plane types: static LDS (two stages | redo flag); split-half: 64 KB + flag as dynamic LDS (above the static limit)
   constexpr bool DYN = SP || KS > 1;
   static_assert(KS == 1 || (!FP8OUT && FAST && KS * 2 * STAGE <= 131072), "the key split is built for the fast body; the rings must fit the LDS");
-  static_assert(QW == 4 || (QW == 2 && KS > 1), "two query waves per workgroup come with the key split");
-  constexpr int NJ = 4 / QW;  // 8-row groups of a 32-row half tile each wave of a key group moves (4 waves: one each)
   __shared__ __attribute__((aligned(16))) char smem_static[DYN ? 16 : 2 * STAGE + 16];
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char* const smem = DYN ? smem_dyn : smem_static;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = KS > 1 ? (wave_all % QW) : wave_all;  // the query wave: 32 queries
-  const int grp = KS > 1 ? (wave_all / QW) : 0;          // the key group (own ring)
+  const int wave = KS > 1 ? (wave_all & 3) : wave_all;  // the query wave: 32 queries
+  const int grp = KS > 1 ? (wave_all >> 2) : 0;         // the key group (own ring)
   char* const ring = smem + grp * (2 * STAGE);
   int id;
   {
@@ -118,7 +116,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   }
   const int unit = id / qblocks, qb = id - unit * qblocks;
   const int seq = unit / heads, head = unit - seq * heads;
-  const int q0 = qb * (32 * QW) + wave * 32;
+  const int q0 = qb * 128 + wave * 32;
   const bool active = q0 < n_tokens;  // wave-uniform
   const int h = lane >> 5, c = lane & 31;
   const long two_d = 2L * D * kPlanes<T>;  // elements per q | k row (split-half: [q_hi | q_lo | k_hi | k_lo])
@@ -138,11 +136,11 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
     }
   }
 
-  // ---- global->LDS: 16 row-groups of 8 rows per stage (8 K + 8 V^T), 2 + 2 per wave of a four-wave key group (4 + 4 with two
-  //      query waves): rows r0 .. r0+7 and r0+32 .. r0+39 of
+  // ---- global->LDS: 16 row-groups of 8 rows per stage (8 K + 8 V^T), 2 + 2 per wave: rows r0 .. r0+7 and r0+32 .. r0+39 of
   //      each tile (the two share one swizzled chunk index). LDS-DMA through buffer descriptors of this (sequence, head):
   //      the per-lane byte offset is tile-invariant (one VGPR each for K and V^T) and the tile's offset is a scalar, so
   //      issuing a tile costs no vector instruction (with per-lane 64-bit addresses it cost 12, and 3-6 % of the kernel) ----
+  constexpr int QW = 4, NJ = 1;
   const unsigned krow_bytes = (unsigned)(two_d * sizeof(T));
   // K descriptor: the n_tokens key rows of this (sequence, head). The last tile addresses up to 63 rows past them: whether the
   // hardware's range check (which covers the vector offset; the scalar offset is implementation-defined) returns zeros for
@@ -152,7 +150,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   const auto ksrd = __builtin_amdgcn_make_buffer_rsrc((void*)(qk + seq_row0 * two_d + (SP ? 2 * D : D) + head * 64), 0, (int)((unsigned)(n_tokens - 1) * krow_bytes + 128u) + klo_bytes, 0x00020000);
   const auto vsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
   const auto vsrd_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + (SP ? v_plane : 0) + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
-  int kvoff[2], vvoff[2];  // NJ <= 2 (a fixed bound: an array of template-dependent size captured by the lambdas below loses the kernel's host stub)
+  int kvoff[NJ], vvoff[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int r0 = (wave + QW * j) * 8 + (lane >> 3);
@@ -407,7 +405,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
       float* const xch = (float*)smem;
       __syncthreads();  // every group has left its last tile
       if (grp > 0 && active) {
-        float* px = xch + ((grp - 1) * QW + wave) * (34 * 64) + lane;
+        float* px = xch + ((grp - 1) * 4 + wave) * (34 * 64) + lane;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -420,7 +418,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
       if (active) {
 #pragma unroll
         for (int g = 1; g < KS; ++g) {
-          const float* px = xch + ((g - 1) * QW + wave) * (34 * 64) + lane;
+          const float* px = xch + ((g - 1) * 4 + wave) * (34 * 64) + lane;
           float a = 1.f, b = 1.f;
           if constexpr (kOffsetFast) {  // f16: each group ran on its own fixed offset (the row maximum of its first tile)
             const float mg = px[33 * 64];
@@ -482,9 +480,9 @@ static int attn_pterms() {
   return v;
 }
 
-// launches that take the small-launch form: sequences of >= 16 key tiles, and so few workgroups of the plain form (128 queries each)
-// that most CUs would idle
-static int kKeySplitMin = 1024, kKeySplitBlocks = 128;
+// launches that take the key-split workgroups: sequences long enough for four groups of >= 4 tiles, and few enough workgroups that
+// CUs would idle (measured break-even between 176 and 352 workgroups)
+static int kKeySplitMin = 1024, kKeySplitBlocks = 192;
 // MD_ATTN_KEYSPLIT=0 turns the key split off (DEBUG-ONLY A/B knob, read once per process)
 static bool key_split_enabled() {
   static int v = -1;
@@ -506,54 +504,52 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
   const dim3 grid((unsigned)blocks), block(256);
-  // small launches over long sequences: 64 queries x two key groups per workgroup (the kernel's header)
-  const bool small = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && out_fp8_inv <= 0.f && key_split_enabled();
-  const int qblocks_s = (n_tokens + 63) / 64;
-  const dim3 grid_s((unsigned)((long)qblocks_s * heads * nseq));
-  auto set_smem = [&](const void* kern, bool* attr_set, int smem) -> int {  // the attribute is per DEVICE: once per (kernel, device ordinal)
-    int ordinal = 0;
-    MD_HIP(hipGetDevice(&ordinal));
-    if (ordinal < 0 || ordinal >= 64 || !attr_set[ordinal]) {
-      MD_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      if (ordinal >= 0 && ordinal < 64) attr_set[ordinal] = true;
-    }
-    return MD_OK;
-  };
   if (prec == MD_PREC_F16X2) {
     if (out_fp8_inv > 0.f || v_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "attention: split-half operands need the V^T plane offset and write split-half rows");
     auto go = [&](auto kern, auto ks_c) -> int {
       constexpr int KS = decltype(ks_c)::value, smem = KS * 2 * 32768 + 16;
+      // the attribute is per DEVICE: it is set once per (kernel, device ordinal), not once per process
       static bool attr_set[64] = {};
-      MD_TRY(set_smem((const void*)kern, attr_set, smem));
-      const dim3 g = KS == 1 ? grid : grid_s;
-      const int qb = KS == 1 ? qblocks : qblocks_s;
-      hipLaunchKernelGGL(kern, g, block, smem, s, (const f16s_t*)qk, (const f16s_t*)vT, (f16s_t*)out, S, n_tokens, heads, D, kpad, qb, 0.f, v_plane);
+      int ordinal = 0;
+      MD_HIP(hipGetDevice(&ordinal));
+      if (ordinal < 0 || ordinal >= 64 || !attr_set[ordinal]) {
+        MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        if (ordinal >= 0 && ordinal < 64) attr_set[ordinal] = true;
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, (const f16s_t*)qk, (const f16s_t*)vT, (f16s_t*)out, S, n_tokens, heads, D, kpad, qblocks, 0.f, v_plane);
       return MD_OK;
     };
     typedef std::integral_constant<int, 1> ks1;
     typedef std::integral_constant<int, 2> ks2;
+    const bool split = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && key_split_enabled();
     if (attn_pterms() == 1) {
-      if (small) MD_TRY(go(attention_kernel<f16s_t, false, true, 1, 2, 2>, ks2()));
+      if (split) MD_TRY(go(attention_kernel<f16s_t, false, true, 1, 2>, ks2()));
       else MD_TRY(go(attention_kernel<f16s_t, false, true, 1>, ks1()));
     } else {
-      if (small) MD_TRY(go(attention_kernel<f16s_t, false, true, 2, 2, 2>, ks2()));
+      if (split) MD_TRY(go(attention_kernel<f16s_t, false, true, 2, 2>, ks2()));
       else MD_TRY(go(attention_kernel<f16s_t, false, true, 2>, ks1()));
     }
   } else if (out_fp8_inv > 0.f) {
     if (prec != MD_PREC_BF16) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: e4m3 output rows are built for bf16 operands");
     hipLaunchKernelGGL((attention_kernel<bf16_t, true, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
-  } else if (small) {
-    constexpr int smem = 2 * 2 * 16384 + 16;
+  } else if (n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && key_split_enabled()) {
+    // key split inside the workgroup (see the kernel's header): chosen by the sequence length alone
+    constexpr int KS = 4, smem = KS * 2 * 16384 + 16;
     auto go = [&](auto kern, auto tag) -> int {
       typedef decltype(tag) TT;
       static bool attr_set[64] = {};
-      MD_TRY(set_smem((const void*)kern, attr_set, smem));
-      hipLaunchKernelGGL(kern, grid_s, block, smem, s, (const TT*)qk, (const TT*)vT, (TT*)out, S, n_tokens, heads, D, kpad, qblocks_s, 0.f, 0L);
+      int ordinal = 0;
+      MD_HIP(hipGetDevice(&ordinal));
+      if (ordinal < 0 || ordinal >= 64 || !attr_set[ordinal]) {
+        MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        if (ordinal >= 0 && ordinal < 64) attr_set[ordinal] = true;
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, (const TT*)qk, (const TT*)vT, (TT*)out, S, n_tokens, heads, D, kpad, qblocks, 0.f, 0L);
       return MD_OK;
     };
-    if (prec == MD_PREC_F16) MD_TRY(go(attention_kernel<f16_t, false, true, 1, 2, 2>, f16_t()));
-    else MD_TRY(go(attention_kernel<bf16_t, false, true, 1, 2, 2>, bf16_t()));
+    if (prec == MD_PREC_F16) MD_TRY(go(attention_kernel<f16_t, false, true, 1, KS>, f16_t()));
+    else MD_TRY(go(attention_kernel<bf16_t, false, true, 1, KS>, bf16_t()));
   } else if (prec == MD_PREC_F16) {
     hipLaunchKernelGGL((attention_kernel<f16_t, false, true>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);

@@ -197,8 +197,8 @@ int md_da3_load(md_device_t dev, const md_da3_cfg* cfg, const char* path, md_mod
  * "allocs" stop moving). image_size x image_width of the config is just the size the model is prepared for at creation.
  * Up to 16 sizes stay cached (least recently used first out).
  * Numerics across batch sizes: in the 16-bit operand modes (bf16 / f16 / f16x2) a launch that leaves most CUs idle behind a long
- * contraction splits it over wave groups, so image i of a batch and the same image alone agree to
- * rounding, not to the bit; the fp32 mode and every Depth Pro call are bit-identical across batch sizes. */
+ * contraction splits it over wave groups, and a small attention launch splits its keys over two groups (DESIGN.md sections 5.1, 9),
+ * so image i of a batch and the same image alone agree to rounding, not to the bit; the fp32 mode and every Depth Pro call are bit-identical across batch sizes. */
 int md_da3_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, int out_kind,
                  void* stream);
 /* `DepthAnything3Inference` (depth_anything3/mod.rs:231-239) for the dual-head `small` variant. Every pointer
