@@ -461,6 +461,19 @@ def test_depth_anything3_small_infer_with_camera(diag, dev):
     assert len(diag.RESULTS) - start >= 7
 
 
+@pytest.mark.parametrize("precision", [1, 4, 0])
+def test_depth_anything3_small_non_square_at_the_real_width(diag, dev, precision):
+    # the reference's `small` preset on a 266 x 518 input (19 x 37 patches): grouped fusion pyramids, the k-split GEMMs, the
+    # fused q/k-norm + RoPE epilogue and the small-launch attention form away from the square 518^2 case
+    from burn_depth_amd.config import DepthAnything3Config
+    cfg = DepthAnything3Config.small()
+    cfg.image_size, cfg.image_width = 266, 518
+    start = len(diag.RESULTS)
+    diag.guarded("da3-small-ns")(diag.run_da3)(dev, cfg, f"da3-small-266x518/p{precision}", 1, precision, f16_weights=True)
+    _assert_new_results_ok(diag, start)
+    assert len(diag.RESULTS) - start >= 10
+
+
 def test_depth_anything3_mono_variant_ignores_camera_inputs(diag, dev):
     # mod.rs:522-527: `(Some(encoder), Some(extr), Some(intr)) => ..., _ => None` -- no encoder, no conditioning
     from burn_depth_amd.config import DepthAnything3Config, Precision
