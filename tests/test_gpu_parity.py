@@ -463,8 +463,8 @@ def test_depth_anything3_small_infer_with_camera(diag, dev):
 
 @pytest.mark.parametrize("precision", [1, 4, 0])
 def test_depth_anything3_small_non_square_at_the_real_width(diag, dev, precision):
-    # the reference's `small` preset on a 266 x 518 input (19 x 37 patches): grouped fusion pyramids, the k-split GEMMs, the
-    # fused q/k-norm + RoPE epilogue and the small-launch attention form away from the square 518^2 case
+    # the reference's `small` preset on a 266 x 518 input (19 x 37 patches, 704 tokens): grouped fusion pyramids, the k-split GEMMs
+    # and the fused q/k-norm + RoPE epilogue away from the square 518^2 case (whose 1370 tokens also take the small-launch attention form)
     from burn_depth_amd.config import DepthAnything3Config
     cfg = DepthAnything3Config.small()
     cfg.image_size, cfg.image_width = 266, 518
