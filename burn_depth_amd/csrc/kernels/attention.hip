@@ -17,6 +17,7 @@
 // order inside a 32-key sub-tile is permuted (bits 2 and 3 of the key index swapped when K rows
 // are read from LDS) so that registers 8s..8s+7 hold the 8 consecutive keys the V^T fragment
 // of k-step s holds.
+#include <atomic>
 #include "ops.h"
 #include "elem.h"
 
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
       const int per = SAFE ? NT : (NT + KS - 1) / KS;
       const int tb = grp * per < NT ? grp * per : NT;
       const int te = SAFE ? (grp == 0 ? NT : 0) : (tb + per < NT ? tb + per : NT);
-      const int n = te - tb;
+      const int n = te > tb ? te - tb : 0;  // an idle group (safe pass: every group but 0) takes exactly `per` barriers below
       const int nfull = (last_partial && te == NT) ? n - 1 : n;  // this group's tiles without masked keys
       auto top_g = [&](int t) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -470,30 +471,32 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   }
 }
 
-// split-half attention: P as one half (1) or as hi + lo (2, the default and what every test and published number uses).
-// MD_ATTN_PTERMS=1 is a DEBUG-ONLY measurement knob (read once per process; it changes the accurate mode's numerics: depth
-// L_inf 3.2e-4 instead of 1.3e-4 for +1 % frames/s) -- not part of the supported configuration surface.
+// split-half attention: P as one half (1) or as hi + lo (2: what the product runs, every test and every published number).
+// The two A/B switches below exist in DIAGNOSTIC builds only (`make DIAG=1` defines MD_DIAG_KNOBS): the shipped library reads no
+// environment variable that changes numerics or kernel choice.
+//   MD_ATTN_PTERMS=1    P in one plane (depth L_inf 3.2e-4 instead of 1.3e-4 for +1 % frames/s)
+//   MD_ATTN_KEYSPLIT=0  the small-launch form off
+#ifdef MD_DIAG_KNOBS
+static int diag_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0] >= '0' && e[0] <= '9') ? e[0] - '0' : dflt;
+}
 static int attn_pterms() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MD_ATTN_PTERMS");
-    v = (e && e[0] == '1') ? 1 : 2;
-  }
+  static const int v = diag_env("MD_ATTN_PTERMS", 2) == 1 ? 1 : 2;
   return v;
 }
+static bool key_split_enabled() {
+  static const int v = diag_env("MD_ATTN_KEYSPLIT", 1);
+  return v != 0;
+}
+#else
+static constexpr int attn_pterms() { return 2; }
+static constexpr bool key_split_enabled() { return true; }
+#endif
 
 // launches that take the small-launch form: sequences of >= 16 key tiles, and so few workgroups of the plain form (128 queries each)
 // that most CUs would idle
-static int kKeySplitMin = 1024, kKeySplitBlocks = 128;
-// MD_ATTN_KEYSPLIT=0 turns the key split off (DEBUG-ONLY A/B knob, read once per process)
-static bool key_split_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MD_ATTN_KEYSPLIT");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
+static constexpr int kKeySplitMin = 1024, kKeySplitBlocks = 128;
 
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
                      int kpad, int prec, hipStream_t s, float out_fp8_inv, long v_plane) {
@@ -510,12 +513,13 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   const bool small = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && out_fp8_inv <= 0.f && key_split_enabled();
   const int qblocks_s = (n_tokens + 63) / 64;
   const dim3 grid_s((unsigned)((long)qblocks_s * heads * nseq));
-  auto set_smem = [&](const void* kern, bool* attr_set, int smem) -> int {  // the attribute is per DEVICE: once per (kernel, device ordinal)
+  auto set_smem = [&](const void* kern, std::atomic<unsigned long>* attr_set, int smem) -> int {  // the attribute is per DEVICE: once per (kernel, device ordinal)
     int ordinal = 0;
     MD_HIP(hipGetDevice(&ordinal));
-    if (ordinal < 0 || ordinal >= 64 || !attr_set[ordinal]) {
+    const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
+    if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {  // concurrent first launches at worst both set the attribute
       MD_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      if (ordinal >= 0 && ordinal < 64) attr_set[ordinal] = true;
+      attr_set->fetch_or(bit, std::memory_order_release);
     }
     return MD_OK;
   };
@@ -523,8 +527,8 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
     if (out_fp8_inv > 0.f || v_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "attention: split-half operands need the V^T plane offset and write split-half rows");
     auto go = [&](auto kern, auto ks_c) -> int {
       constexpr int KS = decltype(ks_c)::value, smem = KS * 2 * 32768 + 16;
-      static bool attr_set[64] = {};
-      MD_TRY(set_smem((const void*)kern, attr_set, smem));
+      static std::atomic<unsigned long> attr_set{0};
+      MD_TRY(set_smem((const void*)kern, &attr_set, smem));
       const dim3 g = KS == 1 ? grid : grid_s;
       const int qb = KS == 1 ? qblocks : qblocks_s;
       hipLaunchKernelGGL(kern, g, block, smem, s, (const f16s_t*)qk, (const f16s_t*)vT, (f16s_t*)out, S, n_tokens, heads, D, kpad, qb, 0.f, v_plane);
@@ -547,8 +551,8 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
     constexpr int smem = 2 * 2 * 16384 + 16;
     auto go = [&](auto kern, auto tag) -> int {
       typedef decltype(tag) TT;
-      static bool attr_set[64] = {};
-      MD_TRY(set_smem((const void*)kern, attr_set, smem));
+      static std::atomic<unsigned long> attr_set{0};
+      MD_TRY(set_smem((const void*)kern, &attr_set, smem));
       hipLaunchKernelGGL(kern, grid_s, block, smem, s, (const TT*)qk, (const TT*)vT, (TT*)out, S, n_tokens, heads, D, kpad, qblocks_s, 0.f, 0L);
       return MD_OK;
     };

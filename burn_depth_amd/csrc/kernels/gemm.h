@@ -149,14 +149,17 @@ struct GemmParams {
 // The contraction split inside the workgroup (gemm_kernel's KSPLIT) changes the summation order of a launch that is small enough to
 // take it, so a result may differ in its last bits between batch sizes. Depth Pro promises (and tests) bit-identical images across batch
 // sizes: the split is off unless the calling thread turned it on -- the Depth-Anything-v3 engine does, around each of its calls.
-void gemm_allow_ksplit(int on);  // per host thread
+int gemm_allow_ksplit(int on);  // per host thread; returns the previous value
 void gemm_count_ksplit_launch();   // diagnostics: md_gemm_ksplit_launches()
 long long gemm_ksplit_launches();
 struct KsplitScope {
-  explicit KsplitScope(int on) { gemm_allow_ksplit(on); }
-  ~KsplitScope() { gemm_allow_ksplit(0); }
+  explicit KsplitScope(int on) : prev_(gemm_allow_ksplit(on)) {}
+  ~KsplitScope() { gemm_allow_ksplit(prev_); }  // nested scopes restore the outer value
   KsplitScope(const KsplitScope&) = delete;
   KsplitScope& operator=(const KsplitScope&) = delete;
+
+ private:
+  int prev_;
 };
 
 enum GemmTile : int { TILE_256x256 = 0, TILE_128x128 = 1, TILE_256x32 = 2, TILE_128x64 = 3, TILE_64x64 = 4, TILE_AUTO = 99 };

@@ -60,7 +60,11 @@ static int pick_tile(const GemmParams& p, int prec) {
 int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
 
 static thread_local int g_ksplit_ok = 0;
-void gemm_allow_ksplit(int on) { g_ksplit_ok = on ? 1 : 0; }
+int gemm_allow_ksplit(int on) {  // returns the previous value (KsplitScope restores it)
+  const int prev = g_ksplit_ok;
+  g_ksplit_ok = on ? 1 : 0;
+  return prev;
+}
 static std::atomic<long long> g_ksplit_launches{0};
 void gemm_count_ksplit_launch() { g_ksplit_launches.fetch_add(1, std::memory_order_relaxed); }
 long long gemm_ksplit_launches() { return g_ksplit_launches.load(std::memory_order_relaxed); }

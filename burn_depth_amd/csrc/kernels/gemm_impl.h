@@ -25,6 +25,7 @@
 //    contiguous range of tiles that share the same A row-panel.
 #pragma once
 
+#include <atomic>
 #include <type_traits>
 #include "elem.h"
 #include "gemm.h"
@@ -1538,14 +1539,14 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   prep_tile_map(p, tiles_m, cdiv(p.N, BN));
   constexpr int smem = 5 * 256 * 128;  // 160 KB: the whole LDS of a CU
   const dim3 grid((unsigned)blocks, (unsigned)(p.batch > 1 ? p.batch : 1));
-  auto go = [&](auto kern, unsigned long* attr_set) -> int {
+  auto go = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
     // hipFuncAttributeMaxDynamicSharedMemorySize is per DEVICE: one bit per device ordinal (a process may drive several GPUs)
     int ordinal = 0;
     MD_HIP(hipGetDevice(&ordinal));
     const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
-    if (!bit || !(*attr_set & bit)) {
+    if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {  // concurrent first launches at worst both set the attribute
       MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      *attr_set |= bit;
+      attr_set->fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
     MD_HIP(hipGetLastError());
@@ -1567,7 +1568,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     else if (vec8 && ((p.epi == EPI_STORE && p.res_mod == 0 && p.act != ACT_GELU) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0))) ek = 2;
   }
   const bool diag = p.stamps != nullptr || p.debug_flags != 0;
-  static unsigned long set[5] = {0, 0, 0, 0, 0}, dset[5] = {0, 0, 0, 0, 0};
+  static std::atomic<unsigned long> set[5], dset[5];  // zero-initialised statics
   if (diag) {  // md_bench_gemm only: the stamped / ablation build exists for dense bf16 operands
     if constexpr (std::is_same<T, bf16_t>::value && AMODE == A_DENSE) {
       switch (ek) {
@@ -1616,14 +1617,14 @@ static int launch_cfg(GemmParams& p, hipStream_t stream) {
   prep_tile_map(p, tiles_m, tiles_n);
   constexpr int smem = 2 * (BM + BN) * 128 * KSPLIT;
   auto kern = gemm_kernel<T, BM, BN, WGM, WGN, AMODE, KSPLIT>;
-  static unsigned long attr_set = 0;  // one bit per device ordinal (the attribute is per device)
+  static std::atomic<unsigned long> attr_set{0};  // one bit per device ordinal (the attribute is per device)
   {
     int ordinal = 0;
     MD_HIP(hipGetDevice(&ordinal));
     const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
-    if (!bit || !(attr_set & bit)) {
+    if (!bit || !(attr_set.load(std::memory_order_acquire) & bit)) {
       MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      attr_set |= bit;
+      attr_set.fetch_or(bit, std::memory_order_release);
     }
   }
   if (KSPLIT > 1) gemm_count_ksplit_launch();

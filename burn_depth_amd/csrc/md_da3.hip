@@ -776,6 +776,7 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
     const size_t need = align_up(n_in, 64) + n_tok + camera_encoder_scratch_floats(B, V, D);
     if (need > d->cam_enc_cap) {
       MD_HIP(hipStreamSynchronize(st));
+      da3_drop_graphs(m);  // graphs captured with camera inputs hold the old buffer's addresses (cam_tok, the staged inputs)
       if (d->cam_enc_ws) MD_HIP(hipFree(d->cam_enc_ws));
       d->cam_enc_ws = nullptr; d->cam_enc_cap = 0;
       MD_HIP(hipMalloc((void**)&d->cam_enc_ws, need * 4));

@@ -145,12 +145,14 @@ inline void add_pack_deconv_pair(md_model_s* m, const std::string& name, const s
 template <typename F>
 inline int run_with_graph(md_model_s* m, hipStream_t st, const std::vector<uintptr_t>& key, bool eligible, F&& body) {
   if (!m->graph_enabled || !eligible || m->timing_enabled || m->taps_enabled) return body();
-  md_model_s::GraphEntry& e = m->graphs[key];
-  if (e.exec) {
-    MD_HIP(hipGraphLaunch(e.exec, st));
-    return MD_OK;
+  {
+    md_model_s::GraphEntry& e = m->graphs[key];  // not held across body(): a body that regrows a buffer drops every graph (and this entry)
+    if (e.exec) {
+      MD_HIP(hipGraphLaunch(e.exec, st));
+      return MD_OK;
+    }
+    if (e.seen++ == 0) return body();
   }
-  if (e.seen++ == 0) return body();
   MD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
   const int s = body();
   hipGraph_t g = nullptr;
@@ -168,7 +170,7 @@ inline int run_with_graph(md_model_s* m, hipStream_t st, const std::vector<uintp
     m->graphs.erase(key);
     MD_FAIL(MD_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
   }
-  e.exec = ex;
+  m->graphs[key].exec = ex;
   MD_HIP(hipGraphLaunch(ex, st));
   return MD_OK;
 }
