@@ -39,6 +39,17 @@ class MdDa3Cfg(C.Structure):
                 ("ln_eps", C.c_float), ("image_width", C.c_int)]
 
 
+class MdNchwView(C.Structure):
+    """md_nchw_view (include/mi_depth.h): one NCHW fp32 tensor with its shape."""
+    _fields_ = [("data", C.c_void_p), ("channels", C.c_int), ("height", C.c_int), ("width", C.c_int)]
+
+
+class MdHeadDebug(C.Structure):
+    """md_head_debug (include/mi_depth.h) = `HeadDebug`, depth_pro/mod.rs:135-142."""
+    _fields_ = [("conv0", C.c_void_p), ("deconv", C.c_void_p), ("conv1", C.c_void_p), ("relu", C.c_void_p),
+                ("pre_out", C.c_void_p), ("canonical", C.c_void_p)]
+
+
 class MdDepthProCfg(C.Structure):
     _fields_ = [
         ("patch_encoder_preset", C.c_char_p),
@@ -79,6 +90,8 @@ SYMBOLS = {
     "md_model_destroy": (_I, [_P]),
     "md_model_fork": (_I, [_P, C.POINTER(_P)]),
     "md_depth_pro_infer": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "md_depth_pro_decoder_from_features": (_I, [_P, C.POINTER(MdNchwView), _I, _I, _I, _P, _P, C.POINTER(C.c_void_p), _I, _P]),
+    "md_depth_pro_head_debug": (_I, [_P, C.POINTER(MdNchwView), _I, _I, C.POINTER(MdHeadDebug), _I, _P]),
     "md_depth_pro_infer_windows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "md_infer_from_rgb": (_I, [_P, _P, C.c_size_t, _I, _I, _I, _P, _P, _P, _I, _P]),
     "md_da3_cfg_default": (None, [C.POINTER(MdDa3Cfg)]),

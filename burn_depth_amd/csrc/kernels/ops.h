@@ -73,7 +73,11 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width = 0);
 
 // layout converters (debug taps, stand-alone ops)
-int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s);
+// ld: logical elements between consecutive output pixels (0 = C); padding columns are left untouched
+int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s, long ld = 0);
+// head_debug's un-fused tail: pre_out = <relu_map pixel, w> + bias, canonical = relu(pre_out); fp32 [pixels] each (either may be NULL)
+int launch_head_tail_debug(const void* relu_map, long ld, long pixels, int C, const float* w, const float* bias, float* pre_out,
+                           float* canonical, int prec, hipStream_t s);
 int launch_nhwc_to_nchw(const void* in, int B, int C, int H, int W, long ld, int coff, float* out, int prec,
                         hipStream_t s);
 // width: logical row width -- needed by MD_PREC_F16X2, whose rows are [hi: width | lo: width] (ignored otherwise)

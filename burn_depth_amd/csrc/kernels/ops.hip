@@ -723,7 +723,7 @@ int launch_rows_to_f32(const void* in, long count, float* out, int prec, hipStre
 
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, int H, int W, T* __restrict__ out,
-                                    int relu) {
+                                    int relu, long ld) {
   const long total = (long)B * C * H * W;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % C);
@@ -734,7 +734,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int B, int C, 
     const int b = (int)(t / H);
     float v = in[(((long)b * C + c) * H + y) * W + xw];
     if (relu) v = fmaxf(v, 0.f);
-    st1p<T>(out + (e / C) * (C * kPlanes<T>) + c, C, v);  // split-half pixels: [hi: C | lo: C]
+    st1p<T>(out + (e / C) * (ld * kPlanes<T>) + c, ld, v);  // ld = logical pixel stride; split-half pixels: [hi: ld | lo: ld]
   }
 }
 template <typename T>
@@ -753,9 +753,32 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, int B, int C, int 
   }
 }
 
-int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s) {
+int launch_nchw_to_nhwc(const float* in, int B, int C, int H, int W, void* out, int prec, int relu, hipStream_t s, long ld) {
   const long total = (long)B * C * H * W;
-  MD_BY_PREC(prec, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W, (T*)out, relu));
+  if (ld != 0 && ld < C) MD_FAIL(MD_ERR_INVALID_ARG, "nchw_to_nhwc: pixel stride %ld below C %d", ld, C);
+  MD_BY_PREC(prec, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, in, B, C, H, W, (T*)out, relu, ld ? ld : (long)C));
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
+// `head_debug`'s un-fused tail (depth_pro/mod.rs:293-296): pre_out = conv_out 1x1 (C -> 1, + bias) on the materialised relu(conv1) map,
+// canonical = relu(pre_out). One thread per pixel (a debug entry: the product path does this inside the fused head epilogue).
+template <typename T>
+__global__ void head_tail_debug_kernel(const T* __restrict__ relu_map, long ld, long pixels, int C, const float* __restrict__ w,
+                                       const float* __restrict__ bias, float* __restrict__ pre_out, float* __restrict__ canonical) {
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < pixels; e += (long)gridDim.x * blockDim.x) {
+    const T* px = relu_map + e * (ld * kPlanes<T>);
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(ld1p<T>(px + c, ld), w[c], acc);
+    acc += bias ? bias[0] : 0.f;
+    if (pre_out) pre_out[e] = acc;
+    if (canonical) canonical[e] = fmaxf(acc, 0.f);
+  }
+}
+int launch_head_tail_debug(const void* relu_map, long ld, long pixels, int C, const float* w, const float* bias, float* pre_out,
+                           float* canonical, int prec, hipStream_t s) {
+  MD_BY_PREC(prec, hipLaunchKernelGGL(head_tail_debug_kernel<T>, dim3(grid_for(pixels)), dim3(256), 0, s, (const T*)relu_map, ld, pixels, C, w,
+                                      bias, pre_out, canonical));
   MD_HIP(hipGetLastError());
   return MD_OK;
 }

@@ -229,6 +229,17 @@ int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int
                      nullptr, 0);
 }
 
+int md_depth_pro_decoder_from_features(md_model_t m, const md_nchw_view* features, int levels, int B, int in_kind,
+                                       float* out_features, float* out_lowres, float* const* out_fusions, int out_kind,
+                                       void* stream) {
+  return model_decoder_from_features(m, features, levels, B, in_kind, out_features, out_lowres, out_fusions, out_kind, (hipStream_t)stream);
+}
+
+int md_depth_pro_head_debug(md_model_t m, const md_nchw_view* feature, int B, int in_kind, const md_head_debug* out, int out_kind,
+                            void* stream) {
+  return model_head_debug(m, feature, B, in_kind, out, out_kind, (hipStream_t)stream);
+}
+
 int md_depth_pro_infer_windows(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                                float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, int parts,
                                float* window_ms, float* tail_ms, void* stream) {
@@ -282,6 +293,7 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
   else if (k == "weight_terms") *out = model_root(m)->wterms;
   else if (k == "allocs") *out = m->alloc_count;
   else if (k == "da3_shape_builds") *out = da3_shape_builds(m);
+  else if (model_decoder_query(m, k, out)) {}
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
 }

@@ -166,6 +166,13 @@ int model_fork(md_model_t src, md_model_t* out);
 inline md_model_s* model_root(md_model_s* m) { return m->parent ? m->parent : m; }
 int model_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth, float* focal,
                 float* fovx, float* fovy, int out_kind, hipStream_t stream, const uint8_t* rgb, size_t rgb_len);
+// DepthPro::decoder_from_features / head_debug (depth_pro/mod.rs:262-307): the decoder / the depth head alone on caller tensors
+int model_decoder_from_features(md_model_t m, const md_nchw_view* features, int levels, int B, int in_kind, float* out_features,
+                                float* out_lowres, float* const* out_fusions, int out_kind, hipStream_t stream);
+int model_head_debug(md_model_t m, const md_nchw_view* feature, int B, int in_kind, const md_head_debug* out, int out_kind,
+                     hipStream_t stream);
+// "decoder_levels" / "decoder_features" / "decoder_level{l}_channels" / "decoder_level{l}_size" of md_model_query; false = not such a key
+bool model_decoder_query(md_model_t m, const std::string& key, int64_t* out);
 // Tile-parallel mode (SURVEY 8(e) "optional second mode": the 35 + 2 ViT sequences of one image never interact before
 // `merge`, layers/encoder.rs:329-348, 379-390): the ViT stage of ONE call is split into `parts` windows of the sequence
 // range; a rank runs its window, every other part's final tokens and hook rows travel to the root, the root runs the rest.

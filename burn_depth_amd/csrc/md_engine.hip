@@ -552,6 +552,7 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   add_pack_c1c3(m, "head.outconv_conv0", "decoder.fusions.0.out_conv", "head.conv0", F, F, F / 2);
   add_pack(m, "head.deconv.weight", PACK_DECONV, F / 2, F / 2, 2);
   add_pack_head_fused(m, "head.deconv_conv1", "head.deconv", "head.conv1", F / 2, F / 2, 32);
+  add_pack(m, "head.conv1.weight", PACK_CONV3, 32, F / 2, 3);  // head_debug's un-fused conv1 (mod.rs:292); 74 KB
   if (cfg.use_fov_head) {
     if (cfg.has_fov_vit) {
       add_pack(m, "fov.encoder_proj.weight", PACK_NK, F / 2, cfg.fv.D, 1);
@@ -1157,7 +1158,7 @@ static int run_encoder_tail(Run& r, const md_model_s::IndexSet& ix) {
   return MD_OK;
 }
 
-static int run_decoder_head(Run& r) {
+static int run_decoder_head(Run& r, bool decoder_only = false) {
   md_model_s* m = r.m;
   md_model_s::Buffers* b = m->buf;
   const ModelCfg& c = m->cfg;
@@ -1220,6 +1221,7 @@ static int run_decoder_head(Run& r) {
     }
   }
   if (m->taps_enabled) MD_TRY(r.tap_nhwc("decoder_feature", feats, F, hw[0], hw[0], Fp));
+  if (decoder_only) return MD_OK;  // decoder_from_features (mod.rs:262-267)
   // depth head (mod.rs:105-112)
   const int F2 = F / 2, F2p = cpad(m, F2);
   if (fused_c0) {
@@ -1258,6 +1260,166 @@ static int run_decoder_head(Run& r) {
     r.end();
   }
   MD_TRY(r.tap_f32("canonical_inverse_depth", b->canonical, r.B, 1, 2 * hw[0], 2 * hw[0]));
+  return MD_OK;
+}
+
+// ---- debug entries on caller tensors: DepthPro::decoder_from_features / head_debug (mod.rs:262-307) ----
+namespace {
+struct DeviceScratch {  // per-call device memory of the debug entries (not a hot path)
+  void* p = nullptr;
+  ~DeviceScratch() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; MD_FAIL(MD_ERR_OOM, "hipMalloc of %zu bytes for a debug entry failed", bytes); }
+    return MD_OK;
+  }
+};
+struct TapsOn {  // the debug entries emit through the tap machinery whatever the model's tap switch says
+  md_model_s* m; bool was;
+  explicit TapsOn(md_model_s* mm) : m(mm), was(mm->taps_enabled) { m->taps_enabled = true; }
+  ~TapsOn() { m->taps_enabled = was; }
+};
+}  // namespace
+
+static void decoder_level_shapes(md_model_s* m, int ddims[5], int hw[5]) {
+  level_sizes(m, hw);
+  const int* dims = m->cfg.pv.feat_dims;
+  ddims[0] = m->cfg.F; ddims[1] = dims[0]; ddims[2] = dims[1]; ddims[3] = dims[2]; ddims[4] = dims[3];
+}
+
+bool model_decoder_query(md_model_t m, const std::string& key, int64_t* out) {
+  if (!m || m->kind != 0) return false;
+  int ddims[5], hw[5];
+  decoder_level_shapes(m, ddims, hw);
+  if (key == "decoder_levels") { *out = 5; return true; }
+  if (key == "decoder_features") { *out = m->cfg.F; return true; }
+  for (int l = 0; l < 5; ++l) {
+    if (key == "decoder_level" + std::to_string(l) + "_channels") { *out = ddims[l]; return true; }
+    if (key == "decoder_level" + std::to_string(l) + "_size") { *out = hw[l]; return true; }
+  }
+  return false;
+}
+
+// caller NCHW fp32 (host or device) -> NHWC T rows of `ld` logical channels (+ an optional relu'd copy)
+static int stage_nchw_feature(md_model_s* m, hipStream_t st, const md_nchw_view& v, int B, int in_kind, float* stage, void* dst, void* dst_relu,
+                              long ld) {
+  const size_t n = (size_t)B * v.channels * v.height * v.width;
+  const float* src = v.data;
+  if (in_kind == MD_MEM_HOST) {
+    MD_HIP(hipMemcpyAsync(stage, v.data, n * 4, hipMemcpyHostToDevice, st));
+    src = stage;
+  }
+  MD_TRY(launch_nchw_to_nhwc(src, B, v.channels, v.height, v.width, dst, m->prec, 0, st, ld));
+  if (dst_relu) MD_TRY(launch_nchw_to_nhwc(src, B, v.channels, v.height, v.width, dst_relu, m->prec, 1, st, ld));
+  return MD_OK;
+}
+
+static int copy_tap_out(md_model_s* m, const char* name, float* out, int out_kind, hipStream_t st) {
+  if (!out) return MD_OK;
+  auto it = m->taps.find(name);
+  if (it == m->taps.end() || !it->second.dev) MD_FAIL(MD_ERR_HIP, "internal: tensor `%s` was not produced", name);
+  if (out_kind == MD_MEM_DEVICE) {
+    MD_HIP(hipMemcpyAsync(out, it->second.dev, it->second.count * 4, hipMemcpyDeviceToDevice, st));
+  } else {
+    MD_HIP(hipStreamSynchronize(st));
+    MD_HIP(hipMemcpy(out, it->second.dev, it->second.count * 4, hipMemcpyDeviceToHost));
+  }
+  return MD_OK;
+}
+
+static int debug_entry_checks(md_model_t m, int B, int in_kind, int out_kind) {
+  if (!m) MD_FAIL(MD_ERR_INVALID_ARG, "model is null");
+  if (m->kind != 0) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth Pro model");
+  if (!model_root(m)->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
+  if (B <= 0 || B > m->cfg.max_batch) MD_FAIL(MD_ERR_SHAPE, "batch %d outside 1 .. max_batch %d", B, m->cfg.max_batch);
+  if ((in_kind != MD_MEM_HOST && in_kind != MD_MEM_DEVICE) || (out_kind != MD_MEM_HOST && out_kind != MD_MEM_DEVICE))
+    MD_FAIL(MD_ERR_INVALID_ARG, "memory kind %d / %d", in_kind, out_kind);
+  return MD_OK;
+}
+
+int model_decoder_from_features(md_model_t m, const md_nchw_view* features, int levels, int B, int in_kind, float* out_features,
+                                float* out_lowres, float* const* out_fusions, int out_kind, hipStream_t stream) {
+  MD_TRY(debug_entry_checks(m, B, in_kind, out_kind));
+  if (!features) MD_FAIL(MD_ERR_INVALID_ARG, "features pointer is null");
+  if (levels != 5) MD_FAIL(MD_ERR_LEVELS, "Got encoder output levels = %d, expected 5.", levels);  // decoder.rs:200-205
+  int ddims[5], hw[5];
+  decoder_level_shapes(m, ddims, hw);
+  size_t max_elems = 0;
+  for (int l = 0; l < 5; ++l) {
+    const md_nchw_view& v = features[l];
+    if (!v.data) MD_FAIL(MD_ERR_INVALID_ARG, "features[%d].data is null", l);
+    if (v.channels != ddims[l] || v.height != hw[l] || v.width != hw[l])
+      MD_FAIL(MD_ERR_SHAPE, "features[%d] is [B,%d,%d,%d]; this model's decoder takes [B,%d,%d,%d]", l, v.channels, v.height, v.width, ddims[l],
+              hw[l], hw[l]);
+    max_elems = std::max(max_elems, (size_t)B * v.channels * v.height * v.width);
+  }
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : (m->own_stream ? m->own_stream : m->dev->stream);
+  md_model_s::Buffers* b = m->buf;
+  DeviceScratch stage;
+  if (in_kind == MD_MEM_HOST) MD_TRY(stage.alloc(max_elems * 4));
+  void* enc[5] = {b->enc0, b->enc1, b->enc2, b->enc3, b->enc4};
+  for (int l = 0; l < 5; ++l)  // level 0 also feeds resnet1 through its relu'd copy (convs[0] is the identity, decoder.rs:155-165)
+    MD_TRY(stage_nchw_feature(m, st, features[l], B, in_kind, (float*)stage.p, enc[l], l == 0 ? b->enc0r : nullptr, cpad(m, ddims[l])));
+  Run r{m, st, B};
+  {
+    TapsOn taps(m);
+    MD_TRY(run_decoder_head(r, true));
+  }
+  MD_TRY(copy_tap_out(m, "decoder_feature", out_features, out_kind, st));
+  MD_TRY(copy_tap_out(m, "decoder_lowres_feature", out_lowres, out_kind, st));
+  if (out_fusions)
+    for (int l = 0; l < 5; ++l) MD_TRY(copy_tap_out(m, ("decoder_fusion_" + std::to_string(l)).c_str(), out_fusions[l], out_kind, st));
+  MD_HIP(hipStreamSynchronize(st));  // the per-call staging is freed on return
+  return MD_OK;
+}
+
+int model_head_debug(md_model_t m, const md_nchw_view* feature, int B, int in_kind, const md_head_debug* out, int out_kind,
+                     hipStream_t stream) {
+  MD_TRY(debug_entry_checks(m, B, in_kind, out_kind));
+  if (!feature || !feature->data || !out) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  int ddims[5], hw[5];
+  decoder_level_shapes(m, ddims, hw);
+  const int F = m->cfg.F, Fp = cpad(m, F), F2 = F / 2, F2p = cpad(m, F2), C1 = 32, C1p = cpad(m, C1), s0 = hw[0];
+  if (feature->channels != F || feature->height != s0 || feature->width != s0)
+    MD_FAIL(MD_ERR_SHAPE, "feature is [B,%d,%d,%d]; this model's head takes [B,%d,%d,%d]", feature->channels, feature->height, feature->width, F, s0, s0);
+  if (!PK(m, "head.conv1.weight")) MD_FAIL(MD_ERR_UNSUPPORTED, "head_debug: the un-fused conv1 operand is not packed");
+  MD_HIP(hipSetDevice(m->dev->ordinal));
+  hipStream_t st = stream ? stream : (m->own_stream ? m->own_stream : m->dev->stream);
+  md_model_s::Buffers* b = m->buf;
+  const size_t px1 = (size_t)B * 4 * s0 * s0;
+  const size_t map_bytes = align_up(px1 * C1p * m->esz * m->xm + 256, 256);
+  DeviceScratch stage, maps, tails;
+  if (in_kind == MD_MEM_HOST) MD_TRY(stage.alloc((size_t)B * F * s0 * s0 * 4));
+  MD_TRY(maps.alloc(2 * map_bytes));
+  MD_TRY(tails.alloc(2 * px1 * 4));
+  void* c1 = maps.p;
+  void* c1r = (char*)maps.p + map_bytes;
+  float* pre = (float*)tails.p;
+  float* can = pre + px1;
+  auto W = [&](const char* n) { return PK(m, n); };
+  auto Bi = [&](const char* n) { return P32(m, n); };
+  MD_TRY(stage_nchw_feature(m, st, *feature, B, in_kind, (float*)stage.p, b->df[0], nullptr, Fp));
+  Run r{m, st, B};
+  TapsOn taps(m);
+  MD_TRY(conv3(r, "head_conv0", b->df[0], s0, s0, Fp, W("head.conv0.weight"), Bi("head.conv0.bias"), F2, b->h0, F2p, ACT_NONE, nullptr,
+               nullptr, nullptr));
+  MD_TRY(deconv2(r, "head_deconv_tap", b->h0, F2p, nullptr, s0, s0, W("head.deconv.weight"), F2p, F2, Bi("head.deconv.bias"), b->h1, F2p, 0));
+  MD_TRY(conv3(r, "head_conv1_debug", b->h1, 2 * s0, 2 * s0, F2p, W("head.conv1.weight"), Bi("head.conv1.bias"), C1, c1, C1p, ACT_NONE,
+               nullptr, nullptr, c1r));
+  MD_TRY(launch_head_tail_debug(c1r, C1p, (long)px1, C1, Bi("head.conv_out.weight"), Bi("head.conv_out.bias"), pre, can, m->prec, st));
+  MD_TRY(r.tap_nhwc("head_conv0", b->h0, F2, s0, s0, F2p));
+  MD_TRY(r.tap_nhwc("head_deconv", b->h1, F2, 2 * s0, 2 * s0, F2p));
+  MD_TRY(r.tap_nhwc("head_conv1", c1, C1, 2 * s0, 2 * s0, C1p));
+  MD_TRY(r.tap_nhwc("head_relu", c1r, C1, 2 * s0, 2 * s0, C1p));
+  MD_TRY(r.tap_f32("head_pre_out", pre, B, 1, 2 * s0, 2 * s0));
+  MD_TRY(r.tap_f32("head_canonical", can, B, 1, 2 * s0, 2 * s0));
+  MD_TRY(copy_tap_out(m, "head_conv0", out->conv0, out_kind, st));
+  MD_TRY(copy_tap_out(m, "head_deconv", out->deconv, out_kind, st));
+  MD_TRY(copy_tap_out(m, "head_conv1", out->conv1, out_kind, st));
+  MD_TRY(copy_tap_out(m, "head_relu", out->relu, out_kind, st));
+  MD_TRY(copy_tap_out(m, "head_pre_out", out->pre_out, out_kind, st));
+  MD_TRY(copy_tap_out(m, "head_canonical", out->canonical, out_kind, st));
+  MD_HIP(hipStreamSynchronize(st));  // the per-call scratch is freed on return
   return MD_OK;
 }
 

@@ -8,6 +8,7 @@ reference repository):
 * ``DepthPro.load_with_config``               -- depth_pro/mod.rs:200-208
 * ``DepthPro.infer(x) -> DepthProInference``  -- depth_pro/mod.rs:312-364
 * ``img_size`` / ``interpolation_method``     -- depth_pro/mod.rs:296,308
+* ``decoder_from_features`` / ``head_debug``  -- depth_pro/mod.rs:262-267, 289-307
 * debug taps                                  -- encoder.rs:106-123, mod.rs:135-142,285-287
 
 PyTorch is used only as plumbing: device buffers (``torch.empty(..., device="cuda")``), the
@@ -59,6 +60,17 @@ class DepthProInference:
     focallength_px: torch.Tensor  # [B]
     fovx_deg: torch.Tensor        # [B]
     fovy_rad: torch.Tensor        # [B]
+
+
+@dataclass
+class HeadDebug:
+    """depth_pro/mod.rs:135-142."""
+    conv0: torch.Tensor      # [B, F/2, s, s]
+    deconv: torch.Tensor     # [B, F/2, 2s, 2s]
+    conv1: torch.Tensor      # [B, 32, 2s, 2s]
+    relu: torch.Tensor       # [B, 32, 2s, 2s]
+    pre_out: torch.Tensor    # [B, 1, 2s, 2s]
+    canonical: torch.Tensor  # [B, 1, 2s, 2s]
 
 
 def _c_cfg(cfg: DepthProConfig) -> Tuple[_lib.MdDepthProCfg, list]:
@@ -240,6 +252,61 @@ class DepthPro:
                                                         _stream_ptr(self.device.ordinal)))
         out = DepthProInference(depth, focal, fovx, fovy)
         return (out, [float(v) for v in wms], float(tms.value)) if timings else out
+
+    # ---- the decoder / the head alone on caller tensors (depth_pro/mod.rs:262-307) --------------
+    def decoder_level_shapes(self) -> List[Tuple[int, int]]:
+        """(channels, size) of the encoder feature each decoder level takes, finest first (encoder.rs:416-434)."""
+        return [(self.query(f"decoder_level{l}_channels"), self.query(f"decoder_level{l}_size"))
+                for l in range(self.query("decoder_levels"))]
+
+    def _view(self, t: torch.Tensor) -> Tuple[torch.Tensor, "_lib.MdNchwView"]:
+        if t.dim() != 4:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,C,H,W], got {tuple(t.shape)}")
+        t = t.contiguous().to(torch.float32)
+        return t, _lib.MdNchwView(C.c_void_p(t.data_ptr()), int(t.shape[1]), int(t.shape[2]), int(t.shape[3]))
+
+    def decoder_from_features(self, features: List[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, List[torch.Tensor]]:
+        """`DepthPro::decoder_from_features(&self, features)` (depth_pro/mod.rs:262-267): the decoder alone on the caller's
+        encoder features (finest first; all on this GPU or all on the host) -> (features, lowres_features, fusion_outputs),
+        fusion_outputs[0] the finest. A wrong level count raises MdError(MD_ERR_LEVELS) where the reference panics
+        (decoder.rs:200-205), a wrong shape MdError(MD_ERR_SHAPE)."""
+        if len(features) == 0:
+            raise _lib.MdError(_lib.MD_ERR_LEVELS, "Got encoder output levels = 0")
+        B = int(features[0].shape[0])
+        if any(int(f.shape[0]) != B or f.is_cuda != features[0].is_cuda for f in features):
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, "features differ in batch size or memory kind")
+        keep, views = zip(*[self._view(f) for f in features])
+        arr = (_lib.MdNchwView * len(views))(*views)
+        dev = torch.device("cuda", self.device.ordinal)
+        F = self.query("decoder_features")
+        shapes = self.decoder_level_shapes()
+        s0, s_last = shapes[0][1], shapes[-1][1]
+        out_feat = torch.empty((B, F, s0, s0), dtype=torch.float32, device=dev)
+        out_low = torch.empty((B, F, s_last, s_last), dtype=torch.float32, device=dev)
+        fus = [torch.empty((B, F, s0 if l == 0 else 2 * shapes[l][1], s0 if l == 0 else 2 * shapes[l][1]), dtype=torch.float32, device=dev)
+               for l in range(len(shapes))]
+        fptr = (C.c_void_p * len(fus))(*[C.c_void_p(t.data_ptr()) for t in fus])
+        in_kind = _lib.MD_MEM_DEVICE if features[0].is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_depth_pro_decoder_from_features(self._h, arr, len(views), B, in_kind, C.c_void_p(out_feat.data_ptr()),
+                                                                C.c_void_p(out_low.data_ptr()), fptr, _lib.MD_MEM_DEVICE,
+                                                                _stream_ptr(self.device.ordinal)))
+        del keep
+        return out_feat, out_low, fus
+
+    def head_debug(self, feature: torch.Tensor) -> HeadDebug:
+        """`DepthPro::head_debug(&self, feature)` (depth_pro/mod.rs:289-307): the depth head layer by layer on the caller's
+        decoder feature [B, F, s, s]."""
+        t, view = self._view(feature)
+        B, _, s, _ = t.shape
+        dev = torch.device("cuda", self.device.ordinal)
+        F2 = self.query("decoder_features") // 2
+        mk = lambda c, hw: torch.empty((B, c, hw, hw), dtype=torch.float32, device=dev)  # noqa: E731
+        hd = HeadDebug(mk(F2, s), mk(F2, 2 * s), mk(32, 2 * s), mk(32, 2 * s), mk(1, 2 * s), mk(1, 2 * s))
+        out = _lib.MdHeadDebug(*[C.c_void_p(x.data_ptr()) for x in (hd.conv0, hd.deconv, hd.conv1, hd.relu, hd.pre_out, hd.canonical)])
+        in_kind = _lib.MD_MEM_DEVICE if t.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(self._lib.md_depth_pro_head_debug(self._h, C.byref(view), int(B), in_kind, C.byref(out), _lib.MD_MEM_DEVICE,
+                                                     _stream_ptr(self.device.ordinal)))
+        return hd
 
     def infer_from_rgb(self, rgb: bytes, width: int, height: int) -> DepthProInference:
         """`infer_from_rgb` (src/inference.rs:128-137); raises MdError(MD_ERR_SHAPE) on a bad length."""

@@ -112,3 +112,37 @@ def compare(ref: ReferenceDump, depth: np.ndarray, fovx_deg: float, fovy_deg: fl
           ds.max_rel <= DEPTH_MAX_REL_THRESHOLD and fx <= FOVX_THRESHOLD and fy <= FOVY_THRESHOLD)
     lines.append("Output matches the reference dump within tolerance." if ok else "Output differs from the reference dump.")
     return Report(lines, ds, fx, fy, ok)
+
+
+def replay_report(ref: ReferenceDump, feature: np.ndarray, lowres: np.ndarray, fusions: List[np.ndarray],
+                  head: Optional[Dict[str, np.ndarray]] = None) -> List[str]:
+    """`compare_decoder_with_reference` (correctness.rs:530-660): the engine's `decoder_from_features` on the DUMP's
+    encoder features against the dump's decoder tensors, in the harness's "[Replay]" lines; `head`: `head_debug` on the
+    dump's `decoder_feature` (head_conv0, head_deconv, head_conv1, head_relu, head_pre_out, canonical_inverse_depth),
+    the stage-by-stage head comparison of correctness.rs:382-390,700-760."""
+    lines: List[str] = []
+
+    def one(label, ours, theirs):
+        if theirs is None:
+            lines.append(f"[Replay] Torch reference missing {label}; skipping.")
+        elif tuple(ours.shape) != tuple(theirs.shape):
+            lines.append(f"[Replay] {label} shape mismatch: torch {list(theirs.shape)}, ours {list(ours.shape)}")
+        else:
+            st = compute_stats(ours, theirs)
+            lines.append(f"[Replay] {label}: mean abs={st.mean_abs:.6f}, max abs={st.max_abs:.6f}, max rel={st.max_rel:.6f}")
+            if st.max_abs > 1e-3:  # correctness.rs:576-596: where the largest difference sits
+                d = np.abs(np.asarray(ours, np.float32) - np.asarray(theirs, np.float32))
+                at = np.unravel_index(int(d.argmax()), d.shape)
+                lines.append(f"[Replay] {label} max diff at {list(at)}: ours={float(np.asarray(ours)[at]):.6f}, "
+                             f"torch={float(np.asarray(theirs)[at]):.6f}, diff={float(d[at]):.6f}")
+
+    one("Decoder feature", feature, ref.optional.get("decoder_feature"))
+    one("Decoder lowres feature", lowres, ref.optional.get("decoder_lowres_feature"))
+    if len(fusions) == len(ref.decoder_fusions):
+        for i, (a, b) in enumerate(zip(fusions, ref.decoder_fusions)):
+            one(f"Decoder fusion {i}", a, b)
+    else:
+        lines.append(f"[Replay] fusion count mismatch: torch {len(ref.decoder_fusions)}, ours {len(fusions)}")
+    for k, v in (head or {}).items():
+        one(f"Head {k}", v, ref.optional.get(k))
+    return lines

@@ -149,6 +149,50 @@ int md_model_fork(md_model_t m, md_model_t* out);
 int md_depth_pro_infer(md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                        float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream);
 
+/* One NCHW fp32 tensor handed across the boundary with its shape: `data` is [B, channels, height, width] (B is the call's). */
+typedef struct md_nchw_view {
+  const float* data;
+  int channels, height, width;
+} md_nchw_view;
+
+/* `DepthPro::decoder_from_features(&self, features: &[Tensor<B,4>]) -> (Tensor<B,4>, Tensor<B,4>, Vec<Tensor<B,4>>)`
+ * (depth_pro/mod.rs:262-267 = `MultiresConvDecoder::forward_with_debug`, layers/decoder.rs:195-222): the decoder alone on
+ * CALLER-SUPPLIED encoder features -- the entry the reference's harness uses to replay the decoder on PyTorch's encoder
+ * features (example/correctness.rs:538-560). `features[l]`, l = 0 .. levels-1, finest first: the default configuration takes
+ * [B,256,768,768], [B,256,384,384], [B,512,192,192], [B,1024,96,96], [B,1024,48,48] (md_model_query "decoder_levels",
+ * "decoder_level{l}_channels", "decoder_level{l}_size"). Outputs, NCHW fp32, any pointer may be NULL to skip it:
+ *   out_features [B, F, s0, s0]  the fused feature map (what the depth head takes),
+ *   out_lowres   [B, F, s4, s4]  `convs[last](features[last])`, the FOV network's input,
+ *   out_fusions[l]               the output of fusion block l (index 0 = finest, as the reference returns them after its
+ *                                `reverse()`): [B, F, 2 s_l, 2 s_l] for l >= 1, [B, F, s0, s0] for l = 0 (== out_features).
+ * A wrong number of levels -> MD_ERR_LEVELS (the reference panics, decoder.rs:200-205); a level whose shape is not the
+ * model's -> MD_ERR_SHAPE (Burn panics on the mismatched convolution / addition). Runs in the model's precision mode on the kernels `md_depth_pro_infer` runs; it is a debug entry (taps
+ * machinery: eager, allocates its fp32 staging per call), not a hot path. */
+int md_depth_pro_decoder_from_features(md_model_t m, const md_nchw_view* features, int levels, int B, int in_kind,
+                                       float* out_features, float* out_lowres, float* const* out_fusions, int out_kind,
+                                       void* stream);
+
+/* `HeadDebug` (depth_pro/mod.rs:135-142): the six tensors `DepthPro::head_debug(&self, feature)` returns (mod.rs:289-307).
+ * NCHW fp32; NULL fields are skipped. With s = the decoder feature's size (768 by default) and F = decoder_features:
+ * conv0 [B,F/2,s,s], deconv [B,F/2,2s,2s], conv1 and relu [B,32,2s,2s], pre_out and canonical [B,1,2s,2s]. */
+typedef struct md_head_debug {
+  float* conv0;
+  float* deconv;
+  float* conv1;
+  float* relu;
+  float* pre_out;
+  float* canonical;
+} md_head_debug;
+
+/* `DepthPro::head_debug(&self, feature: Tensor<B,4>) -> HeadDebug` (depth_pro/mod.rs:289-307): the depth head layer by layer
+ * on a CALLER-SUPPLIED decoder feature [B, F, s, s] (example/correctness.rs:382-390 feeds it the decoder's output). Every
+ * layer runs UN-FUSED here (conv0 3x3, deconv k2s2, conv1 3x3, relu, conv_out 1x1, relu), each tensor materialised in the
+ * model's precision mode; `md_depth_pro_infer` runs the same arithmetic with conv_out . relu behind conv1's accumulators and
+ * the deconv composed into conv1, so in MD_PREC_F32 the two agree to fp32 rounding and in the 16-bit
+ * modes to the rounding of the materialised intermediates. A shape that is not the model's -> MD_ERR_SHAPE. Debug entry. */
+int md_depth_pro_head_debug(md_model_t m, const md_nchw_view* feature, int B, int in_kind, const md_head_debug* out,
+                            int out_kind, void* stream);
+
 /* The same call with the ViT stage run as `parts` consecutive windows of its 37 B sequences (35 B patch tiles + B image +
  * B fov, layers/encoder.rs:329-348, 409; fov.rs:203) on THIS device: the launches the `parts` ranks of
  * md_comm_depth_pro_infer_tiles issue, one rank after the other, without the exchange. Results are bit-identical to
@@ -252,7 +296,9 @@ int md_model_enable_graph(md_model_t m, int enable);
  *       "weight_terms" (MFMA terms per product with a plain weight: 1; MD_PREC_F16X2: 2 = f16-exact weights, 3 otherwise),
  *       "allocs" (device / pinned-host allocations the infer calls of this model have made so far: staging buffers for
  *       host pointers and non-native input sizes grow on demand and are then reused, so the count stops moving once the
- *       largest shapes have been seen), "da3_shape_builds" (Depth-Anything-v3: input sizes whose tables were built). */
+ *       largest shapes have been seen), "da3_shape_builds" (Depth-Anything-v3: input sizes whose tables were built),
+ *       "decoder_levels", "decoder_features", "decoder_level{0..4}_channels", "decoder_level{0..4}_size" (Depth Pro: the
+ *       shapes md_depth_pro_decoder_from_features / md_depth_pro_head_debug take). */
 int md_model_query(md_model_t m, const char* key, int64_t* out);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs

@@ -94,6 +94,59 @@ def test_depth_pro_small_preset_end_to_end(diag, dev, precision):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("precision,B,host,preset", [(1, 1, False, "tiny"), (4, 2, True, "tiny"), (0, 1, False, "tiny"), (3, 1, False, "tiny"),
+                                                     (1, 1, True, "small"), (4, 1, False, "small")])
+def test_decoder_from_features_and_head_debug(diag, dev, precision, B, host, preset):
+    """`DepthPro::decoder_from_features` / `head_debug` (depth_pro/mod.rs:262-307): the decoder and the depth head alone on
+    caller tensors against the oracle (f32 and f16x2 to 1e-4 of each tensor's peak), host and device inputs; the `small` preset is
+    the reference's CI preset (ViT-L, decoder 64: level channel counts differ from the decoder width)."""
+    from burn_depth_amd.config import DepthProConfig
+    cfg = DepthProConfig.tiny_test() if preset == "tiny" else DepthProConfig.small_test()
+    start = len(diag.RESULTS)
+    diag.guarded("replay")(diag.run_decoder_head_replay)(dev, cfg, f"replay-{preset}/p{precision}", B, precision, host_inputs=host,
+                                                         f16_weights=precision == 4)
+    _assert_new_results_ok(diag, start)
+
+
+def test_decoder_from_features_error_paths(dev):
+    # decoder.rs:200-205 panics on a wrong level count; Burn panics on mismatched shapes: both are error codes here
+    from burn_depth_amd import _lib
+    from burn_depth_amd.config import DepthAnything3Config, DepthProConfig
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    from burn_depth_amd.depth_pro import DepthPro
+    import ctypes as C
+    model = DepthPro.new(dev, DepthProConfig.tiny_test(), seed=0)
+    shapes = model.decoder_level_shapes()
+    feats = [torch.zeros(1, c, s, s, device="cuda") for c, s in shapes]
+    with pytest.raises(_lib.MdError) as e:
+        model.decoder_from_features(feats[:4])
+    assert e.value.code == _lib.MD_ERR_LEVELS and "levels = 4" in e.value.message
+    bad = list(feats)
+    bad[2] = torch.zeros(1, shapes[2][0], shapes[2][1] + 1, shapes[2][1] + 1, device="cuda")
+    with pytest.raises(_lib.MdError) as e:
+        model.decoder_from_features(bad)
+    assert e.value.code == _lib.MD_ERR_SHAPE and "features[2]" in e.value.message
+    with pytest.raises(_lib.MdError) as e:
+        model.decoder_from_features([torch.zeros(2, c, s, s, device="cuda") for c, s in shapes])  # max_batch = 1
+    assert e.value.code == _lib.MD_ERR_SHAPE
+    with pytest.raises(_lib.MdError) as e:
+        model.head_debug(torch.zeros(1, shapes[0][0] + 1, shapes[0][1], shapes[0][1], device="cuda"))
+    assert e.value.code == _lib.MD_ERR_SHAPE
+    # partial outputs: NULL pointers are skipped
+    views = (_lib.MdNchwView * 5)(*[_lib.MdNchwView(C.c_void_p(f.data_ptr()), f.shape[1], f.shape[2], f.shape[3]) for f in feats])
+    low = torch.full((1, model.query("decoder_features"), shapes[4][1], shapes[4][1]), float("nan"), device="cuda")
+    _lib.check(_lib.load().md_depth_pro_decoder_from_features(model._h, views, 5, 1, _lib.MD_MEM_DEVICE, None, C.c_void_p(low.data_ptr()), None,
+                                                              _lib.MD_MEM_DEVICE, None))
+    torch.cuda.synchronize()
+    assert torch.isfinite(low).all()
+    model.destroy()
+    da3 = DepthAnything3.new(dev, DepthAnything3Config.tiny_test(), seed=0)
+    v = _lib.MdNchwView(C.c_void_p(feats[0].data_ptr()), 1, 1, 1)
+    out = _lib.MdHeadDebug()
+    assert _lib.load().md_depth_pro_head_debug(da3._h, C.byref(v), 1, _lib.MD_MEM_DEVICE, C.byref(out), _lib.MD_MEM_DEVICE, None) == _lib.MD_ERR_INVALID_ARG
+    da3.destroy()
+
+
 def test_infer_shapes_zeros_input_reference_init(dev):
     # reference: src/lib.rs:179-195 -- zeros [1,3,S,S] through a random-init model: depth [1,S,S], focal [1]
     from burn_depth_amd.config import DepthProConfig
@@ -472,6 +525,42 @@ def test_depth_anything3_small_non_square_at_the_real_width(diag, dev, precision
     diag.guarded("da3-small-ns")(diag.run_da3)(dev, cfg, f"da3-small-266x518/p{precision}", 1, precision, f16_weights=True)
     _assert_new_results_ok(diag, start)
     assert len(diag.RESULTS) - start >= 10
+
+
+def test_camera_scratch_regrowth_drops_the_graphs_that_hold_it(diag, dev):
+    """a replayed `infer_with_camera` graph bakes the camera-encoder scratch's addresses; a later call with more views
+    regrows (frees) that buffer. Views = 1 three times (eager, capture, replay), views = 4 (regrowth), views = 1 again: every
+    result equals the eager model's bit for bit."""
+    import ctypes as C
+    from burn_depth_amd import _lib, weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config, Precision
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    cfg = DepthAnything3Config.tiny_dual_test()
+    cfg.precision = Precision.F32
+    cfg.max_batch = 1
+    g = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    e = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    g.enable_graph(True)
+    torch.manual_seed(2)
+    x = torch.randn(1, 3, 70, 70, device="cuda")
+    cams = {V: tuple(t.cuda().contiguous() for t in diag.camera_inputs(1, V, 70, 70, seed=5 + V)) for V in (1, 4)}
+    depth = torch.empty(1, 70, 70, device="cuda")
+    pose = torch.empty(1, 1, 9, device="cuda")
+    o = _lib.MdDa3Outputs(depth.data_ptr(), None, None, None, pose.data_ptr(), None, None)
+
+    def run(model, V):
+        E, K = cams[V]
+        _lib.check(_lib.load().md_da3_infer_with_camera(model._h, C.c_void_p(x.data_ptr()), 1, 70, 70, _lib.MD_MEM_DEVICE, C.c_void_p(E.data_ptr()),
+                                                        C.c_void_p(K.data_ptr()), V, C.byref(o), _lib.MD_MEM_DEVICE, None))
+        torch.cuda.synchronize()
+        return depth.clone(), pose.clone()
+    want = {V: run(e, V) for V in (1, 4)}
+    assert not torch.equal(want[1][0], want[4][0])
+    for step, V in enumerate((1, 1, 1, 4, 1, 1, 4, 4)):
+        d, p = run(g, V)
+        assert torch.equal(d, want[V][0]) and torch.equal(p, want[V][1]), (step, V)
+    g.destroy()
+    e.destroy()
 
 
 def test_depth_anything3_mono_variant_ignores_camera_inputs(diag, dev):
@@ -979,7 +1068,11 @@ def test_check_parity_cli_against_an_oracle_made_reference_dump(dev, tmp_path):
         ref = R.infer(x, R.weights_to_torch(Wn), cfg, debug=True)
     dump = {"metric_depth": ref["depth"][0].numpy()[:, :, None], "fovx": ref["fovx_deg"].numpy().reshape(1),
             "fovy": np.array([math.degrees(float(ref["fovy_rad"][0]))], np.float32),
-            "canonical_inverse_depth": ref["debug"]["canonical"].numpy()}
+            "canonical_inverse_depth": ref["debug"]["canonical"].numpy(),
+            "decoder_feature": ref["debug"]["decoder_features"].numpy(), "decoder_lowres_feature": ref["debug"]["decoder_lowres"].numpy(),
+            "head_conv0": ref["debug"]["head"]["conv0"].numpy(), "head_deconv": ref["debug"]["head"]["deconv"].numpy(),
+            "head_conv1": ref["debug"]["head"]["conv1"].numpy(), "head_relu": ref["debug"]["head"]["relu"].numpy(),
+            "head_pre_out": ref["debug"]["head"]["pre_out"].numpy()}
     for i, t in enumerate(ref["debug"]["encoder"]["features"]):
         dump[f"encoder_feature_{i}"] = t.numpy()
     for i, t in enumerate(ref["debug"]["fusions"]):
@@ -989,7 +1082,20 @@ def test_check_parity_cli_against_an_oracle_made_reference_dump(dev, tmp_path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     args = ["--weights", wpath, "--image", str(tmp_path / "img.npy"), "--reference", str(tmp_path / "ref.safetensors"), "--preset", "tiny"]
-    assert mod.main(args) == 0                      # fp32 parity mode passes the reference's own thresholds
+    rc, rep = mod.run(args)
+    assert rc == 0                                  # fp32 parity mode passes the reference's own thresholds
+    # the decoder / head replay leg (correctness.rs:530-660): the dump's encoder features through decoder_from_features, the dump's
+    # decoder feature through head_debug -- every "[Replay]" line is present and inside 1e-3 absolute (maps of O(1))
+    import re
+    replay = [l for l in rep.lines if l.startswith("[Replay]")]
+    labels = ["Decoder feature", "Decoder lowres feature"] + [f"Decoder fusion {i}" for i in range(5)] + \
+             [f"Head {k}" for k in ("head_conv0", "head_deconv", "head_conv1", "head_relu", "head_pre_out", "canonical_inverse_depth")]
+    for lab in labels:
+        hit = [l for l in replay if l.startswith(f"[Replay] {lab}:")]
+        assert len(hit) == 1, (lab, replay)
+        assert float(re.search(r"max abs=([0-9.eE+-]+)", hit[0]).group(1)) <= 1e-3, hit[0]
+    assert not any("mismatch" in l or "missing" in l for l in replay), replay
+    assert mod.run(args + ["--no-replay"])[1].lines == [l for l in rep.lines if not l.startswith("[Replay]")]
     rc, rep = mod.run(args + ["--precision", "f16x2"])  # so does the accurate fast mode (fp32-valued weights: three MFMA terms)
     assert rc == 0 and rep.ok and rep.depth.max_rel <= 1e-3 and rep.depth.max_abs <= 1e-3
     # throughput mode: it may exceed the reference's 5e-3 bar, but the harness's VALUES stay inside the bf16 bounds of this

@@ -54,3 +54,29 @@ def test_verdict_uses_the_reference_thresholds():
     assert not parity.compare(ref, d, 53.002, 40.0).ok                # fovx diff 2e-3 > 1e-3
     with pytest.raises(ValueError, match="depth shape mismatch"):
         parity.compare(ref, d[:-1], 53.0, 40.0)
+
+
+def test_replay_report_follows_the_harness_lines():
+    """`compare_decoder_with_reference` (example/correctness.rs:530-660): "[Replay] <label>: mean abs=…" per tensor, the position of
+    the largest difference once it exceeds 1e-3, and the harness's wording for missing / mis-shaped tensors."""
+    t = _dump()
+    rng = np.random.default_rng(1)
+    t["decoder_feature"] = rng.standard_normal((1, 4, 6, 8)).astype(np.float32)
+    t["head_conv1"] = rng.standard_normal((1, 2, 12, 16)).astype(np.float32)
+    ref = parity.load_reference_dump(t)
+    fus = [f.copy() for f in ref.decoder_fusions]
+    assert len(fus) >= 1
+    fus[0] = fus[0].copy()
+    fus[0].reshape(-1)[3] += 0.5  # a difference above the harness's 1e-3 print threshold
+    head = {"head_conv1": t["head_conv1"] + 1e-5, "head_relu": np.zeros((1, 2, 12, 16), np.float32)}
+    lines = parity.replay_report(ref, t["decoder_feature"], np.zeros((1, 4, 3, 4), np.float32), fus, head)
+    assert lines[0].startswith("[Replay] Decoder feature: mean abs=0.000000, max abs=0.000000")
+    assert lines[1] == "[Replay] Torch reference missing Decoder lowres feature; skipping."
+    assert lines[2].startswith("[Replay] Decoder fusion 0: ") and "max abs=0.5" in lines[2]
+    assert lines[3].startswith("[Replay] Decoder fusion 0 max diff at ") and "diff=0.500000" in lines[3]
+    assert any(l.startswith("[Replay] Head head_conv1: ") for l in lines)
+    assert "[Replay] Torch reference missing Head head_relu; skipping." in lines
+    short = parity.replay_report(ref, t["decoder_feature"][:, :2], t["decoder_feature"], fus[:-1] if len(fus) > 1 else [])
+    assert "shape mismatch" in short[0]
+    if len(fus) > 1:
+        assert short[-1].startswith("[Replay] fusion count mismatch")

@@ -24,6 +24,7 @@ def run(argv=None):
     ap.add_argument("--image", required=True)
     ap.add_argument("--reference", required=True)
     ap.add_argument("--precision", choices=["f32", "f16x2", "f16", "bf16"], default="f32")
+    ap.add_argument("--no-replay", action="store_true", help="skip the decoder / head replay on the dump's features (the reference's BURN_SKIP_DECODER_REPLAY)")
     ap.add_argument("--preset", choices=["full", "small", "tiny"], default="full", help="reduced presets are for the test-suite")
     a = ap.parse_args(argv)
     import torch
@@ -54,6 +55,24 @@ def run(argv=None):
             pass
     rep = parity.compare(ref, out.depth[0].cpu().numpy(), float(out.fovx_deg[0]), math.degrees(float(out.fovy_rad[0])), taps)
     print("\n".join(rep.lines))
+    # decoder replay (correctness.rs:530-560): the DUMP's encoder features through `decoder_from_features`, and the head layer by
+    # layer on the dump's decoder feature (`head_debug`, :382-390) -- separates a decoder / head difference from an encoder one
+    if a.no_replay:
+        pass
+    elif len(ref.encoder_features) != model.query("decoder_levels") or any(f.ndim != 4 for f in ref.encoder_features):
+        print("Torch reference missing encoder features; skipping decoder replay.")
+    else:
+        feat, low, fus = model.decoder_from_features([torch.from_numpy(np.ascontiguousarray(f, np.float32)) for f in ref.encoder_features])
+        head = None
+        dfeat = ref.optional.get("decoder_feature")
+        if dfeat is not None and dfeat.ndim == 4:
+            hd = model.head_debug(torch.from_numpy(np.ascontiguousarray(dfeat, np.float32)))
+            head = {"head_conv0": hd.conv0, "head_deconv": hd.deconv, "head_conv1": hd.conv1, "head_relu": hd.relu,
+                    "head_pre_out": hd.pre_out, "canonical_inverse_depth": hd.canonical}
+            head = {k: v.cpu().numpy() for k, v in head.items()}
+        lines = parity.replay_report(ref, feat.cpu().numpy(), low.cpu().numpy(), [t.cpu().numpy() for t in fus], head)
+        print("\n".join(lines))
+        rep = rep._replace(lines=rep.lines + lines)
     model.destroy()
     return (0 if rep.ok else 1), rep
 

@@ -902,6 +902,60 @@ def run_da3_from_tokens(dev, cfg, label, B, precision, lead_row=False, host_inpu
     model.destroy()
 
 
+# tolerance of a replayed stage against the fp32 oracle by precision mode: max|diff| / max|ref| per tensor
+REPLAY_TOL = {Precision.F32: 1e-4, Precision.F16X2: 1e-4, Precision.F16: 4e-3, Precision.BF16: 3e-2}
+
+
+def run_decoder_head_replay(dev, cfg, label, B, precision, host_inputs=False, scheme=Wt.INIT_PARITY, f16_weights=False):
+    """`DepthPro::decoder_from_features` and `DepthPro::head_debug` (depth_pro/mod.rs:262-307) on caller tensors against the
+    oracle's `decoder_forward_debug` / `head_debug` -- the decoder replay of example/correctness.rs:538-560 (PyTorch's encoder
+    features into the decoder) and the head replay of :382-390, with seeded features standing in for PyTorch's."""
+    cfg.precision = precision
+    cfg.max_batch = max(B, 1)
+    model = DepthPro.new(dev, cfg, seed=0, init_scheme=scheme)
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
+    if f16_weights:
+        model.round_weights_to_f16()
+        W = {k: R.f16_round(v) for k, v in W.items()}
+    tol = REPLAY_TOL[precision]
+    shapes = model.decoder_level_shapes()
+    record(f"{label} decoder levels", float(len(shapes)), 5.0, f"shapes={shapes}")
+    g = torch.Generator().manual_seed(11)
+    feats = [torch.randn(B, c, s, s, generator=g) * 0.5 for c, s in shapes]
+    with torch.no_grad():
+        rf, rl, rfus = R.decoder_forward_debug(feats, W)
+    src = feats if host_inputs else [f.cuda() for f in feats]
+    of, ol, ofus = model.decoder_from_features(src)
+    record(f"{label} decoder_from_features features", rel_err(of, rf), tol, f"shape={tuple(of.shape)}")
+    record(f"{label} decoder_from_features lowres", rel_err(ol, rl), tol, f"shape={tuple(ol.shape)}")
+    for i in range(5):
+        record(f"{label} decoder_from_features fusion_{i}", rel_err(ofus[i], rfus[i]), tol, f"shape={tuple(ofus[i].shape)}")
+    record(f"{label} fusion_0 is the feature map", float((ofus[0] != of).sum().item()), 0.0)
+    # the head on the ORACLE's decoder feature (what the reference's harness feeds: the decoder output, correctness.rs:382-390)
+    with torch.no_grad():
+        rh = R.head_debug(rf, W)
+    hd = model.head_debug(rf if host_inputs else rf.cuda())
+    for n in ("conv0", "deconv", "conv1", "relu", "pre_out", "canonical"):
+        got = getattr(hd, n)
+        record(f"{label} head_debug {n}", rel_err(got, rh[n]), tol, f"shape={tuple(got.shape)}")
+    record(f"{label} head_debug relu == max(conv1, 0)", float((hd.relu != hd.conv1.clamp_min(0)).sum().item()), 0.0)
+    record(f"{label} head_debug canonical == max(pre_out, 0)", float((hd.canonical != hd.pre_out.clamp_min(0)).sum().item()), 0.0)
+    # the un-fused head against the product path's fused head on the engine's own decoder feature
+    torch.manual_seed(0)
+    S = model.img_size()
+    x = (torch.rand(B, 3, S, S) - 0.45) / 0.225
+    model.enable_taps(True)
+    model.infer(x.cuda())
+    dfeat = torch.from_numpy(model.read_tap("decoder_feature"))
+    canon = torch.from_numpy(model.read_tap("canonical_inverse_depth"))
+    model.enable_taps(False)
+    hd2 = model.head_debug(dfeat.cuda())
+    record(f"{label} head_debug canonical vs the fused head of infer", rel_err(hd2.canonical, canon), tol, f"canonical max={canon.max().item():.3f}")
+    out_again = model.infer(x.cuda())
+    record(f"{label} infer still finite after the replays", float((~torch.isfinite(out_again.depth)).sum().item()), 0.0)
+    model.destroy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-small", action="store_true")
@@ -963,6 +1017,9 @@ def main():
             guarded("da3 small bf16")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/bf16", 2, Precision.BF16)
             guarded("da3 large fp8")(run_da3)(dev, DepthAnything3Config.metric_large(), "da3-large/fp8", 1, Precision.FP8)
             guarded("da3 small fp8")(run_da3)(dev, DepthAnything3Config.small(), "da3-small/fp8", 1, Precision.FP8)
+    if want("replay"):
+        for pr, nm in ((Precision.F32, "f32"), (Precision.F16X2, "f16x2"), (Precision.BF16, "bf16")):
+            guarded(f"replay tiny {nm}")(run_decoder_head_replay)(dev, DepthProConfig.tiny_test(), f"replay-tiny/{nm}", 1, pr, f16_weights=pr == Precision.F16X2)
     if want("f16"):
         guarded("f16 storage")(check_storage_epilogues)(dev, 3)
         guarded("tiny f16")(run_e2e)(dev, DepthProConfig.tiny_test(), "tiny/f16", 1, (512, 512), Precision.F16)
