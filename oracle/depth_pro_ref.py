@@ -284,17 +284,22 @@ def vit_forward(x: Tensor, W: Dict[str, Tensor], prefix: str, v: ViTConfig, hook
     return torch.cat(outs, 0), [torch.cat(a, 0) for a in (hooks_acc or [])]
 
 
-def interpolate_pos_encoding(pos: Tensor, gh: int, gw: int) -> Tensor:
-    """Public DINOv2 `interpolate_pos_encoding` (offset 0.1, bicubic, no antialias): used when the input
-    grid differs from the pos_embed grid (Depth-Anything-v3 at sizes other than 518). burn_dino's own
-    version is not visible -> parity unpinned."""
+def interpolate_pos_encoding(pos: Tensor, gh: int, gw: int, offset: float = 0.1) -> Tensor:
+    """Public DINOv2 `interpolate_pos_encoding` (bicubic, no antialias, the upstream default `interpolate_offset` = 0.1:
+    scale factors (g + 0.1) / M): used when the input grid differs from the pos_embed grid (Depth-Anything-v3 at sizes
+    other than 518). burn_dino's own version is not visible -> parity unpinned. `offset` = 0 is the other published form
+    (an output SIZE instead of scale factors: upstream with `interpolate_offset = 0`, Hugging Face's `Dinov2Embeddings`);
+    tests/test_oracle_vs_hf.py holds that form to Hugging Face's and measures what the 0.1 moves."""
     n = pos.shape[1] - 1
     M = int(round(math.sqrt(n)))
     if gh == M and gw == M:
         return pos
     D = pos.shape[2]
     patch = pos[:, 1:].reshape(1, M, M, D).permute(0, 3, 1, 2)
-    patch = F.interpolate(patch, scale_factor=((gh + 0.1) / M, (gw + 0.1) / M), mode="bicubic", align_corners=False)
+    if offset:
+        patch = F.interpolate(patch, scale_factor=((gh + offset) / M, (gw + offset) / M), mode="bicubic", align_corners=False)
+    else:
+        patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
     assert patch.shape[-2:] == (gh, gw)
     return torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], 1)
 
