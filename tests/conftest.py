@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullsize: compares with a full-size CPU-oracle frame (30-90 s of host time); runs last, its frame "
+                                       "is computed on a background thread under the earlier tests' GPU work (tools/gpu_diag.py prefetch)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`fullsize` tests go to the end of the run (their relative order kept): their oracle frames are queued at session start
+    and computed while the other tests keep the GPU busy."""
+    tail = [i for i in items if i.get_closest_marker("fullsize")]
+    if tail:
+        items[:] = [i for i in items if not i.get_closest_marker("fullsize")] + tail
 
 
 @pytest.fixture(scope="session")

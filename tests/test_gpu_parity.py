@@ -37,6 +37,27 @@ def dev():
     return Device(0)
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _oracle_frames_ahead(request, diag):
+    """Queues the full-size CPU-oracle frames of the SELECTED `fullsize` tests (in the order those tests run) on gpu_diag's
+    background worker: the suite spent 60 % of its wall time waiting for them with the GPU idle (profiles/r04_pytest_gpu.log:
+    621 s of the driver's 900-s limit)."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config
+    picked = {i.name.split("[")[0] for i in request.session.items}
+    if "test_full_size_default_config_against_the_oracle" in picked:
+        diag.prefetch_full_size("seeded", f16_weights=True, want_q=True)
+    if "test_config3_test_jpg_through_infer_from_rgb" in picked:
+        diag.prefetch_full_size("test_jpg", f16_weights=True)
+    if "test_config1_zeros_reference_init_full_size" in picked:
+        diag.prefetch_full_size("zeros", scheme=Wt.INIT_REFERENCE)
+    if "test_config5_depth_anything3_large_1036" in picked:
+        cfg = DepthAnything3Config.metric_large()
+        cfg.image_size = 1036
+        diag.prefetch_da3(cfg, 1)
+    yield
+
+
 def _assert_new_results_ok(diag, start):
     new = diag.RESULTS[start:]
     assert new, "no checks were recorded"
@@ -395,6 +416,7 @@ def test_infer_from_rgb_matches_tensor_path(dev):
     model.destroy()
 
 
+@pytest.mark.fullsize
 def test_full_size_default_config_against_the_oracle(diag, dev):
     """BASELINE config 3-(ii) / SURVEY 8d: DepthProConfig::default() on one seeded [1,3,1536,1536] frame, VALUES against the
     fp32 CPU oracle in every precision mode, on the seeded weights ROUNDED TO F16 -- what the reference's
@@ -418,6 +440,7 @@ def test_full_size_default_config_against_the_oracle(diag, dev):
     assert len(names) >= 26
 
 
+@pytest.mark.fullsize
 def test_config3_test_jpg_through_infer_from_rgb(diag, dev):
     """BASELINE config 3-(iii): the reference's one real input, assets/image/test.jpg (540 x 360; decoded pixels in
     tests/golden/test_jpg_rgb.npy, generator beside it), through `infer_from_rgb` (src/inference.rs:128-137: u8 -> normalised
@@ -432,6 +455,7 @@ def test_config3_test_jpg_through_infer_from_rgb(diag, dev):
     assert len(new) >= 14
 
 
+@pytest.mark.fullsize
 def test_config1_zeros_reference_init_full_size(diag, dev):
     """BASELINE config 1 on the HIP path: `DepthPro::new` (reference initialisation, bench/inference.rs:25-27) on zeros
     [1,3,1536,1536] (src/lib.rs:179-195 checks shapes and finiteness of exactly this call), VALUES against the oracle in the
@@ -768,6 +792,7 @@ def test_config4_shard_of_eight_images_is_batch_independent(diag, dev):
     assert len(diag.RESULTS) - start >= 4
 
 
+@pytest.mark.fullsize
 @pytest.mark.parametrize("precision", [2, 0, 3, 4, 1])
 def test_config5_depth_anything3_large_1036(diag, dev, precision):
     """BASELINE config 5: Depth-Anything-v3 metric_large (ViT-L/14) on [1,3,1036,1036] (5477 tokens, position embedding

@@ -9,6 +9,8 @@ import argparse
 import math
 import os
 import sys
+import queue
+import threading
 import time
 import traceback
 
@@ -35,9 +37,51 @@ def cfg_key(cfg):
 
 
 def cached(key, fn):
+    ev = _PREFETCH_EVENTS.get(key)
+    if ev is not None:  # a frame the background worker has taken: wait for it instead of computing it twice
+        ev.wait()
     if key not in _ORACLE_CACHE:
         _ORACLE_CACHE[key] = fn()
-    return _ORACLE_CACHE[key]
+    v = _ORACLE_CACHE[key]
+    if isinstance(v, BaseException):
+        raise v
+    return v
+
+
+# ---- oracle frames ahead of their tests ---------------------------------------------------------------------------------
+# The full-size CPU-oracle frames (19 TFLOP each: 30-90 s on the GPU box's host cores) were 60 % of the GPU suite's wall time
+# while the GPU sat idle. `prefetch` queues a frame for ONE background worker thread (frames one after the other, each on all
+# host cores: torch's CPU kernels release the GIL); the tests that need them run last (tests/conftest.py moves `fullsize` tests
+# to the end), so the oracle computes under the other tests' GPU work. Only the CHECKER moves to a thread -- what is compared,
+# and against what, is unchanged.
+_PREFETCH_EVENTS = {}
+_PREFETCH_Q = None
+_PREFETCH_LOCK = threading.Lock()
+
+
+def _prefetch_worker():
+    while True:
+        key, fn, ev = _PREFETCH_Q.get()
+        t = time.time()
+        try:
+            _ORACLE_CACHE[key] = fn()
+        except BaseException as e:  # noqa: BLE001 -- re-raised in the test that asks for the frame
+            _ORACLE_CACHE[key] = e
+        print(f"      [prefetch] oracle frame {key[:3]} ready after {time.time() - t:.1f}s", flush=True)
+        ev.set()
+
+
+def prefetch(key, fn):
+    global _PREFETCH_Q
+    with _PREFETCH_LOCK:
+        if key in _ORACLE_CACHE or key in _PREFETCH_EVENTS:
+            return
+        if _PREFETCH_Q is None:
+            _PREFETCH_Q = queue.Queue()
+            threading.Thread(target=_prefetch_worker, name="oracle-prefetch", daemon=True).start()
+        ev = threading.Event()
+        _PREFETCH_EVENTS[key] = ev
+        _PREFETCH_Q.put((key, fn, ev))
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -561,6 +605,41 @@ def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY,
     return out, ref
 
 
+def full_size_key(frame, f16_weights, scheme, want_q):
+    return ("full", frame, bool(f16_weights), scheme, bool(want_q))
+
+
+def full_size_reference(frame="seeded", f16_weights=False, scheme=Wt.INIT_PARITY, want_q=False):
+    """The CPU-oracle side of `run_full_size`: the input frame, the fp32 oracle's result and (seeded frame, `want_q`) the result of
+    the oracle that rounds every MFMA operand to bf16 where the engine does."""
+    cfg = DepthProConfig()
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
+    if f16_weights:
+        W = {k: R.f16_round(v) for k, v in W.items()}
+    S = cfg.img_size()
+    rgb = None
+    if frame == "seeded":
+        g = torch.Generator().manual_seed(0)  # = torch.manual_seed(0); torch.rand(...): a private generator keeps a worker thread off the global one
+        x = (torch.rand(1, 3, S, S, generator=g) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
+    elif frame == "zeros":
+        x = torch.zeros(1, 3, S, S)
+    else:
+        rgb = np.load(os.path.join(ROOT, "tests", "golden", "test_jpg_rgb.npy"))
+        x = R.rgb_to_input_tensor(rgb.tobytes(), rgb.shape[1], rgb.shape[0])
+    t0 = time.time()
+    with torch.no_grad():
+        ref = R.infer(x, W, cfg)
+    print(f"      full-size oracle fp32 {time.time() - t0:.1f}s ({frame} frame {tuple(x.shape)})", flush=True)
+    refq = None
+    if want_q:
+        # the bf16 mode is ALSO held to the oracle that rounds every MFMA operand where the engine does (as run_e2e does at 512^2)
+        t0 = time.time()
+        with torch.no_grad():
+            refq = R.infer(x, W, cfg, q=R.bf16_round)["depth"]
+        print(f"      full-size oracle with bf16 operand rounding {time.time() - t0:.1f}s", flush=True)
+    return dict(x=x, rgb=rgb, ref=ref, refq=refq)
+
+
 def run_full_size(dev, precisions=(Precision.F32, Precision.F16, Precision.BF16), f16_weights=False, frame="seeded", scheme=Wt.INIT_PARITY, emulated=True):
     """The default DepthProConfig at full size, every precision mode in `precisions` against ONE fp32 CPU-oracle frame (the
     oracle costs ~19 TFLOP: about a minute on the GPU box's host cores). `frame`:
@@ -571,33 +650,10 @@ def run_full_size(dev, precisions=(Precision.F32, Precision.F16, Precision.BF16)
                  tests/golden/test_jpg_rgb.npy) through `infer_from_rgb` (src/inference.rs:128-137) -- both resizes of
                  DepthPro::infer (mod.rs:317-354) run.
     f16_weights: the weights rounded to f16 on both sides, as the reference's checkpoint records hold them (mod.rs:206)."""
-    cfg = DepthProConfig()
-    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
-    if f16_weights:
-        W = {k: R.f16_round(v) for k, v in W.items()}
-    S = cfg.img_size()
-    rgb = None
-    if frame == "seeded":
-        torch.manual_seed(0)
-        x = (torch.rand(1, 3, S, S) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
-    elif frame == "zeros":
-        x = torch.zeros(1, 3, S, S)
-    else:
-        rgb = np.load(os.path.join(ROOT, "tests", "golden", "test_jpg_rgb.npy"))
-        x = R.rgb_to_input_tensor(rgb.tobytes(), rgb.shape[1], rgb.shape[0])
-    t0 = time.time()
-    with torch.no_grad():
-        ref = R.infer(x, W, cfg)
-    print(f"      full-size oracle fp32 {time.time() - t0:.1f}s ({frame} frame {tuple(x.shape)})", flush=True)
+    want_q = frame == "seeded" and Precision.BF16 in precisions and emulated
+    fr = cached(full_size_key(frame, f16_weights, scheme, want_q), lambda: full_size_reference(frame, f16_weights, scheme, want_q))
+    x, rgb, ref, refq = fr["x"], fr["rgb"], fr["ref"], fr["refq"]
     rd = ref["depth"]
-    refq = None
-    if frame == "seeded" and Precision.BF16 in precisions and emulated:
-        # the bf16 mode is ALSO held to the oracle that rounds every MFMA operand where the engine does (as run_e2e does at 512^2)
-        t0 = time.time()
-        with torch.no_grad():
-            refq = R.infer(x, W, cfg, q=R.bf16_round)["depth"]
-        print(f"      full-size oracle with bf16 operand rounding {time.time() - t0:.1f}s", flush=True)
-    del W
     tag = ("" if frame == "seeded" else f"/{frame}") + ("/f16w" if f16_weights else "") + ("/refinit" if scheme == Wt.INIT_REFERENCE else "")
     want_taps = frame == "seeded" and Precision.F32 in precisions and any(int(p) in FULL_TAP_TOL for p in precisions)
     ref_taps = None
@@ -782,6 +838,24 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY, taps=False, f1
     print(f"      da3 kernel time {tot:.2f} ms/batch: " + ", ".join(f"{k}={v[0]:.2f}ms/{v[1]}" for k, v in sorted(tm.items(), key=lambda kv: -kv[1][0])[:12]), flush=True)
     model.enable_timing(False)
     model.destroy()
+
+
+def prefetch_da3(cfg, B, scheme=Wt.INIT_PARITY):
+    """Queues the fp32 oracle frame `run_da3(dev, cfg, .., B, ..)` (seeded input, no taps, fp32-valued weights) will ask for."""
+    from oracle import da3_ref as D3
+    key = ("da3", cfg_key(cfg), B, scheme, False, "seeded")
+
+    def fn():
+        W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, scheme))
+        g = torch.Generator().manual_seed(1)  # = torch.manual_seed(1); torch.randn(...) of run_da3, without touching the global generator
+        x = torch.randn(B, 3, cfg.image_size, cfg.image_width or cfg.image_size, generator=g)
+        with torch.no_grad():
+            return D3.infer(x, W, cfg, debug=False)
+    prefetch(key, fn)
+
+
+def prefetch_full_size(frame="seeded", f16_weights=False, scheme=Wt.INIT_PARITY, want_q=False):
+    prefetch(full_size_key(frame, f16_weights, scheme, want_q), lambda: full_size_reference(frame, f16_weights, scheme, want_q))
 
 
 def camera_inputs(B, V, H, W, seed=3):
