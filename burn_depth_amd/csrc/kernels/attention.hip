@@ -91,15 +91,23 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // last bits of a DA3 result may differ between one image and a batch; Depth Pro's 577-key sequences never take it. The rare safe pass
 // runs un-split on group 0.
 template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1, int QW = 4>
-__global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+__global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2) : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
                                                            int S, int n_tokens, int heads, int D, int kpad, int qblocks,
                                                            float out_fp8_inv, long v_plane) {
   constexpr bool SP = is_split<T>::value;
   constexpr int STAGE = SP ? 32768 : 16384;  // K tile 64x128B + V^T tile 64x128B (split-half: hi tiles, then the lo tiles 16 KB behind)
-  constexpr int LO = 16384;                  // split-half: offset of a stage's lo tiles
-  // one-plane types: static LDS (two stages | redo flag); split-half: 64 KB + flag as dynamic LDS (above the static limit)
+  // Split-half, one key group (the Depth Pro form): the four tiles of a stage are 32 KB, two stages 64 KB = two workgroups per CU, two
+  // waves per SIMD, although the 148 registers allow three. CK (compact K): ONE K buffer (hi | lo, 16 KB) + TWO V^T stages (hi | lo,
+  // 16 KB each) = 48 KB, three workgroups per CU. K is needed only by the score MFMAs at the head of a tile: behind them a second
+  // workgroup barrier ("mid") frees the K buffer and the next tile's K is requested there -- it has the softmax and the P.V MFMAs of
+  // this tile to land --, V^T stays double-buffered and is requested a whole tile ahead as before.
+  constexpr bool CK = SP && KS == 1;
+  constexpr int RING = CK ? 49152 : 2 * STAGE;  // LDS bytes of one key group's buffers
+  // byte offsets inside a stage (CK: inside the K buffer / a V^T stage) of the lo planes, and of the V^T tile
+  constexpr int KLO = CK ? 8192 : 16384, VLO = CK ? 8192 : 16384, VOFF = CK ? 0 : 8192;
+  // one-plane types: static LDS (two stages | redo flag); split-half: 48 / 64 KB + flag as dynamic LDS (above the static limit)
   constexpr bool DYN = SP || KS > 1;
-  static_assert(KS == 1 || (!FP8OUT && FAST && KS * 2 * STAGE <= 131072), "the key split is built for the fast body; the rings must fit the LDS");
+  static_assert(KS == 1 || (!FP8OUT && FAST && KS * RING <= 131072), "the key split is built for the fast body; the rings must fit the LDS");
   static_assert(QW == 4 || (QW == 2 && KS > 1), "two query waves per workgroup come with the key split");
   constexpr int NJ = 4 / QW;  // 8-row groups of a 32-row half tile each wave of a key group moves (4 waves: one each)
   __shared__ __attribute__((aligned(16))) char smem_static[DYN ? 16 : 2 * STAGE + 16];
@@ -110,7 +118,10 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = KS > 1 ? (wave_all % QW) : wave_all;  // the query wave: 32 queries
   const int grp = KS > 1 ? (wave_all / QW) : 0;          // the key group (own ring)
-  char* const ring = smem + grp * (2 * STAGE);
+  char* const ring = smem + grp * RING;
+  // K buffer / V^T stage of tile t
+  auto kbuf = [&](int t) __attribute__((always_inline)) { return CK ? ring : ring + (t & 1) * STAGE; };
+  auto vbuf = [&](int t) __attribute__((always_inline)) { return CK ? ring + 16384 + (t & 1) * 16384 : ring + (t & 1) * STAGE + VOFF; };
   int id;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -162,20 +173,32 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
     vvoff[j] = r0 * kpad * (int)sizeof(T) + lc0 * 16;
   }
   const int NT = (n_tokens + 63) / 64;
-  auto issue = [&](int t) __attribute__((always_inline)) {
+  auto issue_k = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      __attribute__((address_space(3))) char* sb = (__attribute__((address_space(3))) char*)(ring + (t & 1) * STAGE + (wave + QW * j) * 1024);
+      __attribute__((address_space(3))) char* kb = (__attribute__((address_space(3))) char*)(kbuf(t) + (wave + QW * j) * 1024);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, sb + i * 4096, 16, kvoff[j], (t * 64 + i * 32) * (int)krow_bytes, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd, sb + 8192 + i * 4096, 16, vvoff[j], t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
-        if constexpr (SP) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, sb + LO + i * 4096, 16, kvoff[j], (t * 64 + i * 32) * (int)krow_bytes + klo_bytes, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd_lo, sb + LO + 8192 + i * 4096, 16, vvoff[j], t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, kb + i * 4096, 16, kvoff[j], (t * 64 + i * 32) * (int)krow_bytes, 0, 0);
+        if constexpr (SP) __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, kb + KLO + i * 4096, 16, kvoff[j], (t * 64 + i * 32) * (int)krow_bytes + klo_bytes, 0, 0);
       }
     }
+  };
+  auto issue_v = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      __attribute__((address_space(3))) char* vb = (__attribute__((address_space(3))) char*)(vbuf(t) + (wave + QW * j) * 1024);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd, vb + i * 4096, 16, vvoff[j], t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
+        if constexpr (SP) __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd_lo, vb + VLO + i * 4096, 16, vvoff[j], t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
+      }
+    }
+  };
+  // the whole tile's requests (CK: only the V^T half; K follows at the previous tile's mid barrier)
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    if constexpr (!CK) issue_k(t);
+    issue_v(t);
   };
 
   // LDS read offsets. K rows are read through the bit-2/bit-3 swap; V^T rows (= d) directly.
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
     const int R = dt * 32 + c;
-    voff[dt] = 8192 + R * 128 + ((((R >> 1) & 7) ^ h) << 4);  // chunk (sub*4 + 2s' + h) ^ swz
+    voff[dt] = R * 128 + ((((R >> 1) & 7) ^ h) << 4);  // chunk (sub*4 + 2s' + h) ^ swz, inside the V^T tile
   }
 
   constexpr float kDefer = 6.0f;        // log2 units: p <= 64 in the safe body
@@ -208,16 +231,28 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
     __syncthreads();
     if (t + 1 < NT) issue(t + 1);
   };
+  // CK: behind a tile's score MFMAs -- every wave has read its K fragments (the MFMAs that consumed them are issued) -- the single K
+  // buffer takes the next tile's K. An inactive wave (no valid query) meets the same barrier from `idle_mid`.
+  auto mid = [&](int t) __attribute__((always_inline)) {
+    if constexpr (CK) {
+      // a raw barrier behind the wave's own LDS reads: __syncthreads() would also drain vmcnt, i.e. wait for the V^T tile requested
+      // a few hundred cycles ago at the top of this tile
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 1 < NT) issue_k(t + 1);
+    }
+  };
   // S^T[sub] = K[sub] . Q^T (log2 units: q is pre-scaled); register r of lane half h holds local key (r&7) + 8h + 16(r>>3)
   auto scores_sub = [&](int t, int sub, f32x16_t& st) __attribute__((always_inline)) {
-    const char* sb = ring + (t & 1) * STAGE;
+    const char* sb = kbuf(t);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const i32x4_t kf = *(const i32x4_t*)(sb + (koff[sub] ^ (s << 5)));
       const f32x16_t cin = s == 0 ? (f32x16_t){0.f} : st;  // first k-step: inline-constant 0 as C
       st = mfma32<T>(kf, qf[s], cin);
       if constexpr (SP) {  // + k_lo.q_hi + k_hi.q_lo
-        const i32x4_t kl = *(const i32x4_t*)(sb + LO + (koff[sub] ^ (s << 5)));
+        const i32x4_t kl = *(const i32x4_t*)(sb + KLO + (koff[sub] ^ (s << 5)));
         st = mfma32<T>(kl, qf[s], st);
         st = mfma32<T>(kf, qfl[s], st);
       }
@@ -263,7 +298,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   };
   // O^T[dt] += V^T[dt][keys of sub] . P^T[sub]: k-step s2 holds local keys 16 s2 .. 16 s2 + 15 of the 32-key block
   auto pv_sub = [&](int t, int sub, const i32x4_t (&pf)[2], const i32x4_t (&pfl)[2], int nsteps) __attribute__((always_inline)) {
-    const char* sb = ring + (t & 1) * STAGE;
+    const char* sb = vbuf(t);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       if (s2 < nsteps) {
@@ -272,7 +307,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
           const i32x4_t vf = *(const i32x4_t*)(sb + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
           o[dt] = mfma32<T>(vf, pf[s2], o[dt]);
           if constexpr (SP) {  // + v_lo.P (+ v_hi.P_lo)
-            const i32x4_t vl = *(const i32x4_t*)(sb + LO + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
+            const i32x4_t vl = *(const i32x4_t*)(sb + VLO + (voff[dt] ^ ((sub * 4 + 2 * s2) << 4)));
             o[dt] = mfma32<T>(vl, pf[s2], o[dt]);
             if constexpr (PTERMS == 2) o[dt] = mfma32<T>(vf, pfl[s2], o[dt]);
           }
@@ -292,6 +327,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
     scores_sub(t, 0, st0);
     if (two) scores_sub(t, 1, st1);
+    mid(t);
     if constexpr (PARTIAL) {
       mask_sub(t, 0, st0);
       if (two) mask_sub(t, 1, st1);
@@ -339,19 +375,24 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
     m_run = SAFE ? -INFINITY : 0.f;  // safe: alpha = 2^-inf = 0 multiplies zeros at the first tile
     l_run = 0.f;
     if constexpr (KS == 1) {
+      if constexpr (CK) issue_k(0);
       issue(0);
       top(0);
       if (active) {
         if (NFULL == 0) tile(0, safe_c, std::true_type(), check_t());
         else tile(0, safe_c, std::false_type(), check_t());
+      } else {
+        mid(0);
       }
       for (int t = 1; t < NFULL; ++t) {
         top(t);
         if (active) tile(t, safe_c, std::false_type(), std::false_type());
+        else mid(t);
       }
       if (last_partial && NT > 1) {
         top(NT - 1);
         if (active) tile(NT - 1, safe_c, std::true_type(), std::false_type());
+        else mid(NT - 1);
       }
     } else {
       // this group's tiles [tb, te): a quarter of the keys in the fast pass; the safe pass runs on group 0 alone. Every wave of
@@ -390,7 +431,7 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? 2 : 4) void atte
   };
   bool use_safe = !FAST;
   if constexpr (FAST) {
-    int* redo = (int*)(smem + KS * 2 * STAGE);  // behind the stages in either LDS form
+    int* redo = (int*)(smem + KS * RING);  // behind the buffers in every LDS form
     if (tid == 0) *redo = 0;
     pass(std::false_type());
     if (active) bad = bad || __any(!(l_run < kFastSumMax));  // a tile row sum >= 2^100, inf or NaN shows in the total
@@ -526,7 +567,7 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   if (prec == MD_PREC_F16X2) {
     if (out_fp8_inv > 0.f || v_plane <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "attention: split-half operands need the V^T plane offset and write split-half rows");
     auto go = [&](auto kern, auto ks_c) -> int {
-      constexpr int KS = decltype(ks_c)::value, smem = KS * 2 * 32768 + 16;
+      constexpr int KS = decltype(ks_c)::value, smem = (KS == 1 ? 49152 : KS * 2 * 32768) + 16;  // one key group: the compact-K form
       static std::atomic<unsigned long> attr_set{0};
       MD_TRY(set_smem((const void*)kern, &attr_set, smem));
       const dim3 g = KS == 1 ? grid : grid_s;

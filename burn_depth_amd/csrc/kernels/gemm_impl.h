@@ -1238,6 +1238,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             const unsigned yq = (unsigned)fdiv(m, p.fd_psW);
             const unsigned eo = (unsigned)m * k1 + yq * k2 + c_lane;
             *(i32x4_t*)(ob + (size_t)eo * 2u) = raw;
+            if constexpr (is_split<TO>::value) {  // the lo plane's image sits 8 KB behind the hi plane's; its columns o_plane further right
+              const i32x4_t raw_lo = *(const i32x4_t*)(st + 8192 + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+              *(i32x4_t*)(ob + ((size_t)eo + (size_t)p.o_plane) * 2u) = raw_lo;
+            }
           }
         }
         asm volatile("" ::: "memory");
@@ -1470,7 +1474,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           for (int j = 0; j < 8; ++j) prefetch(1, j);
         }
       }
-    } else if constexpr (pixshuf) {
+    } else if constexpr (pixshuf && !is_split<TO>::value) {  // split-half launches reach EK 3 only in its fast form (launch_256)
       const int f = p.ps_f;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
@@ -1585,8 +1589,8 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   (void)dset;
   switch (ek) {
     case 1: return go(gemm256_kernel<T, AMODE, 1, false>, &set[1]);
-    case 3:
-      if constexpr (!is_split<T>::value) return go(gemm256_kernel<T, AMODE, 3, false>, &set[3]);
+    case 3:  // split-half operands: the fast form only (16-byte stores of both planes); anything else takes the generic kind
+      if (!is_split<T>::value || p.ps_fast) return go(gemm256_kernel<T, AMODE, 3, false>, &set[3]);
       break;
     case 2:
       if constexpr (sizeof(typename OutT<T>::type) == 2) return go(gemm256_kernel<T, AMODE, 2, false>, &set[2]);

@@ -294,11 +294,7 @@ def da3_param_specs(cfg: DepthAnything3Config, scheme: int = INIT_REFERENCE) -> 
 
 
 def generate_da3_weights(cfg: DepthAnything3Config, seed: int = 0, scheme: int = INIT_REFERENCE) -> Dict[str, np.ndarray]:
-    out: Dict[str, np.ndarray] = {}
-    for spec in da3_param_specs(cfg, scheme):
-        n = int(np.prod(spec.shape))
-        out[spec.name] = uniform_stream(spec.name, seed, n, spec.lo, spec.hi).reshape(spec.shape)
-    return out
+    return _generate(da3_param_specs(cfg, scheme), seed)
 
 
 # --------------------------------------------------------------------------------------------
@@ -343,11 +339,26 @@ def uniform_stream(name: str, seed: int, count: int, lo: float, hi: float) -> np
 def generate_depth_pro_weights(cfg: DepthProConfig, seed: int = 0,
                                scheme: int = INIT_REFERENCE) -> Dict[str, np.ndarray]:
     """Synthetic weights for ``DepthPro::new`` (random init; depth_pro/mod.rs:145-191)."""
-    out: Dict[str, np.ndarray] = {}
-    for spec in depth_pro_param_specs(cfg, scheme):
+    return _generate(depth_pro_param_specs(cfg, scheme), seed)
+
+
+def _generate(specs, seed: int) -> Dict[str, np.ndarray]:
+    """Every stream is independent of the others (its key is the tensor's name): the 0.95 G values of the default Depth Pro
+    inventory took 34 s on one thread -- most of a full-size parity test's host time -- so the tensors are filled by a small
+    thread pool (numpy's ufuncs release the GIL). Same values, same order of the returned dict."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    specs = list(specs)
+
+    def one(spec):
         n = int(np.prod(spec.shape))
-        out[spec.name] = uniform_stream(spec.name, seed, n, spec.lo, spec.hi).reshape(spec.shape)
-    return out
+        return uniform_stream(spec.name, seed, n, spec.lo, spec.hi).reshape(spec.shape)
+    workers = max(1, min(16, (os.cpu_count() or 1)))
+    if workers == 1 or len(specs) < 4:
+        return {s.name: one(s) for s in specs}
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        vals = list(ex.map(one, specs))
+    return {s.name: v for s, v in zip(specs, vals)}
 
 
 # --------------------------------------------------------------------------------------------

@@ -39,9 +39,10 @@ def dev():
 
 @pytest.fixture(scope="module", autouse=True)
 def _oracle_frames_ahead(request, diag):
-    """Queues the full-size CPU-oracle frames of the SELECTED `fullsize` tests (in the order those tests run) on gpu_diag's
-    background worker: the suite spent 60 % of its wall time waiting for them with the GPU idle (profiles/r04_pytest_gpu.log:
-    621 s of the driver's 900-s limit)."""
+    """Registers the full-size CPU-oracle frames of the SELECTED `fullsize` tests with gpu_diag: when the first of those tests
+    (they run last, tests/conftest.py) asks for its frame, ALL registered frames are computed concurrently in child processes on a
+    share of the host cores each (tools/oracle_frames.py) -- one after the other on all cores they were most of the suite's 621 s
+    (profiles/r04_pytest_gpu.log; the driver's limit is 900 s)."""
     from burn_depth_amd import weights as Wt
     from burn_depth_amd.config import DepthAnything3Config
     picked = {i.name.split("[")[0] for i in request.session.items}

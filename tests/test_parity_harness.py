@@ -80,3 +80,36 @@ def test_replay_report_follows_the_harness_lines():
     assert "shape mismatch" in short[0]
     if len(fus) > 1:
         assert short[-1].startswith("[Replay] fusion count mismatch")
+
+
+def test_full_size_oracle_frames_come_from_child_processes(tmp_path):
+    """tools/gpu_diag.py computes the full-size oracle frames of the GPU suite concurrently in child processes
+    (tools/oracle_frames.py): a registered frame is produced by a child, is the frame the in-process oracle gives, and lands
+    under the cache key the GPU-side runner asks for. (CPU-sized stand-in: Depth-Anything-v3 `small` at 70 x 70.)"""
+    import os
+    import sys
+    import torch
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        import gpu_diag as diag
+        import oracle_frames
+    finally:
+        sys.path.remove(tools)
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config
+    cfg = DepthAnything3Config.small()
+    cfg.image_size = 70
+    key = ("da3", diag.cfg_key(cfg), 1, Wt.INIT_PARITY, False, "seeded")
+    diag._ORACLE_CACHE.pop(key, None)
+    diag.prefetch_da3(cfg, 1)
+    assert key in diag._PENDING_JOBS
+    got = diag.cached(key, lambda: pytest.fail("the registered frame was recomputed in-process"))
+    assert key not in diag._PENDING_JOBS and key in diag._ORACLE_CACHE
+    want = oracle_frames.da3_frame("small", 70, 1, Wt.INIT_PARITY)["out"]
+    assert set(got) == set(want) and torch.equal(got["depth"], want["depth"])
+    # a failing child surfaces in the test that asks for its frame
+    diag.register_frame(("da3", "broken"), {"fp32": "da3:no_such_variant:70:1:1"})
+    with pytest.raises(RuntimeError, match="failed in its child process"):
+        diag.cached(("da3", "broken"), lambda: None)
+    assert diag.host_cpus() >= 1 and diag.host_mem_gb() > 0

@@ -9,8 +9,6 @@ import argparse
 import math
 import os
 import sys
-import queue
-import threading
 import time
 import traceback
 
@@ -37,9 +35,8 @@ def cfg_key(cfg):
 
 
 def cached(key, fn):
-    ev = _PREFETCH_EVENTS.get(key)
-    if ev is not None:  # a frame the background worker has taken: wait for it instead of computing it twice
-        ev.wait()
+    if key in _PENDING_JOBS:  # a registered full-size frame: compute it together with every other registered one, in child processes
+        prefetch_processes()
     if key not in _ORACLE_CACHE:
         _ORACLE_CACHE[key] = fn()
     v = _ORACLE_CACHE[key]
@@ -48,40 +45,96 @@ def cached(key, fn):
     return v
 
 
-# ---- oracle frames ahead of their tests ---------------------------------------------------------------------------------
-# The full-size CPU-oracle frames (19 TFLOP each: 30-90 s on the GPU box's host cores) were 60 % of the GPU suite's wall time
-# while the GPU sat idle. `prefetch` queues a frame for ONE background worker thread (frames one after the other, each on all
-# host cores: torch's CPU kernels release the GIL); the tests that need them run last (tests/conftest.py moves `fullsize` tests
-# to the end), so the oracle computes under the other tests' GPU work. Only the CHECKER moves to a thread -- what is compared,
-# and against what, is unchanged.
-_PREFETCH_EVENTS = {}
-_PREFETCH_Q = None
-_PREFETCH_LOCK = threading.Lock()
+# ---- oracle frames in child processes -----------------------------------------------------------------------------------
+# The full-size CPU-oracle frames (7-19 TFLOP each) were 60 % of the GPU suite's wall time, one after the other on all host
+# cores. `prefetch_processes` computes the frames a run will need CONCURRENTLY, one child process per frame on a share of the
+# cores (tools/oracle_frames.py: no GPU, no library), when the first full-size test asks for one; the tests that need them run
+# last (tests/conftest.py moves `fullsize` tests to the end). Only the CHECKER moves -- what is compared, and against what, is
+# unchanged. (A first form -- a background THREAD under the earlier tests -- made the whole suite slower: two 64-thread OpenMP teams
+# on the same cores, profiles/r05_pytest_gpu_thread_prefetch.log.)
+_PENDING_JOBS = {}   # cache key -> list of (job string, slot) the key's value is assembled from
 
 
-def _prefetch_worker():
-    while True:
-        key, fn, ev = _PREFETCH_Q.get()
-        t = time.time()
+def host_cpus() -> int:
+    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
-            _ORACLE_CACHE[key] = fn()
-        except BaseException as e:  # noqa: BLE001 -- re-raised in the test that asks for the frame
-            _ORACLE_CACHE[key] = e
-        print(f"      [prefetch] oracle frame {key[:3]} ready after {time.time() - t:.1f}s", flush=True)
-        ev.set()
+            txt = open(path).read().split()
+            if path.endswith("cpu.max") and txt[0] != "max":
+                n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            elif path.endswith("quota_us") and int(txt[0]) > 0:
+                n = min(n, max(1, int(int(txt[0]) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
 
 
-def prefetch(key, fn):
-    global _PREFETCH_Q
-    with _PREFETCH_LOCK:
-        if key in _ORACLE_CACHE or key in _PREFETCH_EVENTS:
-            return
-        if _PREFETCH_Q is None:
-            _PREFETCH_Q = queue.Queue()
-            threading.Thread(target=_prefetch_worker, name="oracle-prefetch", daemon=True).start()
-        ev = threading.Event()
-        _PREFETCH_EVENTS[key] = ev
-        _PREFETCH_Q.put((key, fn, ev))
+def host_mem_gb() -> float:
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 64.0
+
+
+def register_frame(key, jobs):
+    """`key`: the oracle-cache key a test will ask for; `jobs`: {slot: job string of tools/oracle_frames.py}."""
+    if key not in _ORACLE_CACHE:
+        _PENDING_JOBS[key] = dict(jobs)
+
+
+def prefetch_processes():
+    """Computes every registered frame now, in parallel child processes, and fills the oracle cache."""
+    import subprocess
+    import tempfile
+    pending = {k: v for k, v in _PENDING_JOBS.items() if k not in _ORACLE_CACHE}
+    _PENDING_JOBS.clear()
+    jobs = sorted({j for v in pending.values() for j in v.values()}, key=lambda j: 0 if j.endswith(":q") else 1)  # the slowest first
+    if not jobs:
+        return
+    cpus, mem = host_cpus(), host_mem_gb()
+    width = max(1, min(len(jobs), int(mem // 24) or 1, max(1, cpus // 8)))  # a Depth Pro frame peaks near 20 GB of host memory
+    threads = max(1, cpus // width)
+    tmp = tempfile.mkdtemp(prefix="oracle_frames_")
+    t0 = time.time()
+    print(f"      [oracle frames] {len(jobs)} frames in {width} child processes x {threads} threads ({cpus} usable cores, {mem:.0f} GB available)", flush=True)
+    running, results, todo = [], {}, list(jobs)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    while todo or running:
+        while todo and len(running) < width:
+            j = todo.pop(0)
+            out = os.path.join(tmp, f"{len(results) + len(running)}.pt")
+            pr = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "oracle_frames.py"), "--job", j, "--out", out, "--threads", str(threads)],
+                                  env=env, cwd=ROOT)
+            running.append((j, out, pr))
+        time.sleep(0.5)
+        for item in list(running):
+            j, out, pr = item
+            rc = pr.poll()
+            if rc is None:
+                continue
+            running.remove(item)
+            if rc != 0 or not os.path.exists(out):
+                results[j] = RuntimeError(f"oracle frame `{j}` failed in its child process (exit code {rc})")
+            else:
+                results[j] = torch.load(out, weights_only=False)
+                os.remove(out)
+    print(f"      [oracle frames] ready after {time.time() - t0:.1f}s", flush=True)
+    for key, slots in pending.items():
+        parts = {slot: results[j] for slot, j in slots.items()}
+        bad = [v for v in parts.values() if isinstance(v, BaseException)]
+        _ORACLE_CACHE[key] = bad[0] if bad else _ASSEMBLE[key[0]](parts)
+
+
+def _assemble_full(parts):
+    fp = parts["fp32"]
+    return dict(x=fp["x"], rgb=fp["rgb"], ref=fp["out"], refq=parts["q"]["out"] if "q" in parts else None)
+
+
+_ASSEMBLE = {"full": _assemble_full, "da3": lambda parts: parts["fp32"]["out"]}
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -610,34 +663,14 @@ def full_size_key(frame, f16_weights, scheme, want_q):
 
 
 def full_size_reference(frame="seeded", f16_weights=False, scheme=Wt.INIT_PARITY, want_q=False):
-    """The CPU-oracle side of `run_full_size`: the input frame, the fp32 oracle's result and (seeded frame, `want_q`) the result of
-    the oracle that rounds every MFMA operand to bf16 where the engine does."""
-    cfg = DepthProConfig()
-    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
-    if f16_weights:
-        W = {k: R.f16_round(v) for k, v in W.items()}
-    S = cfg.img_size()
-    rgb = None
-    if frame == "seeded":
-        g = torch.Generator().manual_seed(0)  # = torch.manual_seed(0); torch.rand(...): a private generator keeps a worker thread off the global one
-        x = (torch.rand(1, 3, S, S, generator=g) - torch.tensor(R.MEAN).view(1, 3, 1, 1)) / torch.tensor(R.STD).view(1, 3, 1, 1)
-    elif frame == "zeros":
-        x = torch.zeros(1, 3, S, S)
-    else:
-        rgb = np.load(os.path.join(ROOT, "tests", "golden", "test_jpg_rgb.npy"))
-        x = R.rgb_to_input_tensor(rgb.tobytes(), rgb.shape[1], rgb.shape[0])
-    t0 = time.time()
-    with torch.no_grad():
-        ref = R.infer(x, W, cfg)
-    print(f"      full-size oracle fp32 {time.time() - t0:.1f}s ({frame} frame {tuple(x.shape)})", flush=True)
-    refq = None
+    """The CPU-oracle side of `run_full_size`, in this process (a registered frame comes from a child process instead,
+    `prefetch_processes`): the input frame, the fp32 oracle's result and (seeded frame, `want_q`) the result of the oracle that
+    rounds every MFMA operand to bf16 where the engine does."""
+    import oracle_frames
+    parts = {"fp32": oracle_frames.full_size_frame(frame, f16_weights, scheme, "fp32")}
     if want_q:
-        # the bf16 mode is ALSO held to the oracle that rounds every MFMA operand where the engine does (as run_e2e does at 512^2)
-        t0 = time.time()
-        with torch.no_grad():
-            refq = R.infer(x, W, cfg, q=R.bf16_round)["depth"]
-        print(f"      full-size oracle with bf16 operand rounding {time.time() - t0:.1f}s", flush=True)
-    return dict(x=x, rgb=rgb, ref=ref, refq=refq)
+        parts["q"] = oracle_frames.full_size_frame(frame, f16_weights, scheme, "q")
+    return _assemble_full(parts)
 
 
 def run_full_size(dev, precisions=(Precision.F32, Precision.F16, Precision.BF16), f16_weights=False, frame="seeded", scheme=Wt.INIT_PARITY, emulated=True):
@@ -841,21 +874,16 @@ def run_da3(dev, cfg, label, B, precision, scheme=Wt.INIT_PARITY, taps=False, f1
 
 
 def prefetch_da3(cfg, B, scheme=Wt.INIT_PARITY):
-    """Queues the fp32 oracle frame `run_da3(dev, cfg, .., B, ..)` (seeded input, no taps, fp32-valued weights) will ask for."""
-    from oracle import da3_ref as D3
-    key = ("da3", cfg_key(cfg), B, scheme, False, "seeded")
-
-    def fn():
-        W = R.weights_to_torch(Wt.generate_da3_weights(cfg, 0, scheme))
-        g = torch.Generator().manual_seed(1)  # = torch.manual_seed(1); torch.randn(...) of run_da3, without touching the global generator
-        x = torch.randn(B, 3, cfg.image_size, cfg.image_width or cfg.image_size, generator=g)
-        with torch.no_grad():
-            return D3.infer(x, W, cfg, debug=False)
-    prefetch(key, fn)
+    """Registers the fp32 oracle frame `run_da3(dev, cfg, .., B, ..)` (seeded input, no taps, fp32-valued weights) will ask for."""
+    register_frame(("da3", cfg_key(cfg), B, scheme, False, "seeded"), {"fp32": f"da3:{cfg.variant}:{cfg.image_size}:{B}:{int(scheme)}"})
 
 
 def prefetch_full_size(frame="seeded", f16_weights=False, scheme=Wt.INIT_PARITY, want_q=False):
-    prefetch(full_size_key(frame, f16_weights, scheme, want_q), lambda: full_size_reference(frame, f16_weights, scheme, want_q))
+    w = "f16w" if f16_weights else "f32w"
+    jobs = {"fp32": f"full:{frame}:{w}:{int(scheme)}:fp32"}
+    if want_q:
+        jobs["q"] = f"full:{frame}:{w}:{int(scheme)}:q"
+    register_frame(full_size_key(frame, f16_weights, scheme, want_q), jobs)
 
 
 def camera_inputs(B, V, H, W, seed=3):
