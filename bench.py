@@ -1138,11 +1138,19 @@ def cpu_baseline(cfg, budget_s: float):
     import torch
     from burn_depth_amd import weights as Wt
     from oracle import depth_pro_ref as R
-    # use this process's CPU share (a 1-GPU box gets 16 cores of the host), not every core of the host
+    # use this process's CPU share, not every core the host shows: the affinity mask cut by the cgroup CPU quota (a 1-GPU box of
+    # this pool shows 256 CPUs under a 16-core quota; on 64 threads the oracle's GEMMs ran at 0.67 of their 16-thread rate,
+    # profiles/r05_host_probe.txt -- rounds 1-4 reported "cores": 64 for what were 16 cores' worth of CPU time)
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota[0] != "max":
+            avail = min(avail, max(1, int(int(quota[0]) / int(quota[1]))))
+    except (OSError, ValueError, IndexError):
+        pass
     threads = max(1, min(avail, 64))
     torch.set_num_threads(threads)
     v = cfg.patch_vit()

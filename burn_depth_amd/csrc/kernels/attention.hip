@@ -516,6 +516,8 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2
 // The two A/B switches below exist in DIAGNOSTIC builds only (`make DIAG=1` defines MD_DIAG_KNOBS): the shipped library reads no
 // environment variable that changes numerics or kernel choice.
 //   MD_ATTN_PTERMS=1    P in one plane (depth L_inf 3.2e-4 instead of 1.3e-4 for +1 % frames/s)
+//                        (round 5: taking the row sums from the ROUNDED probabilities as well -- a consistent normaliser -- changes nothing:
+//                        L_inf 3.0e-4 against 3.3e-4, profiles/r05_attention_f16x2_pterms.txt)
 //   MD_ATTN_KEYSPLIT=0  the small-launch form off
 #ifdef MD_DIAG_KNOBS
 static int diag_env(const char* name, int dflt) {

@@ -146,6 +146,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     // best (qkv 24.3 -> 23.3 ms per step against groups of 4); the 16 n-tiles of fc1 run the same in groups of 4 or 8 and
     // slower ungrouped (34.5 / 34.7 / 34.9 ms)
     p.raster_gn = tn <= 12 ? 0 : 4;
+#ifdef MD_DIAG_KNOBS
+    // DIAG builds only: MD_GEMM_RASTER_GN = n-tiles per raster group (0 = plain n-fastest) for the L2-traffic A/B of
+    // tools/probes/raster_traffic.sh -- the shipped library reads no environment variable
+    if (const char* e = getenv("MD_GEMM_RASTER_GN")) p.raster_gn = atoi(e);
+#endif
   }
   if (p.epi == EPI_HEAD) tile = TILE_256x32;
   if (prec == MD_PREC_F32) return launch_gemm_f32(p, amode, tile, stream);

@@ -14,6 +14,20 @@ def pytest_configure(config):
                                        "is computed on a background thread under the earlier tests' GPU work (tools/gpu_diag.py prefetch)")
 
 
+def pytest_sessionstart(session):
+    """torch's CPU thread pool sized to the cores this process may really use: the GPU boxes show 256 CPUs under a 16-core cgroup
+    quota, and the oracle's GEMMs run at 0.67 of their rate on the default 128 threads (profiles/r05_host_probe.txt)."""
+    try:
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from oracle_frames import host_cpus
+        n = host_cpus()
+        if n < torch.get_num_threads():
+            torch.set_num_threads(n)
+    except Exception:  # noqa: BLE001 -- a sizing hint, never a reason to fail collection
+        pass
+
+
 def pytest_collection_modifyitems(config, items):
     """`fullsize` tests go to the end of the run (their relative order kept): their oracle frames are queued at session start
     and computed while the other tests keep the GPU busy."""

@@ -55,19 +55,7 @@ def cached(key, fn):
 _PENDING_JOBS = {}   # cache key -> list of (job string, slot) the key's value is assembled from
 
 
-def host_cpus() -> int:
-    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when there is one."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max") and txt[0] != "max":
-                n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            elif path.endswith("quota_us") and int(txt[0]) > 0:
-                n = min(n, max(1, int(int(txt[0]) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))))
-        except (OSError, ValueError, IndexError):
-            pass
-    return max(1, n)
+from oracle_frames import host_cpus  # noqa: E402  (quota-aware core count)
 
 
 def host_mem_gb() -> float:

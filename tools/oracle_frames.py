@@ -22,6 +22,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def host_cpus() -> int:
+    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when there is one. (The GPU boxes of this
+    pool show 256 CPUs and run under a 16-core quota: torch's default of 128 threads then runs the oracle's GEMMs at 0.67 of
+    the rate 16-32 threads reach, profiles/r05_host_probe.txt.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def full_size_frame(frame="seeded", f16_weights=False, scheme=1, part="fp32"):
     """Depth Pro default config at [1,3,1536,1536]: the input (`x`, and `rgb` for the test.jpg frame) and the oracle's result --
     part "fp32": `R.infer` (dict), part "q": the depth of the oracle that rounds every MFMA operand to bf16 where the engine does."""
