@@ -21,6 +21,12 @@
 #include "ops.h"
 #include "elem.h"
 
+// Experiment builds only (make EXTRA=-DMD_ATTN_VARIANT=n, tools/probes/attn_prio.sh): wave-priority placements measured in round 5
+// (profiles/r05_attention_prio.txt); 0 = the shipped kernel.
+#ifndef MD_ATTN_VARIANT
+#define MD_ATTN_VARIANT 0
+#endif
+
 namespace md {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -127,6 +133,14 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  if constexpr (MD_ATTN_VARIANT == 3) {  // a static priority per co-resident workgroup: the waves of a SIMD stop arbitrating as equals
+    switch ((blockIdx.x >> 8) & 3) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
   }
   const int unit = id / qblocks, qb = id - unit * qblocks;
   const int seq = unit / heads, head = unit - seq * heads;
@@ -325,9 +339,13 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2
     f32x16_t st0, st1;
     i32x4_t pf0[2], pf1[2], pfl0[2], pfl1[2];
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MD_ATTN_VARIANT == 1) __builtin_amdgcn_s_setprio(1);  // the score MFMAs ahead of the other waves' softmax
+    if constexpr (MD_ATTN_VARIANT == 2) __builtin_amdgcn_s_setprio(0);
     scores_sub(t, 0, st0);
     if (two) scores_sub(t, 1, st1);
     mid(t);
+    if constexpr (MD_ATTN_VARIANT == 1) __builtin_amdgcn_s_setprio(0);
+    if constexpr (MD_ATTN_VARIANT == 2) __builtin_amdgcn_s_setprio(1);  // the exponentials + P.V MFMAs ahead of the other waves' scores
     if constexpr (PARTIAL) {
       mask_sub(t, 0, st0);
       if (two) mask_sub(t, 1, st1);

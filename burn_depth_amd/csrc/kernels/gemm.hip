@@ -145,6 +145,11 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
     // raster group width, from a sweep on the Depth Pro step (B = 8): up to 12 n-tiles (qkv) plain n-fastest order is
     // best (qkv 24.3 -> 23.3 ms per step against groups of 4); the 16 n-tiles of fc1 run the same in groups of 4 or 8 and
     // slower ungrouped (34.5 / 34.7 / 34.9 ms)
+    // Round 5 re-measured it with the fabric-side counter (tools/probes/raster_traffic.sh -> profiles/r05_raster_traffic.txt): qkv in groups
+    // of 4 reads HALF the fabric bytes of the plain order (800 against 1572 MB per launch at B = 4) and runs 4 % faster STAND-ALONE (984
+    // against 944 TFLOP/s) -- and 3.8 % SLOWER inside the model on one box, twice (24.10 / 24.15 against 24.98 / 25.13 ms per step; fc1 the
+    // other way, 36.3 against 35.8: profiles/r05_raster_inmodel.txt). The bytes these launches re-read from the fabric are not what
+    // their time is made of; the rule stays.
     p.raster_gn = tn <= 12 ? 0 : 4;
 #ifdef MD_DIAG_KNOBS
     // DIAG builds only: MD_GEMM_RASTER_GN = n-tiles per raster group (0 = plain n-fastest) for the L2-traffic A/B of
