@@ -462,6 +462,8 @@ def main(argv=None) -> int:
                              "the ~226 launches cost 0.7 % of a step, so inside the timed region only the roofline family is timed") if table_steps else None,
             "kernels": kernels,
         }
+        if world == 1:
+            out["box"] = box_probe(tdev)
         if args.accuracy:
             out["accuracy"] = accuracy_report(dev, cfg.precision)
         ref_frame = None
@@ -525,6 +527,29 @@ def _dominant(model, step, fl, peak, steps=3):
     tfl = fl[dom] / (per_step * 1e-3) / 1e12
     return {"kernel": dom, "bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfl / peak, 4), "traffic": None,
             "avg_launch_ms": round(per_step / max(calls // steps, 1), 4), "ms_per_step": round(per_step, 4), "launches_per_step": calls // steps}
+
+
+def box_probe(tdev):
+    """Which class of box this run landed on (plumbing only: a torch device-to-device copy, no engine kernel). The MI355X boxes of the
+    pool differ in what their memory side sustains -- the HBM-bound LayerNorm family takes 9.8 ms per step on some and 13.7 on others
+    with byte-identical kernels (rounds 3-5) -- so a line carries the copy rate of ITS box: compare HBM-bound
+    families across runs against it, not against each other."""
+    import torch
+    n = 1 << 28  # 1 GiB of floats read + 1 GiB written per copy
+    a = torch.empty(n, dtype=torch.float32, device=tdev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        b.copy_(a)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 5
+    del a, b
+    return {"d2d_copy_tbs": round(2 * n * 4 / (ms * 1e-3) / 1e12, 3), "what": "torch copy_ of 1 GiB (read + written bytes over time): the box's achievable HBM rate",
+            "device": torch.cuda.get_device_name(0)}
 
 
 def measure_host_io(model, B, S, resident_fps, steps=4):
@@ -1114,7 +1139,7 @@ def pmc_traffic(kernel: str, B: int, args):
     WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
     gfx950 corrections of MI355X_MICROARCH.md and writes profiles/rNN_traffic.json). None if the
     passes were made for another batch/precision."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)

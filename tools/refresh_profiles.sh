@@ -2,7 +2,7 @@
 # Re-creates the judged measurement artifacts on a GPU box (run from the repo root through gpurun):
 #   gpurun_out/prof_fetch|prof_write  separate --pmc passes (FETCH_SIZE / WRITE_SIZE) of the bench command
 #   gpurun_out/traffic.json           per-launch HBM bytes per kernel family (tools/pmc_traffic.py); also copied to
-#                                     profiles/r04_traffic.json of the box's snapshot so the bench line below carries it
+#                                     profiles/${ROUND}_traffic.json (ROUND defaults to r05) of the box's snapshot so the bench line below carries it
 #   gpurun_out/bench.json             default bench line (roofline.traffic + cpu_baseline included)
 #   gpurun_out/prof_stats/            rocprofv3 --kernel-trace --stats of the same command (+ its own bench line)
 # Copy the summaries into profiles/ afterwards.
@@ -20,7 +20,7 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_w
   > "$OUT/bench_write.json" 2> "$OUT/prof_write.err" || exit 4
 python3 "$ROOT/tools/pmc_traffic.py" "$OUT/prof_fetch" "$OUT/prof_write" "$OUT/launch_order.json" "$OUT/traffic.json" \
   "$BATCH" bf16 full > "$OUT/traffic.txt" || exit 5
-cp "$OUT/traffic.json" "$ROOT/profiles/r04_traffic.json"
+cp "$OUT/traffic.json" "$ROOT/profiles/${ROUND:-r05}_traffic.json"
 timeout -k 10 500 python3 "$ROOT/bench.py" --steps 10 --warmup 3 --side-kernels > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -- \
   python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench_prof.json" 2> "$OUT/prof_stats.err" || exit 2
