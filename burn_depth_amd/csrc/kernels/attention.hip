@@ -21,12 +21,6 @@
 #include "ops.h"
 #include "elem.h"
 
-// Experiment builds only (make EXTRA=-DMD_ATTN_VARIANT=n, tools/probes/attn_prio.sh): wave-priority placements measured in round 5
-// (profiles/r05_attention_prio.txt); 0 = the shipped kernel.
-#ifndef MD_ATTN_VARIANT
-#define MD_ATTN_VARIANT 0
-#endif
-
 namespace md {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -96,12 +90,11 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // the same work either way; spreading it over twice the CUs is what shortens the chain.) The rule depends on the launch size, so the
 // last bits of a DA3 result may differ between one image and a batch; Depth Pro's 577-key sequences never take it. The rare safe pass
 // runs un-split on group 0.
-// LD (loader wave, round 5; one-plane types, one key group, four query waves): a FIFTH wave per workgroup issues every LDS-DMA piece of a
-// tile (16 instructions) and waits for them; the four query waves never touch the vector-memory pipe inside the loop -- the in-kernel
-// ablation prices their four LDS-DMA issues per tile at 18 % of the kernel. Five waves at 112 registers are three workgroups per CU
-// (12 query waves + 3 loaders) instead of four.
-template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1, int QW = 4, bool LD = false>
-__global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? (KS == 1 ? 3 : 2) : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+// (Round 5 measured and removed -- commit 6e0680d has the code: a loader-wave form, a fifth wave per workgroup issuing every LDS-DMA piece so that
+// the query waves never touch the vector-memory pipe: correct, 0.84x, profiles/r05_attention_loader_wave.txt; s_setprio placements: nothing,
+// profiles/r05_attention_prio.txt.)
+template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1, int QW = 4>
+__global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2) : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
                                                            int S, int n_tokens, int heads, int D, int kpad, int qblocks,
                                                            float out_fp8_inv, long v_plane) {
   constexpr bool SP = is_split<T>::value;
@@ -119,15 +112,13 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
   constexpr bool DYN = SP || KS > 1;
   static_assert(KS == 1 || (!FP8OUT && FAST && KS * RING <= 131072), "the key split is built for the fast body; the rings must fit the LDS");
   static_assert(QW == 4 || (QW == 2 && KS > 1), "two query waves per workgroup come with the key split");
-  static_assert(!LD || (!is_split<T>::value && KS == 1 && QW == 4), "the loader-wave form is built for one-plane types, one key group");
-  constexpr int NJ = LD ? 4 : 4 / QW;  // 8-row groups of a 32-row half tile each wave of a key group moves (4 waves: one each; the loader: all four)
+  constexpr int NJ = 4 / QW;  // 8-row groups of a 32-row half tile each wave of a key group moves (4 waves: one each)
   __shared__ __attribute__((aligned(16))) char smem_static[DYN ? 16 : 2 * STAGE + 16];
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char* const smem = DYN ? smem_dyn : smem_static;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = LD && wave_all == QW;              // wave-uniform: the workgroup's fifth wave
   const int wave = KS > 1 ? (wave_all % QW) : wave_all;  // the query wave: 32 queries
   const int grp = KS > 1 ? (wave_all / QW) : 0;          // the key group (own ring)
   char* const ring = smem + grp * RING;
@@ -140,18 +131,10 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  if constexpr (MD_ATTN_VARIANT == 3) {  // a static priority per co-resident workgroup: the waves of a SIMD stop arbitrating as equals
-    switch ((blockIdx.x >> 8) & 3) {
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      case 3: __builtin_amdgcn_s_setprio(3); break;
-      default: break;
-    }
-  }
   const int unit = id / qblocks, qb = id - unit * qblocks;
   const int seq = unit / heads, head = unit - seq * heads;
   const int q0 = qb * (32 * QW) + wave * 32;
-  const bool active = q0 < n_tokens && !loader;  // wave-uniform
+  const bool active = q0 < n_tokens;  // wave-uniform
   const int h = lane >> 5, c = lane & 31;
   const long two_d = 2L * D * kPlanes<T>;  // elements per q | k row (split-half: [q_hi | q_lo | k_hi | k_lo])
   const long seq_row0 = (long)seq * S;
@@ -184,12 +167,10 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
   const auto ksrd = __builtin_amdgcn_make_buffer_rsrc((void*)(qk + seq_row0 * two_d + (SP ? 2 * D : D) + head * 64), 0, (int)((unsigned)(n_tokens - 1) * krow_bytes + 128u) + klo_bytes, 0x00020000);
   const auto vsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
   const auto vsrd_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(vT + (SP ? v_plane : 0) + ((long)seq * heads + head) * 64 * kpad), 0, 64 * kpad * (int)sizeof(T), 0x00020000);
-  int kvoff[4], vvoff[4];  // NJ <= 4 (a fixed bound: an array of template-dependent size captured by the lambdas below loses the kernel's host stub)
-  const int grp0 = LD ? 0 : wave;  // the first 8-row group this wave moves (the loader: all of them)
-  constexpr int GST = LD ? 1 : QW;  // ... and the step to its next one
+  int kvoff[2], vvoff[2];  // NJ <= 2 (a fixed bound: an array of template-dependent size captured by the lambdas below loses the kernel's host stub)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int r0 = (grp0 + GST * j) * 8 + (lane >> 3);
+    const int r0 = (wave + QW * j) * 8 + (lane >> 3);
     const int lc0 = (lane & 7) ^ ((r0 >> 1) & 7);
     kvoff[j] = r0 * (int)krow_bytes + lc0 * 16;
     vvoff[j] = r0 * kpad * (int)sizeof(T) + lc0 * 16;
@@ -198,7 +179,7 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
   auto issue_k = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      __attribute__((address_space(3))) char* kb = (__attribute__((address_space(3))) char*)(kbuf(t) + (grp0 + GST * j) * 1024);
+      __attribute__((address_space(3))) char* kb = (__attribute__((address_space(3))) char*)(kbuf(t) + (wave + QW * j) * 1024);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrd, kb + i * 4096, 16, kvoff[j], (t * 64 + i * 32) * (int)krow_bytes, 0, 0);
@@ -209,7 +190,7 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
   auto issue_v = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      __attribute__((address_space(3))) char* vb = (__attribute__((address_space(3))) char*)(vbuf(t) + (grp0 + GST * j) * 1024);
+      __attribute__((address_space(3))) char* vb = (__attribute__((address_space(3))) char*)(vbuf(t) + (wave + QW * j) * 1024);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrd, vb + i * 4096, 16, vvoff[j], t * 128 + i * 32 * kpad * (int)sizeof(T), 0, 0);
@@ -219,7 +200,6 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
   };
   // the whole tile's requests (CK: only the V^T half; K follows at the previous tile's mid barrier)
   auto issue = [&](int t) __attribute__((always_inline)) {
-    if (LD && !loader) return;  // the query waves of the loader-wave form never issue
     if constexpr (!CK) issue_k(t);
     issue_v(t);
   };
@@ -348,13 +328,9 @@ __global__ __launch_bounds__(64 * QW * KS + (LD ? 64 : 0), is_split<T>::value ? 
     f32x16_t st0, st1;
     i32x4_t pf0[2], pf1[2], pfl0[2], pfl1[2];
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (MD_ATTN_VARIANT == 1) __builtin_amdgcn_s_setprio(1);  // the score MFMAs ahead of the other waves' softmax
-    if constexpr (MD_ATTN_VARIANT == 2) __builtin_amdgcn_s_setprio(0);
     scores_sub(t, 0, st0);
     if (two) scores_sub(t, 1, st1);
     mid(t);
-    if constexpr (MD_ATTN_VARIANT == 1) __builtin_amdgcn_s_setprio(0);
-    if constexpr (MD_ATTN_VARIANT == 2) __builtin_amdgcn_s_setprio(1);  // the exponentials + P.V MFMAs ahead of the other waves' scores
     if constexpr (PARTIAL) {
       mask_sub(t, 0, st0);
       if (two) mask_sub(t, 1, st1);
@@ -632,13 +608,8 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
     hipLaunchKernelGGL((attention_kernel<f16_t, false, true>), grid, block, 0, s, (const f16_t*)qk, (const f16_t*)vT, (f16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
   } else {
-#if MD_ATTN_VARIANT == 4
-    hipLaunchKernelGGL((attention_kernel<bf16_t, false, true, 1, 1, 4, true>), grid, dim3(320), 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
-                       n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
-#else
     hipLaunchKernelGGL((attention_kernel<bf16_t, false, true>), grid, block, 0, s, (const bf16_t*)qk, (const bf16_t*)vT, (bf16_t*)out, S,
                        n_tokens, heads, D, kpad, qblocks, out_fp8_inv, 0L);
-#endif
   }
   MD_HIP(hipGetLastError());
   return MD_OK;

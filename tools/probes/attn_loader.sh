@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the MD_ATTN_VARIANT=4 code lives at commit 6e0680d (removed afterwards: correct, 0.84x).
 # The loader-wave form of the bf16 attention kernel (MD_ATTN_VARIANT=4: a fifth wave per workgroup issues every LDS-DMA piece) against the
 # shipped kernel (0): operator checks, stand-alone rate, in-model step. Run from the repo root on the GPU box:
 #   bash tools/probes/attn_loader.sh > gpurun_out/attn_loader.txt

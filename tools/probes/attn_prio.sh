@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the MD_ATTN_VARIANT code these builds select lives at commit 6e0680d (removed afterwards: every variant measured null or slower).
 # Wave-priority placements in the fused attention kernel (MD_ATTN_VARIANT, kernels/attention.hip): builds each variant on the GPU box
 # and times the Depth Pro launch (T.N = 296 x 577, 16 heads, bf16 fast body) and DA3's N = 5477. Run from the repo root:
 #   bash tools/probes/attn_prio.sh > gpurun_out/attn_prio.txt
