@@ -597,23 +597,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-  for (long row = wave_id; row < rows; row += nwaves) {
-    const float* xr = x + row * D;
-    const bool repl = tok0 != nullptr && row % S == 0;  // wave-uniform
-    if (repl) xr = tok0 + (row / S) * tok0_stride;
-    f32x4_t v[NV];
-    float sum = 0.f;
+  // the row a wave works on was requested one iteration earlier, BEFORE the previous row's stores: vmcnt retires loads and stores in order, so
+  // a row's loads issued behind the previous row's stores would wait for those stores' acknowledgements (MD_LN_NO_PREFETCH: the plain loop)
+  auto row_src = [&](long row, unsigned& seq, bool& repl) __attribute__((always_inline)) {
+    // 32-bit division (the launcher holds rows below 2^31): the 64-bit form is ~170 vector instructions per row
+    seq = (unsigned)row / (unsigned)S;
+    repl = tok0 != nullptr && (unsigned)row - seq * (unsigned)S == 0u;  // wave-uniform
+    return repl ? tok0 + (long)seq * tok0_stride : x + row * D;
+  };
+  auto load_row = [&](const float* xr, f32x4_t (&v)[NV]) __attribute__((always_inline)) {
+    // every load of the row in one straight-line block: the token-0 write-back used to sit INSIDE this loop (round 4), which cut it into four
+    // conditional blocks -- one load in flight per wave instead of four -- and cost the Depth Pro step 4 ms (LayerNorm 197 -> 277 us per
+    // launch, 5.3 -> 3.8 TB/s: what the round-4 review saw as a 9.9 / 13.7 ms "discrepancy" between two of that round's bench records)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int i = lane * 4 + k * 256;
-      if (i < D) {
-        v[k] = *(const f32x4_t*)(xr + i);
-        if (repl) *(f32x4_t*)(x_rw + row * D + i) = v[k];
-        sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-      } else {
-        v[k] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      v[k] = i < D ? *(const f32x4_t*)(xr + i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4_t v[NV], vn[NV];
+  unsigned seq = 0, seq_n = 0;
+  bool repl = false, repl_n = false;
+  if (wave_id < rows) load_row(row_src(wave_id, seq, repl), v);
+  for (long row = wave_id; row < rows; row += nwaves) {
+#ifndef MD_LN_NO_PREFETCH
+    const long next = row + nwaves;
+    if (next < rows) load_row(row_src(next, seq_n, repl_n), vn);
+#else
+    if (row != wave_id) load_row(row_src(row, seq, repl), v);
+#endif
+    float sum = 0.f;
+    if (repl) {  // wave-uniform, one row per sequence of ONE launch per frame
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = lane * 4 + k * 256;
+        if (i < D) *(f32x4_t*)(x_rw + row * D + i) = v[k];
       }
     }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
@@ -625,25 +647,75 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
-    const int gi = group_of_seq(g, (int)(row / S));
+    const int gi = group_of_seq(g, (int)seq);
     const float* gamma = MD_SEL4(g.a, gi);
     const float* beta = MD_SEL4(g.b, gi);
+    // gamma / beta of the whole row before the first store: a load issued behind a store waits for that store's acknowledgement (vmcnt counts
+    // loads and stores together, in order), which put one store round trip between the row's four output vectors
+    f32x4_t gv[NV], bv[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int i = lane * 4 + k * 256;
-      if (i < D) {
-        f32x4_t y = (v[k] - mean) * rstd;
-        if (gamma) y = y * *(const f32x4_t*)(gamma + i) + *(const f32x4_t*)(beta + i);
-        if constexpr (sizeof(TO) == 4) {
-          *(f32x4_t*)((float*)out + row * D + i) = y;
-        } else if constexpr (sizeof(TO) == 1) {  // e4m3 MFMA operand on a static scale
-          y = y * fp8_inv_scale;
-          *(int*)((char*)out + row * D + i) = pack4_fp8(y[0], y[1], y[2], y[3]);
+      const bool in = gamma != nullptr && i < D;
+      gv[k] = in ? *(const f32x4_t*)(gamma + i) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+      bv[k] = in ? *(const f32x4_t*)(beta + i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // every output vector of the row is COMPUTED before the first store is issued, into registers of its own: hipcc reused one register
+    // pair for the packed data of all four stores and put an `s_waitcnt vmcnt(0)` (= the previous store's acknowledgement; gfx950 counts
+    // stores in vmcnt and a store's data registers stay reserved until it retires) in front of each -- three store round trips per row
+    f32x4_t y[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      y[k] = (v[k] - mean) * rstd;
+      if (gamma) y[k] = y[k] * gv[k] + bv[k];
+    }
+    if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = lane * 4 + k * 256;
+        if (i < D) *(f32x4_t*)((float*)out + row * D + i) = y[k];
+      }
+    } else if constexpr (sizeof(TO) == 1) {  // e4m3 MFMA operand on a static scale
+      int w[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const f32x4_t q = y[k] * fp8_inv_scale;
+        w[k] = pack4_fp8(q[0], q[1], q[2], q[3]);
+        asm volatile("" : "+v"(w[k]));
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = lane * 4 + k * 256;
+        if (i < D) *(int*)((char*)out + row * D + i) = w[k];
+      }
+    } else {
+      i32x2_t hi[NV], lo[NV];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        if constexpr (is_split<TO>::value) {
+          split4<TO>(y[k], hi[k], lo[k]);
+          asm volatile("" : "+v"(lo[k][0]), "+v"(lo[k][1]));
         } else {
-          store4p<TO>(out + row * (D * kPlanes<TO>) + i, D, y);  // split-half rows: [hi: D | lo: D]
+          hi[k] = pack4<TO>(y[k]);
+        }
+        asm volatile("" : "+v"(hi[k][0]), "+v"(hi[k][1]));  // materialised here: nothing of the packing sinks behind a store
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = lane * 4 + k * 256;
+        if (i < D) {
+          TO* op = out + row * (D * kPlanes<TO>) + i;  // split-half rows: [hi: D | lo: D]
+          *(i32x2_t*)op = hi[k];
+          if constexpr (is_split<TO>::value) *(i32x2_t*)(op + D) = lo[k];
         }
       }
     }
+#ifndef MD_LN_NO_PREFETCH
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = vn[k];
+    seq = seq_n;
+    repl = repl_n;
+#endif
   }
 }
 
@@ -651,6 +723,7 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
                      int out_f32, hipStream_t s, float fp8_inv_scale, const float* tok0, int tok0_stride, float* x_rw) {
   if (tok0 && x_rw != x) MD_FAIL(MD_ERR_INVALID_ARG, "layernorm: the token-0 replacement writes back into the input rows");
   if (D % 4 != 0 || D > 1024) MD_FAIL(MD_ERR_UNSUPPORTED, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+  if (rows < 0 || rows > 0x7fffffffL || S <= 0) MD_FAIL(MD_ERR_UNSUPPORTED, "layernorm: %ld rows of sequences of %d", rows, S);
   const int nv = (D + 255) / 256;
   const int grid = grid_for(rows * 64);
   const bool f32o = out_f32 || prec == MD_PREC_F32;
