@@ -1,7 +1,7 @@
 #!/bin/bash
-# The f16 / f16x2 GELU epilogue (kernels/gemm_impl.h): the packed degree-16 polynomial in the shifted variable (default) against the
-# Abramowitz & Stegun 7.1.26 form of rounds 2-4 (EXTRA=-DMD_GELU_AS), on one box. Run from the repo root: bash tools/probes/gelu_ab.sh
-for v in "" "-DMD_GELU_AS"; do
+# The f16 / f16x2 GELU epilogue (kernels/gemm_impl.h): the packed degree-16 polynomial in the shifted variable (EXTRA=-DMD_GELU_POLY16) against the
+# shipped Abramowitz & Stegun 7.1.26 form, on one box. Run from the repo root: bash tools/probes/gelu_ab.sh
+for v in "-DMD_GELU_POLY16" ""; do
   touch burn_depth_amd/csrc/kernels/gemm_impl.h
   make -C burn_depth_amd/csrc EXTRA="$v" -j16 > /dev/null 2>&1 || { echo "variant '$v': build failed"; continue; }
   echo "== EXTRA='$v'"
