@@ -81,6 +81,43 @@ int main(int argc, char** argv) {
   CHECK(md_depth_pro_infer(model, x, 1, S, S, MD_MEM_HOST, d2, &f2, &fovx, &fovy2, MD_MEM_HOST, NULL));
   printf("zeros %dx%d: depth[0]=%.9g focallength_px=%.9g fovx_deg=%.9g\n", S, S, d2[0], f2, fovx);
 
+  /* DepthPro::decoder_from_features / head_debug (depth_pro/mod.rs:262-307): the decoder and the depth head alone on the CALLER's tensors.
+   * Level shapes come from the model; zero features exercise the plumbing (the biases still reach the outputs). */
+  int64_t levels = 0, F = 0;
+  CHECK(md_model_query(model, "decoder_levels", &levels));
+  CHECK(md_model_query(model, "decoder_features", &F));
+  md_nchw_view views[8];
+  float* fus[8] = {0};
+  int64_t s0 = 0, s_last = 0;
+  for (int l = 0; l < (int)levels && l < 8; ++l) {
+    char key[64];
+    int64_t c = 0, sz = 0;
+    snprintf(key, sizeof key, "decoder_level%d_channels", l);
+    CHECK(md_model_query(model, key, &c));
+    snprintf(key, sizeof key, "decoder_level%d_size", l);
+    CHECK(md_model_query(model, key, &sz));
+    views[l].data = (const float*)calloc((size_t)(c * sz * sz), sizeof(float));
+    views[l].channels = (int)c; views[l].height = (int)sz; views[l].width = (int)sz;
+    const int64_t e = l == 0 ? sz : 2 * sz;
+    fus[l] = (float*)malloc((size_t)(F * e * e) * sizeof(float));
+    if (l == 0) s0 = sz;
+    s_last = sz;
+  }
+  float* dfeat = (float*)malloc((size_t)(F * s0 * s0) * sizeof(float));
+  float* dlow = (float*)malloc((size_t)(F * s_last * s_last) * sizeof(float));
+  CHECK(md_depth_pro_decoder_from_features(model, views, (int)levels, 1, MD_MEM_HOST, dfeat, dlow, fus, MD_MEM_HOST, NULL));
+  md_nchw_view fv = {dfeat, (int)F, (int)s0, (int)s0};
+  md_head_debug hd = {0};
+  float* canon = (float*)malloc((size_t)(4 * s0 * s0) * sizeof(float));
+  hd.canonical = canon;  /* the other five HeadDebug tensors are skipped (NULL) */
+  CHECK(md_depth_pro_head_debug(model, &fv, 1, MD_MEM_HOST, &hd, MD_MEM_HOST, NULL));
+  printf("replay: decoder feature[0]=%.9g fusion_0 == feature: %d, head canonical[0]=%.9g\n", dfeat[0],
+         memcmp(dfeat, fus[0], (size_t)(F * s0 * s0) * sizeof(float)) == 0, canon[0]);
+  const int rc_levels = md_depth_pro_decoder_from_features(model, views, (int)levels - 1, 1, MD_MEM_HOST, dfeat, NULL, NULL, MD_MEM_HOST, NULL);
+  printf("four levels: status %d (%s)\n", rc_levels, rc_levels == MD_ERR_LEVELS ? "MD_ERR_LEVELS" : "unexpected");
+  for (int l = 0; l < (int)levels && l < 8; ++l) { free((void*)views[l].data); free(fus[l]); }
+  free(dfeat); free(dlow); free(canon);
+
   /* the reference's Err(String) on a wrong buffer length (src/inference.rs:90-95) is a status code here */
   const int rc = md_infer_from_rgb(model, rgb, 10, w, h, MD_MEM_HOST, depth, &focal, &fovy, MD_MEM_HOST, NULL);
   printf("short rgb buffer: status %d (%s)\n", rc, rc == MD_ERR_SHAPE ? "MD_ERR_SHAPE" : "unexpected");
@@ -88,5 +125,5 @@ int main(int argc, char** argv) {
   free(x); free(d2); free(depth); free(rgb);
   CHECK(md_model_destroy(model));
   CHECK(md_device_close(dev));
-  return finite && rc == MD_ERR_SHAPE ? 0 : 2;
+  return finite && rc == MD_ERR_SHAPE && rc_levels == MD_ERR_LEVELS ? 0 : 2;
 }

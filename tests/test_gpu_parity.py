@@ -327,7 +327,7 @@ def test_imported_upstream_checkpoint_matches_the_oracle(dev, tmp_path):
 
 def test_plain_c_program_against_the_abi(dev, tmp_path):
     """examples/infer_c_abi.c: gcc + include/mi_depth.h + libmi_depth.so only (no Python, torch or HIP header in the program)
-    -- DepthPro::new on the reduced configuration, infer_from_rgb, infer on zeros, the short-buffer error. Its printed
+    -- DepthPro::new on the reduced configuration, infer_from_rgb, infer on zeros, decoder_from_features + head_debug, the error codes. Its printed
     numbers (%.9g round-trips an fp32) must equal what the Python mirror gets from the same library and seed."""
     import re
     import subprocess
@@ -366,6 +366,14 @@ def test_plain_c_program_against_the_abi(dev, tmp_path):
     z = model.infer(torch.zeros(1, 3, 512, 512, device="cuda"))
     assert p32(m2, 1) == f32(z.depth.reshape(-1)[0]) and p32(m2, 2) == f32(z.focallength_px)
     assert p32(m2, 3) == f32(z.fovx_deg)
+    # the replay entries from plain C (md_nchw_view / md_head_debug as C structs): zero encoder features through the decoder, its
+    # feature through the head, the level-count refusal as a status code
+    m3 = re.search(rf"replay: decoder feature\[0\]={num} fusion_0 == feature: 1, head canonical\[0\]={num}", out)
+    assert m3 and "four levels: status -9 (MD_ERR_LEVELS)" in out, out
+    feats = [torch.zeros(1, c, s_, s_, device="cuda") for c, s_ in model.decoder_level_shapes()]
+    feat, _, fus = model.decoder_from_features(feats)
+    assert p32(m3, 1) == f32(feat.reshape(-1)[0]) and torch.equal(fus[0], feat)
+    assert p32(m3, 2) == f32(model.head_debug(feat).canonical.reshape(-1)[0])
     model.destroy()
 
 
