@@ -1043,6 +1043,12 @@ def run_decoder_head_replay(dev, cfg, label, B, precision, host_inputs=False, sc
     record(f"{label} head_debug canonical vs the fused head of infer", rel_err(hd2.canonical, canon), tol, f"canonical max={canon.max().item():.3f}")
     out_again = model.infer(x.cuda())
     record(f"{label} infer still finite after the replays", float((~torch.isfinite(out_again.depth)).sum().item()), 0.0)
+    # a fork (own workspace, the root's weights) gives the same bits
+    fk = model.fork()
+    ff, fl_, ffus = fk.decoder_from_features(src)
+    record(f"{label} fork: decoder_from_features bit-equal to the root", float((ff != of).sum().item() + (fl_ != ol).sum().item() + sum((a != b).sum().item() for a, b in zip(ffus, ofus))), 0.0)
+    record(f"{label} fork: head_debug bit-equal to the root", float((fk.head_debug(dfeat.cuda()).canonical != hd2.canonical).sum().item()), 0.0)
+    fk.destroy()
     model.destroy()
 
 
