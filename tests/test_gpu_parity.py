@@ -130,6 +130,18 @@ def test_decoder_from_features_and_head_debug(diag, dev, precision, B, host, pre
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("precision", [1, 4, 0])
+def test_decoder_from_features_and_head_debug_default_config(diag, dev, precision):
+    """The replay entries at the REAL shapes (`DepthProConfig::default()`: encoder features [256@768^2, 256@384^2, 512@192^2, 1024@96^2,
+    1024@48^2], the head from 768^2 to 1536^2) on an f16 checkpoint of the seeded weights, against ONE oracle run of the decoder and the
+    head (4.9 TFLOP on the host) shared by the three precision modes."""
+    from burn_depth_amd.config import DepthProConfig
+    start = len(diag.RESULTS)
+    diag.guarded("replay-full")(diag.run_decoder_head_replay)(dev, DepthProConfig(), f"replay-full/p{precision}", 1, precision, f16_weights=True)
+    _assert_new_results_ok(diag, start)
+    assert any("decoder_from_features fusion_0" in r[0] and "shape=(1, 256, 768, 768)" in r[4] for r in diag.RESULTS[start:])
+
+
 def test_decoder_from_features_error_paths(dev):
     # decoder.rs:200-205 panics on a wrong level count; Burn panics on mismatched shapes: both are error codes here
     from burn_depth_amd import _lib

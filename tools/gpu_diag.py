@@ -1010,10 +1010,16 @@ def run_decoder_head_replay(dev, cfg, label, B, precision, host_inputs=False, sc
     tol = REPLAY_TOL[precision]
     shapes = model.decoder_level_shapes()
     record(f"{label} decoder levels", float(len(shapes)), 5.0, f"shapes={shapes}")
-    g = torch.Generator().manual_seed(11)
-    feats = [torch.randn(B, c, s, s, generator=g) * 0.5 for c, s in shapes]
-    with torch.no_grad():
-        rf, rl, rfus = R.decoder_forward_debug(feats, W)
+    def oracle_side():
+        g = torch.Generator().manual_seed(11)
+        feats_ = [torch.randn(B, c, s, s, generator=g) * 0.5 for c, s in shapes]
+        with torch.no_grad():
+            dec = R.decoder_forward_debug(feats_, W)
+            head = R.head_debug(dec[0], W)
+        return feats_, dec, head
+    # one oracle run serves every precision of a configuration (the default configuration's decoder + head are 4.9 TFLOP on the host)
+    feats, (rf, rl, rfus), rh = cached(("replay", cfg_key(cfg), B, scheme, bool(f16_weights)), oracle_side)
+    del W
     src = feats if host_inputs else [f.cuda() for f in feats]
     of, ol, ofus = model.decoder_from_features(src)
     record(f"{label} decoder_from_features features", rel_err(of, rf), tol, f"shape={tuple(of.shape)}")
@@ -1022,8 +1028,6 @@ def run_decoder_head_replay(dev, cfg, label, B, precision, host_inputs=False, sc
         record(f"{label} decoder_from_features fusion_{i}", rel_err(ofus[i], rfus[i]), tol, f"shape={tuple(ofus[i].shape)}")
     record(f"{label} fusion_0 is the feature map", float((ofus[0] != of).sum().item()), 0.0)
     # the head on the ORACLE's decoder feature (what the reference's harness feeds: the decoder output, correctness.rs:382-390)
-    with torch.no_grad():
-        rh = R.head_debug(rf, W)
     hd = model.head_debug(rf if host_inputs else rf.cuda())
     for n in ("conv0", "deconv", "conv1", "relu", "pre_out", "canonical"):
         got = getattr(hd, n)
