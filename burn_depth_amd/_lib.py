@@ -106,6 +106,7 @@ SYMBOLS = {
     "md_da3_infer_from_tokens": (_I, [_P, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _P, _I, _P]),
     "md_da3_param_inventory": (_I, [C.POINTER(MdDa3Cfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_model_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "md_model_set_option": (_I, [_P, C.c_char_p, C.c_int64]),
     "md_model_enable_taps": (_I, [_P, _I]),
     "md_model_read_tap": (_I, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int64 * 4)]),
     "md_model_enable_timing": (_I, [_P, _I]),

@@ -544,6 +544,13 @@ static constexpr bool key_split_enabled() { return true; }
 // that most CUs would idle
 static constexpr int kKeySplitMin = 1024, kKeySplitBlocks = 128;
 
+static thread_local int g_attn_small_ok = 1;
+int attention_allow_small(int on) {
+  const int prev = g_attn_small_ok;
+  g_attn_small_ok = on ? 1 : 0;
+  return prev;
+}
+
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
                      int kpad, int prec, hipStream_t s, float out_fp8_inv, long v_plane) {
   if (prec != MD_PREC_BF16 && prec != MD_PREC_F16 && prec != MD_PREC_F16X2) MD_FAIL(MD_ERR_UNSUPPORTED, "fused attention takes bf16, f16 or split-half operands (precision %d)", prec);
@@ -556,7 +563,7 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
   const dim3 grid((unsigned)blocks), block(256);
   // small launches over long sequences: 64 queries x two key groups per workgroup (the kernel's header)
-  const bool small = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && out_fp8_inv <= 0.f && key_split_enabled();
+  const bool small = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && out_fp8_inv <= 0.f && key_split_enabled() && g_attn_small_ok != 0;
   const int qblocks_s = (n_tokens + 63) / 64;
   const dim3 grid_s((unsigned)((long)qblocks_s * heads * nseq));
   auto set_smem = [&](const void* kern, std::atomic<unsigned long>* attr_set, int smem) -> int {  // the attribute is per DEVICE: once per (kernel, device ordinal)

@@ -167,5 +167,18 @@ inline float attn_qscale(int prec) { return prec == MD_PREC_F32 ? 1.0f : kAttnQS
 // elements behind its hi plane, out rows [hi: D | lo: D]; scores on three MFMA terms, P.V on two or three (attention.hip).
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
                      int kpad, int prec, hipStream_t s, float out_fp8_inv = 0.f, long v_plane = 0);
+// Per host thread: may launch_attention pick its small-launch form (64 queries x two key groups per workgroup for launches of few
+// workgroups over long sequences -- another summation order than the plain form's)? Default 1. Returns the previous value. A model
+// in batch-invariant mode (md_model_set_option) runs with 0: one image gives the same bits alone and inside a batch.
+int attention_allow_small(int on);
+struct AttnSmallScope {
+  explicit AttnSmallScope(int on) : prev_(attention_allow_small(on)) {}
+  ~AttnSmallScope() { attention_allow_small(prev_); }
+  AttnSmallScope(const AttnSmallScope&) = delete;
+  AttnSmallScope& operator=(const AttnSmallScope&) = delete;
+
+ private:
+  int prev_;
+};
 
 }  // namespace md

@@ -293,9 +293,28 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
   else if (k == "weight_terms") *out = model_root(m)->wterms;
   else if (k == "allocs") *out = m->alloc_count;
   else if (k == "da3_shape_builds") *out = da3_shape_builds(m);
+  else if (k == "batch_invariant") *out = m->batch_invariant ? 1 : 0;
   else if (model_decoder_query(m, k, out)) {}
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
+}
+
+int md_model_set_option(md_model_t m, const char* key, int64_t value) {
+  if (!m || !key) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  const std::string k = key;
+  if (k == "batch_invariant") {
+    if (value != 0 && value != 1) MD_FAIL(MD_ERR_INVALID_ARG, "batch_invariant takes 0 or 1");
+    if (m->batch_invariant != (value != 0)) {
+      m->batch_invariant = value != 0;
+      MD_HIP(hipSetDevice(m->dev->ordinal));
+      MD_HIP(hipDeviceSynchronize());
+      for (auto& kv : m->graphs)  // captured graphs hold the kernel forms of the old setting
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      m->graphs.clear();
+    }
+    return MD_OK;
+  }
+  MD_FAIL(MD_ERR_INVALID_ARG, "unknown option `%s`", key);
 }
 
 int md_model_enable_taps(md_model_t m, int enable) {

@@ -698,7 +698,8 @@ static int da3_infer_eager(md_model_t m, const float* nchw, int B, int H, int W,
                            hipStream_t stream) {
   if (!m || m->kind != 1 || !m->da3) MD_FAIL(MD_ERR_INVALID_ARG, "not a Depth-Anything-v3 model");
   if (!m->committed) MD_FAIL(MD_ERR_INVALID_ARG, "weights were modified; call md_model_commit_weights first");
-  const KsplitScope ksplit(1);  // small long-K launches may split their contraction inside the workgroup (kernels/gemm.h)
+  const KsplitScope ksplit(m->batch_invariant ? 0 : 1);  // small long-K launches may split their contraction inside the workgroup (kernels/gemm.h)
+  const AttnSmallScope attn_small(m->batch_invariant ? 0 : 1);  // ... and few-workgroup attention launches their keys (kernels/ops.h)
   const bool from_tokens = outp.tokens[0] != nullptr;
   if ((!nchw && !from_tokens) || (!outp.depth && !outp.raw_logits)) MD_FAIL(MD_ERR_INVALID_ARG, "null pointer");
   if (outp.raw_logits && (outp.depth || outp.depth_confidence || outp.aux || outp.aux_confidence || outp.pose_encoding || outp.extrinsics || outp.intrinsics))

@@ -131,6 +131,9 @@ struct md_model_s {
 
   // ---- hipGraph replay of the launch schedule (md_model_enable_graph) ----
   bool graph_enabled = false;
+  // md_model_set_option("batch_invariant"): no launch-size-dependent kernel form (k-split GEMM, small-launch attention): an image's result
+  // has the same bits alone and inside a batch, like the reference's `infer` (a pure batch map, encoder.rs:216-225)
+  bool batch_invariant = false;
   struct GraphEntry {
     int seen = 0;
     hipGraphExec_t exec = nullptr;

@@ -154,6 +154,11 @@ class DepthPro:
         _lib.check(self._lib.md_model_query(self._h, key.encode(), C.byref(v)))
         return int(v.value)
 
+    def set_option(self, key: str, value: int) -> None:
+        """md_model_set_option: "batch_invariant" = 1 makes a Depth-Anything-v3 model's 16-bit results independent of the batch an image
+        sits in (no launch-size-dependent kernel form), as the reference's `infer` is a pure batch map."""
+        _lib.check(self._lib.md_model_set_option(self._h, key.encode(), C.c_int64(int(value))))
+
     def img_size(self) -> int:
         return self.query("img_size")
 

@@ -301,6 +301,14 @@ int md_model_enable_graph(md_model_t m, int enable);
  *       shapes md_depth_pro_decoder_from_features / md_depth_pro_head_debug take). */
 int md_model_query(md_model_t m, const char* key, int64_t* out);
 
+/* Model options. "batch_invariant" (0 | 1, default 0): the reference's `infer` is a pure batch map (the batch is only ever concatenated,
+ * layers/encoder.rs:216-225; depth_anything3/mod.rs:495-564) -- an image gives the same tensor alone and inside a batch. Depth Pro models
+ * always do (bit for bit, tested). Depth-Anything-v3 models in the 16-bit modes pick two kernel forms by LAUNCH SIZE (the k-split
+ * GEMM of small long-K launches and the two-key-group attention of few-workgroup launches, DESIGN.md sections 5.1 / 5.2): deterministic,
+ * but another summation order -- the last bits of an image's result can then differ between B = 1 and B = 8. With the option set
+ * neither form is used (config 2: ~8 % slower at B = 1) and the batch map is exact. Also a md_model_query key. */
+int md_model_set_option(md_model_t m, const char* key, int64_t value);
+
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs
  * mod.rs:285-287). After an infer, copy the named intermediate (converted to NCHW fp32, the
  * reference's layout) to host memory. `dims` receives up to 4 dims. Names follow

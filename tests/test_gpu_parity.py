@@ -1092,6 +1092,50 @@ def test_depth_anything3_small_batch_independence_and_partial_outputs(dev):
     m.destroy()
 
 
+@pytest.mark.parametrize("precision", [0, 4])
+def test_depth_anything3_small_batch_invariant_option(dev, precision):
+    """`md_model_set_option("batch_invariant", 1)`: the reference's `infer` is a pure batch map (depth_anything3/mod.rs:495-564); the engine's
+    16-bit modes choose two kernel forms by launch size (k-split GEMM, two-key-group attention), so at 518^2 image 0 of a batch of two and
+    the same image alone differ in their last bits by default -- and must not once the option is set. Every output field, bf16 and f16x2."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthAnything3Config
+    from burn_depth_amd.depth_anything3 import DepthAnything3
+    cfg = DepthAnything3Config.small()
+    cfg.precision = precision
+    cfg.max_batch = 2
+    m = DepthAnything3.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    torch.manual_seed(5)
+    x = torch.randn(2, 3, 518, 518, device="cuda")
+    fields = ("depth", "depth_confidence", "aux", "aux_confidence", "pose_encoding", "extrinsics", "intrinsics")
+
+    def diff():
+        two, one = m.infer(x), m.infer(x[:1].contiguous())
+        return {f: float((getattr(two, f)[0] != getattr(one, f)[0]).sum().item()) for f in fields}, two
+    assert m.query("batch_invariant") == 0
+    default_diff, ref_two = diff()
+    m.set_option("batch_invariant", 1)
+    assert m.query("batch_invariant") == 1
+    inv_diff, inv_two = diff()
+    assert all(v == 0.0 for v in inv_diff.values()), inv_diff
+    # the option changes summation orders, not the result: both settings agree to the mode's rounding
+    rel = ((inv_two.depth - ref_two.depth).abs() / ref_two.depth.abs()).max().item()
+    assert rel <= (5e-2 if precision == 0 else 1e-4), rel
+    # (the default is ALLOWED to differ across batch sizes -- include/mi_depth.h says so --; at this size it does, through the attention form)
+    print("elements of image 0 that differ between B = 2 and B = 1 by default:", default_diff)
+    # a replayed graph of the old setting is not reused
+    m.enable_graph(True)
+    d = torch.empty(1, 518, 518, device="cuda")
+    for _ in range(3):
+        m.infer_into(x[:1].contiguous(), d)
+    m.set_option("batch_invariant", 0)
+    m.infer_into(x[:1].contiguous(), d)
+    torch.cuda.synchronize()
+    assert torch.isfinite(d).all()
+    with pytest.raises(Exception):
+        m.set_option("no_such_option", 1)
+    m.destroy()
+
+
 def test_check_parity_cli_against_an_oracle_made_reference_dump(dev, tmp_path):
     """tools/check_parity.py = the reference's example/correctness.rs flow: image -> infer_from_rgb -> compare with a
     PyTorch-side dump by the harness's names and thresholds. The dump here is produced by the CPU oracle."""
