@@ -660,9 +660,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       gv[k] = in ? *(const f32x4_t*)(gamma + i) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
       bv[k] = in ? *(const f32x4_t*)(beta + i) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-    // every output vector of the row is COMPUTED before the first store is issued, into registers of its own: hipcc reused one register
-    // pair for the packed data of all four stores and put an `s_waitcnt vmcnt(0)` (= the previous store's acknowledgement; gfx950 counts
-    // stores in vmcnt and a store's data registers stay reserved until it retires) in front of each -- three store round trips per row
+    // every output vector of the row is COMPUTED before the first store is issued, into registers of its own: in the per-vector form hipcc's
+    // code had an `s_waitcnt vmcnt(0)` in front of each of the row's stores (one register pair held the packed data of all four; vmcnt
+    // retires loads and stores in order, so each wait was the previous store's acknowledgement) -- three store round trips per row
     f32x4_t y[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
