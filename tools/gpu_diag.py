@@ -110,6 +110,10 @@ def prefetch_processes():
             else:
                 results[j] = torch.load(out, weights_only=False)
                 os.remove(out)
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
     print(f"      [oracle frames] ready after {time.time() - t0:.1f}s", flush=True)
     for key, slots in pending.items():
         parts = {slot: results[j] for slot, j in slots.items()}
