@@ -140,6 +140,7 @@ SYMBOLS = {
     "md_comm_broadcast_weights": (_I, [_P, _P, _I]),
     "md_comm_scatter_images": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),
     "md_comm_gather_depth": (_I, [_P, _P, _P, C.c_size_t, _I, _P]),
+    "md_depth_pro_infer_tiles_loopback": (_I, [C.POINTER(_P), _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "md_comm_depth_pro_infer_tiles": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     "md_param_inventory": (_I, [C.POINTER(MdDepthProCfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),
     "md_uniform_stream": (_I, [C.c_char_p, C.c_uint64, C.c_size_t, C.c_float, C.c_float, _P]),

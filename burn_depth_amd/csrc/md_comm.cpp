@@ -178,6 +178,66 @@ int tile_exchange(void* ctx, int parts, const ShardSegment (*seg)[3], hipStream_
 }
 }  // namespace
 
+namespace {
+// Loopback transport of the tile-parallel mode: the "ranks" are models on ONE device; a non-root part records where its three row ranges
+// live, the root copies them into its own workspace where the RCCL form would have received them.
+struct LoopbackTable {
+  std::vector<ShardSegment> sent;  // [parts][3]: the segments every non-root part "sent" (pointers into ITS workspace)
+  int parts, root, me;
+};
+int loopback_exchange(void* ctx, int parts, const ShardSegment (*seg)[3], hipStream_t st) {
+  LoopbackTable* t = (LoopbackTable*)ctx;
+  if (parts != t->parts) MD_FAIL(MD_ERR_INVALID_ARG, "loopback exchange: %d parts, expected %d", parts, t->parts);
+  if (t->me != t->root) {  // what tile_exchange's ncclSend calls would have moved
+    for (int k = 0; k < 3; ++k) t->sent[(size_t)t->me * 3 + k] = seg[t->me][k];
+    return MD_OK;
+  }
+  for (int p = 0; p < parts; ++p) {
+    if (p == t->root) continue;
+    for (int k = 0; k < 3; ++k) {
+      const ShardSegment& from = t->sent[(size_t)p * 3 + k];
+      // sender and receiver walk the same table: a disagreement about a segment's size is the bug this entry exists to catch
+      if (from.bytes != seg[p][k].bytes)
+        MD_FAIL(MD_ERR_INVALID_ARG, "loopback exchange: part %d segment %d is %zu bytes on the sender and %zu on the root", p, k, from.bytes, seg[p][k].bytes);
+      if (from.bytes) MD_HIP(hipMemcpyAsync(seg[p][k].ptr, from.ptr, from.bytes, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  return MD_OK;
+}
+}  // namespace
+
+int md_depth_pro_infer_tiles_loopback(const md_model_t* models, int parts, int root, const float* nchw, int B, int H, int W, int in_kind,
+                                      float* depth, float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, void* stream) {
+  if (!models || !nchw) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");
+  if (parts < 1 || parts > 64 || root < 0 || root >= parts) MD_FAIL(MD_ERR_INVALID_ARG, "%d parts, root %d", parts, root);
+  for (int p = 0; p < parts; ++p) {
+    if (!models[p] || models[p]->kind != 0) MD_FAIL(MD_ERR_INVALID_ARG, "models[%d] is not a Depth Pro model", p);
+    if (models[p]->dev != models[0]->dev) MD_FAIL(MD_ERR_INVALID_ARG, "the loopback ranks live on one device");
+    for (int q = 0; q < p; ++q)
+      if (models[q] == models[p]) MD_FAIL(MD_ERR_INVALID_ARG, "models[%d] and models[%d] are the same context (a rank owns its workspace)", q, p);
+  }
+  MD_HIP(hipSetDevice(models[0]->dev->ordinal));
+  hipStream_t st = stream ? (hipStream_t)stream : models[0]->dev->stream;  // ONE stream orders the parts and the copies
+  LoopbackTable t;
+  t.parts = parts; t.root = root;
+  t.sent.assign((size_t)parts * 3, ShardSegment{nullptr, 0});
+  const size_t elems = (size_t)B * 3 * H * W;
+  auto run_part = [&](int p) -> int {
+    float* x_dev = nullptr;
+    MD_TRY(model_stage_input(models[p], nchw, elems, in_kind, st, &x_dev));  // the broadcast of the RCCL form
+    t.me = p;
+    ShardPlan sp;
+    sp.parts = parts; sp.part = p; sp.root = root;
+    sp.exchange = loopback_exchange; sp.ctx = &t;
+    const bool is_root = p == root;
+    return model_infer_sharded(models[p], x_dev, B, H, W, MD_MEM_DEVICE, is_root ? depth : nullptr, is_root ? focallength_px : nullptr,
+                               is_root ? fovx_deg : nullptr, is_root ? fovy_rad : nullptr, out_kind, st, sp);
+  };
+  for (int p = 0; p < parts; ++p)
+    if (p != root) MD_TRY(run_part(p));
+  return run_part(root);
+}
+
 int md_comm_depth_pro_infer_tiles(md_comm_t c, md_model_t m, const float* nchw, int B, int H, int W, int in_kind, float* depth,
                                   float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind, int root, void* stream) {
   if (!c || !m) MD_FAIL(MD_ERR_INVALID_ARG, "null argument");

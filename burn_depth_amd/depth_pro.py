@@ -313,6 +313,26 @@ class DepthPro:
                                                      _stream_ptr(self.device.ordinal)))
         return hd
 
+    @staticmethod
+    def infer_tiles_loopback(contexts: List["DepthPro"], x: torch.Tensor, root: int = 0) -> DepthProInference:
+        """The tile-parallel single-image call (`NativeComm.infer_tiles`) with a loopback transport: `contexts` (a model and its forks)
+        stand for the ranks, each runs its window of the ViT stage in its own workspace, the root copies the other windows' tokens and
+        hook rows where RCCL would deliver them (md_depth_pro_infer_tiles_loopback). Bit-identical to `infer`; a one-GPU test entry."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise _lib.MdError(_lib.MD_ERR_SHAPE, f"expected [B,3,H,W], got {tuple(x.shape)}")
+        x = x.contiguous().to(torch.float32)
+        B, _, H, W = x.shape
+        me = contexts[root]
+        dev = torch.device("cuda", me.device.ordinal)
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        focal, fovx, fovy = (torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(3))
+        arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+        in_kind = _lib.MD_MEM_DEVICE if x.is_cuda else _lib.MD_MEM_HOST
+        _lib.check(me._lib.md_depth_pro_infer_tiles_loopback(arr, len(contexts), int(root), C.c_void_p(x.data_ptr()), B, H, W, in_kind,
+                                                             C.c_void_p(depth.data_ptr()), C.c_void_p(focal.data_ptr()), C.c_void_p(fovx.data_ptr()),
+                                                             C.c_void_p(fovy.data_ptr()), _lib.MD_MEM_DEVICE, _stream_ptr(me.device.ordinal)))
+        return DepthProInference(depth, focal, fovx, fovy)
+
     def infer_from_rgb(self, rgb: bytes, width: int, height: int) -> DepthProInference:
         """`infer_from_rgb` (src/inference.rs:128-137); raises MdError(MD_ERR_SHAPE) on a bad length."""
         dev = torch.device("cuda", self.device.ordinal)

@@ -448,6 +448,15 @@ int md_comm_gather_depth(md_comm_t c, const float* shard_dev, float* all_dev, si
 int md_comm_depth_pro_infer_tiles(md_comm_t comm, md_model_t model, const float* nchw, int B, int H, int W, int in_kind,
                                   float* depth, float* focallength_px, float* fovx_deg, float* fovy_rad, int out_kind,
                                   int root, void* stream);
+/* The tile-parallel call with a LOOPBACK transport: the `parts` ranks are `parts` inference contexts on ONE device (a model and its
+ * md_model_fork contexts, or separately created models with the same weights), each runs ITS window of the ViT stage in its own
+ * workspace, and where md_comm_depth_pro_infer_tiles would ncclSend / ncclRecv a part's final tokens and hook rows, the root copies
+ * them out of that part's workspace (sender and receiver sizes are compared: MD_ERR_INVALID_ARG on a mismatch). Everything of the
+ * N > 1 code path except RCCL itself runs -- window clipping per rank, the segment table, the root-only tail -- on one GPU; the
+ * result is bit-identical to md_depth_pro_infer. Test entry (single-GPU boxes cannot form a two-rank communicator). */
+int md_depth_pro_infer_tiles_loopback(const md_model_t* models, int parts, int root, const float* nchw, int B, int H, int W,
+                                      int in_kind, float* depth, float* focallength_px, float* fovx_deg, float* fovy_rad,
+                                      int out_kind, void* stream);
 
 /* ---- host-only utilities (no GPU needed) ---------------------------------------------------- */
 /* The parameter inventory of `DepthPro::new` for a config: returns the number of parameters; for

@@ -1356,6 +1356,44 @@ def test_tile_parallel_windows_are_bit_identical(dev, precision):
     m.destroy()
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16x2"])
+def test_tile_parallel_loopback_ranks_are_bit_identical(dev, precision):
+    """The N > 1 code path of the tile-parallel mode with everything but RCCL: `parts` inference contexts on one GPU (a model and its
+    forks: own workspaces, shared weights) stand for the ranks, each runs ITS window (`ShardPlan.part = p`), the root receives the other
+    windows' final tokens and hook rows through a loopback transport that copies workspace to workspace where `tile_exchange` would
+    ncclSend / ncclRecv (md_depth_pro_infer_tiles_loopback; sender / receiver segment sizes are compared). The result equals `infer`
+    bit for bit for every root and part count; poisoned non-root workspaces prove the rows really travel."""
+    from burn_depth_amd import _lib
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig, Precision
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.tiny_test()
+    cfg.precision = {"f32": Precision.F32, "bf16": Precision.BF16, "f16x2": Precision.F16X2}[precision]
+    cfg.max_batch = 2
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    torch.manual_seed(12)
+    x = torch.randn(2, 3, 512, 512, device="cuda")
+    want = m.infer(x)
+    ctxs = [m] + [m.fork() for _ in range(4)]
+    # leave DIFFERENT data in every context's workspace first: a window the root failed to receive would show
+    for i, c in enumerate(ctxs):
+        c.infer(torch.randn(2, 3, 512, 512, device="cuda") * (i + 2))
+    for parts, root in ((1, 0), (2, 0), (2, 1), (3, 1), (5, 0), (5, 4)):
+        got = DepthPro.infer_tiles_loopback(ctxs[:parts], x, root=root)
+        for a, b in ((got.depth, want.depth), (got.fovx_deg, want.fovx_deg), (got.focallength_px, want.focallength_px), (got.fovy_rad, want.fovy_rad)):
+            assert torch.equal(a, b), (precision, parts, root)
+    x1 = torch.randn(1, 3, 360, 540, device="cuda")  # B = 1 with resizes: 37 sequences over 5 ranks (ragged windows across the three encoders)
+    assert torch.equal(DepthPro.infer_tiles_loopback(ctxs, x1, root=2).depth, m.infer(x1).depth)
+    host = DepthPro.infer_tiles_loopback(ctxs[:3], x.cpu(), root=0)  # host input: every rank stages it (the broadcast of the RCCL form)
+    assert torch.equal(host.depth, want.depth)
+    with pytest.raises(_lib.MdError) as e:
+        DepthPro.infer_tiles_loopback([m, m], x)  # a rank owns its workspace
+    assert e.value.code == _lib.MD_ERR_INVALID_ARG
+    for f in ctxs[1:]:
+        f.destroy()
+    m.destroy()
+
+
 def test_tile_parallel_full_size_projection(dev):
     """The default model at [1,3,1536,1536] in bf16: 8 windows of the 37 sequences equal the one-pass result bit for bit, and
     the per-window / tail device times give the projected latency of the 8-GPU tile-parallel call (before the exchange)."""
