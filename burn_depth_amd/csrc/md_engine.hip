@@ -557,6 +557,9 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
     if (cfg.has_fov_vit) {
       add_pack(m, "fov.encoder_proj.weight", PACK_NK, F / 2, cfg.fv.D, 1);
       add_pack(m, "fov.downsample_blocks.0.conv.weight", PACK_DIRECT, F / 2, F, 3, true);
+      // the same weight as an implicit-GEMM operand: the stride-2 downsample of the lowres feature (fov.rs:79-87,185) is 2.7 GFLOP at B = 8 and
+      // took 374 us as a direct convolution (one wave per output pixel) -- the MFMA family's stride-2 3x3 form does it in a tenth of that
+      add_pack_as(m, "fov.downsample_blocks.0.conv.gemm", "fov.downsample_blocks.0.conv.weight", PACK_CONV3, F / 2, F, 3);
       add_pack(m, "fov.head_blocks.0.conv.weight", PACK_DIRECT, F / 4, F / 2, 3, true);
       add_pack(m, "fov.head_blocks.1.conv.weight", PACK_DIRECT, F / 8, F / 4, 3, true);
       add_pack(m, "fov.head_blocks.2.conv.weight", PACK_DIRECT, 1, F / 8, 6, true);
@@ -1461,9 +1464,19 @@ static int run_fov(Run& r, const md_model_s::IndexSet& ix) {
   if (c.has_fov_vit) {
     r.begin("fov_head");
     // fov.rs:178-227: downsample(lowres) + Linear(tokens) -> head convs
-    MD_TRY(launch_conv_direct(lowres, m->prec, nullptr, B, hw[4], hw[4], F, Wd("fov.downsample_blocks.0.conv.weight"),
-                              Bi("fov.downsample_blocks.0.conv.bias"), F / 2, 3, 2, 1, 1, stage[0], r.st));
     int h = (hw[4] + 2 - 3) / 2 + 1;
+    if (PK(m, "fov.downsample_blocks.0.conv.gemm") && (F / 2) % 4 == 0) {
+      GemmParams p;
+      p.N = F / 2; p.ngroups = 1; p.g_rows[0] = B * h * h;
+      p.W[0] = PK(m, "fov.downsample_blocks.0.conv.gemm"); p.bias[0] = Bi("fov.downsample_blocks.0.conv.bias");
+      p.A = lowres; p.cH = hw[4]; p.cW = hw[4]; p.cOH = h; p.cOW = h; p.cstride = 2; p.zero_page = m->zero_page;
+      split_conv_a(m, p, Fp, 0);
+      p.epi = EPI_STORE; p.act = ACT_RELU; p.out_f32 = 1; p.out = stage[0]; p.ldo = F / 2;
+      MD_TRY(launch_gemm(p, A_CONV3, m->prec, TILE_AUTO, r.st));
+    } else {
+      MD_TRY(launch_conv_direct(lowres, m->prec, nullptr, B, hw[4], hw[4], F, Wd("fov.downsample_blocks.0.conv.weight"),
+                                Bi("fov.downsample_blocks.0.conv.bias"), F / 2, 3, 2, 1, 1, stage[0], r.st));
+    }
     if (h != g) MD_FAIL(MD_ERR_UNSUPPORTED, "fov: downsampled lowres %d does not match the token grid %d", h, g);
     r.end();
     MD_TRY(gemm_rows(r, "fov_proj", b->tok, c.pv.D, ix.fov, (long)B * m->P, PK(m, "fov.encoder_proj.weight"), F / 2, c.pv.D,

@@ -56,6 +56,25 @@ inline void add_pack(md_model_s* m, const std::string& name, int kind, int d0, i
   m->packs.push_back(e);
 }
 
+// a second packed form of a parameter under a name of its own (e.g. a convolution weight both as a direct-convolution and as an
+// implicit-GEMM operand)
+inline void add_pack_as(md_model_s* m, const std::string& pack_name, const std::string& param, int kind, int d0, int d1, int k) {
+  auto it = m->pindex.find(param);
+  if (it == m->pindex.end()) return;
+  PackEntry e;
+  e.param = it->second;
+  e.kind = kind;
+  e.d0 = d0;
+  e.d1 = d1;
+  e.k = k;
+  e.f32 = 0;
+  const int contraction = kind == PACK_DECONV ? d0 : d1;
+  e.kp = round_up(contraction, m->ke);
+  e.bytes = pack_bytes(m, e);
+  m->pack_index[pack_name] = (int)m->packs.size();
+  m->packs.push_back(e);
+}
+
 // deconv k2s2 (no bias) followed by a 1x1 conv: packed as ONE deconv whose weight is their product
 // W'[ci][co][q] = sum_m Wd[ci][m][q] * Wo[co][m]  (decoder.rs:124-141 applies out_conv right after deconv)
 inline void add_pack_composed(md_model_s* m, const std::string& name, const std::string& deconv, const std::string& conv1x1,
