@@ -1,0 +1,691 @@
+"""Generator of the assembly-owned Depth Pro attention kernel (gfx950): one workgroup = one (sequence, head) of 577 tokens.
+
+  four waves, one per SIMD (512 registers each); wave w owns queries 1 + 144 w .. 144 w + 144 as nine 16-query blocks, and
+  a sixteenth of every key tile for query 0 (the class token: its partial O, l of the four waves add at the end -- the
+  fast body keeps no running maximum);  S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_16x16x32_bf16, row sums on the matrix
+  pipe (an all-ones A operand), O / l in AGPRs, S / P / fragments in VGPRs;  K and V^T tiles of 64 keys through a 4-stage
+  LDS ring filled by LDS-DMA three tiles ahead, one counted vmcnt + s_barrier per tile;  software pipeline over
+  (32-key half, query block) steps: S(n) | exp, pack (n-1) | P.V + sum (n-2).
+
+The contract of burn_depth_amd/csrc/kernels/attention.hip holds (q pre-scaled to log2 units, V^T rows padded to kpad keys with
+finite values, p = 2^s with no maximum for bf16: a row sum outside [2^-64, 2^100) raises redo[unit] and the HIP kernel's safe body
+runs that unit again).  python tools/attn_asm/gen_attn577.py > burn_depth_amd/csrc/kernels/attn577_gfx950.s"""
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from isa import I, R, v, a, s, M0, VCC, EXEC, Pool, check_hazards  # noqa: E402
+
+NB = 9            # 16-query blocks per wave
+NTF = 9           # full 64-key tiles (577 = 9 * 64 + 1)
+STAGE = 16384     # K tile 8 KB | V^T tile 8 KB
+NSTAGE = 4
+RING = STAGE * NSTAGE
+SCRATCH = 0       # class-token partials reuse the ring once every DMA has landed
+LDS_BYTES = RING
+
+
+class K:
+    def __init__(self):
+        self.p = []
+        self.vp = Pool("v", 0, 256)
+        self.sp = Pool("s", 0, 100)
+
+    def e(self, op, dst=(), src=(), **m):
+        ins = I(op, dst, src, **m)
+        self.p.append(ins)
+        return ins
+
+    def label(self, name):
+        self.e("label", (), (name,))
+
+    def nop(self, n):
+        self.e("s_nop", (), (n,))
+
+
+def build():
+    k = K()
+    e = k.e
+    # ---------------- registers ----------------
+    s_karg = s(0, 2)
+    s_head, s_seq = s(2), s(3)
+    s_qk, s_vt, s_out, s_redo = s(4, 2), s(6, 2), s(8, 2), s(10, 2)
+    s_S, s_n, s_heads, s_D, s_kpad = s(12), s(13), s(14), s(15), s(16)
+    s_w, s_rowB, s_kpadB = s(17), s(18), s(19)
+    s_qd, s_kd, s_vd, s_od = s(20, 4), s(24, 4), s(28, 4), s(32, 4)
+    s_kso, s_vso, s_dst, s_cnt = s(36), s(37), s(38), s(39)   # DMA cursors (K / V^T source offsets of the next tile, LDS stage), loop counter
+    t0, t1, t2, t3 = s(40), s(41), s(42), s(43)
+    s_mmain, s_mcls = s(44, 2), s(46, 2)
+    s_bad = s(48, 2)
+    s_kp0, s_kp1, s_vp0, s_vp1 = s(50), s(51), s(52), s(53)   # per-wave piece offsets inside a tile (source side)
+    s_mk, s_mv = s(54), s(55)                                # per-wave piece offsets inside a stage (LDS side)
+    s_t4, s_t5 = s(56), s(57)
+    s_bo = s(58)                                              # block source / destination offset cursor
+    s_tmp64 = s(60, 2)
+    s_lo, s_hi = s(62), s(63)
+    s_kmax = s(64)
+
+    vp = k.vp
+    v_tid = vp.take()          # v0 = work-item id
+    v_lane, v_r, v_g, vt0, vt1, vt2, vt3 = (vp.take() for _ in range(7))
+    v_q = [vp.take(8, 4) for _ in range(NB)]       # Q fragments: [k-step 0 | k-step 1]
+    v_qc = vp.take(8, 4)
+    v_kf = [vp.take(16, 4) for _ in range(2)]      # K fragments of a 32-key half: (bsel * 2 + kstep) * 4
+    v_vf = [vp.take(16, 4) for _ in range(2)]      # V^T fragments of a 32-key half: db * 4
+    v_kc = vp.take(8, 4)                           # class-token K fragments (this wave's 16 keys of the tile)
+    v_vc = vp.take(16, 4)                          # class-token V^T fragments: db * 4 + {lo, lo, zero, zero}
+    v_sb = [vp.take(8, 4) for _ in range(2)]       # scores of a step: kb0 | kb1
+    v_pb = [vp.take(4, 4) for _ in range(2)]
+    v_sc = vp.take(4, 4)
+    v_pc = vp.take(4, 4)
+    v_ones = vp.take(4, 4)
+    v_koff = [vp.take() for _ in range(2)]         # LDS read cursors (stage included)
+    v_voff = [vp.take() for _ in range(2)]
+    v_kcoff = [vp.take() for _ in range(2)]
+    v_vcoff = vp.take()
+    v_dk = [vp.take() for _ in range(2)]           # LDS-DMA source offsets (even / odd piece)
+    v_dv = [vp.take() for _ in range(2)]
+    v_qo, v_qco, v_oo, v_oco = vp.take(), vp.take(), vp.take(), vp.take()
+    v_zero = vp.take()
+    v_e = [vp.take() for _ in range(8)]            # epilogue temporaries
+    a_o = [[a((b * 4 + db) * 4, 4) for db in range(4)] for b in range(NB)]
+    a_oc = [a(NB * 16 + db * 4, 4) for db in range(4)]
+    a_l = [a(NB * 16 + 16 + b * 4, 4) for b in range(NB)]
+    a_lc = a(NB * 16 + 16 + NB * 4, 4)
+    n_acc = NB * 16 + 16 + NB * 4 + 4
+
+    # ---------------- prologue ----------------
+    e("s_load_dwordx8", s(4, 8), (s_karg, 0x0))
+    e("s_load_dwordx4", s(12, 4), (s_karg, 0x20))
+    e("s_load_dword", s_kpad, (s_karg, 0x30))
+    e("v_and_b32", v_lane, (63, v_tid))
+    e("v_lshrrev_b32", vt0, (6, v_tid))
+    e("v_and_b32", v_r, (15, v_lane))
+    e("v_lshrrev_b32", v_g, (4, v_lane))
+    e("v_mov_b32", v_zero, (0,))
+    e("v_readfirstlane_b32", s_w, (vt0,))
+    e("s_waitcnt", lgkmcnt=0)
+    k.nop(3)
+    e("s_lshl_b32", s_rowB, (s_D, 2))
+    e("s_lshl_b32", s_kpadB, (s_kpad, 1))
+    # Q / K descriptors: qk + (seq * S) * rowB + head * 128
+    e("s_mul_i32", t0, (s_seq, s_S))
+    e("s_mul_hi_u32", t1, (t0, s_rowB))
+    e("s_mul_i32", t0, (t0, s_rowB))
+    e("s_lshl_b32", t2, (s_head, 7))
+    e("s_add_u32", t0, (t0, t2))
+    e("s_addc_u32", t1, (t1, 0))
+    e("s_add_u32", s_qd[0], (s_qk[0], t0))
+    e("s_addc_u32", s_qd[1], (s_qk[1], t1))
+    e("s_lshl_b32", t2, (s_D, 1))
+    e("s_add_u32", s_kd[0], (s_qd[0], t2))
+    e("s_addc_u32", s_kd[1], (s_qd[1], 0))
+    e("s_and_b32", s_qd[1], (s_qd[1], 0xFFFF))
+    e("s_and_b32", s_kd[1], (s_kd[1], 0xFFFF))
+    e("s_mul_i32", s_qd[2], (s_n, s_rowB))
+    e("s_sub_u32", t2, (s_n, 1))
+    e("s_mul_i32", s_kd[2], (t2, s_rowB))
+    e("s_add_u32", s_kd[2], (s_kd[2], 128))
+    e("s_mov_b32", s_qd[3], (0x00020000,))
+    e("s_mov_b32", s_kd[3], (0x00020000,))
+    # V^T descriptor: vT + (seq * heads + head) * 64 * kpadB
+    e("s_mul_i32", t0, (s_seq, s_heads))
+    e("s_add_u32", t0, (t0, s_head))          # unit
+    e("s_lshl_b32", t2, (s_kpadB, 6))
+    e("s_mul_hi_u32", t1, (t0, t2))
+    e("s_mul_i32", t3, (t0, t2))
+    e("s_add_u32", s_vd[0], (s_vt[0], t3))
+    e("s_addc_u32", s_vd[1], (s_vt[1], t1))
+    e("s_and_b32", s_vd[1], (s_vd[1], 0xFFFF))
+    e("s_mov_b32", s_vd[2], (t2,))
+    e("s_mov_b32", s_vd[3], (0x00020000,))
+    # redo flag address
+    e("s_lshl_b32", t3, (t0, 2))
+    e("s_add_u32", s_redo[0], (s_redo[0], t3))
+    e("s_addc_u32", s_redo[1], (s_redo[1], 0))
+    # output descriptor: out + (seq * S) * (2 D) + head * 128
+    e("s_mul_i32", t0, (s_seq, s_S))
+    e("s_lshl_b32", t2, (s_D, 1))
+    e("s_mul_hi_u32", t1, (t0, t2))
+    e("s_mul_i32", t0, (t0, t2))
+    e("s_lshl_b32", t3, (s_head, 7))
+    e("s_add_u32", t0, (t0, t3))
+    e("s_addc_u32", t1, (t1, 0))
+    e("s_add_u32", s_od[0], (s_out[0], t0))
+    e("s_addc_u32", s_od[1], (s_out[1], t1))
+    e("s_and_b32", s_od[1], (s_od[1], 0xFFFF))
+    e("s_mul_i32", s_od[2], (s_n, t2))
+    e("s_mov_b32", s_od[3], (0x00020000,))
+    # per-wave piece offsets
+    e("s_lshl_b32", t0, (s_w, 4))             # 16 w = first K / V^T row of this wave's two pieces
+    e("s_mul_i32", s_kp0, (t0, s_rowB))
+    e("s_lshl_b32", t1, (s_rowB, 3))
+    e("s_add_u32", s_kp1, (s_kp0, t1))
+    e("s_mul_i32", s_vp0, (t0, s_kpadB))
+    e("s_lshl_b32", t1, (s_kpadB, 3))
+    e("s_add_u32", s_vp1, (s_vp0, t1))
+    e("s_lshl_b32", s_mk, (s_w, 11))          # 2 w * 1024
+    e("s_add_u32", s_mv, (s_mk, 8192))
+    # LDS-DMA source offsets of a lane: row8 = lane >> 3, pc = lane & 7
+    e("v_lshrrev_b32", vt0, (3, v_lane))      # row8
+    e("v_and_b32", vt1, (7, v_lane))          # pc
+    e("v_lshrrev_b32", vt2, (1, vt0))         # row8 >> 1
+    e("v_and_b32", vt3, (1, vt2))
+    e("v_lshlrev_b32", vt3, (1, vt3))         # fK (even piece) = R1 << 1
+    e("v_xor_b32", vt3, (vt3, vt1))
+    e("v_lshlrev_b32", vt3, (4, vt3))
+    e("v_mul_lo_u32", v_dk[0], (vt0, s_rowB))
+    e("v_add_u32", v_dk[0], (v_dk[0], vt3))
+    e("v_xor_b32", v_dk[1], (64, v_dk[0]))
+    e("v_xor_b32", vt3, (vt2, vt1))           # pc ^ (row8 >> 1): fV of an even piece
+    e("v_lshlrev_b32", vt3, (4, vt3))
+    e("v_mul_lo_u32", v_dv[0], (vt0, s_kpadB))
+    e("v_add_u32", v_dv[0], (v_dv[0], vt3))
+    e("v_xor_b32", v_dv[1], (64, v_dv[0]))
+
+    def dma_piece(which, first_in_group=False):
+        """one 1-KiB piece of the tile at the DMA cursors: which = 0 / 1 (K even / odd), 2 / 3 (V^T even / odd)"""
+        if which < 2:
+            e("s_add_u32", M0, (s_dst, s_mk))
+            if which == 1:
+                e("s_add_u32", M0, (M0, 1024))
+            e("s_add_u32", s_t4, (s_kso, s_kp0 if which == 0 else s_kp1))
+            e("buffer_load_dwordx4", (), (v_dk[which], s_kd, s_t4), lds=True)
+        else:
+            e("s_add_u32", M0, (s_dst, s_mv))
+            if which == 3:
+                e("s_add_u32", M0, (M0, 1024))
+            e("s_add_u32", s_t5, (s_vso, s_vp0 if which == 2 else s_vp1))
+            e("buffer_load_dwordx4", (), (v_dv[which - 2], s_vd, s_t5), lds=True)
+
+    def dma_advance():
+        e("s_lshl_b32", t0, (s_rowB, 6))
+        e("s_add_u32", s_kso, (s_kso, t0))
+        e("s_add_u32", s_vso, (s_vso, 128))
+        e("s_min_u32", s_kso, (s_kso, s_kmax))   # the requests past the last tile (the loop issues three tiles ahead) re-read the last one
+        e("s_min_u32", s_vso, (s_vso, NTF * 128))
+        e("s_add_u32", s_dst, (s_dst, STAGE))
+        e("s_and_b32", s_dst, (s_dst, RING - 1))
+
+    e("s_mul_i32", s_kmax, (s_rowB, NTF * 64))
+    e("s_mov_b32", s_kso, (0,))
+    e("s_mov_b32", s_vso, (0,))
+    e("s_mov_b32", s_dst, (0,))
+    for wpc in range(4):
+        dma_piece(wpc)
+    dma_advance()
+    # Q fragments: lane (n, g) <- Q[q][32 s + 8 g ..]; q = 1 + 144 w + 16 b + n
+    e("s_mul_i32", t0, (s_w, 144))
+    e("s_add_u32", t0, (t0, 1))
+    e("v_add_u32", vt0, (t0, v_r))
+    e("v_mul_lo_u32", v_qo, (vt0, s_rowB))
+    e("v_lshlrev_b32", v_qco, (4, v_g))
+    e("v_add_u32", v_qo, (v_qo, v_qco))
+    e("s_lshl_b32", t2, (s_D, 1))
+    e("v_mul_lo_u32", v_oo, (vt0, t2))
+    e("v_lshlrev_b32", v_oco, (3, v_g))
+    e("v_add_u32", v_oo, (v_oo, v_oco))
+    e("s_mov_b32", s_bo, (0,))
+    e("s_lshl_b32", t1, (s_rowB, 4))
+    for b in range(NB):
+        for st in range(2):
+            e("buffer_load_dwordx4", v_q[b][4 * st:4 * st + 4], (v_qo, s_qd, s_bo), offset=64 * st)
+        if b + 1 < NB:
+            e("s_add_u32", s_bo, (s_bo, t1))
+    for st in range(2):
+        e("buffer_load_dwordx4", v_qc[4 * st:4 * st + 4], (v_qco, s_qd, 0), offset=64 * st)
+    for _ in range(2):
+        for wpc in range(4):
+            dma_piece(wpc)
+        dma_advance()
+    # accumulators, constants
+    for i in range(n_acc):
+        e("v_accvgpr_write_b32", a(i), (0,))
+    for j in range(4):
+        e("v_mov_b32", v_ones[j], (0x3F803F80,))
+    for db in range(4):
+        e("v_mov_b32", v_vc[db * 4 + 2], (0,))
+        e("v_mov_b32", v_vc[db * 4 + 3], (0,))
+    e("v_mov_b32", v_pc[2], (0,))
+    e("v_mov_b32", v_pc[3], (0,))
+    e("v_cmp_eq_u32", s_mmain, (v_g, 0))
+    e("s_mov_b64", s_mcls, (0,))
+    e("s_cmp_eq_u32", (), (s_w, 0))
+    e("s_cbranch_scc0", (), ("L_not_w0",))
+    e("s_mov_b64", s_mcls, (s_mmain,))
+    k.label("L_not_w0")
+    e("s_mov_b64", s_bad, (0,))
+    e("s_mov_b32", s_lo, (0x1f800000,))     # 2^-64
+    e("s_mov_b32", s_hi, (0x71800000,))     # 2^100
+    # LDS read cursors
+    #  K:  (8 (r >> 2) + (r & 3)) * 128 + (((4 s + g) ^ f) << 4), f = ((r >> 1) & 1) << 1 | ((r >> 2) & 1) << 2
+    e("v_lshrrev_b32", vt0, (2, v_r))
+    e("v_lshlrev_b32", vt0, (3, vt0))
+    e("v_and_b32", vt1, (3, v_r))
+    e("v_or_b32", vt0, (vt0, vt1))
+    e("v_lshlrev_b32", vt0, (7, vt0))         # row * 128
+    e("v_and_b32", vt1, (6, v_r))              # bits 1, 2 of r in place = f
+    e("v_xor_b32", vt2, (vt1, v_g))           # (0 + g) ^ f
+    e("v_lshlrev_b32", vt2, (4, vt2))
+    e("v_add_u32", v_koff[0], (vt0, vt2))
+    e("v_xor_b32", v_koff[1], (64, v_koff[0]))
+    #  V^T: r * 128 + (((4 half + g) ^ ((r >> 1) & 7)) << 4)
+    e("v_lshlrev_b32", vt0, (7, v_r))
+    e("v_lshrrev_b32", vt1, (1, v_r))
+    e("v_xor_b32", vt2, (vt1, v_g))
+    e("v_lshlrev_b32", vt2, (4, vt2))
+    e("v_add_u32", v_voff[0], (vt0, vt2))
+    e("v_xor_b32", v_voff[1], (64, v_voff[0]))
+    #  class-token K: (16 w + r) * 128 + (((4 s + g) ^ fc) << 4), fc = ((r >> 1) & 1) << 1 | ((r >> 3) & 1) << 2
+    e("s_lshl_b32", t0, (s_w, 4))
+    e("v_add_u32", vt0, (t0, v_r))
+    e("v_lshlrev_b32", vt0, (7, vt0))
+    e("v_and_b32", vt1, (2, v_r))
+    e("v_lshrrev_b32", vt2, (3, v_r))
+    e("v_lshlrev_b32", vt2, (2, vt2))
+    e("v_or_b32", vt1, (vt1, vt2))
+    e("v_xor_b32", vt1, (vt1, v_g))
+    e("v_lshlrev_b32", vt1, (4, vt1))
+    e("v_add_u32", v_kcoff[0], (vt0, vt1))
+    e("v_xor_b32", v_kcoff[1], (64, v_kcoff[0]))
+    #  class-token V^T: r * 128 + (((2 w + (g >> 1)) ^ (r >> 1)) << 4) + (g & 1) * 8
+    e("v_lshlrev_b32", vt0, (7, v_r))
+    e("v_lshrrev_b32", vt1, (1, v_g))
+    e("s_lshl_b32", t0, (s_w, 1))
+    e("v_add_u32", vt1, (t0, vt1))
+    e("v_lshrrev_b32", vt2, (1, v_r))
+    e("v_xor_b32", vt1, (vt1, vt2))
+    e("v_lshlrev_b32", vt1, (4, vt1))
+    e("v_and_b32", vt2, (1, v_g))
+    e("v_lshlrev_b32", vt2, (3, vt2))
+    e("v_add_u32", v_vcoff, (vt0, vt1))
+    e("v_add_u32", v_vcoff, (v_vcoff, vt2))
+
+    # ---------------- pipeline pieces ----------------
+    def bump(regs):
+        for r_ in regs:
+            e("v_add_u32", r_, (STAGE, r_))
+        for r_ in regs:
+            e("v_and_b32", r_, (RING - 1, r_))
+
+    def k_read(hb, j, half_imm):
+        bsel, st = j >> 1, j & 1
+        e("ds_read_b128", v_kf[hb][4 * j:4 * j + 4], (v_koff[st],), offset=bsel * 512 + half_imm * 4096)
+
+    def v_read(hb, db, half):
+        e("ds_read_b128", v_vf[hb][4 * db:4 * db + 4], (v_voff[half],), offset=8192 + db * 2048)
+
+    def cls_reads_k():
+        for st in range(2):
+            e("ds_read_b128", v_kc[4 * st:4 * st + 4], (v_kcoff[st],))
+
+    def cls_reads_v():
+        for db in range(4):
+            e("ds_read_b64", v_vc[4 * db:4 * db + 2], (v_vcoff,), offset=8192 + db * 2048)
+
+    def mf(dst, A, B, C):
+        return I("v_mfma_f32_16x16x32_bf16", (dst,), (A, B, C))
+
+    def s_mfmas(n):
+        b, half = n % NB, (n // NB) & 1
+        sb, kf = v_sb[n & 1], v_kf[half]
+        return [mf(sb[0:4], kf[0:4], v_q[b][0:4], 0), mf(sb[4:8], kf[8:12], v_q[b][0:4], 0),
+                mf(sb[0:4], kf[4:8], v_q[b][4:8], sb[0:4]), mf(sb[4:8], kf[12:16], v_q[b][4:8], sb[4:8])]
+
+    def e_valu(n):
+        sb, pb = v_sb[n & 1], v_pb[n & 1]
+        ex = [I("v_exp_f32", (sb[j],), (sb[j],)) for j in range(8)]
+        cv = [I("v_cvt_pk_bf16_f32", (pb[j],), (sb[2 * j], sb[2 * j + 1])) for j in range(4)]
+        return ex, cv
+
+    def pv_mfmas(n):
+        b, half = n % NB, (n // NB) & 1
+        pb, vf = v_pb[n & 1], v_vf[half]
+        return [mf(a_o[b][db], vf[4 * db:4 * db + 4], pb, a_o[b][db]) for db in range(4)] + [mf(a_l[b], v_ones, pb, a_l[b])]
+
+    def emit_slot(n, do_s, do_e, do_pv, extras_head=(), extras=()):
+        """MFMAs of S(n) then P.V(n-2); the exponentials and packs of step n-1 between them; `extras` one behind each of the first MFMAs"""
+        for x in extras_head:
+            x()
+        ms = (s_mfmas(n) if do_s else []) + (pv_mfmas(n - 2) if do_pv else [])
+        ex, cv = e_valu(n - 1) if do_e else ([], [])
+        fill = []   # per MFMA gap
+        order = ex[:6] + [ex[6], cv[0], ex[7], cv[1], cv[2], cv[3]] if do_e else []
+        gaps = max(len(ms), 1)
+        per = [[] for _ in range(gaps)]
+        if do_e:
+            # one exponential behind each of the first six MFMAs, then (exp, pack) pairs, the last two packs behind the last MFMA
+            plan = [[0], [1], [2], [3], [4], [5], [6, 7], [8, 9], [10, 11]]
+            if len(ms) == 9:
+                for gi, idxs in enumerate(plan):
+                    per[gi] = [order[j] for j in idxs]
+            else:
+                q = 0
+                for gi in range(gaps):
+                    take = (len(order) - q + (gaps - gi) - 1) // (gaps - gi)
+                    per[gi] = order[q:q + take]
+                    q += take
+        ext = list(extras)
+        if not ms:
+            for x in ext:
+                x()
+            for ins in per[0]:
+                k.p.append(ins)
+            return
+        for gi, m_ in enumerate(ms):
+            k.p.append(m_)
+            if ext:
+                ext.pop(0)()
+            for ins in per[gi]:
+                k.p.append(ins)
+        for x in ext:
+            x()
+
+    def cls_s():
+        k.p.append(mf(v_sc, v_kc[0:4], v_qc[0:4], 0))
+        k.p.append(mf(v_sc, v_kc[4:8], v_qc[4:8], v_sc))
+
+    def cls_e():
+        for j in range(4):
+            e("v_exp_f32", v_sc[j], (v_sc[j],))
+        k.nop(0)
+        e("v_cvt_pk_bf16_f32", v_pc[0], (v_sc[0], v_sc[1]))
+        e("v_cvt_pk_bf16_f32", v_pc[1], (v_sc[2], v_sc[3]))
+
+    def cls_pv():
+        for db in range(4):
+            k.p.append(mf(a_oc[db], v_vc[4 * db:4 * db + 4], v_pc, a_oc[db]))
+        k.p.append(mf(a_lc, v_ones, v_pc, a_lc))
+
+    def tile(first):
+        for n in range(18):
+            head, ext = [], []
+            if n == 0:
+                head.append(lambda: e("s_waitcnt", lgkmcnt=0))
+            if first and n == 1:
+                head.append(lambda: k.nop(7))   # E(0) eight states behind S(0): slot 0 of the first tile carries four MFMAs only
+            if n == 1:
+                ext.append(cls_reads_k)
+            if n == 2:
+                ext.append(cls_reads_v)
+            if 2 <= n <= 5:
+                ext.append(lambda j=n - 2: k_read(1, j, 1))
+            if 3 <= n <= 6:
+                ext.append(lambda db=n - 3: v_read(1, db, 1))
+            if n == 9:
+                head.append(lambda: e("s_waitcnt", lgkmcnt=0))
+                head.append(lambda: e("s_waitcnt", vmcnt=4))
+                head.append(lambda: e("s_barrier"))
+            if 9 <= n <= 12:
+                ext.append(lambda wpc=n - 9: dma_piece(wpc))
+            if n == 10:
+                head.append(cls_s)
+                head.append(lambda: bump(v_koff))
+            if n == 11:
+                head.append(lambda: bump(v_voff))
+            if 11 <= n <= 14:
+                ext.append(lambda j=n - 11: k_read(0, j, 0))
+            if 12 <= n <= 15:
+                ext.append(lambda db=n - 12: v_read(0, db, 0))
+            if n == 13:
+                head.append(cls_e)
+            if n == 15:
+                head.append(cls_pv)
+            if n == 16:
+                head.append(lambda: bump(v_kcoff + [v_vcoff]))
+                head.append(dma_advance)
+            emit_slot(n, True, not (first and n < 1), not (first and n < 2), head, ext)
+
+    # ---------------- first tile: wait for tile 0 and Q, read the first fragments ----------------
+    e("s_waitcnt", vmcnt=8)
+    e("s_barrier")
+    for j in range(4):
+        k_read(0, j, 0)
+    for db in range(4):
+        v_read(0, db, 0)
+    tile(True)
+    e("s_mov_b32", s_cnt, (NTF - 1,))
+    k.label("L_tile")
+    tile(False)
+    e("s_sub_u32", s_cnt, (s_cnt, 1))
+    e("s_cmp_lg_u32", (), (s_cnt, 0))
+    e("s_cbranch_scc1", (), ("L_tile",))
+    # drain: exp / pack of step 17, P.V of steps 16 and 17
+    emit_slot(18, False, True, True)
+    k.nop(1)
+    emit_slot(19, False, False, True)
+    # ---------------- last tile: one key (tile-relative key 0 = row 0 of kb0: lanes with g == 0, register 0) ----------------
+    e("s_waitcnt", lgkmcnt=0)
+    cls_reads_k()
+    cls_reads_v()
+    k.nop(7)
+    for hb in range(2):
+        for j in range(1, 4):
+            e("v_mov_b32", v_pb[hb][j], (0,))
+    e("v_mov_b32", v_pc[1], (0,))
+    e("s_waitcnt", lgkmcnt=0)
+
+    def tail_s(b):
+        sb = v_sb[b & 1]
+        return [mf(sb[0:4], v_kf[0][0:4], v_q[b][0:4], 0), mf(sb[0:4], v_kf[0][4:8], v_q[b][4:8], sb[0:4])]
+
+    def tail_e(b):
+        sb, pb = v_sb[b & 1], v_pb[b & 1]
+        return [I("v_exp_f32", (sb[0],), (sb[0],)), I("v_cndmask_b32", (sb[0],), (0, sb[0], s_mmain)),
+                I("v_cvt_pk_bf16_f32", (pb[0],), (sb[0], 0))]
+
+    def tail_pv(b):
+        pb = v_pb[b & 1]
+        return [mf(a_o[b][db], v_vf[0][4 * db:4 * db + 4], pb, a_o[b][db]) for db in range(4)] + [mf(a_l[b], v_ones, pb, a_l[b])]
+
+    for n in range(NB + 2):
+        ms = (tail_s(n) if n < NB else []) + (tail_pv(n - 2) if 0 <= n - 2 < NB else [])
+        va = tail_e(n - 1) if 0 <= n - 1 < NB else []
+        if n == NB:   # the class token's scores ride in the first slot without S MFMAs
+            cls_s()
+        for m_ in ms:
+            k.p.append(m_)
+        if va:        # scores of step n-1: eight states behind their MFMAs (the early slots carry too few instructions for that)
+            if n <= 2:
+                k.nop(7)
+            k.p.append(va[0])
+            k.nop(1)
+            k.p.append(va[1])
+            k.p.append(va[2])
+            k.nop(1)
+    k.nop(7)
+    e("v_exp_f32", v_sc[0], (v_sc[0],))
+    k.nop(1)
+    e("v_cndmask_b32", v_sc[0], (0, v_sc[0], s_mcls))
+    k.nop(1)
+    e("v_cvt_pk_bf16_f32", v_pc[0], (v_sc[0], 0))
+    k.nop(1)
+    cls_pv()
+    # ---------------- epilogue ----------------
+    e("s_waitcnt", vmcnt=0)
+    e("s_barrier")
+    k.nop(7)
+    # class-token partials through the (now idle) ring: scratch[w][j][lane], j = 0..15 O, 16 l
+    e("s_mul_i32", t0, (s_w, 17 * 256))
+    e("v_lshlrev_b32", vt0, (2, v_lane))
+    e("v_add_u32", vt0, (t0, vt0))
+    for db in range(4):
+        for i in range(4):
+            e("v_accvgpr_read_b32", v_e[i], (a_oc[db][i],))
+        k.nop(1)
+        for i in range(4):
+            e("ds_write_b32", (), (vt0, v_e[i]), offset=(db * 4 + i) * 256)
+    e("v_accvgpr_read_b32", v_e[0], (a_lc[0],))
+    k.nop(1)
+    e("ds_write_b32", (), (vt0, v_e[0]), offset=16 * 256)
+    e("s_waitcnt", lgkmcnt=0)
+    e("s_barrier")
+    e("s_cmp_eq_u32", (), (s_w, 0))
+    e("s_cbranch_scc0", (), ("L_main_out",))
+    # wave 0: add the four partials (its own included, from LDS), normalise, store row 0 (lanes with n == 0)
+    e("v_lshlrev_b32", vt0, (2, v_lane))
+    e("ds_read_b32", v_e[4], (vt0,), offset=16 * 256)
+    for ww in range(1, 4):
+        e("ds_read_b32", v_e[5], (vt0,), offset=ww * 17 * 256 + 16 * 256)
+        e("s_waitcnt", lgkmcnt=0)
+        e("v_add_f32", v_e[4], (v_e[4], v_e[5]))
+    k.nop(1)
+    e("v_cmp_nle_f32", VCC, (s_lo, v_e[4]))      # not (2^-64 <= l): too small, or NaN
+    e("s_or_b64", s_bad, (s_bad, VCC))
+    e("v_cmp_ngt_f32", VCC, (s_hi, v_e[4]))      # not (2^100 > l): too large, inf or NaN
+    e("s_or_b64", s_bad, (s_bad, VCC))
+    e("v_rcp_f32", v_e[4], (v_e[4],))
+    e("v_cmp_eq_u32", VCC, (v_r, 0))
+    e("s_mov_b64", s_tmp64, (EXEC,))
+    for db in range(4):
+        for i in range(4):
+            e("ds_read_b32", v_e[i], (vt0,), offset=(db * 4 + i) * 256)
+        for ww in range(1, 4):
+            for i in range(4):
+                e("ds_read_b32", vt1 if i == 0 else (vt2 if i == 1 else (vt3 if i == 2 else v_e[5])), (vt0,), offset=ww * 17 * 256 + (db * 4 + i) * 256)
+            e("s_waitcnt", lgkmcnt=0)
+            e("v_add_f32", v_e[0], (v_e[0], vt1))
+            e("v_add_f32", v_e[1], (v_e[1], vt2))
+            e("v_add_f32", v_e[2], (v_e[2], vt3))
+            e("v_add_f32", v_e[3], (v_e[3], v_e[5]))
+        k.nop(1)
+        for i in range(4):
+            e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
+        k.nop(1)
+        e("v_cvt_pk_bf16_f32", v_e[6], (v_e[0], v_e[1]))
+        e("v_cvt_pk_bf16_f32", v_e[7], (v_e[2], v_e[3]))
+        k.nop(1)
+        e("s_mov_b64", EXEC, (VCC,))
+        e("buffer_store_dwordx2", (), (v_e[6:8] if False else R("v", v_e[6].i, 2), v_oco, s_od, 0), offset=32 * db)
+        e("s_mov_b64", EXEC, (s_tmp64,))
+        k.nop(1)
+    k.label("L_main_out")
+    e("s_mov_b32", s_bo, (0,))
+    e("s_lshl_b32", t1, (s_D, 5))             # 16 rows * 2 D bytes
+    for b in range(NB):
+        e("v_accvgpr_read_b32", v_e[4], (a_l[b][0],))
+        k.nop(1)
+        e("v_cmp_nle_f32", VCC, (s_lo, v_e[4]))
+        e("s_or_b64", s_bad, (s_bad, VCC))
+        e("v_cmp_ngt_f32", VCC, (s_hi, v_e[4]))
+        e("s_or_b64", s_bad, (s_bad, VCC))
+        e("v_rcp_f32", v_e[4], (v_e[4],))
+        for db in range(4):
+            for i in range(4):
+                e("v_accvgpr_read_b32", v_e[i], (a_o[b][db][i],))
+            k.nop(0)
+            for i in range(4):
+                e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
+            k.nop(0)
+            pk = R("v", v_e[6].i, 2)
+            e("v_cvt_pk_bf16_f32", pk[0], (v_e[0], v_e[1]))
+            e("v_cvt_pk_bf16_f32", pk[1], (v_e[2], v_e[3]))
+            k.nop(0)
+            e("buffer_store_dwordx2", (), (pk, v_oo, s_od, s_bo), offset=32 * db)
+        if b + 1 < NB:
+            e("s_add_u32", s_bo, (s_bo, t1))
+    # a row sum out of range: this unit runs again in the HIP kernel's safe body
+    e("s_or_b32", t0, (s_bad[0], s_bad[1]))
+    e("s_cbranch_scc0", (), ("L_done",))
+    e("v_mov_b32", v_e[0], (1,))
+    e("s_mov_b64", EXEC, (1,))
+    k.nop(1)
+    e("global_store_dword", (), (v_zero, v_e[0], s_redo))
+    k.label("L_done")
+    e("s_waitcnt", vmcnt=0)
+    e("s_endpgm")
+    k.n_vgpr = k.vp.next
+    k.n_acc = n_acc
+    return k
+
+
+HEADER = """\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.amdhsa_code_object_version 6
+\t.text
+\t.protected\tmd_attn577_bf16
+\t.globl\tmd_attn577_bf16
+\t.p2align\t8
+\t.type\tmd_attn577_bf16,@function
+md_attn577_bf16:
+"""
+
+FOOTER = """\t.section\t.rodata,"a",@progbits
+\t.p2align\t6, 0x0
+\t.amdhsa_kernel md_attn577_bf16
+\t\t.amdhsa_group_segment_fixed_size {lds}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size 56
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 1
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr 96
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+\t.text
+\t.amdgpu_metadata
+---
+amdhsa.kernels:
+  - .agpr_count:     256
+    .args:
+      - {{.address_space: global, .offset: 0, .size: 8, .value_kind: global_buffer}}
+      - {{.address_space: global, .offset: 8, .size: 8, .value_kind: global_buffer}}
+      - {{.address_space: global, .offset: 16, .size: 8, .value_kind: global_buffer}}
+      - {{.address_space: global, .offset: 24, .size: 8, .value_kind: global_buffer}}
+      - {{.offset: 32, .size: 4, .value_kind: by_value}}
+      - {{.offset: 36, .size: 4, .value_kind: by_value}}
+      - {{.offset: 40, .size: 4, .value_kind: by_value}}
+      - {{.offset: 44, .size: 4, .value_kind: by_value}}
+      - {{.offset: 48, .size: 4, .value_kind: by_value}}
+      - {{.offset: 52, .size: 4, .value_kind: by_value}}
+    .group_segment_fixed_size: {lds}
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 56
+    .max_flat_workgroup_size: 256
+    .name:           md_attn577_bf16
+    .private_segment_fixed_size: 0
+    .sgpr_count:     96
+    .sgpr_spill_count: 0
+    .symbol:         md_attn577_bf16.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     512
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+\t.end_amdgpu_metadata
+"""
+
+
+def render(k):
+    out = [HEADER]
+    for ins in k.p:
+        t = ins.text()
+        out.append(t + "\n" if ins.op == "label" else "\t" + t + "\n")
+    out.append(FOOTER.format(lds=LDS_BYTES))
+    return "".join(out)
+
+
+if __name__ == "__main__":
+    kk = build()
+    bad = check_hazards(kk.p)
+    if bad:
+        for b_ in bad[:40]:
+            print("HAZARD", b_, file=sys.stderr)
+        sys.exit(1)
+    print(f"; generated by tools/attn_asm/gen_attn577.py: {len(kk.p)} instructions, {kk.n_vgpr} VGPRs, {kk.n_acc} AGPRs", file=sys.stderr)
+    sys.stdout.write(render(kk))
