@@ -132,6 +132,7 @@ SYMBOLS = {
     "md_gemm_pick_tile": (_I, [_I, _I, _I, _I]),
     "md_bench_attention": (_I, [_P, _I, _I, _I, _I, _F]),
     "md_bench_attention_ex": (_I, [_P, _I, _I, _I, _I, C.c_float, _I, _F]),
+    "md_debug_attention_asm": (_I, [_I]),
     "md_comm_unique_id": (_I, [_P]),
     "md_comm_init_rank": (_I, [_P, _P, _I, _I, C.POINTER(_P)]),
     "md_comm_rank": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),

@@ -18,6 +18,7 @@
 // are read from LDS) so that registers 8s..8s+7 hold the 8 consecutive keys the V^T fragment
 // of k-step s holds.
 #include <atomic>
+#include <mutex>
 #include "ops.h"
 #include "elem.h"
 
@@ -93,10 +94,12 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) {
 // (Round 5 measured and removed -- commit 6e0680d has the code: a loader-wave form, a fifth wave per workgroup issuing every LDS-DMA piece so that
 // the query waves never touch the vector-memory pipe: correct, 0.84x, profiles/r05_attention_loader_wave.txt; s_setprio placements: nothing,
 // profiles/r05_attention_prio.txt.)
+// The body of one workgroup: `id` = its logical (unit, query block) index. Two kernels run it: attention_kernel (one workgroup per
+// index, XCD-aware block order) and attention_redo_kernel (the safe body over the units the assembly kernel flagged).
 template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1, int QW = 4>
-__global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2) : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
-                                                           int S, int n_tokens, int heads, int D, int kpad, int qblocks,
-                                                           float out_fp8_inv, long v_plane) {
+__device__ __forceinline__ void attention_body(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+                                               int S, int n_tokens, int heads, int D, int kpad, int qblocks,
+                                               float out_fp8_inv, long v_plane, const int id) {
   constexpr bool SP = is_split<T>::value;
   constexpr int STAGE = SP ? 32768 : 16384;  // K tile 64x128B + V^T tile 64x128B (split-half: hi tiles, then the lo tiles 16 KB behind)
   // Split-half, one key group (the Depth Pro form): the four tiles of a stage are 32 KB, two stages 64 KB = two workgroups per CU, two
@@ -125,12 +128,6 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2
   // K buffer / V^T stage of tile t
   auto kbuf = [&](int t) __attribute__((always_inline)) { return CK ? ring : ring + (t & 1) * STAGE; };
   auto vbuf = [&](int t) __attribute__((always_inline)) { return CK ? ring + 16384 + (t & 1) * 16384 : ring + (t & 1) * STAGE + VOFF; };
-  int id;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   const int unit = id / qblocks, qb = id - unit * qblocks;
   const int seq = unit / heads, head = unit - seq * heads;
   const int q0 = qb * (32 * QW) + wave * 32;
@@ -515,6 +512,37 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2
   }
 }
 
+template <typename T, bool FP8OUT, bool FAST, int PTERMS = 1, int KS = 1, int QW = 4>
+__global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2) : 4) void attention_kernel(const T* __restrict__ qk, const T* __restrict__ vT, T* __restrict__ out,
+                                                           int S, int n_tokens, int heads, int D, int kpad, int qblocks,
+                                                           float out_fp8_inv, long v_plane) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  attention_body<T, FP8OUT, FAST, PTERMS, KS, QW>(qk, vT, out, S, n_tokens, heads, D, kpad, qblocks, out_fp8_inv, v_plane, id);
+}
+
+// The units (sequence, head) whose row sums left the fast body's range in the assembly kernel (attn577_gfx950.s raises redo[unit]): the
+// running-maximum body over all their queries, the flag cleared. A thread reads one flag; a workgroup without a raised flag among its
+// 256 units -- every workgroup of every launch on trained weights -- is one load and one barrier.
+__global__ __launch_bounds__(256) void attention_redo_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
+                                                             int S, int n_tokens, int heads, int D, int kpad, int qblocks, int* __restrict__ redo, int nunits) {
+  __shared__ int raised[256];
+  const int tid = threadIdx.x, u = blockIdx.x * 256 + tid;
+  const int f = u < nunits ? redo[u] : 0;
+  if (!__syncthreads_or(f)) return;
+  raised[tid] = f;
+  __syncthreads();
+  for (int j = 0; j < 256; ++j) {
+    if (!raised[j]) continue;  // workgroup-uniform
+    for (int qb = 0; qb < qblocks; ++qb) {
+      __syncthreads();  // the previous block's last tile has been read by every wave before the stages are refilled
+      attention_body<bf16_t, false, false>(qk, vT, out, S, n_tokens, heads, D, kpad, qblocks, 0.f, 0L, (blockIdx.x * 256 + j) * qblocks + qb);
+    }
+  }
+  if (f) redo[u] = 0;
+}
+
 // split-half attention: P as one half (1) or as hi + lo (2: what the product runs, every test and every published number).
 // The two A/B switches below exist in DIAGNOSTIC builds only (`make DIAG=1` defines MD_DIAG_KNOBS): the shipped library reads no
 // environment variable that changes numerics or kernel choice.
@@ -551,8 +579,75 @@ int attention_allow_small(int on) {
   return prev;
 }
 
+// ---- the assembly-owned Depth Pro form (kernels/attn577_gfx950.s, generated by tools/attn_asm/gen_attn577.py) ----
+// bf16, exactly 577 tokens (576 patches + the class token), head_dim 64: one workgroup of four waves per (sequence, head), one wave
+// per SIMD with the whole register file. Its code object is embedded in this library (attn577_blob.S) and loaded per device by
+// attention_asm_prepare() -- hipModuleLoadData is not capturable, so the model calls that when it is created, not at first launch.
+extern "C" const unsigned char md_attn577_co[];
+namespace {
+struct AsmKernel {
+  std::atomic<int> state{0};  // 0 not loaded, 1 loaded, -1 failed
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+};
+AsmKernel g_asm[64];
+std::mutex g_asm_mu;
+thread_local int g_attn_asm_ok = 1;
+}  // namespace
+
+int attention_allow_asm(int on) {
+  const int prev = g_attn_asm_ok;
+  g_attn_asm_ok = on ? 1 : 0;
+  return prev;
+}
+
+int attention_asm_prepare() {
+  int ordinal = 0;
+  MD_HIP(hipGetDevice(&ordinal));
+  if (ordinal < 0 || ordinal >= 64) return MD_OK;  // such a device runs the HIP kernel
+  AsmKernel& k = g_asm[ordinal];
+  if (k.state.load(std::memory_order_acquire) != 0) return MD_OK;
+  std::lock_guard<std::mutex> lock(g_asm_mu);
+  if (k.state.load(std::memory_order_acquire) != 0) return MD_OK;
+  if (hipModuleLoadData(&k.mod, md_attn577_co) != hipSuccess || hipModuleGetFunction(&k.fn, k.mod, "md_attn577_bf16") != hipSuccess) {
+    (void)hipGetLastError();
+    k.state.store(-1, std::memory_order_release);
+    MD_FAIL(MD_ERR_HIP, "attention: the embedded gfx950 code object did not load on device %d", ordinal);
+  }
+  k.state.store(1, std::memory_order_release);
+  return MD_OK;
+}
+
+static bool attention_asm_eligible(int n_tokens, int D, int heads, int kpad, int prec, float out_fp8_inv, const int* redo) {
+  if (!redo || !g_attn_asm_ok || prec != MD_PREC_BF16 || n_tokens != 577 || D != heads * 64 || kpad < 640 || out_fp8_inv > 0.f) return false;
+  int ordinal = 0;
+  if (hipGetDevice(&ordinal) != hipSuccess || ordinal < 0 || ordinal >= 64) return false;
+  return g_asm[ordinal].state.load(std::memory_order_acquire) == 1;
+}
+
+static int launch_attention_asm(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D, int kpad,
+                                int* redo, hipStream_t s) {
+  int ordinal = 0;
+  MD_HIP(hipGetDevice(&ordinal));
+  struct Args {
+    const void *qk, *vT;
+    void* out;
+    int* redo;
+    int S, n_tokens, heads, D, kpad, pad;
+  } args = {qk, vT, out, redo, S, n_tokens, heads, D, kpad, 0};
+  size_t size = sizeof(args);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  MD_HIP(hipModuleLaunchKernel(g_asm[ordinal].fn, (unsigned)heads, (unsigned)nseq, 1, 256, 1, 1, 0, s, nullptr, extra));
+  // the units it flagged (a row sum outside [2^-64, 2^100): never on trained weights) run again in the running-maximum body
+  const int nunits = nseq * heads, qblocks = (n_tokens + 127) / 128;
+  hipLaunchKernelGGL(attention_redo_kernel, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+                     (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, redo, nunits);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
-                     int kpad, int prec, hipStream_t s, float out_fp8_inv, long v_plane) {
+                     int kpad, int prec, hipStream_t s, float out_fp8_inv, long v_plane, int* redo) {
   if (prec != MD_PREC_BF16 && prec != MD_PREC_F16 && prec != MD_PREC_F16X2) MD_FAIL(MD_ERR_UNSUPPORTED, "fused attention takes bf16, f16 or split-half operands (precision %d)", prec);
   if (D != heads * 64) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   if (kpad % 64 != 0 || kpad < (n_tokens + 63) / 64 * 64)
@@ -561,6 +656,8 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   const int qblocks = (n_tokens + 127) / 128;
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
+  if (nseq <= 65535 && attention_asm_eligible(n_tokens, D, heads, kpad, prec, out_fp8_inv, redo))
+    return launch_attention_asm(qk, vT, out, nseq, S, n_tokens, heads, D, kpad, redo, s);
   const dim3 grid((unsigned)blocks), block(256);
   // small launches over long sequences: 64 queries x two key groups per workgroup (the kernel's header)
   const bool small = n_tokens >= kKeySplitMin && blocks <= kKeySplitBlocks && out_fp8_inv <= 0.f && key_split_enabled() && g_attn_small_ok != 0;

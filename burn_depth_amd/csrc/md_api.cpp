@@ -559,7 +559,11 @@ int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int hea
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * es));
   MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, attn_qscale(precision), precision, st));
   if (precision != MD_PREC_F32) {
-    MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st, 0.f, (long)T * heads * 64 * kpad));
+    DevBuf redo;  // zeroed flags: 577-token bf16 launches take the assembly kernel, like the model's
+    MD_TRY(redo.alloc((size_t)T * heads * 4));
+    if (precision == MD_PREC_BF16) MD_TRY(attention_asm_prepare());
+    MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st, 0.f, (long)T * heads * 64 * kpad, (int*)redo.p));
+    MD_HIP(hipStreamSynchronize(st));  // `redo` is released at the end of this scope
   } else {
     MD_TRY(sc.alloc((size_t)T * heads * SS * kpad * 4));
     GemmParams p;
@@ -806,12 +810,15 @@ int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int p
   MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * 2));
   MD_TRY(fill_random(qk.p, (size_t)T * SS * 2 * D, precision, 3, qk_scale, st));
   MD_TRY(fill_random(vT.p, (size_t)T * heads * 64 * kpad, precision, 4, 1.0f, st));
-  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st));
+  DevBuf redo;
+  MD_TRY(redo.alloc((size_t)T * heads * 4));
+  if (precision == MD_PREC_BF16) MD_TRY(attention_asm_prepare());
+  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st, 0.f, 0, (int*)redo.p));
   hipEvent_t e0, e1;
   MD_HIP(hipEventCreate(&e0));
   MD_HIP(hipEventCreate(&e1));
   MD_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st));
+  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st, 0.f, 0, (int*)redo.p));
   MD_HIP(hipEventRecord(e1, st));
   MD_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -821,6 +828,8 @@ int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int p
   *avg_ms = ms / iters;
   return MD_OK;
 }
+
+int md_debug_attention_asm(int on) { return attention_allow_asm(on); }
 
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms) {
   return md_bench_attention_ex(dev, T, n_tokens, heads, MD_PREC_BF16, 0.7f, iters, avg_ms);

@@ -296,6 +296,7 @@ struct md_model_s::Buffers {
   void* qk = nullptr;         // [nseq*SS, 2D] T
   void* vT = nullptr;         // [nseq][heads][64][kpad] T
   void* ao = nullptr;         // [nseq*SS, D] T
+  int* attn_redo = nullptr;   // [nseq*heads] flags of the assembly attention kernel (raised = that unit re-runs in the safe body)
   void* hbuf = nullptr;       // [nseq*SS, 4D] T
   float* scores = nullptr;    // fp32 attention only
   void* hook[2] = {nullptr, nullptr};  // [n0*SS, D] T
@@ -374,6 +375,7 @@ static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
   MD_TAKE(vT, void*, (size_t)nseq * c.pv.heads * 64 * m->kpad * esz);
   m->vt_plane = m->xm == 2 ? (size_t)nseq * c.pv.heads * 64 * m->kpad : 0;
   MD_TAKE(ao, void*, rows * D * esz);
+  MD_TAKE(attn_redo, int*, (size_t)nseq * c.pv.heads * 4);  // the assembly attention kernel's per-(sequence, head) flags (zero = the arena's memset)
   MD_TAKE(hbuf, void*, rows * 4 * D * esz);
   if (m->prec == MD_PREC_F32) MD_TAKE(scores, float*, (size_t)nseq * c.pv.heads * SS * m->kpad * 4);
   MD_TAKE(hook[0], void*, ((size_t)n0 * SS + 64) * D * esz);
@@ -622,6 +624,7 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   }
   int st = plan_workspace(m, false, nullptr);
   if (st != MD_OK) return fail(st);
+  if (m->prec == MD_PREC_BF16 && (st = attention_asm_prepare()) != MD_OK) return fail(st);  // the code object loads here, never inside a capture
   if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
   (void)hipMemset(m->zero_page, 0, 4096);
   (void)hipDeviceSynchronize();
@@ -714,6 +717,7 @@ int model_fork(md_model_t src, md_model_t* out) {
   if (hipMemset(m->ws.base, 0, need) != hipSuccess) return fail(MD_ERR_HIP);  // padding rows / channels / keys: finite zeros
   int st = plan_workspace(m, false, nullptr);
   if (st != MD_OK) return fail(st);
+  if (m->prec == MD_PREC_BF16 && (st = attention_asm_prepare()) != MD_OK) return fail(st);  // the code object loads here, never inside a capture
   if (hipMalloc(&m->zero_page, 4096) != hipSuccess) return fail(MD_ERR_OOM);
   (void)hipMemset(m->zero_page, 0, 4096);
   (void)hipDeviceSynchronize();
@@ -1019,7 +1023,8 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
     void* vT_w = (char*)b->vT + (size_t)s_lo * vt_seq;
     if (m->prec != MD_PREC_F32) {
       r.begin("attention");
-      MD_TRY(launch_attention(trow(b->qk, 2 * D), vT_w, trow(b->ao, D), WS, SS, NT, heads, D, m->kpad, m->prec, r.st, 0.f, (long)m->vt_plane));
+      MD_TRY(launch_attention(trow(b->qk, 2 * D), vT_w, trow(b->ao, D), WS, SS, NT, heads, D, m->kpad, m->prec, r.st, 0.f, (long)m->vt_plane,
+                              b->attn_redo));
       r.end();
     } else {
       // fp32: scores = q k^T (batched GEMM) -> row softmax -> P V^T^T (batched GEMM)

@@ -406,6 +406,11 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
  * body), 4.0 and above logits beyond its +-32 check (the running-maximum body). */
 int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int precision, float qk_scale, int iters,
                           float* avg_ms);
+/* Per host thread: may bf16 attention launches of exactly 577 tokens (Depth Pro: 576 patches + the class token) take the
+ * assembly-owned gfx950 kernel (kernels/attn577_gfx950.s)? Default 1; returns the previous value. 0 runs the HIP kernel that
+ * every other shape runs -- an A/B switch for benches and parity tests, not a numerics option: both forms compute the same
+ * sums (the assembly kernel adds the rounded probabilities on the matrix pipe). Graphs captured before a change keep their form. */
+int md_debug_attention_asm(int on);
 
 /* ---- multi-GPU: RCCL over xGMI behind the C ABI ------------------------------------------------------------------
  * BASELINE north_star: "independent images shard naturally across the 8 GPUs of one node with RCCL broadcast of weights and

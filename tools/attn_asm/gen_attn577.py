@@ -43,7 +43,11 @@ class K:
         self.e("s_nop", (), (n,))
 
 
-def build():
+def build(abl=()):
+    """abl: timing-only ablations (results are wrong): 'loop2' doubles the tile loop, 'noexp' drops the exponentials and packs,
+    'nodma' the LDS-DMA requests inside the loop, 'nolds' the fragment reads inside the loop, 'nostore' the output stores,
+    'nopv' / 'nos' the P.V (+ sum) / score MFMAs"""
+    abl = set(abl)
     k = K()
     e = k.e
     # ---------------- registers ----------------
@@ -183,8 +187,12 @@ def build():
     e("v_add_u32", v_dv[0], (v_dv[0], vt3))
     e("v_xor_b32", v_dv[1], (64, v_dv[0]))
 
+    in_loop = [False]
+
     def dma_piece(which, first_in_group=False):
         """one 1-KiB piece of the tile at the DMA cursors: which = 0 / 1 (K even / odd), 2 / 3 (V^T even / odd)"""
+        if in_loop[0] and "nodma" in abl:
+            return
         if which < 2:
             e("s_add_u32", M0, (s_dst, s_mk))
             if which == 1:
@@ -309,10 +317,14 @@ def build():
             e("v_and_b32", r_, (RING - 1, r_))
 
     def k_read(hb, j, half_imm):
+        if in_loop[0] and "nolds" in abl:
+            return
         bsel, st = j >> 1, j & 1
         e("ds_read_b128", v_kf[hb][4 * j:4 * j + 4], (v_koff[st],), offset=bsel * 512 + half_imm * 4096)
 
     def v_read(hb, db, half):
+        if in_loop[0] and "nolds" in abl:
+            return
         e("ds_read_b128", v_vf[hb][4 * db:4 * db + 4], (v_voff[half],), offset=8192 + db * 2048)
 
     def cls_reads_k():
@@ -347,7 +359,9 @@ def build():
         """MFMAs of S(n) then P.V(n-2); the exponentials and packs of step n-1 between them; `extras` one behind each of the first MFMAs"""
         for x in extras_head:
             x()
-        ms = (s_mfmas(n) if do_s else []) + (pv_mfmas(n - 2) if do_pv else [])
+        ms = (s_mfmas(n) if do_s and "nos" not in abl else []) + (pv_mfmas(n - 2) if do_pv and "nopv" not in abl else [])
+        if "noexp" in abl:
+            do_e = False
         ex, cv = e_valu(n - 1) if do_e else ([], [])
         fill = []   # per MFMA gap
         order = ex[:6] + [ex[6], cv[0], ex[7], cv[1], cv[2], cv[3]] if do_e else []
@@ -444,9 +458,11 @@ def build():
     for db in range(4):
         v_read(0, db, 0)
     tile(True)
-    e("s_mov_b32", s_cnt, (NTF - 1,))
+    e("s_mov_b32", s_cnt, ((NTF - 1) * (2 if "loop2" in abl else 1),))
     k.label("L_tile")
+    in_loop[0] = True
     tile(False)
+    in_loop[0] = False
     e("s_sub_u32", s_cnt, (s_cnt, 1))
     e("s_cmp_lg_u32", (), (s_cnt, 0))
     e("s_cbranch_scc1", (), ("L_tile",))
@@ -581,7 +597,8 @@ def build():
             e("v_cvt_pk_bf16_f32", pk[0], (v_e[0], v_e[1]))
             e("v_cvt_pk_bf16_f32", pk[1], (v_e[2], v_e[3]))
             k.nop(0)
-            e("buffer_store_dwordx2", (), (pk, v_oo, s_od, s_bo), offset=32 * db)
+            if "nostore" not in abl:
+                e("buffer_store_dwordx2", (), (pk, v_oo, s_od, s_bo), offset=32 * db)
         if b + 1 < NB:
             e("s_add_u32", s_bo, (s_bo, t1))
     # a row sum out of range: this unit runs again in the HIP kernel's safe body
@@ -681,9 +698,9 @@ def render(k):
 
 
 if __name__ == "__main__":
-    kk = build()
+    kk = build([a_ for a_ in sys.argv[1:] if not a_.startswith("-")])
     bad = check_hazards(kk.p)
-    if bad:
+    if bad and "--force" not in sys.argv:
         for b_ in bad[:40]:
             print("HAZARD", b_, file=sys.stderr)
         sys.exit(1)
