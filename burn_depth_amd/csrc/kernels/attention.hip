@@ -589,6 +589,7 @@ struct AsmKernel {
   std::atomic<int> state{0};  // 0 not loaded, 1 loaded, -1 failed
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
+  int cus = 0;  // one persistent workgroup per CU (it owns the CU: 512 registers per wave, one wave per SIMD)
 };
 AsmKernel g_asm[64];
 std::mutex g_asm_mu;
@@ -614,12 +615,16 @@ int attention_asm_prepare() {
     k.state.store(-1, std::memory_order_release);
     MD_FAIL(MD_ERR_HIP, "attention: the embedded gfx950 code object did not load on device %d", ordinal);
   }
+  hipDeviceProp_t prop;
+  MD_HIP(hipGetDeviceProperties(&prop, ordinal));
+  k.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   k.state.store(1, std::memory_order_release);
   return MD_OK;
 }
 
 static bool attention_asm_eligible(int n_tokens, int D, int heads, int kpad, int prec, float out_fp8_inv, const int* redo) {
   if (!redo || !g_attn_asm_ok || prec != MD_PREC_BF16 || n_tokens != 577 || D != heads * 64 || kpad < 640 || out_fp8_inv > 0.f) return false;
+  if ((heads & (heads - 1)) != 0) return false;  // unit -> (sequence, head) is a shift and a mask
   int ordinal = 0;
   if (hipGetDevice(&ordinal) != hipSuccess || ordinal < 0 || ordinal >= 64) return false;
   return g_asm[ordinal].state.load(std::memory_order_acquire) == 1;
@@ -629,17 +634,22 @@ static int launch_attention_asm(const void* qk, const void* vT, void* out, int n
                                 int* redo, hipStream_t s) {
   int ordinal = 0;
   MD_HIP(hipGetDevice(&ordinal));
+  const int nunits = nseq * heads;
+  int hlog = 0;
+  while ((1 << hlog) < heads) ++hlog;
+  const int grid = nunits < g_asm[ordinal].cus ? nunits : g_asm[ordinal].cus;
   struct Args {
     const void *qk, *vT;
     void* out;
     int* redo;
-    int S, n_tokens, heads, D, kpad, pad;
-  } args = {qk, vT, out, redo, S, n_tokens, heads, D, kpad, 0};
+    int S, n_tokens, heads, D, kpad, heads_log2, nunits, grid;
+  } args = {qk, vT, out, redo, S, n_tokens, heads, D, kpad, hlog, nunits, grid};
+  static_assert(sizeof(Args) == 64, "the kernel reads this layout (gen_attn577.py)");
   size_t size = sizeof(args);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  MD_HIP(hipModuleLaunchKernel(g_asm[ordinal].fn, (unsigned)heads, (unsigned)nseq, 1, 256, 1, 1, 0, s, nullptr, extra));
+  MD_HIP(hipModuleLaunchKernel(g_asm[ordinal].fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra));
   // the units it flagged (a row sum outside [2^-64, 2^100): never on trained weights) run again in the running-maximum body
-  const int nunits = nseq * heads, qblocks = (n_tokens + 127) / 128;
+  const int qblocks = (n_tokens + 127) / 128;
   hipLaunchKernelGGL(attention_redo_kernel, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
                      (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, redo, nunits);
   MD_HIP(hipGetLastError());
@@ -656,7 +666,7 @@ int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S,
   const int qblocks = (n_tokens + 127) / 128;
   const long blocks = (long)qblocks * heads * nseq;
   if (nseq <= 0 || blocks > 0x7fffffffL) MD_FAIL(MD_ERR_UNSUPPORTED, "attention: %d sequences", nseq);
-  if (nseq <= 65535 && attention_asm_eligible(n_tokens, D, heads, kpad, prec, out_fp8_inv, redo))
+  if (attention_asm_eligible(n_tokens, D, heads, kpad, prec, out_fp8_inv, redo))
     return launch_attention_asm(qk, vT, out, nseq, S, n_tokens, heads, D, kpad, redo, s);
   const dim3 grid((unsigned)blocks), block(256);
   // small launches over long sequences: 64 queries x two key groups per workgroup (the kernel's header)

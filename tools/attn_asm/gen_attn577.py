@@ -22,7 +22,7 @@ STAGE = 16384     # K tile 8 KB | V^T tile 8 KB
 NSTAGE = 4
 RING = STAGE * NSTAGE
 SCRATCH = 0       # class-token partials reuse the ring once every DMA has landed
-LDS_BYTES = RING
+LDS_BYTES = RING + 4 * 17 * 16 + 64   # the ring | the class token's partial sums
 
 
 class K:
@@ -50,13 +50,18 @@ def build(abl=()):
     abl = set(abl)
     k = K()
     e = k.e
+    uniq = [0]
+
+    def lab(stem):
+        uniq[0] += 1
+        return f"L_{stem}_{uniq[0]}"
+
     # ---------------- registers ----------------
     s_karg = s(0, 2)
-    s_head, s_seq = s(2), s(3)
+    s_wg = s(2)
     s_qk, s_vt, s_out, s_redo = s(4, 2), s(6, 2), s(8, 2), s(10, 2)
-    s_S, s_n, s_heads, s_D, s_kpad = s(12), s(13), s(14), s(15), s(16)
-    s_w, s_rowB, s_kpadB = s(17), s(18), s(19)
-    s_qd, s_kd, s_vd, s_od = s(20, 4), s(24, 4), s(28, 4), s(32, 4)
+    s_S, s_n, s_heads, s_D, s_kpad, s_hlog, s_nunits, s_grid = (s(12 + i) for i in range(8))
+    s_kd, s_vd, s_od = s(24, 4), s(28, 4), s(32, 4)           # LDS-DMA descriptors (K, V^T); output rows of the current unit
     s_kso, s_vso, s_dst, s_cnt = s(36), s(37), s(38), s(39)   # DMA cursors (K / V^T source offsets of the next tile, LDS stage), loop counter
     t0, t1, t2, t3 = s(40), s(41), s(42), s(43)
     s_mmain, s_mcls = s(44, 2), s(46, 2)
@@ -67,7 +72,11 @@ def build(abl=()):
     s_bo = s(58)                                              # block source / destination offset cursor
     s_tmp64 = s(60, 2)
     s_lo, s_hi = s(62), s(63)
-    s_kmax = s(64)
+    s_dmat = s(64)                                            # index (inside its unit) of the next tile the DMA requests
+    s_w, s_rowB, s_kpadB = s(65), s(66), s(67)
+    s_unit, s_unit_n, s_last = s(68), s(69), s(70)
+    s_qd_n, s_kd_n, s_vd_n, s_od_n = s(72, 4), s(76, 4), s(80, 4), s(84, 4)   # the NEXT unit's descriptors
+    s_rd, s_rd_n = s(88, 2), s(90, 2)                         # redo flag address of the current / next unit
 
     vp = k.vp
     v_tid = vp.take()          # v0 = work-item id
@@ -91,17 +100,19 @@ def build(abl=()):
     v_dv = [vp.take() for _ in range(2)]
     v_qo, v_qco, v_oo, v_oco = vp.take(), vp.take(), vp.take(), vp.take()
     v_zero = vp.take()
-    v_e = [vp.take() for _ in range(8)]            # epilogue temporaries
+    v_scr = vp.take()                              # class-token scratch address of this lane
+    v_e8 = vp.take(8, 2)                           # epilogue temporaries (v_e[6:7] is a 64-bit store operand: even-aligned)
+    v_e = [v_e8[i] for i in range(8)]
     a_o = [[a((b * 4 + db) * 4, 4) for db in range(4)] for b in range(NB)]
     a_oc = [a(NB * 16 + db * 4, 4) for db in range(4)]
     a_l = [a(NB * 16 + 16 + b * 4, 4) for b in range(NB)]
     a_lc = a(NB * 16 + 16 + NB * 4, 4)
     n_acc = NB * 16 + 16 + NB * 4 + 4
+    n_store = [0]
 
     # ---------------- prologue ----------------
     e("s_load_dwordx8", s(4, 8), (s_karg, 0x0))
-    e("s_load_dwordx4", s(12, 4), (s_karg, 0x20))
-    e("s_load_dword", s_kpad, (s_karg, 0x30))
+    e("s_load_dwordx8", s(12, 8), (s_karg, 0x20))
     e("v_and_b32", v_lane, (63, v_tid))
     e("v_lshrrev_b32", vt0, (6, v_tid))
     e("v_and_b32", v_r, (15, v_lane))
@@ -112,54 +123,65 @@ def build(abl=()):
     k.nop(3)
     e("s_lshl_b32", s_rowB, (s_D, 2))
     e("s_lshl_b32", s_kpadB, (s_kpad, 1))
-    # Q / K descriptors: qk + (seq * S) * rowB + head * 128
-    e("s_mul_i32", t0, (s_seq, s_S))
-    e("s_mul_hi_u32", t1, (t0, s_rowB))
-    e("s_mul_i32", t0, (t0, s_rowB))
-    e("s_lshl_b32", t2, (s_head, 7))
-    e("s_add_u32", t0, (t0, t2))
-    e("s_addc_u32", t1, (t1, 0))
-    e("s_add_u32", s_qd[0], (s_qk[0], t0))
-    e("s_addc_u32", s_qd[1], (s_qk[1], t1))
-    e("s_lshl_b32", t2, (s_D, 1))
-    e("s_add_u32", s_kd[0], (s_qd[0], t2))
-    e("s_addc_u32", s_kd[1], (s_qd[1], 0))
-    e("s_and_b32", s_qd[1], (s_qd[1], 0xFFFF))
-    e("s_and_b32", s_kd[1], (s_kd[1], 0xFFFF))
-    e("s_mul_i32", s_qd[2], (s_n, s_rowB))
-    e("s_sub_u32", t2, (s_n, 1))
-    e("s_mul_i32", s_kd[2], (t2, s_rowB))
-    e("s_add_u32", s_kd[2], (s_kd[2], 128))
-    e("s_mov_b32", s_qd[3], (0x00020000,))
-    e("s_mov_b32", s_kd[3], (0x00020000,))
-    # V^T descriptor: vT + (seq * heads + head) * 64 * kpadB
-    e("s_mul_i32", t0, (s_seq, s_heads))
-    e("s_add_u32", t0, (t0, s_head))          # unit
-    e("s_lshl_b32", t2, (s_kpadB, 6))
-    e("s_mul_hi_u32", t1, (t0, t2))
-    e("s_mul_i32", t3, (t0, t2))
-    e("s_add_u32", s_vd[0], (s_vt[0], t3))
-    e("s_addc_u32", s_vd[1], (s_vt[1], t1))
-    e("s_and_b32", s_vd[1], (s_vd[1], 0xFFFF))
-    e("s_mov_b32", s_vd[2], (t2,))
-    e("s_mov_b32", s_vd[3], (0x00020000,))
-    # redo flag address
-    e("s_lshl_b32", t3, (t0, 2))
-    e("s_add_u32", s_redo[0], (s_redo[0], t3))
-    e("s_addc_u32", s_redo[1], (s_redo[1], 0))
-    # output descriptor: out + (seq * S) * (2 D) + head * 128
-    e("s_mul_i32", t0, (s_seq, s_S))
-    e("s_lshl_b32", t2, (s_D, 1))
-    e("s_mul_hi_u32", t1, (t0, t2))
-    e("s_mul_i32", t0, (t0, t2))
-    e("s_lshl_b32", t3, (s_head, 7))
-    e("s_add_u32", t0, (t0, t3))
-    e("s_addc_u32", t1, (t1, 0))
-    e("s_add_u32", s_od[0], (s_out[0], t0))
-    e("s_addc_u32", s_od[1], (s_out[1], t1))
-    e("s_and_b32", s_od[1], (s_od[1], 0xFFFF))
-    e("s_mul_i32", s_od[2], (s_n, t2))
-    e("s_mov_b32", s_od[3], (0x00020000,))
+
+    def unit_descriptors():
+        """the descriptors of unit s_unit_n = (sequence, head) into the `next` set"""
+        seq, head = s_t4, s_t5
+        e("s_lshr_b32", seq, (s_unit_n, s_hlog))
+        e("s_sub_u32", t0, (s_heads, 1))
+        e("s_and_b32", head, (s_unit_n, t0))
+        # q | k rows: qk + (seq * S) * rowB + head * 128
+        e("s_mul_i32", t0, (seq, s_S))
+        e("s_mul_hi_u32", t1, (t0, s_rowB))
+        e("s_mul_i32", t0, (t0, s_rowB))
+        e("s_lshl_b32", t2, (head, 7))
+        e("s_add_u32", t0, (t0, t2))
+        e("s_addc_u32", t1, (t1, 0))
+        e("s_add_u32", s_qd_n[0], (s_qk[0], t0))
+        e("s_addc_u32", s_qd_n[1], (s_qk[1], t1))
+        e("s_lshl_b32", t2, (s_D, 1))
+        e("s_add_u32", s_kd_n[0], (s_qd_n[0], t2))
+        e("s_addc_u32", s_kd_n[1], (s_qd_n[1], 0))
+        e("s_and_b32", s_qd_n[1], (s_qd_n[1], 0xFFFF))
+        e("s_and_b32", s_kd_n[1], (s_kd_n[1], 0xFFFF))
+        e("s_mul_i32", s_qd_n[2], (s_n, s_rowB))
+        e("s_sub_u32", t2, (s_n, 1))
+        e("s_mul_i32", s_kd_n[2], (t2, s_rowB))
+        e("s_add_u32", s_kd_n[2], (s_kd_n[2], 128))
+        e("s_mov_b32", s_qd_n[3], (0x00020000,))
+        e("s_mov_b32", s_kd_n[3], (0x00020000,))
+        # V^T: vT + unit * 64 * kpadB
+        e("s_lshl_b32", t2, (s_kpadB, 6))
+        e("s_mul_hi_u32", t1, (s_unit_n, t2))
+        e("s_mul_i32", t3, (s_unit_n, t2))
+        e("s_add_u32", s_vd_n[0], (s_vt[0], t3))
+        e("s_addc_u32", s_vd_n[1], (s_vt[1], t1))
+        e("s_and_b32", s_vd_n[1], (s_vd_n[1], 0xFFFF))
+        e("s_mov_b32", s_vd_n[2], (t2,))
+        e("s_mov_b32", s_vd_n[3], (0x00020000,))
+        # redo flag
+        e("s_lshl_b32", t3, (s_unit_n, 2))
+        e("s_add_u32", s_rd_n[0], (s_redo[0], t3))
+        e("s_addc_u32", s_rd_n[1], (s_redo[1], 0))
+        # output rows: out + (seq * S) * (2 D) + head * 128
+        e("s_mul_i32", t0, (seq, s_S))
+        e("s_lshl_b32", t2, (s_D, 1))
+        e("s_mul_hi_u32", t1, (t0, t2))
+        e("s_mul_i32", t0, (t0, t2))
+        e("s_lshl_b32", t3, (head, 7))
+        e("s_add_u32", t0, (t0, t3))
+        e("s_addc_u32", t1, (t1, 0))
+        e("s_add_u32", s_od_n[0], (s_out[0], t0))
+        e("s_addc_u32", s_od_n[1], (s_out[1], t1))
+        e("s_and_b32", s_od_n[1], (s_od_n[1], 0xFFFF))
+        e("s_mul_i32", s_od_n[2], (s_n, t2))
+        e("s_mov_b32", s_od_n[3], (0x00020000,))
+
+    e("s_mov_b32", s_unit_n, (s_wg,))
+    unit_descriptors()
+    for j in range(0, 4, 2):
+        e("s_mov_b64", s_kd[j:j + 2], (s_kd_n[j:j + 2],))
+        e("s_mov_b64", s_vd[j:j + 2], (s_vd_n[j:j + 2],))
     # per-wave piece offsets
     e("s_lshl_b32", t0, (s_w, 4))             # 16 w = first K / V^T row of this wave's two pieces
     e("s_mul_i32", s_kp0, (t0, s_rowB))
@@ -189,7 +211,7 @@ def build(abl=()):
 
     in_loop = [False]
 
-    def dma_piece(which, first_in_group=False):
+    def dma_piece(which):
         """one 1-KiB piece of the tile at the DMA cursors: which = 0 / 1 (K even / odd), 2 / 3 (V^T even / odd)"""
         if in_loop[0] and "nodma" in abl:
             return
@@ -207,22 +229,47 @@ def build(abl=()):
             e("buffer_load_dwordx4", (), (v_dv[which - 2], s_vd, s_t5), lds=True)
 
     def dma_advance():
+        """behind a tile's four pieces: the next tile of the unit, or -- behind its last tile -- the first tile of the NEXT unit"""
+        l_sw, l_done = lab("dma_switch"), lab("dma_next")
+        e("s_add_u32", s_dmat, (s_dmat, 1))
+        e("s_cmp_eq_u32", (), (s_dmat, NTF + 1))
+        e("s_cbranch_scc1", (), (l_sw,))
         e("s_lshl_b32", t0, (s_rowB, 6))
         e("s_add_u32", s_kso, (s_kso, t0))
         e("s_add_u32", s_vso, (s_vso, 128))
-        e("s_min_u32", s_kso, (s_kso, s_kmax))   # the requests past the last tile (the loop issues three tiles ahead) re-read the last one
-        e("s_min_u32", s_vso, (s_vso, NTF * 128))
+        e("s_branch", (), (l_done,))
+        k.label(l_sw)
+        e("s_mov_b32", s_dmat, (0,))
+        e("s_mov_b32", s_kso, (0,))
+        e("s_mov_b32", s_vso, (0,))
+        for j in range(0, 4, 2):
+            e("s_mov_b64", s_kd[j:j + 2], (s_kd_n[j:j + 2],))
+            e("s_mov_b64", s_vd[j:j + 2], (s_vd_n[j:j + 2],))
+        k.label(l_done)
         e("s_add_u32", s_dst, (s_dst, STAGE))
         e("s_and_b32", s_dst, (s_dst, RING - 1))
 
-    e("s_mul_i32", s_kmax, (s_rowB, NTF * 64))
+    def q_loads():
+        """Q fragments of the NEXT unit: lane (n, g) <- Q[q][32 s + 8 g ..]; q = 1 + 144 w + 16 b + n (class token: q = 0)"""
+        e("s_mov_b32", s_bo, (0,))
+        e("s_lshl_b32", t1, (s_rowB, 4))
+        for b in range(NB):
+            for st in range(2):
+                e("buffer_load_dwordx4", v_q[b][4 * st:4 * st + 4], (v_qo, s_qd_n, s_bo), offset=64 * st)
+            if b + 1 < NB:
+                e("s_add_u32", s_bo, (s_bo, t1))
+        for st in range(2):
+            e("buffer_load_dwordx4", v_qc[4 * st:4 * st + 4], (v_qco, s_qd_n, 0), offset=64 * st)
+        return 2 * NB + 2
+
     e("s_mov_b32", s_kso, (0,))
     e("s_mov_b32", s_vso, (0,))
     e("s_mov_b32", s_dst, (0,))
-    for wpc in range(4):
-        dma_piece(wpc)
-    dma_advance()
-    # Q fragments: lane (n, g) <- Q[q][32 s + 8 g ..]; q = 1 + 144 w + 16 b + n
+    e("s_mov_b32", s_dmat, (0,))
+    for _ in range(3):
+        for wpc in range(4):
+            dma_piece(wpc)
+        dma_advance()
     e("s_mul_i32", t0, (s_w, 144))
     e("s_add_u32", t0, (t0, 1))
     e("v_add_u32", vt0, (t0, v_r))
@@ -233,22 +280,8 @@ def build(abl=()):
     e("v_mul_lo_u32", v_oo, (vt0, t2))
     e("v_lshlrev_b32", v_oco, (3, v_g))
     e("v_add_u32", v_oo, (v_oo, v_oco))
-    e("s_mov_b32", s_bo, (0,))
-    e("s_lshl_b32", t1, (s_rowB, 4))
-    for b in range(NB):
-        for st in range(2):
-            e("buffer_load_dwordx4", v_q[b][4 * st:4 * st + 4], (v_qo, s_qd, s_bo), offset=64 * st)
-        if b + 1 < NB:
-            e("s_add_u32", s_bo, (s_bo, t1))
-    for st in range(2):
-        e("buffer_load_dwordx4", v_qc[4 * st:4 * st + 4], (v_qco, s_qd, 0), offset=64 * st)
-    for _ in range(2):
-        for wpc in range(4):
-            dma_piece(wpc)
-        dma_advance()
-    # accumulators, constants
-    for i in range(n_acc):
-        e("v_accvgpr_write_b32", a(i), (0,))
+    q_loads()
+    # constants
     for j in range(4):
         e("v_mov_b32", v_ones[j], (0x3F803F80,))
     for db in range(4):
@@ -262,9 +295,13 @@ def build(abl=()):
     e("s_cbranch_scc0", (), ("L_not_w0",))
     e("s_mov_b64", s_mcls, (s_mmain,))
     k.label("L_not_w0")
-    e("s_mov_b64", s_bad, (0,))
     e("s_mov_b32", s_lo, (0x1f800000,))     # 2^-64
     e("s_mov_b32", s_hi, (0x71800000,))     # 2^100
+    # class-token scratch: [wave][17][4 lane groups] floats behind the ring; a lane with n == 0 owns slot g
+    e("s_mul_i32", t0, (s_w, 17 * 16))
+    e("v_lshlrev_b32", v_scr, (2, v_g))
+    e("v_add_u32", v_scr, (t0, v_scr))
+    e("v_add_u32", v_scr, (RING, v_scr))
     # LDS read cursors
     #  K:  (8 (r >> 2) + (r & 3)) * 128 + (((4 s + g) ^ f) << 4), f = ((r >> 1) & 1) << 1 | ((r >> 2) & 1) << 2
     e("v_lshrrev_b32", vt0, (2, v_r))
@@ -350,20 +387,21 @@ def build(abl=()):
         cv = [I("v_cvt_pk_bf16_f32", (pb[j],), (sb[2 * j], sb[2 * j + 1])) for j in range(4)]
         return ex, cv
 
-    def pv_mfmas(n):
+    def pv_mfmas(n, fresh=False):
+        """fresh: the unit's first products into these accumulators (C = 0 instead of the previous unit's sums)"""
         b, half = n % NB, (n // NB) & 1
         pb, vf = v_pb[n & 1], v_vf[half]
-        return [mf(a_o[b][db], vf[4 * db:4 * db + 4], pb, a_o[b][db]) for db in range(4)] + [mf(a_l[b], v_ones, pb, a_l[b])]
+        return [mf(a_o[b][db], vf[4 * db:4 * db + 4], pb, 0 if fresh else a_o[b][db]) for db in range(4)] + \
+               [mf(a_l[b], v_ones, pb, 0 if fresh else a_l[b])]
 
-    def emit_slot(n, do_s, do_e, do_pv, extras_head=(), extras=()):
+    def emit_slot(n, do_s, do_e, do_pv, extras_head=(), extras=(), fresh=False):
         """MFMAs of S(n) then P.V(n-2); the exponentials and packs of step n-1 between them; `extras` one behind each of the first MFMAs"""
         for x in extras_head:
             x()
-        ms = (s_mfmas(n) if do_s and "nos" not in abl else []) + (pv_mfmas(n - 2) if do_pv and "nopv" not in abl else [])
+        ms = (s_mfmas(n) if do_s and "nos" not in abl else []) + (pv_mfmas(n - 2, fresh) if do_pv and "nopv" not in abl else [])
         if "noexp" in abl:
             do_e = False
         ex, cv = e_valu(n - 1) if do_e else ([], [])
-        fill = []   # per MFMA gap
         order = ex[:6] + [ex[6], cv[0], ex[7], cv[1], cv[2], cv[3]] if do_e else []
         gaps = max(len(ms), 1)
         per = [[] for _ in range(gaps)]
@@ -406,10 +444,10 @@ def build(abl=()):
         e("v_cvt_pk_bf16_f32", v_pc[0], (v_sc[0], v_sc[1]))
         e("v_cvt_pk_bf16_f32", v_pc[1], (v_sc[2], v_sc[3]))
 
-    def cls_pv():
+    def cls_pv(fresh=False):
         for db in range(4):
-            k.p.append(mf(a_oc[db], v_vc[4 * db:4 * db + 4], v_pc, a_oc[db]))
-        k.p.append(mf(a_lc, v_ones, v_pc, a_lc))
+            k.p.append(mf(a_oc[db], v_vc[4 * db:4 * db + 4], v_pc, 0 if fresh else a_oc[db]))
+        k.p.append(mf(a_lc, v_ones, v_pc, 0 if fresh else a_lc))
 
     def tile(first):
         for n in range(18):
@@ -427,6 +465,8 @@ def build(abl=()):
             if 3 <= n <= 6:
                 ext.append(lambda db=n - 3: v_read(1, db, 1))
             if n == 9:
+                # every fragment of this tile is in registers (read in slots 1-6, waited for here): behind the barrier its stage takes
+                # tile t + 3, and tile t + 1 -- requested two tiles ago -- is visible to every wave
                 head.append(lambda: e("s_waitcnt", lgkmcnt=0))
                 head.append(lambda: e("s_waitcnt", vmcnt=4))
                 head.append(lambda: e("s_barrier"))
@@ -444,19 +484,36 @@ def build(abl=()):
             if n == 13:
                 head.append(cls_e)
             if n == 15:
-                head.append(cls_pv)
+                head.append(lambda: cls_pv(first))
             if n == 16:
                 head.append(lambda: bump(v_kcoff + [v_vcoff]))
                 head.append(dma_advance)
-            emit_slot(n, True, not (first and n < 1), not (first and n < 2), head, ext)
+            emit_slot(n, True, not (first and n < 1), not (first and n < 2), head, ext, fresh=first and n - 2 < NB)
 
-    # ---------------- first tile: wait for tile 0 and Q, read the first fragments ----------------
-    e("s_waitcnt", vmcnt=8)
+    # ---------------- the first unit: wait for its first tiles and Q, read the first fragments ----------------
+    e("s_waitcnt", vmcnt=0)
     e("s_barrier")
     for j in range(4):
         k_read(0, j, 0)
     for db in range(4):
         v_read(0, db, 0)
+    k.label("L_unit")
+    for j in range(0, 4, 2):
+        e("s_mov_b64", s_od[j:j + 2], (s_od_n[j:j + 2],))
+    e("s_mov_b64", s_rd, (s_rd_n,))
+    e("s_mov_b32", s_unit, (s_unit_n,))
+    # the next unit of this workgroup (the last one names itself: its requests re-read tiles nobody uses)
+    e("s_add_u32", s_unit_n, (s_unit, s_grid))
+    e("s_mov_b32", s_last, (0,))
+    e("s_cmp_lt_u32", (), (s_unit_n, s_nunits))
+    e("s_cbranch_scc1", (), ("L_has_next",))
+    e("s_mov_b32", s_unit_n, (s_unit,))
+    e("s_mov_b32", s_last, (1,))
+    k.label("L_has_next")
+    unit_descriptors()
+    e("s_mov_b64", s_bad, (0,))
+    vm_q = I("s_waitcnt", (), (), vmcnt=0)   # patched below: the Q loads (and everything older) have landed; only this unit's output stores may be in flight
+    k.p.append(vm_q)
     tile(True)
     e("s_mov_b32", s_cnt, ((NTF - 1) * (2 if "loop2" in abl else 1),))
     k.label("L_tile")
@@ -517,32 +574,47 @@ def build(abl=()):
     e("v_cvt_pk_bf16_f32", v_pc[0], (v_sc[0], 0))
     k.nop(1)
     cls_pv()
-    # ---------------- epilogue ----------------
-    e("s_waitcnt", vmcnt=0)
+    # ---------------- hand-over to the next unit: its first tile (requested at tile 7) is visible behind this barrier ----------------
+    e("s_waitcnt", vmcnt=4)
     e("s_barrier")
+    for wpc in range(4):
+        dma_piece(wpc)          # the next unit's tile 2 into the stage of this unit's tile 8
+    dma_advance()
+    bump(v_koff + v_voff)
+    bump(v_kcoff + [v_vcoff])
+    for j in range(4):
+        k_read(0, j, 0)
+    for db in range(4):
+        v_read(0, db, 0)
+    n_q = q_loads()
+    e("v_mov_b32", v_pc[1], (0,)) if False else None
+    # ---------------- epilogue ----------------
     k.nop(7)
-    # class-token partials through the (now idle) ring: scratch[w][j][lane], j = 0..15 O, 16 l
-    e("s_mul_i32", t0, (s_w, 17 * 256))
-    e("v_lshlrev_b32", vt0, (2, v_lane))
-    e("v_add_u32", vt0, (t0, vt0))
+    # class-token partials: lanes with n == 0 write O (16 values) and l to scratch[w][j][g]
+    e("v_cmp_eq_u32", VCC, (v_r, 0))
+    e("s_mov_b64", s_tmp64, (EXEC,))
     for db in range(4):
         for i in range(4):
             e("v_accvgpr_read_b32", v_e[i], (a_oc[db][i],))
         k.nop(1)
+        e("s_mov_b64", EXEC, (VCC,))
         for i in range(4):
-            e("ds_write_b32", (), (vt0, v_e[i]), offset=(db * 4 + i) * 256)
+            e("ds_write_b32", (), (v_scr, v_e[i]), offset=(db * 4 + i) * 16)
+        e("s_mov_b64", EXEC, (s_tmp64,))
     e("v_accvgpr_read_b32", v_e[0], (a_lc[0],))
     k.nop(1)
-    e("ds_write_b32", (), (vt0, v_e[0]), offset=16 * 256)
+    e("s_mov_b64", EXEC, (VCC,))
+    e("ds_write_b32", (), (v_scr, v_e[0]), offset=16 * 16)
+    e("s_mov_b64", EXEC, (s_tmp64,))
     e("s_waitcnt", lgkmcnt=0)
     e("s_barrier")
     e("s_cmp_eq_u32", (), (s_w, 0))
     e("s_cbranch_scc0", (), ("L_main_out",))
-    # wave 0: add the four partials (its own included, from LDS), normalise, store row 0 (lanes with n == 0)
-    e("v_lshlrev_b32", vt0, (2, v_lane))
-    e("ds_read_b32", v_e[4], (vt0,), offset=16 * 256)
+    # wave 0: add the four partials, normalise, store row 0 (lanes with n == 0: lane group g holds d = 16 db + 4 g + i)
+    e("s_mov_b64", EXEC, (VCC,))
+    e("ds_read_b32", v_e[4], (v_scr,), offset=16 * 16)
     for ww in range(1, 4):
-        e("ds_read_b32", v_e[5], (vt0,), offset=ww * 17 * 256 + 16 * 256)
+        e("ds_read_b32", v_e[5], (v_scr,), offset=ww * 17 * 16 + 16 * 16)
         e("s_waitcnt", lgkmcnt=0)
         e("v_add_f32", v_e[4], (v_e[4], v_e[5]))
     k.nop(1)
@@ -551,19 +623,16 @@ def build(abl=()):
     e("v_cmp_ngt_f32", VCC, (s_hi, v_e[4]))      # not (2^100 > l): too large, inf or NaN
     e("s_or_b64", s_bad, (s_bad, VCC))
     e("v_rcp_f32", v_e[4], (v_e[4],))
-    e("v_cmp_eq_u32", VCC, (v_r, 0))
-    e("s_mov_b64", s_tmp64, (EXEC,))
     for db in range(4):
         for i in range(4):
-            e("ds_read_b32", v_e[i], (vt0,), offset=(db * 4 + i) * 256)
+            e("ds_read_b32", v_e[i], (v_scr,), offset=(db * 4 + i) * 16)
         for ww in range(1, 4):
+            tmps = [vt1, vt2, vt3, v_e[5]]
             for i in range(4):
-                e("ds_read_b32", vt1 if i == 0 else (vt2 if i == 1 else (vt3 if i == 2 else v_e[5])), (vt0,), offset=ww * 17 * 256 + (db * 4 + i) * 256)
+                e("ds_read_b32", tmps[i], (v_scr,), offset=ww * 17 * 16 + (db * 4 + i) * 16)
             e("s_waitcnt", lgkmcnt=0)
-            e("v_add_f32", v_e[0], (v_e[0], vt1))
-            e("v_add_f32", v_e[1], (v_e[1], vt2))
-            e("v_add_f32", v_e[2], (v_e[2], vt3))
-            e("v_add_f32", v_e[3], (v_e[3], v_e[5]))
+            for i in range(4):
+                e("v_add_f32", v_e[i], (v_e[i], tmps[i]))
         k.nop(1)
         for i in range(4):
             e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
@@ -571,10 +640,9 @@ def build(abl=()):
         e("v_cvt_pk_bf16_f32", v_e[6], (v_e[0], v_e[1]))
         e("v_cvt_pk_bf16_f32", v_e[7], (v_e[2], v_e[3]))
         k.nop(1)
-        e("s_mov_b64", EXEC, (VCC,))
-        e("buffer_store_dwordx2", (), (v_e[6:8] if False else R("v", v_e[6].i, 2), v_oco, s_od, 0), offset=32 * db)
-        e("s_mov_b64", EXEC, (s_tmp64,))
+        e("buffer_store_dwordx2", (), (R("v", v_e[6].i, 2), v_oco, s_od, 0), offset=32 * db)
         k.nop(1)
+    e("s_mov_b64", EXEC, (s_tmp64,))
     k.label("L_main_out")
     e("s_mov_b32", s_bo, (0,))
     e("s_lshl_b32", t1, (s_D, 5))             # 16 rows * 2 D bytes
@@ -599,18 +667,26 @@ def build(abl=()):
             k.nop(0)
             if "nostore" not in abl:
                 e("buffer_store_dwordx2", (), (pk, v_oo, s_od, s_bo), offset=32 * db)
+                n_store[0] += 1
         if b + 1 < NB:
             e("s_add_u32", s_bo, (s_bo, t1))
     # a row sum out of range: this unit runs again in the HIP kernel's safe body
     e("s_or_b32", t0, (s_bad[0], s_bad[1]))
-    e("s_cbranch_scc0", (), ("L_done",))
+    e("s_cbranch_scc0", (), ("L_flag_done",))
     e("v_mov_b32", v_e[0], (1,))
+    e("s_mov_b64", s_tmp64, (EXEC,))
     e("s_mov_b64", EXEC, (1,))
     k.nop(1)
-    e("global_store_dword", (), (v_zero, v_e[0], s_redo))
-    k.label("L_done")
+    e("global_store_dword", (), (v_zero, v_e[0], s_rd))
+    e("s_mov_b64", EXEC, (s_tmp64,))
+    k.label("L_flag_done")
+    e("s_cmp_eq_u32", (), (s_last, 0))
+    e("s_cbranch_scc1", (), ("L_unit",))
     e("s_waitcnt", vmcnt=0)
     e("s_endpgm")
+    # at L_unit the younger vector-memory operations are this wave's output stores (the class token's four, wave 0 only, are the oldest
+    # of them): with no more than the main stores in flight, the Q loads and every LDS-DMA piece in front of them have landed
+    vm_q.mods["vmcnt"] = min(n_store[0], 63)
     k.n_vgpr = k.vp.next
     k.n_acc = n_acc
     return k
@@ -631,11 +707,11 @@ FOOTER = """\t.section\t.rodata,"a",@progbits
 \t.amdhsa_kernel md_attn577_bf16
 \t\t.amdhsa_group_segment_fixed_size {lds}
 \t\t.amdhsa_private_segment_fixed_size 0
-\t\t.amdhsa_kernarg_size 56
+\t\t.amdhsa_kernarg_size 64
 \t\t.amdhsa_user_sgpr_count 2
 \t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
 \t\t.amdhsa_system_sgpr_workgroup_id_x 1
-\t\t.amdhsa_system_sgpr_workgroup_id_y 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 0
 \t\t.amdhsa_system_sgpr_workgroup_id_z 0
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr 512
@@ -665,9 +741,11 @@ amdhsa.kernels:
       - {{.offset: 44, .size: 4, .value_kind: by_value}}
       - {{.offset: 48, .size: 4, .value_kind: by_value}}
       - {{.offset: 52, .size: 4, .value_kind: by_value}}
+      - {{.offset: 56, .size: 4, .value_kind: by_value}}
+      - {{.offset: 60, .size: 4, .value_kind: by_value}}
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 56
+    .kernarg_segment_size: 64
     .max_flat_workgroup_size: 256
     .name:           md_attn577_bf16
     .private_segment_fixed_size: 0

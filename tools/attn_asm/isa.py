@@ -401,7 +401,10 @@ class Emu:
                 else:
                     w.exec = self.rd64(w, sr[0])
             else:
-                val = self.rd64(w, sr[0]) if isinstance(sr[0], R) and sr[0].k == "s" else (w.exec if isinstance(sr[0], R) else int(sr[0]))
+                if isinstance(sr[0], R):
+                    val = self.rd64(w, sr[0]) if sr[0].k == "s" else (w.vcc if sr[0].k == "vcc" else w.exec)
+                else:
+                    val = int(sr[0])
                 w.s[d[0].i] = u32(val & 0xFFFFFFFF)
                 w.s[d[0].i + 1] = u32(val >> 32)
             return
