@@ -22,7 +22,8 @@ STAGE = 16384     # K tile 8 KB | V^T tile 8 KB
 NSTAGE = 4
 RING = STAGE * NSTAGE
 SCRATCH = 0       # class-token partials reuse the ring once every DMA has landed
-LDS_BYTES = RING + 4 * 17 * 16 + 64   # the ring | the class token's partial sums
+OSTAGE = RING + 2048     # per wave: one 16-query output block, 16 rows of 128 B at a 144-byte pitch
+LDS_BYTES = OSTAGE + 4 * 16 * 144   # the ring | the class token's partial sums | the output staging
 
 
 class K:
@@ -55,6 +56,26 @@ def build(abl=()):
     def lab(stem):
         uniq[0] += 1
         return f"L_{stem}_{uniq[0]}"
+
+    def stamp(slot):
+        """timing experiments ('stamps'): wave 0 of workgroup 0 stores s_memtime into dbg[unit_count * 8 + slot] (qwords behind the flags)"""
+        if "stamps" not in abl:
+            return
+        l_skip = lab("nostamp")
+        e("s_or_b32", s(59), (s(2), s(65)))          # workgroup 0, wave 0
+        e("s_cbranch_scc1", (), (l_skip,))
+        e("s_cmp_gt_u32", (), (s(71), 3))
+        e("s_cbranch_scc1", (), (l_skip,))
+        e("s_or_b32", s(59), (s(20), s(21)))        # a null debug pointer: no stamps
+        e("s_cbranch_scc0", (), (l_skip,))
+        e("s_memtime", s(22, 2), ())
+        e("s_waitcnt", lgkmcnt=0)
+        e("v_mov_b32", v(254), (s(22),))
+        e("v_mov_b32", v(255), (s(23),))
+        e("s_lshl_b32", s(59), (s(71), 6))
+        e("v_mov_b32", v(253), (s(59),))
+        e("global_store_dwordx2", (), (v(253), v(254, 2), s(20, 2)), offset=slot * 8)
+        k.label(l_skip)
 
     # ---------------- registers ----------------
     s_karg = s(0, 2)
@@ -101,6 +122,7 @@ def build(abl=()):
     v_qo, v_qco, v_oo, v_oco = vp.take(), vp.take(), vp.take(), vp.take()
     v_zero = vp.take()
     v_scr = vp.take()                              # class-token scratch address of this lane
+    v_ost, v_ord, v_oo2 = vp.take(), vp.take(), vp.take()   # output staging: write / read address, row-wise store offset
     v_e8 = vp.take(8, 2)                           # epilogue temporaries (v_e[6:7] is a 64-bit store operand: even-aligned)
     v_e = [v_e8[i] for i in range(8)]
     a_o = [[a((b * 4 + db) * 4, 4) for db in range(4)] for b in range(NB)]
@@ -121,6 +143,11 @@ def build(abl=()):
     e("v_readfirstlane_b32", s_w, (vt0,))
     e("s_waitcnt", lgkmcnt=0)
     k.nop(3)
+    if "stamps" in abl:
+        e("s_load_dwordx2", s(20, 2), (s_karg, 0x40))
+        e("s_mov_b32", s(71), (0,))
+        e("s_waitcnt", lgkmcnt=0)
+        stamp(0)
     e("s_lshl_b32", s_rowB, (s_D, 2))
     e("s_lshl_b32", s_kpadB, (s_kpad, 1))
 
@@ -302,6 +329,25 @@ def build(abl=()):
     e("v_lshlrev_b32", v_scr, (2, v_g))
     e("v_add_u32", v_scr, (t0, v_scr))
     e("v_add_u32", v_scr, (RING, v_scr))
+    # output staging: a lane (n, g) writes its 4 values of d-block db at row n, byte 32 db + 8 g; a lane l reads row (l >> 3) (+ 8), chunk l & 7
+    e("s_mul_i32", t0, (s_w, 16 * 144))
+    e("s_add_u32", t0, (t0, OSTAGE))
+    e("v_mul_u32_u24", v_ost, (144, v_r))
+    e("v_lshlrev_b32", vt0, (3, v_g))
+    e("v_add_u32", v_ost, (v_ost, vt0))
+    e("v_add_u32", v_ost, (t0, v_ost))
+    e("v_lshrrev_b32", vt0, (3, v_lane))          # row of the read-back
+    e("v_and_b32", vt1, (7, v_lane))
+    e("v_lshlrev_b32", vt1, (4, vt1))             # chunk * 16
+    e("v_mul_u32_u24", v_ord, (144, vt0))
+    e("v_add_u32", v_ord, (v_ord, vt1))
+    e("v_add_u32", v_ord, (t0, v_ord))
+    e("s_mul_i32", t0, (s_w, 144))
+    e("s_add_u32", t0, (t0, 1))
+    e("v_add_u32", vt0, (t0, vt0))                # query row 1 + 144 w + (l >> 3)
+    e("s_lshl_b32", t2, (s_D, 1))
+    e("v_mul_lo_u32", v_oo2, (vt0, t2))
+    e("v_add_u32", v_oo2, (v_oo2, vt1))
     # LDS read cursors
     #  K:  (8 (r >> 2) + (r & 3)) * 128 + (((4 s + g) ^ f) << 4), f = ((r >> 1) & 1) << 1 | ((r >> 2) & 1) << 2
     e("v_lshrrev_b32", vt0, (2, v_r))
@@ -514,7 +560,9 @@ def build(abl=()):
     e("s_mov_b64", s_bad, (0,))
     vm_q = I("s_waitcnt", (), (), vmcnt=0)   # patched below: the Q loads (and everything older) have landed; only this unit's output stores may be in flight
     k.p.append(vm_q)
+    stamp(1)
     tile(True)
+    stamp(2)
     e("s_mov_b32", s_cnt, ((NTF - 1) * (2 if "loop2" in abl else 1),))
     k.label("L_tile")
     in_loop[0] = True
@@ -523,6 +571,7 @@ def build(abl=()):
     e("s_sub_u32", s_cnt, (s_cnt, 1))
     e("s_cmp_lg_u32", (), (s_cnt, 0))
     e("s_cbranch_scc1", (), ("L_tile",))
+    stamp(3)
     # drain: exp / pack of step 17, P.V of steps 16 and 17
     emit_slot(18, False, True, True)
     k.nop(1)
@@ -574,6 +623,7 @@ def build(abl=()):
     e("v_cvt_pk_bf16_f32", v_pc[0], (v_sc[0], 0))
     k.nop(1)
     cls_pv()
+    stamp(4)
     # ---------------- hand-over to the next unit: its first tile (requested at tile 7) is visible behind this barrier ----------------
     e("s_waitcnt", vmcnt=4)
     e("s_barrier")
@@ -587,6 +637,7 @@ def build(abl=()):
     for db in range(4):
         v_read(0, db, 0)
     n_q = q_loads()
+    stamp(5)
     e("v_mov_b32", v_pc[1], (0,)) if False else None
     # ---------------- epilogue ----------------
     k.nop(7)
@@ -644,8 +695,20 @@ def build(abl=()):
         k.nop(1)
     e("s_mov_b64", EXEC, (s_tmp64,))
     k.label("L_main_out")
+    # nine 16-query blocks: normalise, pack, stage the block through LDS (a lane holds 4 values of 4 d-blocks of ONE row; the rows leave as
+    # whole 128-byte lines, 16 bytes per lane: per-lane 8-byte stores at a 2-KB row pitch held this section at 10.5k cycles, 22 % of a unit)
     e("s_mov_b32", s_bo, (0,))
     e("s_lshl_b32", t1, (s_D, 5))             # 16 rows * 2 D bytes
+    e("s_lshl_b32", t2, (s_D, 4))             # 8 rows
+    rd = [v_sb[0], v_sb[1]]                   # read-back data of block b: [rows l >> 3 | rows 8 + (l >> 3)]
+
+    def block_stores(b):
+        e("buffer_store_dwordx4", (), (rd[b & 1][0:4], v_oo2, s_od, s_bo), offset=0)
+        e("s_add_u32", s_t4, (s_bo, t2))
+        e("buffer_store_dwordx4", (), (rd[b & 1][4:8], v_oo2, s_od, s_t4), offset=0)
+        e("s_add_u32", s_bo, (s_bo, t1))
+        n_store[0] += 2
+
     for b in range(NB):
         e("v_accvgpr_read_b32", v_e[4], (a_l[b][0],))
         k.nop(1)
@@ -660,16 +723,18 @@ def build(abl=()):
             k.nop(0)
             for i in range(4):
                 e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
-            k.nop(0)
             pk = R("v", v_e[6].i, 2)
             e("v_cvt_pk_bf16_f32", pk[0], (v_e[0], v_e[1]))
             e("v_cvt_pk_bf16_f32", pk[1], (v_e[2], v_e[3]))
-            k.nop(0)
-            if "nostore" not in abl:
-                e("buffer_store_dwordx2", (), (pk, v_oo, s_od, s_bo), offset=32 * db)
-                n_store[0] += 1
-        if b + 1 < NB:
-            e("s_add_u32", s_bo, (s_bo, t1))
+            e("ds_write_b64", (), (v_ost, pk), offset=32 * db)
+        e("ds_read_b128", rd[b & 1][0:4], (v_ord,), offset=0)
+        e("ds_read_b128", rd[b & 1][4:8], (v_ord,), offset=8 * 144)
+        if b >= 1 and "nostore" not in abl:   # the previous block's rows: its two reads are six LDS operations back
+            e("s_waitcnt", lgkmcnt=6)
+            block_stores(b - 1)
+    if "nostore" not in abl:
+        e("s_waitcnt", lgkmcnt=0)
+        block_stores(NB - 1)
     # a row sum out of range: this unit runs again in the HIP kernel's safe body
     e("s_or_b32", t0, (s_bad[0], s_bad[1]))
     e("s_cbranch_scc0", (), ("L_flag_done",))
@@ -680,6 +745,9 @@ def build(abl=()):
     e("global_store_dword", (), (v_zero, v_e[0], s_rd))
     e("s_mov_b64", EXEC, (s_tmp64,))
     k.label("L_flag_done")
+    stamp(6)
+    if "stamps" in abl:
+        e("s_add_u32", s(71), (s(71), 1))
     e("s_cmp_eq_u32", (), (s_last, 0))
     e("s_cbranch_scc1", (), ("L_unit",))
     e("s_waitcnt", vmcnt=0)
@@ -689,6 +757,7 @@ def build(abl=()):
     vm_q.mods["vmcnt"] = min(n_store[0], 63)
     k.n_vgpr = k.vp.next
     k.n_acc = n_acc
+    k.kernarg = 72 if "stamps" in abl else 64
     return k
 
 
@@ -707,7 +776,7 @@ FOOTER = """\t.section\t.rodata,"a",@progbits
 \t.amdhsa_kernel md_attn577_bf16
 \t\t.amdhsa_group_segment_fixed_size {lds}
 \t\t.amdhsa_private_segment_fixed_size 0
-\t\t.amdhsa_kernarg_size 64
+\t\t.amdhsa_kernarg_size {karg}
 \t\t.amdhsa_user_sgpr_count 2
 \t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
 \t\t.amdhsa_system_sgpr_workgroup_id_x 1
@@ -743,9 +812,9 @@ amdhsa.kernels:
       - {{.offset: 52, .size: 4, .value_kind: by_value}}
       - {{.offset: 56, .size: 4, .value_kind: by_value}}
       - {{.offset: 60, .size: 4, .value_kind: by_value}}
-    .group_segment_fixed_size: {lds}
+{dbgarg}    .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 64
+    .kernarg_segment_size: {karg}
     .max_flat_workgroup_size: 256
     .name:           md_attn577_bf16
     .private_segment_fixed_size: 0
@@ -771,7 +840,9 @@ def render(k):
     for ins in k.p:
         t = ins.text()
         out.append(t + "\n" if ins.op == "label" else "\t" + t + "\n")
-    out.append(FOOTER.format(lds=LDS_BYTES))
+    karg = getattr(k, "kernarg", 64)
+    dbgarg = "      - {.address_space: global, .offset: 64, .size: 8, .value_kind: global_buffer}\n" if karg > 64 else ""
+    out.append(FOOTER.format(lds=LDS_BYTES, karg=karg, dbgarg=dbgarg))
     return "".join(out)
 
 

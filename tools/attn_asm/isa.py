@@ -133,6 +133,8 @@ class I:
             if m.get("offset"):
                 t += f" offset:{m['offset']}"
             return t
+        if o == "s_memtime":
+            return f"s_memtime {f(d[0])}"
         if o.startswith("global_store"):
             t = f"{o} {f(sr[0])}, {f(sr[1])}, {f(sr[2])}"
             if m.get("offset"):

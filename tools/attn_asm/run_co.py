@@ -38,10 +38,12 @@ def main():
     class Args(C.Structure):
         _fields_ = [("qk", C.c_void_p), ("vT", C.c_void_p), ("out", C.c_void_p), ("redo", C.c_void_p),
                     ("S", C.c_int), ("n", C.c_int), ("heads", C.c_int), ("D", C.c_int), ("kpad", C.c_int), ("hlog", C.c_int),
-                    ("nunits", C.c_int), ("grid", C.c_int)]
+                    ("nunits", C.c_int), ("grid", C.c_int), ("dbg", C.c_void_p)]
 
     grid = min(T * heads, 256)
-    args = Args(qk.data_ptr(), vT.data_ptr(), out.data_ptr(), redo.data_ptr(), S, N, heads, D, kpad, 4, T * heads, grid)
+    args = Args(qk.data_ptr(), vT.data_ptr(), out.data_ptr(), redo.data_ptr(), S, N, heads, D, kpad, 4, T * heads, grid, 0)
+    dbg = torch.zeros(64, device="cuda", dtype=torch.int64)
+    args.dbg = dbg.data_ptr()
     size = C.c_size_t(C.sizeof(args))
     extra = (C.c_void_p * 5)(1, C.cast(C.pointer(args), C.c_void_p), 2, C.cast(C.pointer(size), C.c_void_p), 3)
     fl = 4.0 * T * heads * N * N * 64
@@ -69,6 +71,17 @@ def main():
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 10)
         print(f"{var or 'kernel':28s} {best * 1e3:8.1f} us  {fl / best / 1e9:6.0f} TF  per unit and CU {best * 1e3 / (T * heads / 256):6.2f} us", flush=True)
+        if "stamps" in var:
+            st = dbg.cpu().numpy().reshape(8, 8)
+            names = ["entry", "unit start", "tile 0", "loop", "drain+tail", "hand-over", "epilogue", ""]
+            for u in range(4):
+                row = st[u]
+                prev = st[u - 1][6] if u else row[0]
+                parts = []
+                for j in range(1, 7):
+                    parts.append(f"{names[j]} {int(row[j] - prev)}")
+                    prev = row[j]
+                print(f"   unit {u}: " + ", ".join(parts) + f" | total {int(row[6] - (st[u - 1][6] if u else row[0]))} ticks")
         hip.hipModuleUnload(mod)
 
 
