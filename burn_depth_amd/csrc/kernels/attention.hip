@@ -523,21 +523,23 @@ __global__ __launch_bounds__(64 * QW * KS, is_split<T>::value ? (KS == 1 ? 3 : 2
 }
 
 // The units (sequence, head) whose row sums left the fast body's range in the assembly kernel (attn577_gfx950.s raises redo[unit]): the
-// running-maximum body over all their queries, the flag cleared. A thread reads one flag; a workgroup without a raised flag among its
-// 256 units -- every workgroup of every launch on trained weights -- is one load and one barrier.
+// running-maximum body over all their queries, the flag cleared. A workgroup looks at kRedoUnits units; one without a raised flag --
+// every workgroup of every launch on trained weights -- is one load and one barrier. (All units flagged, the bench's qk_scale = 4:
+// each workgroup walks kRedoUnits x 5 query blocks one after the other.)
+constexpr int kRedoUnits = 4;
 __global__ __launch_bounds__(256) void attention_redo_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vT, bf16_t* __restrict__ out,
                                                              int S, int n_tokens, int heads, int D, int kpad, int qblocks, int* __restrict__ redo, int nunits) {
-  __shared__ int raised[256];
-  const int tid = threadIdx.x, u = blockIdx.x * 256 + tid;
-  const int f = u < nunits ? redo[u] : 0;
+  __shared__ int raised[kRedoUnits];
+  const int tid = threadIdx.x, u = blockIdx.x * kRedoUnits + tid;
+  const int f = (tid < kRedoUnits && u < nunits) ? redo[u] : 0;
   if (!__syncthreads_or(f)) return;
-  raised[tid] = f;
+  if (tid < kRedoUnits) raised[tid] = f;
   __syncthreads();
-  for (int j = 0; j < 256; ++j) {
+  for (int j = 0; j < kRedoUnits; ++j) {
     if (!raised[j]) continue;  // workgroup-uniform
     for (int qb = 0; qb < qblocks; ++qb) {
       __syncthreads();  // the previous block's last tile has been read by every wave before the stages are refilled
-      attention_body<bf16_t, false, false>(qk, vT, out, S, n_tokens, heads, D, kpad, qblocks, 0.f, 0L, (blockIdx.x * 256 + j) * qblocks + qb);
+      attention_body<bf16_t, false, false>(qk, vT, out, S, n_tokens, heads, D, kpad, qblocks, 0.f, 0L, (blockIdx.x * kRedoUnits + j) * qblocks + qb);
     }
   }
   if (f) redo[u] = 0;
@@ -650,7 +652,7 @@ static int launch_attention_asm(const void* qk, const void* vT, void* out, int n
   MD_HIP(hipModuleLaunchKernel(g_asm[ordinal].fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra));
   // the units it flagged (a row sum outside [2^-64, 2^100): never on trained weights) run again in the running-maximum body
   const int qblocks = (n_tokens + 127) / 128;
-  hipLaunchKernelGGL(attention_redo_kernel, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
+  hipLaunchKernelGGL(attention_redo_kernel, dim3((unsigned)((nunits + kRedoUnits - 1) / kRedoUnits)), dim3(256), 0, s, (const bf16_t*)qk, (const bf16_t*)vT,
                      (bf16_t*)out, S, n_tokens, heads, D, kpad, qblocks, redo, nunits);
   MD_HIP(hipGetLastError());
   return MD_OK;

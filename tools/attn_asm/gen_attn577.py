@@ -70,11 +70,11 @@ def build(abl=()):
         e("s_cbranch_scc0", (), (l_skip,))
         e("s_memtime", s(22, 2), ())
         e("s_waitcnt", lgkmcnt=0)
-        e("v_mov_b32", v(254), (s(22),))
-        e("v_mov_b32", v(255), (s(23),))
+        e("v_mov_b32", v(6), (s(22),))             # vt2 | vt3: prologue temporaries (an even pair), dead at every stamp point
+        e("v_mov_b32", v(7), (s(23),))
         e("s_lshl_b32", s(59), (s(71), 6))
-        e("v_mov_b32", v(253), (s(59),))
-        e("global_store_dwordx2", (), (v(253), v(254, 2), s(20, 2)), offset=slot * 8)
+        e("v_mov_b32", v(5), (s(59),))
+        e("global_store_dwordx2", (), (v(5), v(6, 2), s(20, 2)), offset=slot * 8)
         k.label(l_skip)
 
     # ---------------- registers ----------------
@@ -123,13 +123,20 @@ def build(abl=()):
     v_zero = vp.take()
     v_scr = vp.take()                              # class-token scratch address of this lane
     v_ost, v_ord, v_oo2 = vp.take(), vp.take(), vp.take()   # output staging: write / read address, row-wise store offset
-    v_e8 = vp.take(8, 2)                           # epilogue temporaries (v_e[6:7] is a 64-bit store operand: even-aligned)
-    v_e = [v_e8[i] for i in range(8)]
+    v_e = [v_kc[i] for i in range(8)]              # epilogue temporaries: the class token's K fragments are dead there (v_e[6:7]: even pair)
+    n_stage_v = 24                                 # the NEXT unit's Q fragments wait in 24 VGPRs + 56 AGPRs (requested inside tile 0)
+    v_qs = vp.take(n_stage_v, 4)
     a_o = [[a((b * 4 + db) * 4, 4) for db in range(4)] for b in range(NB)]
     a_oc = [a(NB * 16 + db * 4, 4) for db in range(4)]
     a_l = [a(NB * 16 + 16 + b * 4, 4) for b in range(NB)]
     a_lc = a(NB * 16 + 16 + NB * 4, 4)
     n_acc = NB * 16 + 16 + NB * 4 + 4
+    a_qs = a(n_acc, 80 - n_stage_v)
+    assert n_acc + 80 - n_stage_v <= 256
+
+    def q_stage(j):
+        """staging register (4 dwords) of Q fragment j = 2 * block + kstep (block 9 = the class token)"""
+        return v_qs[4 * j:4 * j + 4] if 4 * j < n_stage_v else a_qs[4 * j - n_stage_v:4 * j - n_stage_v + 4]
     n_store = [0]
 
     # ---------------- prologue ----------------
@@ -276,18 +283,23 @@ def build(abl=()):
         e("s_add_u32", s_dst, (s_dst, STAGE))
         e("s_and_b32", s_dst, (s_dst, RING - 1))
 
-    def q_loads():
-        """Q fragments of the NEXT unit: lane (n, g) <- Q[q][32 s + 8 g ..]; q = 1 + 144 w + 16 b + n (class token: q = 0)"""
-        e("s_mov_b32", s_bo, (0,))
-        e("s_lshl_b32", t1, (s_rowB, 4))
-        for b in range(NB):
-            for st in range(2):
-                e("buffer_load_dwordx4", v_q[b][4 * st:4 * st + 4], (v_qo, s_qd_n, s_bo), offset=64 * st)
-            if b + 1 < NB:
-                e("s_add_u32", s_bo, (s_bo, t1))
-        for st in range(2):
-            e("buffer_load_dwordx4", v_qc[4 * st:4 * st + 4], (v_qco, s_qd_n, 0), offset=64 * st)
-        return 2 * NB + 2
+    def q_load(j, staged):
+        """Q fragment j of the NEXT unit: lane (n, g) <- Q[q][32 s + 8 g ..]; q = 1 + 144 w + 16 b + n (class token: q = 0)"""
+        b, st = j >> 1, j & 1
+        dst = q_stage(j) if staged else (v_q[b][4 * st:4 * st + 4] if b < NB else v_qc[4 * st:4 * st + 4])
+        if b < NB:
+            e("s_mul_i32", s_bo, (s_rowB, 16 * b))
+            e("buffer_load_dwordx4", dst, (v_qo, s_qd_n, s_bo), offset=64 * st)
+        else:
+            e("buffer_load_dwordx4", dst, (v_qco, s_qd_n, 0), offset=64 * st)
+
+    def q_unstage():
+        for j in range(2 * NB + 2):
+            b, st = j >> 1, j & 1
+            dst = v_q[b][4 * st:4 * st + 4] if b < NB else v_qc[4 * st:4 * st + 4]
+            src = q_stage(j)
+            for i in range(4):
+                e("v_mov_b32" if src.k == "v" else "v_accvgpr_read_b32", dst[i], (src[i],))
 
     e("s_mov_b32", s_kso, (0,))
     e("s_mov_b32", s_vso, (0,))
@@ -307,7 +319,8 @@ def build(abl=()):
     e("v_mul_lo_u32", v_oo, (vt0, t2))
     e("v_lshlrev_b32", v_oco, (3, v_g))
     e("v_add_u32", v_oo, (v_oo, v_oco))
-    q_loads()
+    for j in range(2 * NB + 2):
+        q_load(j, True)         # through the staging registers like every later unit's (L_unit copies them)
     # constants
     for j in range(4):
         e("v_mov_b32", v_ones[j], (0x3F803F80,))
@@ -495,6 +508,8 @@ def build(abl=()):
             k.p.append(mf(a_oc[db], v_vc[4 * db:4 * db + 4], v_pc, 0 if fresh else a_oc[db]))
         k.p.append(mf(a_lc, v_ones, v_pc, 0 if fresh else a_lc))
 
+    b0_waits = []
+
     def tile(first):
         for n in range(18):
             head, ext = [], []
@@ -510,11 +525,21 @@ def build(abl=()):
                 ext.append(lambda j=n - 2: k_read(1, j, 1))
             if 3 <= n <= 6:
                 ext.append(lambda db=n - 3: v_read(1, db, 1))
+            if first:   # the NEXT unit's Q fragments, into the staging registers: two per slot in front of the barrier, the class token's two behind it
+                js = [2 * n, 2 * n + 1] if n <= 8 else ([18 + n - 13] if 13 <= n <= 14 else [])
+                for j in js:
+                    ext.append(lambda j=j: q_load(j, True))
             if n == 9:
                 # every fragment of this tile is in registers (read in slots 1-6, waited for here): behind the barrier its stage takes
                 # tile t + 3, and tile t + 1 -- requested two tiles ago -- is visible to every wave
                 head.append(lambda: e("s_waitcnt", lgkmcnt=0))
-                head.append(lambda: e("s_waitcnt", vmcnt=4))
+                if first:   # tile 1 was requested at the previous unit's tile 8: younger are that unit's last request (4 pieces), its output
+                            # stores and the staged Q loads of slots 0-8 (patched once the stores are counted)
+                    w0 = I("s_waitcnt", (), (), vmcnt=0)
+                    b0_waits.append(w0)
+                    head.append(lambda w0=w0: k.p.append(w0))
+                else:
+                    head.append(lambda: e("s_waitcnt", vmcnt=4))
                 head.append(lambda: e("s_barrier"))
             if 9 <= n <= 12:
                 ext.append(lambda wpc=n - 9: dma_piece(wpc))
@@ -560,6 +585,7 @@ def build(abl=()):
     e("s_mov_b64", s_bad, (0,))
     vm_q = I("s_waitcnt", (), (), vmcnt=0)   # patched below: the Q loads (and everything older) have landed; only this unit's output stores may be in flight
     k.p.append(vm_q)
+    q_unstage()
     stamp(1)
     tile(True)
     stamp(2)
@@ -636,7 +662,6 @@ def build(abl=()):
         k_read(0, j, 0)
     for db in range(4):
         v_read(0, db, 0)
-    n_q = q_loads()
     stamp(5)
     e("v_mov_b32", v_pc[1], (0,)) if False else None
     # ---------------- epilogue ----------------
@@ -661,38 +686,43 @@ def build(abl=()):
     e("s_barrier")
     e("s_cmp_eq_u32", (), (s_w, 0))
     e("s_cbranch_scc0", (), ("L_main_out",))
-    # wave 0: add the four partials, normalise, store row 0 (lanes with n == 0: lane group g holds d = 16 db + 4 g + i)
+    # wave 0: add the four partials, normalise, store row 0 (lanes with n == 0: lane group g holds d = 16 db + 4 g + i); the reads in
+    # batches of 4 / 32 with one wait each (one wait per 4 reads held this wave -- and with it the workgroup -- for ~3k cycles)
     e("s_mov_b64", EXEC, (VCC,))
-    e("ds_read_b32", v_e[4], (v_scr,), offset=16 * 16)
-    for ww in range(1, 4):
-        e("ds_read_b32", v_e[5], (v_scr,), offset=ww * 17 * 16 + 16 * 16)
-        e("s_waitcnt", lgkmcnt=0)
-        e("v_add_f32", v_e[4], (v_e[4], v_e[5]))
-    k.nop(1)
+    tmp = [v_sb[0][i] for i in range(8)] + [v_sb[1][i] for i in range(8)] + [v_pb[0][i] for i in range(4)] + [v_pb[1][i] for i in range(4)] + \
+          [v_sc[i] for i in range(4)] + [vt1, vt2, vt3, v_e[5]]
+    for ww in range(4):
+        e("ds_read_b32", tmp[ww], (v_scr,), offset=ww * 17 * 16 + 16 * 16)
+    e("s_waitcnt", lgkmcnt=0)
+    e("v_add_f32", tmp[0], (tmp[0], tmp[1]))
+    e("v_add_f32", tmp[2], (tmp[2], tmp[3]))
+    e("v_add_f32", v_e[4], (tmp[0], tmp[2]))
     e("v_cmp_nle_f32", VCC, (s_lo, v_e[4]))      # not (2^-64 <= l): too small, or NaN
     e("s_or_b64", s_bad, (s_bad, VCC))
     e("v_cmp_ngt_f32", VCC, (s_hi, v_e[4]))      # not (2^100 > l): too large, inf or NaN
     e("s_or_b64", s_bad, (s_bad, VCC))
     e("v_rcp_f32", v_e[4], (v_e[4],))
-    for db in range(4):
-        for i in range(4):
-            e("ds_read_b32", v_e[i], (v_scr,), offset=(db * 4 + i) * 16)
-        for ww in range(1, 4):
-            tmps = [vt1, vt2, vt3, v_e[5]]
+    for half_ in range(2):
+        for dbl in range(2):
+            db = 2 * half_ + dbl
+            for ww in range(4):
+                for i in range(4):
+                    e("ds_read_b32", tmp[dbl * 16 + ww * 4 + i], (v_scr,), offset=ww * 17 * 16 + (db * 4 + i) * 16)
+        e("s_waitcnt", lgkmcnt=0)
+        for dbl in range(2):
+            db = 2 * half_ + dbl
+            t_ = tmp[dbl * 16:dbl * 16 + 16]
             for i in range(4):
-                e("ds_read_b32", tmps[i], (v_scr,), offset=ww * 17 * 16 + (db * 4 + i) * 16)
-            e("s_waitcnt", lgkmcnt=0)
+                e("v_add_f32", t_[i], (t_[i], t_[4 + i]))
+                e("v_add_f32", t_[8 + i], (t_[8 + i], t_[12 + i]))
             for i in range(4):
-                e("v_add_f32", v_e[i], (v_e[i], tmps[i]))
-        k.nop(1)
-        for i in range(4):
-            e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
-        k.nop(1)
-        e("v_cvt_pk_bf16_f32", v_e[6], (v_e[0], v_e[1]))
-        e("v_cvt_pk_bf16_f32", v_e[7], (v_e[2], v_e[3]))
-        k.nop(1)
-        e("buffer_store_dwordx2", (), (R("v", v_e[6].i, 2), v_oco, s_od, 0), offset=32 * db)
-        k.nop(1)
+                e("v_add_f32", t_[i], (t_[i], t_[8 + i]))
+            for i in range(4):
+                e("v_mul_f32", t_[i], (t_[i], v_e[4]))
+            e("v_cvt_pk_bf16_f32", v_e[6], (t_[0], t_[1]))
+            e("v_cvt_pk_bf16_f32", v_e[7], (t_[2], t_[3]))
+            e("buffer_store_dwordx2", (), (R("v", v_e[6].i, 2), v_oco, s_od, 0), offset=32 * db)
+            k.nop(1)
     e("s_mov_b64", EXEC, (s_tmp64,))
     k.label("L_main_out")
     # nine 16-query blocks: normalise, pack, stage the block through LDS (a lane holds 4 values of 4 d-blocks of ONE row; the rows leave as
@@ -755,6 +785,8 @@ def build(abl=()):
     # at L_unit the younger vector-memory operations are this wave's output stores (the class token's four, wave 0 only, are the oldest
     # of them): with no more than the main stores in flight, the Q loads and every LDS-DMA piece in front of them have landed
     vm_q.mods["vmcnt"] = min(n_store[0], 63)
+    for w0 in b0_waits:
+        w0.mods["vmcnt"] = min(4 + n_store[0] + 18, 63)   # 18 of the staged Q loads sit in front of the barrier
     k.n_vgpr = k.vp.next
     k.n_acc = n_acc
     k.kernarg = 72 if "stamps" in abl else 64

@@ -636,8 +636,9 @@ class Emu:
                     la = (w.m0 & 0xFFFF) + lane * 16
                     self.lds[la:la + 16] = data.view(np.uint8)
                 else:
+                    bank = w.a if d[0].k == "a" else w.v
                     for j in range(4):
-                        w.v[d[0].i + j, lane] = data[j]
+                        bank[d[0].i + j, lane] = data[j]
             return
         if o in ("buffer_store_dwordx2", "buffer_store_dword", "buffer_store_dwordx4"):
             n = {"buffer_store_dword": 1, "buffer_store_dwordx2": 2, "buffer_store_dwordx4": 4}[o]
