@@ -137,6 +137,8 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="replay the launch schedule from a hipGraph and drop the per-kernel HIP events from the timed region "
                          "(no `kernels` / `roofline` in the line: latency mode for the single-image configurations)")
+    ap.add_argument("--attention-form", choices=["asm", "hip"], default="asm",
+                    help="bf16 Depth Pro attention (577 tokens): the assembly-owned gfx950 kernel (the product) or the HIP kernel every other shape runs -- an A/B switch (md_debug_attention_asm), recorded in config.attention_form when it is not the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-launch HIP events in the timed region (the `kernels` / `roofline` objects are then empty): measures what the events themselves cost")
     ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the whole-frame CPU baseline may take (predicted from a 2-tile probe); beyond it the sampled estimate is reported")
@@ -215,6 +217,9 @@ def main(argv=None) -> int:
 
     dev = Device(local_rank)
     tdev = torch.device("cuda", local_rank)
+    if args.attention_form == "hip":  # before the model exists: its graphs capture whichever form the first infer launches
+        from burn_depth_amd import _lib as _l
+        _l.load().md_debug_attention_asm(0)
     if args.model in ("da3_large", "da3_small"):
         return bench_da3(args, dev, tdev, world, rank)
     if args.tile_parallel:
@@ -447,6 +452,7 @@ def main(argv=None) -> int:
                        "batch_per_gpu": B, "batch_note": "8 images per GPU = BASELINE config 4's shard; config 3 as SURVEY 8(d) words it (B = 1) is configs[0]" if B == 8 else None,
                        "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
                        "parallelism": f"dp{world}",
+                       "attention_form": "attn577_gfx950.s (assembly-owned, one persistent workgroup per CU)" if (args.attention_form == "asm" and args.precision == "bf16" and args.preset == "full") else "hip kernel",
                        "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather,
                        "comm": "native md_comm_* (RCCL point-to-point groups on a side stream)" if ncomm is not None else ("torch.distributed (RCCL)" if world > 1 else None),
                        # what the communicator itself reports (ncclCommCount / the process group's size), beside WORLD_SIZE

@@ -942,6 +942,44 @@ def test_resize_nhwc_operator(dev):
             assert (got_q - want_q).abs().max() <= tol * want_q.abs().max()
 
 
+@pytest.mark.parametrize("T,heads", [(3, 4), (1, 16), (20, 16)])
+def test_attention_assembly_kernel_against_the_hip_kernel_and_the_reference(diag, dev, T, heads):
+    """bf16 attention over exactly 577 tokens (Depth Pro: 576 patches + the class token) runs the assembly-owned kernel
+    (kernels/attn577_gfx950.s: one persistent workgroup per CU, 4 x 144 queries + the class token, 16x16x32 MFMA, row sums on the
+    matrix pipe); md_debug_attention_asm(0) runs the HIP kernel on the same operands. Both against the fp64 reference with the
+    operator check's tolerances and against each other; 20 x 16 = 320 units make workgroups walk a second unit (the hand-over).
+    Reference for the arithmetic: /root/reference/src/model/depth_pro/layers/encoder.rs:346-348 (softmax(q k^T / sqrt(d)) v)."""
+    import torch
+    from burn_depth_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(100 + T)
+    qkv = torch.randn(T, 577, 3 * heads * 64, generator=g)
+    qkv[..., :heads * 64] *= 2.0
+    want = diag.attn_ref(qkv, heads, diag.bf)
+    x = qkv.cuda()
+    prev = lib.md_debug_attention_asm(1)
+    try:
+        got_asm = ops.attention(dev, x, heads, 0)
+        lib.md_debug_attention_asm(0)
+        got_hip = ops.attention(dev, x, heads, 0)
+    finally:
+        lib.md_debug_attention_asm(prev)
+    for name, got in (("assembly", got_asm), ("hip", got_hip)):
+        assert diag.rel_err(got, want) <= 8e-3, name
+        assert diag.mean_rel(got, want) <= 2.5e-3, name
+    # the two kernels differ in the row sums only (rounded probabilities on the matrix pipe / unrounded fp32 adds): a bf16 ulp of the output
+    assert diag.rel_err(got_asm, got_hip) <= 8e-3
+    assert bool((got_asm != got_hip).any()), "both runs took the same kernel: the switch is not wired"
+    # a logit far outside the fast body's range in ONE unit: that unit is recomputed by the running-maximum body, the flag cleared
+    qkv2 = qkv.clone()
+    qkv2[0, 300, heads * 64:heads * 64 + 64] = qkv2[0, 5, :64] * 9.0
+    want2 = diag.attn_ref(qkv2, heads, diag.bf)
+    for _ in range(2):  # twice: the second run must not see a stale flag
+        got2 = ops.attention(dev, qkv2.cuda(), heads, 0)
+        assert bool(torch.isfinite(got2).all())
+        assert diag.rel_err(got2, want2) <= 8e-3
+
+
 def test_full_size_properties(dev):
     """BASELINE config 3 at full size ([1,3,1536,1536], default config, bf16): size-independent checks --
     determinism, batch independence of the result, finite/positive depth, fov-depth scaling law

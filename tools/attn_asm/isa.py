@@ -582,10 +582,11 @@ class Emu:
             else:
                 cr = np.zeros((4, 64), np.float32)
             out = np.zeros((4, 64), np.float32)
-            for lane in range(64):
-                n, g = lane & 15, lane >> 4
-                for i in range(4):
-                    out[i, lane] = np.float32(Dm[4 * g + i, n] + cr[i, lane])
+            with np.errstate(all="ignore"):
+                for lane in range(64):
+                    n, g = lane & 15, lane >> 4
+                    for i in range(4):
+                        out[i, lane] = np.float32(Dm[4 * g + i, n] + cr[i, lane])
             for i in range(4):
                 self.wr(w, d[0][i], out[i].view(np.uint32))
             return
