@@ -22,8 +22,9 @@ STAGE = 16384     # K tile 8 KB | V^T tile 8 KB
 NSTAGE = 4
 RING = STAGE * NSTAGE
 SCRATCH = 0       # class-token partials reuse the ring once every DMA has landed
-OSTAGE = RING + 2048     # per wave: one 16-query output block, 16 rows of 128 B at a 144-byte pitch
-LDS_BYTES = OSTAGE + 4 * 16 * 144   # the ring | the class token's partial sums | the output staging
+OSTAGE = RING + 2048     # per wave: its 144 output rows of 128 B (16-byte chunks XOR-swizzled by the row), 18 KB
+OWAVE = 144 * 128
+LDS_BYTES = OSTAGE + 4 * OWAVE   # the ring | the class token's partial sums | the output staging
 
 
 class K:
@@ -66,15 +67,15 @@ def build(abl=()):
         e("s_cbranch_scc1", (), (l_skip,))
         e("s_cmp_gt_u32", (), (s(71), 3))
         e("s_cbranch_scc1", (), (l_skip,))
-        e("s_or_b32", s(59), (s(20), s(21)))        # a null debug pointer: no stamps
+        e("s_or_b32", s(59), (s(92), s(93)))        # a null debug pointer: no stamps
         e("s_cbranch_scc0", (), (l_skip,))
-        e("s_memtime", s(22, 2), ())
+        e("s_memtime", s(94, 2), ())
         e("s_waitcnt", lgkmcnt=0)
-        e("v_mov_b32", v(6), (s(22),))             # vt2 | vt3: prologue temporaries (an even pair), dead at every stamp point
-        e("v_mov_b32", v(7), (s(23),))
+        e("v_mov_b32", v(6), (s(94),))             # vt2 | vt3: prologue temporaries (an even pair), dead at every stamp point
+        e("v_mov_b32", v(7), (s(95),))
         e("s_lshl_b32", s(59), (s(71), 6))
         e("v_mov_b32", v(5), (s(59),))
-        e("global_store_dwordx2", (), (v(5), v(6, 2), s(20, 2)), offset=slot * 8)
+        e("global_store_dwordx2", (), (v(5), v(6, 2), s(92, 2)), offset=slot * 8)
         k.label(l_skip)
 
     # ---------------- registers ----------------
@@ -98,10 +99,13 @@ def build(abl=()):
     s_unit, s_unit_n, s_last = s(68), s(69), s(70)
     s_qd_n, s_kd_n, s_vd_n, s_od_n = s(72, 4), s(76, 4), s(80, 4), s(84, 4)   # the NEXT unit's descriptors
     s_rd, s_rd_n = s(88, 2), s(90, 2)                         # redo flag address of the current / next unit
+    s_od_p = s(20, 4)                                         # the PREVIOUS unit's output rows (its staged blocks leave during this unit's tiles)
+    s_tbo = s(3)                                              # their row offset cursor
 
     vp = k.vp
     v_tid = vp.take()          # v0 = work-item id
-    v_lane, v_r, v_g, vt0, vt1, vt2, vt3 = (vp.take() for _ in range(7))
+    v_lane, v_g, vt0, vt1, vt2, vt3, v_sp = (vp.take() for _ in range(7))   # v0..v7: prologue / epilogue temporaries; inside the tile
+    v_trk = [v(0, 4), v(4, 4)]                                               # loop the two quads carry the previous unit's rows to their stores
     v_q = [vp.take(8, 4) for _ in range(NB)]       # Q fragments: [k-step 0 | k-step 1]
     v_qc = vp.take(8, 4)
     v_kf = [vp.take(16, 4) for _ in range(2)]      # K fragments of a 32-key half: (bsel * 2 + kstep) * 4
@@ -119,10 +123,10 @@ def build(abl=()):
     v_vcoff = vp.take()
     v_dk = [vp.take() for _ in range(2)]           # LDS-DMA source offsets (even / odd piece)
     v_dv = [vp.take() for _ in range(2)]
-    v_qo, v_qco, v_oo, v_oco = vp.take(), vp.take(), vp.take(), vp.take()
+    v_qo, v_qco, v_r, v_oco = vp.take(), vp.take(), vp.take(), vp.take()
     v_zero = vp.take()
     v_scr = vp.take()                              # class-token scratch address of this lane
-    v_ost, v_ord, v_oo2 = vp.take(), vp.take(), vp.take()   # output staging: write / read address, row-wise store offset
+    v_ost, v_ord, v_oo2 = vp.take(), vp.take(), vp.take()   # output staging: write address, read cursor, row-wise store offset
     v_e = [v_kc[i] for i in range(8)]              # epilogue temporaries: the class token's K fragments are dead there (v_e[6:7]: even pair)
     n_stage_v = 24                                 # the NEXT unit's Q fragments wait in 24 VGPRs + 56 AGPRs (requested inside tile 0)
     v_qs = vp.take(n_stage_v, 4)
@@ -151,7 +155,7 @@ def build(abl=()):
     e("s_waitcnt", lgkmcnt=0)
     k.nop(3)
     if "stamps" in abl:
-        e("s_load_dwordx2", s(20, 2), (s_karg, 0x40))
+        e("s_load_dwordx2", s(92, 2), (s_karg, 0x40))
         e("s_mov_b32", s(71), (0,))
         e("s_waitcnt", lgkmcnt=0)
         stamp(0)
@@ -315,10 +319,7 @@ def build(abl=()):
     e("v_mul_lo_u32", v_qo, (vt0, s_rowB))
     e("v_lshlrev_b32", v_qco, (4, v_g))
     e("v_add_u32", v_qo, (v_qo, v_qco))
-    e("s_lshl_b32", t2, (s_D, 1))
-    e("v_mul_lo_u32", v_oo, (vt0, t2))
     e("v_lshlrev_b32", v_oco, (3, v_g))
-    e("v_add_u32", v_oo, (v_oo, v_oco))
     for j in range(2 * NB + 2):
         q_load(j, True)         # through the staging registers like every later unit's (L_unit copies them)
     # constants
@@ -342,25 +343,39 @@ def build(abl=()):
     e("v_lshlrev_b32", v_scr, (2, v_g))
     e("v_add_u32", v_scr, (t0, v_scr))
     e("v_add_u32", v_scr, (RING, v_scr))
-    # output staging: a lane (n, g) writes its 4 values of d-block db at row n, byte 32 db + 8 g; a lane l reads row (l >> 3) (+ 8), chunk l & 7
-    e("s_mul_i32", t0, (s_w, 16 * 144))
+    # output staging (128-byte rows, 16-byte chunks XOR-swizzled by row & 7): a lane (n, g) writes its 4 values of d-block db at row n,
+    # logical chunk 2 db + (g >> 1), byte (g & 1) * 8 -- address = v_ost ^ (32 db) + block * 2048; a lane l reads physical chunk l & 7 of
+    # row l >> 3 (+ 8) = logical chunk (l & 7) ^ ((l >> 3) & 7), which is where it stores it in the output row
+    e("s_mul_i32", t0, (s_w, OWAVE))
     e("s_add_u32", t0, (t0, OSTAGE))
-    e("v_mul_u32_u24", v_ost, (144, v_r))
-    e("v_lshlrev_b32", vt0, (3, v_g))
+    e("v_lshrrev_b32", vt0, (1, v_g))
+    e("v_and_b32", vt1, (7, v_r))
+    e("v_xor_b32", vt0, (vt0, vt1))               # X = (g >> 1) ^ (n & 7)
+    e("v_lshlrev_b32", vt0, (4, vt0))
+    e("v_and_b32", vt1, (1, v_g))
+    e("v_lshlrev_b32", vt1, (3, vt1))
+    e("v_add_u32", vt0, (vt0, vt1))
+    e("v_lshlrev_b32", v_ost, (7, v_r))
     e("v_add_u32", v_ost, (v_ost, vt0))
     e("v_add_u32", v_ost, (t0, v_ost))
     e("v_lshrrev_b32", vt0, (3, v_lane))          # row of the read-back
-    e("v_and_b32", vt1, (7, v_lane))
-    e("v_lshlrev_b32", vt1, (4, vt1))             # chunk * 16
-    e("v_mul_u32_u24", v_ord, (144, vt0))
-    e("v_add_u32", v_ord, (v_ord, vt1))
+    e("v_and_b32", vt1, (7, v_lane))              # physical chunk
+    e("v_lshlrev_b32", v_ord, (7, vt0))
+    e("v_lshlrev_b32", vt2, (4, vt1))
+    e("v_add_u32", v_ord, (v_ord, vt2))
     e("v_add_u32", v_ord, (t0, v_ord))
+    e("v_xor_b32", vt1, (vt1, vt0))               # logical chunk (rows below 8: row & 7 = row)
+    e("v_lshlrev_b32", vt1, (4, vt1))
     e("s_mul_i32", t0, (s_w, 144))
     e("s_add_u32", t0, (t0, 1))
     e("v_add_u32", vt0, (t0, vt0))                # query row 1 + 144 w + (l >> 3)
     e("s_lshl_b32", t2, (s_D, 1))
     e("v_mul_lo_u32", v_oo2, (vt0, t2))
     e("v_add_u32", v_oo2, (v_oo2, vt1))
+    for j in range(4):
+        e("s_mov_b32", s_od_p[j], (0,))           # no previous unit yet: a descriptor of zero records drops the stores
+        e("s_mov_b32", s_od[j], (0,))
+    e("s_mov_b32", s_tbo, (0,))
     # LDS read cursors
     #  K:  (8 (r >> 2) + (r & 3)) * 128 + (((4 s + g) ^ f) << 4), f = ((r >> 1) & 1) << 1 | ((r >> 2) & 1) << 2
     e("v_lshrrev_b32", vt0, (2, v_r))
@@ -508,8 +523,6 @@ def build(abl=()):
             k.p.append(mf(a_oc[db], v_vc[4 * db:4 * db + 4], v_pc, 0 if fresh else a_oc[db]))
         k.p.append(mf(a_lc, v_ones, v_pc, 0 if fresh else a_lc))
 
-    b0_waits = []
-
     def tile(first):
         for n in range(18):
             head, ext = [], []
@@ -533,13 +546,11 @@ def build(abl=()):
                 # every fragment of this tile is in registers (read in slots 1-6, waited for here): behind the barrier its stage takes
                 # tile t + 3, and tile t + 1 -- requested two tiles ago -- is visible to every wave
                 head.append(lambda: e("s_waitcnt", lgkmcnt=0))
-                if first:   # tile 1 was requested at the previous unit's tile 8: younger are that unit's last request (4 pieces), its output
-                            # stores and the staged Q loads of slots 0-8 (patched once the stores are counted)
-                    w0 = I("s_waitcnt", (), (), vmcnt=0)
-                    b0_waits.append(w0)
-                    head.append(lambda w0=w0: k.p.append(w0))
-                else:
-                    head.append(lambda: e("s_waitcnt", vmcnt=4))
+                if first:   # tile 1 was requested at the previous unit's tile 8: younger are two trickled stores, the hand-over's request
+                            # (4 pieces) and the 18 staged Q loads of slots 0-8 (wave 0's four class-token stores only make the wait stricter)
+                    head.append(lambda: e("s_waitcnt", vmcnt=24))
+                else:       # younger than tile t + 1's pieces: two trickled stores, tile t + 2's pieces, two more stores
+                    head.append(lambda: e("s_waitcnt", vmcnt=8))
                 head.append(lambda: e("s_barrier"))
             if 9 <= n <= 12:
                 ext.append(lambda wpc=n - 9: dma_piece(wpc))
@@ -556,6 +567,21 @@ def build(abl=()):
                 head.append(cls_e)
             if n == 15:
                 head.append(lambda: cls_pv(first))
+            if n in (7, 8):     # one staged block (16 rows) of the PREVIOUS unit per tile: read back here, stored behind this tile's requests
+                ext.append(lambda h=n - 7: e("ds_read_b128", v_trk[h], (v_ord,), offset=1024 * h))
+            if n in (13, 14) and "nostore" not in abl:
+                def trickle_store(h=n - 13):
+                    if h:
+                        e("s_lshl_b32", s_t5, (s_D, 4))        # 8 rows further
+                        e("s_add_u32", s_t5, (s_t5, s_tbo))
+                    e("buffer_store_dwordx4", (), (v_trk[h], v_oo2, s_od_p, s_t5 if h else s_tbo))
+                ext.append(trickle_store)
+            if n == 15:
+                def trickle_advance():
+                    e("v_add_u32", v_ord, (2048, v_ord))
+                    e("s_lshl_b32", t0, (s_D, 5))              # 16 rows
+                    e("s_add_u32", s_tbo, (s_tbo, t0))
+                head.append(trickle_advance)
             if n == 16:
                 head.append(lambda: bump(v_kcoff + [v_vcoff]))
                 head.append(dma_advance)
@@ -570,7 +596,9 @@ def build(abl=()):
         v_read(0, db, 0)
     k.label("L_unit")
     for j in range(0, 4, 2):
+        e("s_mov_b64", s_od_p[j:j + 2], (s_od[j:j + 2],))     # the unit just finished: its rows wait in the staging area
         e("s_mov_b64", s_od[j:j + 2], (s_od_n[j:j + 2],))
+    e("s_mov_b32", s_tbo, (0,))
     e("s_mov_b64", s_rd, (s_rd_n,))
     e("s_mov_b32", s_unit, (s_unit_n,))
     # the next unit of this workgroup (the last one names itself: its requests re-read tiles nobody uses)
@@ -583,8 +611,8 @@ def build(abl=()):
     k.label("L_has_next")
     unit_descriptors()
     e("s_mov_b64", s_bad, (0,))
-    vm_q = I("s_waitcnt", (), (), vmcnt=0)   # patched below: the Q loads (and everything older) have landed; only this unit's output stores may be in flight
-    k.p.append(vm_q)
+    e("s_waitcnt", vmcnt=8)   # this unit's Q fragments were requested nine tiles ago (the previous unit's tile 0): far more than eight
+                              # vector-memory operations are younger, so this does not drain the hand-over's requests
     q_unstage()
     stamp(1)
     tile(True)
@@ -651,7 +679,7 @@ def build(abl=()):
     cls_pv()
     stamp(4)
     # ---------------- hand-over to the next unit: its first tile (requested at tile 7) is visible behind this barrier ----------------
-    e("s_waitcnt", vmcnt=4)
+    e("s_waitcnt", vmcnt=8)     # younger: tile 7's two trickled stores, tile 8's request (4 pieces) and stores
     e("s_barrier")
     for wpc in range(4):
         dma_piece(wpc)          # the next unit's tile 2 into the stage of this unit's tile 8
@@ -725,20 +753,9 @@ def build(abl=()):
             k.nop(1)
     e("s_mov_b64", EXEC, (s_tmp64,))
     k.label("L_main_out")
-    # nine 16-query blocks: normalise, pack, stage the block through LDS (a lane holds 4 values of 4 d-blocks of ONE row; the rows leave as
-    # whole 128-byte lines, 16 bytes per lane: per-lane 8-byte stores at a 2-KB row pitch held this section at 10.5k cycles, 22 % of a unit)
-    e("s_mov_b32", s_bo, (0,))
-    e("s_lshl_b32", t1, (s_D, 5))             # 16 rows * 2 D bytes
-    e("s_lshl_b32", t2, (s_D, 4))             # 8 rows
-    rd = [v_sb[0], v_sb[1]]                   # read-back data of block b: [rows l >> 3 | rows 8 + (l >> 3)]
-
-    def block_stores(b):
-        e("buffer_store_dwordx4", (), (rd[b & 1][0:4], v_oo2, s_od, s_bo), offset=0)
-        e("s_add_u32", s_t4, (s_bo, t2))
-        e("buffer_store_dwordx4", (), (rd[b & 1][4:8], v_oo2, s_od, s_t4), offset=0)
-        e("s_add_u32", s_bo, (s_bo, t1))
-        n_store[0] += 2
-
+    # nine 16-query blocks: normalise, pack, and leave the rows in the wave's LDS staging area. They go out as whole 128-byte lines, 16 bytes
+    # per lane, two stores per tile of the NEXT unit (`trickle`): a burst of stores here kept this wave's vector-memory queue -- and the next
+    # unit's first requests behind it -- busy for ~5k cycles (per-lane 8-byte stores at the 2-KB row pitch: 10.5k)
     for b in range(NB):
         e("v_accvgpr_read_b32", v_e[4], (a_l[b][0],))
         k.nop(1)
@@ -750,21 +767,15 @@ def build(abl=()):
         for db in range(4):
             for i in range(4):
                 e("v_accvgpr_read_b32", v_e[i], (a_o[b][db][i],))
-            k.nop(0)
+            if db:
+                e("v_xor_b32", v_e[5], (32 * db, v_ost))
             for i in range(4):
                 e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
             pk = R("v", v_e[6].i, 2)
             e("v_cvt_pk_bf16_f32", pk[0], (v_e[0], v_e[1]))
             e("v_cvt_pk_bf16_f32", pk[1], (v_e[2], v_e[3]))
-            e("ds_write_b64", (), (v_ost, pk), offset=32 * db)
-        e("ds_read_b128", rd[b & 1][0:4], (v_ord,), offset=0)
-        e("ds_read_b128", rd[b & 1][4:8], (v_ord,), offset=8 * 144)
-        if b >= 1 and "nostore" not in abl:   # the previous block's rows: its two reads are six LDS operations back
-            e("s_waitcnt", lgkmcnt=6)
-            block_stores(b - 1)
-    if "nostore" not in abl:
-        e("s_waitcnt", lgkmcnt=0)
-        block_stores(NB - 1)
+            e("ds_write_b64", (), (v_e[5] if db else v_ost, pk), offset=b * 2048)
+    e("v_add_u32", v_ord, (-NB * 2048, v_ord))   # the next unit's tiles read the staging area from its first block again
     # a row sum out of range: this unit runs again in the HIP kernel's safe body
     e("s_or_b32", t0, (s_bad[0], s_bad[1]))
     e("s_cbranch_scc0", (), ("L_flag_done",))
@@ -780,13 +791,23 @@ def build(abl=()):
         e("s_add_u32", s(71), (s(71), 1))
     e("s_cmp_eq_u32", (), (s_last, 0))
     e("s_cbranch_scc1", (), ("L_unit",))
+    # the workgroup's last unit: nobody is left to carry its rows out
+    e("s_mov_b32", s_tbo, (0,))
+    e("s_lshl_b32", t1, (s_D, 4))             # 8 rows
+    for b in range(NB):
+        for h in range(2):
+            e("ds_read_b128", v_trk[h], (v_ord,), offset=b * 2048 + 1024 * h)
+        e("s_waitcnt", lgkmcnt=0)
+        if "nostore" not in abl:
+            e("buffer_store_dwordx4", (), (v_trk[0], v_oo2, s_od, s_tbo))
+            e("s_add_u32", s_tbo, (s_tbo, t1))
+            e("buffer_store_dwordx4", (), (v_trk[1], v_oo2, s_od, s_tbo))
+            e("s_add_u32", s_tbo, (s_tbo, t1))
+            k.nop(1)
     e("s_waitcnt", vmcnt=0)
     e("s_endpgm")
     # at L_unit the younger vector-memory operations are this wave's output stores (the class token's four, wave 0 only, are the oldest
     # of them): with no more than the main stores in flight, the Q loads and every LDS-DMA piece in front of them have landed
-    vm_q.mods["vmcnt"] = min(n_store[0], 63)
-    for w0 in b0_waits:
-        w0.mods["vmcnt"] = min(4 + n_store[0] + 18, 63)   # 18 of the staged Q loads sit in front of the barrier
     k.n_vgpr = k.vp.next
     k.n_acc = n_acc
     k.kernarg = 72 if "stamps" in abl else 64
@@ -816,7 +837,7 @@ FOOTER = """\t.section\t.rodata,"a",@progbits
 \t\t.amdhsa_system_sgpr_workgroup_id_z 0
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr 512
-\t\t.amdhsa_next_free_sgpr 96
+\t\t.amdhsa_next_free_sgpr 100
 \t\t.amdhsa_accum_offset 256
 \t\t.amdhsa_reserve_vcc 1
 \t\t.amdhsa_float_round_mode_32 0
@@ -850,7 +871,7 @@ amdhsa.kernels:
     .max_flat_workgroup_size: 256
     .name:           md_attn577_bf16
     .private_segment_fixed_size: 0
-    .sgpr_count:     96
+    .sgpr_count:     100
     .sgpr_spill_count: 0
     .symbol:         md_attn577_bf16.kd
     .uniform_work_group_size: 1
