@@ -547,8 +547,8 @@ def build(abl=()):
                 # tile t + 3, and tile t + 1 -- requested two tiles ago -- is visible to every wave
                 head.append(lambda: e("s_waitcnt", lgkmcnt=0))
                 if first:   # tile 1 was requested at the previous unit's tile 8: younger are two trickled stores, the hand-over's request
-                            # (4 pieces) and the 18 staged Q loads of slots 0-8 (wave 0's four class-token stores only make the wait stricter)
-                    head.append(lambda: e("s_waitcnt", vmcnt=24))
+                            # (4 pieces), the class token's store and the 18 staged Q loads of slots 0-8
+                    head.append(lambda: e("s_waitcnt", vmcnt=25))
                 else:       # younger than tile t + 1's pieces: two trickled stores, tile t + 2's pieces, two more stores
                     head.append(lambda: e("s_waitcnt", vmcnt=8))
                 head.append(lambda: e("s_barrier"))
@@ -712,45 +712,40 @@ def build(abl=()):
     e("s_mov_b64", EXEC, (s_tmp64,))
     e("s_waitcnt", lgkmcnt=0)
     e("s_barrier")
-    e("s_cmp_eq_u32", (), (s_w, 0))
-    e("s_cbranch_scc0", (), ("L_main_out",))
-    # wave 0: add the four partials, normalise, store row 0 (lanes with n == 0: lane group g holds d = 16 db + 4 g + i); the reads in
-    # batches of 4 / 32 with one wait each (one wait per 4 reads held this wave -- and with it the workgroup -- for ~3k cycles)
+    # every wave finishes ONE 16-channel block of the class token's row (d-block w): the four waves' partial sums of l and of its own block
+    # from the scratch, one wait, normalise, one 8-byte store from the lanes with n == 0 (lane group g holds d = 16 w + 4 g + i).
+    # (Wave 0 doing the whole row held the workgroup's next barrier for ~1k cycles.)
     e("s_mov_b64", EXEC, (VCC,))
-    tmp = [v_sb[0][i] for i in range(8)] + [v_sb[1][i] for i in range(8)] + [v_pb[0][i] for i in range(4)] + [v_pb[1][i] for i in range(4)] + \
-          [v_sc[i] for i in range(4)] + [vt1, vt2, vt3, v_e[5]]
+    tmp = [v_sb[0][i] for i in range(8)] + [v_sb[1][i] for i in range(8)] + [v_pb[0][i] for i in range(4)]
+    e("s_mul_i32", t0, (s_w, 17 * 16))
+    e("v_subrev_u32", v_e[5], (t0, v_scr))           # scratch of wave 0 at this lane's slot
+    e("s_lshl_b32", t0, (s_w, 6))
+    e("v_add_u32", v_e[6], (t0, v_e[5]))             # ... at value 4 w
     for ww in range(4):
-        e("ds_read_b32", tmp[ww], (v_scr,), offset=ww * 17 * 16 + 16 * 16)
+        e("ds_read_b32", tmp[16 + ww], (v_e[5],), offset=ww * 17 * 16 + 16 * 16)
+        for i in range(4):
+            e("ds_read_b32", tmp[ww * 4 + i], (v_e[6],), offset=ww * 17 * 16 + i * 16)
     e("s_waitcnt", lgkmcnt=0)
-    e("v_add_f32", tmp[0], (tmp[0], tmp[1]))
-    e("v_add_f32", tmp[2], (tmp[2], tmp[3]))
-    e("v_add_f32", v_e[4], (tmp[0], tmp[2]))
+    e("v_add_f32", tmp[16], (tmp[16], tmp[17]))
+    e("v_add_f32", tmp[18], (tmp[18], tmp[19]))
+    e("v_add_f32", v_e[4], (tmp[16], tmp[18]))
     e("v_cmp_nle_f32", VCC, (s_lo, v_e[4]))      # not (2^-64 <= l): too small, or NaN
     e("s_or_b64", s_bad, (s_bad, VCC))
     e("v_cmp_ngt_f32", VCC, (s_hi, v_e[4]))      # not (2^100 > l): too large, inf or NaN
     e("s_or_b64", s_bad, (s_bad, VCC))
     e("v_rcp_f32", v_e[4], (v_e[4],))
-    for half_ in range(2):
-        for dbl in range(2):
-            db = 2 * half_ + dbl
-            for ww in range(4):
-                for i in range(4):
-                    e("ds_read_b32", tmp[dbl * 16 + ww * 4 + i], (v_scr,), offset=ww * 17 * 16 + (db * 4 + i) * 16)
-        e("s_waitcnt", lgkmcnt=0)
-        for dbl in range(2):
-            db = 2 * half_ + dbl
-            t_ = tmp[dbl * 16:dbl * 16 + 16]
-            for i in range(4):
-                e("v_add_f32", t_[i], (t_[i], t_[4 + i]))
-                e("v_add_f32", t_[8 + i], (t_[8 + i], t_[12 + i]))
-            for i in range(4):
-                e("v_add_f32", t_[i], (t_[i], t_[8 + i]))
-            for i in range(4):
-                e("v_mul_f32", t_[i], (t_[i], v_e[4]))
-            e("v_cvt_pk_bf16_f32", v_e[6], (t_[0], t_[1]))
-            e("v_cvt_pk_bf16_f32", v_e[7], (t_[2], t_[3]))
-            e("buffer_store_dwordx2", (), (R("v", v_e[6].i, 2), v_oco, s_od, 0), offset=32 * db)
-            k.nop(1)
+    for i in range(4):
+        e("v_add_f32", tmp[i], (tmp[i], tmp[4 + i]))
+        e("v_add_f32", tmp[8 + i], (tmp[8 + i], tmp[12 + i]))
+    for i in range(4):
+        e("v_add_f32", tmp[i], (tmp[i], tmp[8 + i]))
+    for i in range(4):
+        e("v_mul_f32", tmp[i], (tmp[i], v_e[4]))
+    e("v_cvt_pk_bf16_f32", v_e[6], (tmp[0], tmp[1]))
+    e("v_cvt_pk_bf16_f32", v_e[7], (tmp[2], tmp[3]))
+    e("s_lshl_b32", t0, (s_w, 5))
+    e("buffer_store_dwordx2", (), (R("v", v_e[6].i, 2), v_oco, s_od, t0))
+    k.nop(1)
     e("s_mov_b64", EXEC, (s_tmp64,))
     k.label("L_main_out")
     # nine 16-query blocks: normalise, pack, and leave the rows in the wave's LDS staging area. They go out as whole 128-byte lines, 16 bytes

@@ -489,7 +489,7 @@ class Emu:
         if o in ("v_mov_b32", "v_accvgpr_write_b32", "v_accvgpr_read_b32"):
             self.wr(w, d[0], self.rd(w, sr[0]))
             return
-        if o in ("v_lshlrev_b32", "v_lshrrev_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_mul_lo_u32",
+        if o in ("v_lshlrev_b32", "v_lshrrev_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_mul_lo_u32",
                  "v_mul_u32_u24"):
             x = self.rd(w, sr[0]).astype(np.uint64)
             y = self.rd(w, sr[1]).astype(np.uint64)
@@ -507,6 +507,8 @@ class Emu:
                 r = x + y
             elif o == "v_sub_u32":
                 r = x - y
+            elif o == "v_subrev_u32":
+                r = y - x
             elif o == "v_mul_u32_u24":
                 r = (x & 0xFFFFFF) * (y & 0xFFFFFF)
             else:
