@@ -23,7 +23,7 @@ NSTAGE = 4
 RING = STAGE * NSTAGE
 SCRATCH = 0       # class-token partials reuse the ring once every DMA has landed
 OSTAGE = RING + 2048     # per wave: its 144 output rows of 128 B (16-byte chunks XOR-swizzled by the row), 18 KB
-OWAVE = 144 * 128
+OWAVE = 144 * 128 + 1024     # + one 1-KiB piece: the sequence's first rows (the class token's query)
 LDS_BYTES = OSTAGE + 4 * OWAVE   # the ring | the class token's partial sums | the output staging
 
 
@@ -58,23 +58,27 @@ def build(abl=()):
         uniq[0] += 1
         return f"L_{stem}_{uniq[0]}"
 
-    def stamp(slot):
+    def stamp2(slot):
+        if "stamps2" in abl:
+            stamp(slot, True)
+
+    def stamp(slot, fine=False):
         """timing experiments ('stamps'): wave 0 of workgroup 0 stores s_memtime into dbg[unit_count * 8 + slot] (qwords behind the flags)"""
-        if "stamps" not in abl:
+        if "stamps" not in abl or (("stamps2" in abl) != fine and slot not in (0, 1, 6)):
             return
         l_skip = lab("nostamp")
-        e("s_or_b32", s(59), (s(2), s(65)))          # workgroup 0, wave 0
+        e("s_or_b32", s(96), (s(2), s(65)))          # workgroup 0, wave 0
         e("s_cbranch_scc1", (), (l_skip,))
-        e("s_cmp_gt_u32", (), (s(71), 3))
+        e("s_cmp_gt_u32", (), (s(97), 3))
         e("s_cbranch_scc1", (), (l_skip,))
-        e("s_or_b32", s(59), (s(92), s(93)))        # a null debug pointer: no stamps
+        e("s_or_b32", s(96), (s(92), s(93)))        # a null debug pointer: no stamps
         e("s_cbranch_scc0", (), (l_skip,))
         e("s_memtime", s(94, 2), ())
         e("s_waitcnt", lgkmcnt=0)
         e("v_mov_b32", v(6), (s(94),))             # vt2 | vt3: prologue temporaries (an even pair), dead at every stamp point
         e("v_mov_b32", v(7), (s(95),))
-        e("s_lshl_b32", s(59), (s(71), 6))
-        e("v_mov_b32", v(5), (s(59),))
+        e("s_lshl_b32", s(96), (s(97), 6))
+        e("v_mov_b32", v(5), (s(96),))
         e("global_store_dwordx2", (), (v(5), v(6, 2), s(92, 2)), offset=slot * 8)
         k.label(l_skip)
 
@@ -100,6 +104,7 @@ def build(abl=()):
     s_qd_n, s_kd_n, s_vd_n, s_od_n = s(72, 4), s(76, 4), s(80, 4), s(84, 4)   # the NEXT unit's descriptors
     s_rd, s_rd_n = s(88, 2), s(90, 2)                         # redo flag address of the current / next unit
     s_od_p = s(20, 4)                                         # the PREVIOUS unit's output rows (its staged blocks leave during this unit's tiles)
+    s_qso, s_qm0 = s(59), s(71)                               # the next unit's Q rows: source offset / LDS address of the next 16-row block
     s_tbo = s(3)                                              # their row offset cursor
 
     vp = k.vp
@@ -123,25 +128,17 @@ def build(abl=()):
     v_vcoff = vp.take()
     v_dk = [vp.take() for _ in range(2)]           # LDS-DMA source offsets (even / odd piece)
     v_dv = [vp.take() for _ in range(2)]
-    v_qo, v_qco, v_r, v_oco = vp.take(), vp.take(), vp.take(), vp.take()
+    v_qrdc, v_r, v_oco = vp.take(), vp.take(), vp.take()
+    v_qrd = [vp.take() for _ in range(2)]          # Q fragments in the wave's staging area: row n, chunk (4 s + g) ^ f(n)
     v_zero = vp.take()
     v_scr = vp.take()                              # class-token scratch address of this lane
     v_ost, v_ord, v_oo2 = vp.take(), vp.take(), vp.take()   # output staging: write address, read cursor, row-wise store offset
     v_e = [v_kc[i] for i in range(8)]              # epilogue temporaries: the class token's K fragments are dead there (v_e[6:7]: even pair)
-    n_stage_v = 24                                 # the NEXT unit's Q fragments wait in 24 VGPRs + 56 AGPRs (requested inside tile 0)
-    v_qs = vp.take(n_stage_v, 4)
     a_o = [[a((b * 4 + db) * 4, 4) for db in range(4)] for b in range(NB)]
     a_oc = [a(NB * 16 + db * 4, 4) for db in range(4)]
     a_l = [a(NB * 16 + 16 + b * 4, 4) for b in range(NB)]
     a_lc = a(NB * 16 + 16 + NB * 4, 4)
     n_acc = NB * 16 + 16 + NB * 4 + 4
-    a_qs = a(n_acc, 80 - n_stage_v)
-    assert n_acc + 80 - n_stage_v <= 256
-
-    def q_stage(j):
-        """staging register (4 dwords) of Q fragment j = 2 * block + kstep (block 9 = the class token)"""
-        return v_qs[4 * j:4 * j + 4] if 4 * j < n_stage_v else a_qs[4 * j - n_stage_v:4 * j - n_stage_v + 4]
-    n_store = [0]
 
     # ---------------- prologue ----------------
     e("s_load_dwordx8", s(4, 8), (s_karg, 0x0))
@@ -156,7 +153,7 @@ def build(abl=()):
     k.nop(3)
     if "stamps" in abl:
         e("s_load_dwordx2", s(92, 2), (s_karg, 0x40))
-        e("s_mov_b32", s(71), (0,))
+        e("s_mov_b32", s(97), (0,))
         e("s_waitcnt", lgkmcnt=0)
         stamp(0)
     e("s_lshl_b32", s_rowB, (s_D, 2))
@@ -287,23 +284,42 @@ def build(abl=()):
         e("s_add_u32", s_dst, (s_dst, STAGE))
         e("s_and_b32", s_dst, (s_dst, RING - 1))
 
-    def q_load(j, staged):
-        """Q fragment j of the NEXT unit: lane (n, g) <- Q[q][32 s + 8 g ..]; q = 1 + 144 w + 16 b + n (class token: q = 0)"""
-        b, st = j >> 1, j & 1
-        dst = q_stage(j) if staged else (v_q[b][4 * st:4 * st + 4] if b < NB else v_qc[4 * st:4 * st + 4])
-        if b < NB:
-            e("s_mul_i32", s_bo, (s_rowB, 16 * b))
-            e("buffer_load_dwordx4", dst, (v_qo, s_qd_n, s_bo), offset=64 * st)
-        else:
-            e("buffer_load_dwordx4", dst, (v_qco, s_qd_n, 0), offset=64 * st)
+    def q_reset():
+        """Q cursors at the NEXT unit's first block: rows 1 + 144 w ..., the wave's staging area"""
+        e("s_mul_i32", s_qso, (s_w, 144))
+        e("s_add_u32", s_qso, (s_qso, 1))
+        e("s_mul_i32", s_qso, (s_qso, s_rowB))
+        e("s_mul_i32", s_qm0, (s_w, OWAVE))
+        e("s_add_u32", s_qm0, (s_qm0, OSTAGE))
 
-    def q_unstage():
-        for j in range(2 * NB + 2):
-            b, st = j >> 1, j & 1
-            dst = v_q[b][4 * st:4 * st + 4] if b < NB else v_qc[4 * st:4 * st + 4]
-            src = q_stage(j)
-            for i in range(4):
-                e("v_mov_b32" if src.k == "v" else "v_accvgpr_read_b32", dst[i], (src[i],))
+    def q_piece(pc_):
+        """one 8-row piece of the next unit's Q rows into the 2-KB slot of the staging area whose output block has just left (LDS-DMA: whole
+        lines; 20 per-lane loads of the MFMA fragments touched 64 separate 16-byte segments each and cost ~120 cycles apiece)"""
+        e("s_add_u32", M0, (s_qm0, 1024 * pc_))
+        if pc_:
+            e("s_lshl_b32", s_t4, (s_rowB, 3))
+            e("s_add_u32", s_t4, (s_t4, s_qso))
+        else:
+            k.nop(0)
+        e("buffer_load_dwordx4", (), (v_dk[pc_], s_qd_n, s_t4 if pc_ else s_qso), lds=True)
+        if pc_:
+            e("s_lshl_b32", s_t4, (s_rowB, 4))
+            e("s_add_u32", s_qso, (s_qso, s_t4))
+            e("s_add_u32", s_qm0, (s_qm0, 2048))
+
+    def q_cls_piece():
+        e("s_mul_i32", s_t4, (s_w, OWAVE))
+        e("s_add_u32", M0, (s_t4, OSTAGE + 144 * 128))
+        k.nop(0)
+        e("buffer_load_dwordx4", (), (v_dk[0], s_qd_n, 0), lds=True)
+
+    def q_reads():
+        """the staged Q rows into the MFMA fragments (B operand: lane (n, g) <- Q[row n][32 s + 8 g ..])"""
+        for b in range(NB):
+            for st in range(2):
+                e("ds_read_b128", v_q[b][4 * st:4 * st + 4], (v_qrd[st],), offset=b * 2048)
+        for st in range(2):
+            e("ds_read_b128", v_qc[4 * st:4 * st + 4], (v_qrdc,), offset=64 * st)
 
     e("s_mov_b32", s_kso, (0,))
     e("s_mov_b32", s_vso, (0,))
@@ -313,15 +329,28 @@ def build(abl=()):
         for wpc in range(4):
             dma_piece(wpc)
         dma_advance()
-    e("s_mul_i32", t0, (s_w, 144))
-    e("s_add_u32", t0, (t0, 1))
-    e("v_add_u32", vt0, (t0, v_r))
-    e("v_mul_lo_u32", v_qo, (vt0, s_rowB))
-    e("v_lshlrev_b32", v_qco, (4, v_g))
-    e("v_add_u32", v_qo, (v_qo, v_qco))
+    q_reset()
+    for _ in range(NB):
+        q_piece(0)
+        q_piece(1)
+    q_cls_piece()
     e("v_lshlrev_b32", v_oco, (3, v_g))
-    for j in range(2 * NB + 2):
-        q_load(j, True)         # through the staging registers like every later unit's (L_unit copies them)
+    # Q fragment read addresses: staging + n * 128 + (((4 s + g) ^ f(n)) << 4), f(n) = ((n >> 1) & 1) << 1 | ((n >> 3) & 1) << 2 (the K image's swizzle)
+    e("s_mul_i32", t0, (s_w, OWAVE))
+    e("s_add_u32", t0, (t0, OSTAGE))
+    e("v_and_b32", vt1, (2, v_r))
+    e("v_lshrrev_b32", vt2, (3, v_r))
+    e("v_lshlrev_b32", vt2, (2, vt2))
+    e("v_or_b32", vt1, (vt1, vt2))
+    e("v_xor_b32", vt1, (vt1, v_g))
+    e("v_lshlrev_b32", vt1, (4, vt1))
+    e("v_lshlrev_b32", vt0, (7, v_r))
+    e("v_add_u32", v_qrd[0], (vt0, vt1))
+    e("v_add_u32", v_qrd[0], (t0, v_qrd[0]))
+    e("v_xor_b32", v_qrd[1], (64, v_qrd[0]))
+    e("v_lshlrev_b32", v_qrdc, (4, v_g))
+    e("s_add_u32", t0, (t0, 144 * 128))
+    e("v_add_u32", v_qrdc, (t0, v_qrdc))
     # constants
     for j in range(4):
         e("v_mov_b32", v_ones[j], (0x3F803F80,))
@@ -538,20 +567,19 @@ def build(abl=()):
                 ext.append(lambda j=n - 2: k_read(1, j, 1))
             if 3 <= n <= 6:
                 ext.append(lambda db=n - 3: v_read(1, db, 1))
-            if first:   # the NEXT unit's Q fragments, into the staging registers: two per slot in front of the barrier, the class token's two behind it
-                js = [2 * n, 2 * n + 1] if n <= 8 else ([18 + n - 13] if 13 <= n <= 14 else [])
-                for j in js:
-                    ext.append(lambda j=j: q_load(j, True))
             if n == 9:
                 # every fragment of this tile is in registers (read in slots 1-6, waited for here): behind the barrier its stage takes
                 # tile t + 3, and tile t + 1 -- requested two tiles ago -- is visible to every wave
                 head.append(lambda: e("s_waitcnt", lgkmcnt=0))
-                if first:   # tile 1 was requested at the previous unit's tile 8: younger are two trickled stores, the hand-over's request
-                            # (4 pieces), the class token's store and the 18 staged Q loads of slots 0-8
-                    head.append(lambda: e("s_waitcnt", vmcnt=25))
-                else:       # younger than tile t + 1's pieces: two trickled stores, tile t + 2's pieces, two more stores
-                    head.append(lambda: e("s_waitcnt", vmcnt=8))
+                if first:
+                    head.append(lambda: stamp2(2))
+                # tile t + 1's pieces must have landed. Younger than them, per tile: two trickled stores, two Q pieces, the next tile's four
+                # pieces -- twelve in the steady state; at the tiles around a unit's start fewer (tile 0: stores and Q pieces of the previous
+                # unit's tile 8, the hand-over's four pieces, the class token's store = 9; tile 1: 10): nine is right everywhere
+                head.append(lambda: e("s_waitcnt", vmcnt=9))
                 head.append(lambda: e("s_barrier"))
+                if first:
+                    head.append(lambda: stamp2(3))
             if 9 <= n <= 12:
                 ext.append(lambda wpc=n - 9: dma_piece(wpc))
             if n == 10:
@@ -576,6 +604,10 @@ def build(abl=()):
                         e("s_add_u32", s_t5, (s_t5, s_tbo))
                     e("buffer_store_dwordx4", (), (v_trk[h], v_oo2, s_od_p, s_t5 if h else s_tbo))
                 ext.append(trickle_store)
+            if n in (15, 16):   # ... and the slot of the staging area it came from takes 16 rows of the NEXT unit's Q
+                ext.append(lambda h=n - 15: q_piece(h))
+            if first and n == 17:
+                ext.append(q_cls_piece)
             if n == 15:
                 def trickle_advance():
                     e("v_add_u32", v_ord, (2048, v_ord))
@@ -594,6 +626,7 @@ def build(abl=()):
         k_read(0, j, 0)
     for db in range(4):
         v_read(0, db, 0)
+    q_reads()
     k.label("L_unit")
     for j in range(0, 4, 2):
         e("s_mov_b64", s_od_p[j:j + 2], (s_od[j:j + 2],))     # the unit just finished: its rows wait in the staging area
@@ -611,12 +644,11 @@ def build(abl=()):
     k.label("L_has_next")
     unit_descriptors()
     e("s_mov_b64", s_bad, (0,))
-    e("s_waitcnt", vmcnt=8)   # this unit's Q fragments were requested nine tiles ago (the previous unit's tile 0): far more than eight
-                              # vector-memory operations are younger, so this does not drain the hand-over's requests
-    q_unstage()
+    q_reset()
     stamp(1)
     tile(True)
     stamp(2)
+    stamp2(4)
     e("s_mov_b32", s_cnt, ((NTF - 1) * (2 if "loop2" in abl else 1),))
     k.label("L_tile")
     in_loop[0] = True
@@ -679,7 +711,8 @@ def build(abl=()):
     cls_pv()
     stamp(4)
     # ---------------- hand-over to the next unit: its first tile (requested at tile 7) is visible behind this barrier ----------------
-    e("s_waitcnt", vmcnt=8)     # younger: tile 7's two trickled stores, tile 8's request (4 pieces) and stores
+    e("s_waitcnt", vmcnt=0)     # the next unit's tile 0 (requested at tile 7) AND its last Q piece (tile 8): everything this wave has in flight
+                                # is at least a drain and a tail old
     e("s_barrier")
     for wpc in range(4):
         dma_piece(wpc)          # the next unit's tile 2 into the stage of this unit's tile 8
@@ -690,6 +723,7 @@ def build(abl=()):
         k_read(0, j, 0)
     for db in range(4):
         v_read(0, db, 0)
+    q_reads()                   # in front of the epilogue: it writes this unit's output rows over them
     stamp(5)
     e("v_mov_b32", v_pc[1], (0,)) if False else None
     # ---------------- epilogue ----------------
@@ -747,6 +781,7 @@ def build(abl=()):
     e("buffer_store_dwordx2", (), (R("v", v_e[6].i, 2), v_oco, s_od, t0))
     k.nop(1)
     e("s_mov_b64", EXEC, (s_tmp64,))
+    stamp2(5)
     k.label("L_main_out")
     # nine 16-query blocks: normalise, pack, and leave the rows in the wave's LDS staging area. They go out as whole 128-byte lines, 16 bytes
     # per lane, two stores per tile of the NEXT unit (`trickle`): a burst of stores here kept this wave's vector-memory queue -- and the next
@@ -783,7 +818,7 @@ def build(abl=()):
     k.label("L_flag_done")
     stamp(6)
     if "stamps" in abl:
-        e("s_add_u32", s(71), (s(71), 1))
+        e("s_add_u32", s(97), (s(97), 1))
     e("s_cmp_eq_u32", (), (s_last, 0))
     e("s_cbranch_scc1", (), ("L_unit",))
     # the workgroup's last unit: nobody is left to carry its rows out
@@ -832,7 +867,7 @@ FOOTER = """\t.section\t.rodata,"a",@progbits
 \t\t.amdhsa_system_sgpr_workgroup_id_z 0
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr 512
-\t\t.amdhsa_next_free_sgpr 100
+\t\t.amdhsa_next_free_sgpr {nsgpr}
 \t\t.amdhsa_accum_offset 256
 \t\t.amdhsa_reserve_vcc 1
 \t\t.amdhsa_float_round_mode_32 0
@@ -866,7 +901,7 @@ amdhsa.kernels:
     .max_flat_workgroup_size: 256
     .name:           md_attn577_bf16
     .private_segment_fixed_size: 0
-    .sgpr_count:     100
+    .sgpr_count:     {nsgpr}
     .sgpr_spill_count: 0
     .symbol:         md_attn577_bf16.kd
     .uniform_work_group_size: 1
@@ -890,7 +925,7 @@ def render(k):
         out.append(t + "\n" if ins.op == "label" else "\t" + t + "\n")
     karg = getattr(k, "kernarg", 64)
     dbgarg = "      - {.address_space: global, .offset: 64, .size: 8, .value_kind: global_buffer}\n" if karg > 64 else ""
-    out.append(FOOTER.format(lds=LDS_BYTES, karg=karg, dbgarg=dbgarg))
+    out.append(FOOTER.format(lds=LDS_BYTES, karg=karg, dbgarg=dbgarg, nsgpr=100 if karg > 64 else 96))
     return "".join(out)
 
 

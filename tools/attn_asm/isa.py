@@ -636,7 +636,7 @@ class Emu:
                 else:
                     data = np.zeros(4, np.uint32)
                 if m.get("lds"):
-                    la = (w.m0 & 0xFFFF) + lane * 16
+                    la = (w.m0 & 0x3FFFF) + lane * 16
                     self.lds[la:la + 16] = data.view(np.uint8)
                 else:
                     bank = w.a if d[0].k == "a" else w.v

@@ -74,6 +74,8 @@ def main():
         if "stamps" in var:
             st = dbg.cpu().numpy().reshape(8, 8)
             names = ["entry", "unit start", "tile 0", "loop", "drain+tail", "hand-over", "epilogue", ""]
+            if "stamps2" in var:
+                names = ["entry", "unit start", "tile 0 to B(0)", "B(0) wait+barrier", "rest of tile 0", "... to the class token done", "main out", ""]
             for u in range(4):
                 row = st[u]
                 prev = st[u - 1][6] if u else row[0]
