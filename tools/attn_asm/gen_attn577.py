@@ -663,6 +663,9 @@ def build(abl=()):
     k.nop(1)
     emit_slot(19, False, False, True)
     # ---------------- last tile: one key (tile-relative key 0 = row 0 of kb0: lanes with g == 0, register 0) ----------------
+    # Its MFMAs (9 x 7) leave the vector issue mostly idle, so the unit's output work rides beside them: block b is final once P.V(b) of
+    # this tile has been issued, and is normalised, packed and written to the staging area three slots later. The staging slot of block b
+    # holds the NEXT unit's Q rows until slot b reads them into the fragment registers (S(b) was their last reader).
     e("s_waitcnt", lgkmcnt=0)
     cls_reads_k()
     cls_reads_v()
@@ -671,36 +674,59 @@ def build(abl=()):
         for j in range(1, 4):
             e("v_mov_b32", v_pb[hb][j], (0,))
     e("v_mov_b32", v_pc[1], (0,))
+    e("s_waitcnt", vmcnt=0)     # the next unit's tile 0 (requested at tile 7) and its last Q piece (tile 8): everything in flight is a drain old
     e("s_waitcnt", lgkmcnt=0)
+    cls_s()                     # the class token's scores first: its K fragments' registers are the output work's temporaries
 
     def tail_s(b):
         sb = v_sb[b & 1]
         return [mf(sb[0:4], v_kf[0][0:4], v_q[b][0:4], 0), mf(sb[0:4], v_kf[0][4:8], v_q[b][4:8], sb[0:4])]
 
-    def tail_e(b):
+    def tail_e(b, pad):
         sb, pb = v_sb[b & 1], v_pb[b & 1]
-        return [I("v_exp_f32", (sb[0],), (sb[0],)), I("v_cndmask_b32", (sb[0],), (0, sb[0], s_mmain)),
-                I("v_cvt_pk_bf16_f32", (pb[0],), (sb[0], 0))]
+        return ([I("s_nop", (), (7,))] if pad else []) + \
+               [I("v_exp_f32", (sb[0],), (sb[0],)), I("s_nop", (), (1,)), I("v_cndmask_b32", (sb[0],), (0, sb[0], s_mmain)),
+                I("v_cvt_pk_bf16_f32", (pb[0],), (sb[0], 0)), I("s_nop", (), (1,))]
 
     def tail_pv(b):
         pb = v_pb[b & 1]
         return [mf(a_o[b][db], v_vf[0][4 * db:4 * db + 4], pb, a_o[b][db]) for db in range(4)] + [mf(a_l[b], v_ones, pb, a_l[b])]
 
-    for n in range(NB + 2):
-        ms = (tail_s(n) if n < NB else []) + (tail_pv(n - 2) if 0 <= n - 2 < NB else [])
-        va = tail_e(n - 1) if 0 <= n - 1 < NB else []
-        if n == NB:   # the class token's scores ride in the first slot without S MFMAs
-            cls_s()
-        for m_ in ms:
+    def out_block(b):
+        """normalise, pack and stage block b (its rows leave as whole lines during the next unit's tiles)"""
+        o = [I("v_accvgpr_read_b32", (v_e[4],), (a_l[b][0],)),
+             I("v_cmp_nle_f32", (VCC,), (s_lo, v_e[4])), I("s_or_b64", (s_bad,), (s_bad, VCC)),     # not (2^-64 <= l): too small, or NaN
+             I("v_cmp_ngt_f32", (VCC,), (s_hi, v_e[4])), I("s_or_b64", (s_bad,), (s_bad, VCC)),     # not (2^100 > l): too large, inf or NaN
+             I("v_rcp_f32", (v_e[4],), (v_e[4],))]
+        pk = R("v", v_e[6].i, 2)
+        for db in range(4):
+            o += [I("v_accvgpr_read_b32", (v_e[i],), (a_o[b][db][i],)) for i in range(4)]
+            if db:
+                o.append(I("v_xor_b32", (v_e[5],), (32 * db, v_ost)))
+            o += [I("v_mul_f32", (v_e[i],), (v_e[i], v_e[4])) for i in range(4)]
+            o += [I("v_cvt_pk_bf16_f32", (pk[0],), (v_e[0], v_e[1])), I("v_cvt_pk_bf16_f32", (pk[1],), (v_e[2], v_e[3])),
+                  I("ds_write_b64", (), (v_e[5] if db else v_ost, pk), offset=b * 2048)]
+        return o
+
+    for n in range(NB + 3):
+        sm = tail_s(n) if n < NB else []
+        pm = tail_pv(n - 2) if 0 <= n - 2 < NB else []
+        va = tail_e(n - 1, n <= 2) if 0 <= n - 1 < NB else []
+        va += out_block(n - 3) if 0 <= n - 3 < NB else []
+        for m_ in sm:
             k.p.append(m_)
-        if va:        # scores of step n-1: eight states behind their MFMAs (the early slots carry too few instructions for that)
-            if n <= 2:
-                k.nop(7)
-            k.p.append(va[0])
-            k.nop(1)
-            k.p.append(va[1])
-            k.p.append(va[2])
-            k.nop(1)
+        if n < NB:      # S(n) was the last reader of this block's Q fragments: the next unit's come in from the staging slot
+            for st in range(2):
+                e("ds_read_b128", v_q[n][4 * st:4 * st + 4], (v_qrd[st],), offset=n * 2048)
+        per = (len(va) + len(pm) - 1) // len(pm) if pm else len(va)
+        q_ = 0
+        for m_ in pm:
+            k.p.append(m_)
+            for ins in va[q_:q_ + per]:
+                k.p.append(ins)
+            q_ += per
+        for ins in va[q_:]:
+            k.p.append(ins)
     k.nop(7)
     e("v_exp_f32", v_sc[0], (v_sc[0],))
     k.nop(1)
@@ -709,10 +735,10 @@ def build(abl=()):
     e("v_cvt_pk_bf16_f32", v_pc[0], (v_sc[0], 0))
     k.nop(1)
     cls_pv()
+    for st in range(2):
+        e("ds_read_b128", v_qc[4 * st:4 * st + 4], (v_qrdc,), offset=64 * st)
     stamp(4)
     # ---------------- hand-over to the next unit: its first tile (requested at tile 7) is visible behind this barrier ----------------
-    e("s_waitcnt", vmcnt=0)     # the next unit's tile 0 (requested at tile 7) AND its last Q piece (tile 8): everything this wave has in flight
-                                # is at least a drain and a tail old
     e("s_barrier")
     for wpc in range(4):
         dma_piece(wpc)          # the next unit's tile 2 into the stage of this unit's tile 8
@@ -723,7 +749,6 @@ def build(abl=()):
         k_read(0, j, 0)
     for db in range(4):
         v_read(0, db, 0)
-    q_reads()                   # in front of the epilogue: it writes this unit's output rows over them
     stamp(5)
     e("v_mov_b32", v_pc[1], (0,)) if False else None
     # ---------------- epilogue ----------------
@@ -782,29 +807,6 @@ def build(abl=()):
     k.nop(1)
     e("s_mov_b64", EXEC, (s_tmp64,))
     stamp2(5)
-    k.label("L_main_out")
-    # nine 16-query blocks: normalise, pack, and leave the rows in the wave's LDS staging area. They go out as whole 128-byte lines, 16 bytes
-    # per lane, two stores per tile of the NEXT unit (`trickle`): a burst of stores here kept this wave's vector-memory queue -- and the next
-    # unit's first requests behind it -- busy for ~5k cycles (per-lane 8-byte stores at the 2-KB row pitch: 10.5k)
-    for b in range(NB):
-        e("v_accvgpr_read_b32", v_e[4], (a_l[b][0],))
-        k.nop(1)
-        e("v_cmp_nle_f32", VCC, (s_lo, v_e[4]))
-        e("s_or_b64", s_bad, (s_bad, VCC))
-        e("v_cmp_ngt_f32", VCC, (s_hi, v_e[4]))
-        e("s_or_b64", s_bad, (s_bad, VCC))
-        e("v_rcp_f32", v_e[4], (v_e[4],))
-        for db in range(4):
-            for i in range(4):
-                e("v_accvgpr_read_b32", v_e[i], (a_o[b][db][i],))
-            if db:
-                e("v_xor_b32", v_e[5], (32 * db, v_ost))
-            for i in range(4):
-                e("v_mul_f32", v_e[i], (v_e[i], v_e[4]))
-            pk = R("v", v_e[6].i, 2)
-            e("v_cvt_pk_bf16_f32", pk[0], (v_e[0], v_e[1]))
-            e("v_cvt_pk_bf16_f32", pk[1], (v_e[2], v_e[3]))
-            e("ds_write_b64", (), (v_e[5] if db else v_ost, pk), offset=b * 2048)
     e("v_add_u32", v_ord, (-NB * 2048, v_ord))   # the next unit's tiles read the staging area from its first block again
     # a row sum out of range: this unit runs again in the HIP kernel's safe body
     e("s_or_b32", t0, (s_bad[0], s_bad[1]))
