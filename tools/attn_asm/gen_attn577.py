@@ -674,7 +674,6 @@ def build(abl=()):
         for j in range(1, 4):
             e("v_mov_b32", v_pb[hb][j], (0,))
     e("v_mov_b32", v_pc[1], (0,))
-    e("s_waitcnt", vmcnt=0)     # the next unit's tile 0 (requested at tile 7) and its last Q piece (tile 8): everything in flight is a drain old
     e("s_waitcnt", lgkmcnt=0)
     cls_s()                     # the class token's scores first: its K fragments' registers are the output work's temporaries
 
@@ -699,23 +698,33 @@ def build(abl=()):
              I("v_cmp_ngt_f32", (VCC,), (s_hi, v_e[4])), I("s_or_b64", (s_bad,), (s_bad, VCC)),     # not (2^100 > l): too large, inf or NaN
              I("v_rcp_f32", (v_e[4],), (v_e[4],))]
         pk = R("v", v_e[6].i, 2)
+        inv2 = R("v", v_e[4].i, 2)       # 1 / l twice: the second operand of the packed multiplies
         for db in range(4):
             o += [I("v_accvgpr_read_b32", (v_e[i],), (a_o[b][db][i],)) for i in range(4)]
-            if db:
-                o.append(I("v_xor_b32", (v_e[5],), (32 * db, v_ost)))
-            o += [I("v_mul_f32", (v_e[i],), (v_e[i], v_e[4])) for i in range(4)]
+            if db == 0:
+                o.append(I("v_mov_b32", (v_e[5],), (v_e[4],)))
+            else:
+                o.append(I("v_xor_b32", (v_sp,), (32 * db, v_ost)))
+            o += [I("v_pk_mul_f32", (R("v", v_e[0].i, 2),), (R("v", v_e[0].i, 2), inv2)),
+                  I("v_pk_mul_f32", (R("v", v_e[2].i, 2),), (R("v", v_e[2].i, 2), inv2))]
             o += [I("v_cvt_pk_bf16_f32", (pk[0],), (v_e[0], v_e[1])), I("v_cvt_pk_bf16_f32", (pk[1],), (v_e[2], v_e[3])),
-                  I("ds_write_b64", (), (v_e[5] if db else v_ost, pk), offset=b * 2048)]
+                  I("ds_write_b64", (), (v_sp if db else v_ost, pk), offset=b * 2048)]
         return o
 
     for n in range(NB + 3):
         sm = tail_s(n) if n < NB else []
         pm = tail_pv(n - 2) if 0 <= n - 2 < NB else []
         va = tail_e(n - 1, n <= 2) if 0 <= n - 1 < NB else []
+        if n >= NB + 1:     # the last slots carry few or no MFMAs: the sums of the blocks they finish were written a handful of instructions ago
+            va.append(I("s_nop", (), (3,)))
         va += out_block(n - 3) if 0 <= n - 3 < NB else []
         for m_ in sm:
             k.p.append(m_)
         if n < NB:      # S(n) was the last reader of this block's Q fragments: the next unit's come in from the staging slot
+            # (its two pieces were requested at tile n; every later tile issued eight vector-memory operations -- four K / V^T pieces, two
+            # stores, two Q pieces: that many may still be in flight. The last block's wait is a full drain, a whole tail behind its request;
+            # the hand-over's barrier then sees the next unit's tile 0, requested at tile 7, landed on every wave)
+            e("s_waitcnt", vmcnt=min(63, 8 * (NB - 1 - n)))
             for st in range(2):
                 e("ds_read_b128", v_q[n][4 * st:4 * st + 4], (v_qrd[st],), offset=n * 2048)
         per = (len(va) + len(pm) - 1) // len(pm) if pm else len(va)

@@ -534,6 +534,13 @@ class Emu:
                 r = {"v_mul_f32": x * y, "v_add_f32": x + y, "v_max_f32": np.maximum(x, y), "v_min_f32": np.minimum(x, y)}[o]
             self.wr(w, d[0], r.astype(np.float32).view(np.uint32))
             return
+        if o == "v_pk_mul_f32":
+            for j in range(2):
+                x = self.rd(w, sr[0][j]).view(np.float32)
+                y = self.rd(w, sr[1][j]).view(np.float32)
+                with np.errstate(all="ignore"):
+                    self.wr(w, d[0][j], (x * y).astype(np.float32).view(np.uint32))
+            return
         if o == "v_cvt_pk_bf16_f32":
             x = self.rd(w, sr[0]).view(np.float32)
             y = self.rd(w, sr[1]).view(np.float32)
