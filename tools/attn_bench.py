@@ -1,7 +1,8 @@
 """Attention kernel micro-benchmark (md_bench_attention_ex): useful TFLOP/s = 4 * T * heads * N^2 * 64 / time.
 usage: python tools/attn_bench.py                       Depth Pro shapes at B = 1 / 8, DA3 518^2 / 1036^2; bf16 fast body,
                                                          bf16 running-maximum body, f16
-       python tools/attn_bench.py T N heads prec scale  one configuration (for rocprofv3 --pmc passes, tools/pmc_collect.sh)"""
+       python tools/attn_bench.py T N heads prec scale [hip|asm]  one configuration (for rocprofv3 --pmc passes, tools/pmc_collect.sh);
+                                                         `hip` keeps 577-token bf16 launches off the assembly kernel (md_debug_attention_asm)"""
 import ctypes as C
 import os
 import sys
@@ -17,6 +18,8 @@ def main():
     ms = C.c_float()
     if len(sys.argv) >= 6:
         T, N, heads, prec = (int(a) for a in sys.argv[1:5])
+        if len(sys.argv) >= 7:
+            lib.md_debug_attention_asm(0 if sys.argv[6] == "hip" else 1)
         _lib.check(lib.md_bench_attention_ex(dev.handle, T, N, heads, prec, C.c_float(float(sys.argv[5])), 10, C.byref(ms)))
         fl = 4.0 * T * heads * N * N * 64
         print(f"T={T} N={N} heads={heads} prec={prec}: {ms.value:.4f} ms = {fl / ms.value / 1e9:.0f} TFLOP/s", flush=True)
