@@ -131,6 +131,7 @@ def build(abl=()):
     v_qrdc, v_r, v_oco = vp.take(), vp.take(), vp.take()
     v_qrd = [vp.take() for _ in range(2)]          # Q fragments in the wave's staging area: row n, chunk (4 s + g) ^ f(n)
     v_zero = vp.take()
+    v_lmin, v_lsum = vp.take(), vp.take()          # the unit's row sums: smallest, and their total (an inf or a NaN shows in the total)
     v_scr = vp.take()                              # class-token scratch address of this lane
     v_ost, v_ord, v_oo2 = vp.take(), vp.take(), vp.take()   # output staging: write address, read cursor, row-wise store offset
     v_e = [v_kc[i] for i in range(8)]              # epilogue temporaries: the class token's K fragments are dead there (v_e[6:7]: even pair)
@@ -693,10 +694,14 @@ def build(abl=()):
 
     def out_block(b):
         """normalise, pack and stage block b (its rows leave as whole lines during the next unit's tiles)"""
-        o = [I("v_accvgpr_read_b32", (v_e[4],), (a_l[b][0],)),
-             I("v_cmp_nle_f32", (VCC,), (s_lo, v_e[4])), I("s_or_b64", (s_bad,), (s_bad, VCC)),     # not (2^-64 <= l): too small, or NaN
-             I("v_cmp_ngt_f32", (VCC,), (s_hi, v_e[4])), I("s_or_b64", (s_bad,), (s_bad, VCC)),     # not (2^100 > l): too large, inf or NaN
-             I("v_rcp_f32", (v_e[4],), (v_e[4],))]
+        # the range check wants every row sum inside [2^-64, 2^100): the smallest of the wave's sums and their total (which an inf or a NaN
+        # cannot leave finite) are compared once per unit -- a compare + scalar OR per block stalled on the VALU -> SALU hand-over each time
+        o = [I("v_accvgpr_read_b32", (v_e[4],), (a_l[b][0],))]
+        if b == 0:
+            o += [I("v_mov_b32", (v_lmin,), (v_e[4],)), I("v_mov_b32", (v_lsum,), (v_e[4],))]
+        else:
+            o += [I("v_min_f32", (v_lmin,), (v_lmin, v_e[4])), I("v_add_f32", (v_lsum,), (v_lsum, v_e[4]))]
+        o.append(I("v_rcp_f32", (v_e[4],), (v_e[4],)))
         pk = R("v", v_e[6].i, 2)
         inv2 = R("v", v_e[4].i, 2)       # 1 / l twice: the second operand of the packed multiplies
         for db in range(4):
@@ -817,6 +822,10 @@ def build(abl=()):
     e("s_mov_b64", EXEC, (s_tmp64,))
     stamp2(5)
     e("v_add_u32", v_ord, (-NB * 2048, v_ord))   # the next unit's tiles read the staging area from its first block again
+    e("v_cmp_nle_f32", VCC, (s_lo, v_lmin))      # not (2^-64 <= the smallest row sum): too small, or NaN
+    e("s_or_b64", s_bad, (s_bad, VCC))
+    e("v_cmp_ngt_f32", VCC, (s_hi, v_lsum))      # not (2^100 > the total): a sum too large, inf or NaN
+    e("s_or_b64", s_bad, (s_bad, VCC))
     # a row sum out of range: this unit runs again in the HIP kernel's safe body
     e("s_or_b32", t0, (s_bad[0], s_bad[1]))
     e("s_cbranch_scc0", (), ("L_flag_done",))
