@@ -1,15 +1,21 @@
-"""Generator of the assembly-owned Depth Pro attention kernel (gfx950): one workgroup = one (sequence, head) of 577 tokens.
+"""Generator of the assembly-owned Depth Pro attention kernel (gfx950): bf16, 577 tokens, head_dim 64.
 
-  four waves, one per SIMD (512 registers each); wave w owns queries 1 + 144 w .. 144 w + 144 as nine 16-query blocks, and
-  a sixteenth of every key tile for query 0 (the class token: its partial O, l of the four waves add at the end -- the
-  fast body keeps no running maximum);  S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_16x16x32_bf16, row sums on the matrix
-  pipe (an all-ones A operand), O / l in AGPRs, S / P / fragments in VGPRs;  K and V^T tiles of 64 keys through a 4-stage
-  LDS ring filled by LDS-DMA three tiles ahead, one counted vmcnt + s_barrier per tile;  software pipeline over
-  (32-key half, query block) steps: S(n) | exp, pack (n-1) | P.V + sum (n-2).
+  One PERSISTENT workgroup per CU walks the (sequence, head) units; four waves, one per SIMD with the whole 512-register file.
+  Wave w owns queries 1 + 144 w .. 144 w + 144 as nine 16-query blocks, and a sixteenth of every key tile for query 0 (the class token:
+  its partial O, l of the four waves add at the end -- the fast body keeps no running maximum).  S^T = K.Q^T and O^T = V^T.P^T on
+  v_mfma_f32_16x16x32_bf16, the row sums on the matrix pipe (an all-ones A operand), O / l in AGPRs, S / P / fragments in VGPRs.
+  K and V^T tiles of 64 keys through a 4-stage LDS ring filled by LDS-DMA three tiles ahead (across units), one counted vmcnt +
+  s_barrier per tile; software pipeline over (32-key half, query block) steps: S(n) | exp, pack (n-1) | P.V + sum (n-2).
+  A wave's 19-KB staging area in LDS holds, slot by slot, the previous unit's output rows (leaving as whole lines, two stores per
+  tile) and then the next unit's Q rows (arriving by LDS-DMA, read into the fragment registers in the last tile); the output work of a
+  unit rides beside the MFMAs of its last (one-key) tile.
 
 The contract of burn_depth_amd/csrc/kernels/attention.hip holds (q pre-scaled to log2 units, V^T rows padded to kpad keys with
 finite values, p = 2^s with no maximum for bf16: a row sum outside [2^-64, 2^100) raises redo[unit] and the HIP kernel's safe body
-runs that unit again).  python tools/attn_asm/gen_attn577.py > burn_depth_amd/csrc/kernels/attn577_gfx950.s"""
+runs that unit again).
+  python tools/attn_asm/gen_attn577.py > burn_depth_amd/csrc/kernels/attn577_gfx950.s     (make -C burn_depth_amd/csrc asm)
+  python tools/attn_asm/gen_attn577.py --force <ablation> ...                             timing-only variants (tools/attn_asm/run_co.py)
+Checked on the CPU by tools/attn_asm/emu_test.py / tests/test_attn_asm.py (isa.py: wait-state checker + functional emulator)."""
 import sys
 import os
 
@@ -21,8 +27,7 @@ NTF = 9           # full 64-key tiles (577 = 9 * 64 + 1)
 STAGE = 16384     # K tile 8 KB | V^T tile 8 KB
 NSTAGE = 4
 RING = STAGE * NSTAGE
-SCRATCH = 0       # class-token partials reuse the ring once every DMA has landed
-OSTAGE = RING + 2048     # per wave: its 144 output rows of 128 B (16-byte chunks XOR-swizzled by the row), 18 KB
+OSTAGE = RING + 2048     # behind the ring: 2 KB for the class token's partial sums, then per wave its 144 rows of 128 B (16-byte chunks XOR-swizzled by the row)
 OWAVE = 144 * 128 + 1024     # + one 1-KiB piece: the sequence's first rows (the class token's query)
 LDS_BYTES = OSTAGE + 4 * OWAVE   # the ring | the class token's partial sums | the output staging
 
