@@ -53,7 +53,8 @@ class K:
 def build(abl=()):
     """abl: timing-only ablations (results are wrong): 'loop2' doubles the tile loop, 'noexp' drops the exponentials and packs,
     'nodma' the LDS-DMA requests inside the loop, 'nolds' the fragment reads inside the loop, 'nostore' the output stores,
-    'nopv' / 'nos' the P.V (+ sum) / score MFMAs"""
+    'nopv' / 'nos' the P.V (+ sum) / score MFMAs; schedule experiments 'ilv', 'pvfirst', 'plan2', 'plan3' (profiles/r05_attention_asm_stamps.txt:
+    the shipped order won)"""
     abl = set(abl)
     k = K()
     e = k.e
@@ -507,7 +508,13 @@ def build(abl=()):
         """MFMAs of S(n) then P.V(n-2); the exponentials and packs of step n-1 between them; `extras` one behind each of the first MFMAs"""
         for x in extras_head:
             x()
-        ms = (s_mfmas(n) if do_s and "nos" not in abl else []) + (pv_mfmas(n - 2, fresh) if do_pv and "nopv" not in abl else [])
+        sm_ = s_mfmas(n) if do_s and "nos" not in abl else []
+        pm_ = pv_mfmas(n - 2, fresh) if do_pv and "nopv" not in abl else []
+        ms = sm_ + pm_
+        if "ilv" in abl and len(sm_) == 4 and len(pm_) == 5:      # experiment: S and P.V MFMAs alternate (more distance inside the S chains)
+            ms = [sm_[0], pm_[0], sm_[1], pm_[1], sm_[2], pm_[2], sm_[3], pm_[3], pm_[4]]
+        if "pvfirst" in abl and len(sm_) == 4 and len(pm_) == 5:  # experiment: P.V in front of S
+            ms = pm_ + sm_
         if "noexp" in abl:
             do_e = False
         ex, cv = e_valu(n - 1) if do_e else ([], [])
@@ -517,6 +524,12 @@ def build(abl=()):
         if do_e:
             # one exponential behind each of the first six MFMAs, then (exp, pack) pairs, the last two packs behind the last MFMA
             plan = [[0], [1], [2], [3], [4], [5], [6, 7], [8, 9], [10, 11]]
+            if "plan2" in abl:      # experiment: two exponentials behind each of the first four MFMAs, the packs behind the rest
+                order = ex + cv
+                plan = [[0, 1], [2, 3], [4, 5], [6, 7], [8], [9], [10], [11], []]
+            if "plan3" in abl:      # experiment: packs as early as their exponentials allow
+                order = [ex[0], ex[1], ex[2], cv[0], ex[3], ex[4], cv[1], ex[5], ex[6], cv[2], ex[7], cv[3]]
+                plan = [[0], [1], [2, 3], [4], [5, 6], [7], [8, 9], [10], [11]]
             if len(ms) == 9:
                 for gi, idxs in enumerate(plan):
                     per[gi] = [order[j] for j in idxs]
