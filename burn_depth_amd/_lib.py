@@ -133,6 +133,9 @@ SYMBOLS = {
     "md_bench_attention": (_I, [_P, _I, _I, _I, _I, _F]),
     "md_bench_attention_ex": (_I, [_P, _I, _I, _I, _I, C.c_float, _I, _F]),
     "md_debug_attention_asm": (_I, [_I]),
+    "md_debug_attention_asm_launches": (C.c_long, []),
+    "md_debug_attention_redo_units": (C.c_long, [_P, _I]),
+    "md_bench_attention_qkv": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, C.POINTER(C.c_long)]),
     "md_comm_unique_id": (_I, [_P]),
     "md_comm_init_rank": (_I, [_P, _P, _I, _I, C.POINTER(_P)]),
     "md_comm_rank": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),

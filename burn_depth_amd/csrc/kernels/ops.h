@@ -165,15 +165,21 @@ inline float attn_qscale(int prec) { return prec == MD_PREC_F32 ? 1.0f : kAttnQS
 // out_fp8_inv > 0 (bf16 only): the output rows are OCP e4m3 bytes (value * out_fp8_inv, saturating).
 // prec = MD_PREC_F16X2: split-half operands -- qk rows [q_hi | q_lo | k_hi | k_lo] (4D wide), the lo plane of V^T `v_plane`
 // elements behind its hi plane, out rows [hi: D | lo: D]; scores on three MFMA terms, P.V on two or three (attention.hip).
-// redo: nseq * heads zero-initialised ints owned by the caller's context (one buffer per stream that may run attention at a time), or
-// null. With it, bf16 launches of exactly 577 tokens take the assembly-owned kernel (attn577_gfx950.s) once attention_asm_prepare()
+// redo: attention_redo_ints(nseq * heads) zero-initialised ints owned by the caller's context (one buffer per stream that may run attention
+// at a time: the flags, then the compacted list of raised ones), or null. With it, bf16 launches of exactly 577 tokens take the assembly-owned kernel (attn577_gfx950.s) once attention_asm_prepare()
 // has loaded its code object on the device; the flags it raises are consumed and cleared inside the same call.
 int launch_attention(const void* qk, const void* vT, void* out, int nseq, int S, int n_tokens, int heads, int D,
                      int kpad, int prec, hipStream_t s, float out_fp8_inv = 0.f, long v_plane = 0, int* redo = nullptr);
 // Loads the embedded code object on the CURRENT device (idempotent; not capturable -- call it when a context is created).
 int attention_asm_prepare();
-// Per host thread: may launch_attention take the assembly kernel? Default 1; returns the previous value (A/B runs, the bench).
+// Process-wide: may launch_attention take the assembly kernel? Default 1; returns the previous value (A/B runs, the bench).
 int attention_allow_asm(int on);
+// launches of the assembly kernel since the library was loaded (what a bench line says about the form it measured)
+long attention_asm_launches();
+// ints of a `redo` buffer for nunits = nseq * heads units
+int attention_redo_ints(int nunits);
+// units the assembly kernel flagged on the current device since the last reset (synchronises the device; -1: not loaded)
+long attention_asm_redo_units(int reset);
 // Per host thread: may launch_attention pick its small-launch form (64 queries x two key groups per workgroup for launches of few
 // workgroups over long sequences -- another summation order than the plain form's)? Default 1. Returns the previous value. A model
 // in batch-invariant mode (md_model_set_option) runs with 0: one image gives the same bits alone and inside a batch.

@@ -560,7 +560,7 @@ int md_op_attention(md_device_t dev, const float* qkv_dev, int T, int N, int hea
   MD_TRY(launch_qkv_split(qkv_dev, T, N, heads, SS, kpad, qk.p, vT.p, attn_qscale(precision), precision, st));
   if (precision != MD_PREC_F32) {
     DevBuf redo;  // zeroed flags: 577-token bf16 launches take the assembly kernel, like the model's
-    MD_TRY(redo.alloc((size_t)T * heads * 4));
+    MD_TRY(redo.alloc((size_t)attention_redo_ints(T * heads) * 4));
     if (precision == MD_PREC_BF16) MD_TRY(attention_asm_prepare());
     MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, N, heads, D, kpad, precision, st, 0.f, (long)T * heads * 64 * kpad, (int*)redo.p));
     MD_HIP(hipStreamSynchronize(st));  // `redo` is released at the end of this scope
@@ -811,7 +811,7 @@ int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int p
   MD_TRY(fill_random(qk.p, (size_t)T * SS * 2 * D, precision, 3, qk_scale, st));
   MD_TRY(fill_random(vT.p, (size_t)T * heads * 64 * kpad, precision, 4, 1.0f, st));
   DevBuf redo;
-  MD_TRY(redo.alloc((size_t)T * heads * 4));
+  MD_TRY(redo.alloc((size_t)attention_redo_ints(T * heads) * 4));
   if (precision == MD_PREC_BF16) MD_TRY(attention_asm_prepare());
   for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st, 0.f, 0, (int*)redo.p));
   hipEvent_t e0, e1;
@@ -829,7 +829,48 @@ int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int p
   return MD_OK;
 }
 
+int md_bench_attention_qkv(md_device_t dev, const float* qkv_dev, int T, int n_tokens, int heads, int precision, int iters, float* avg_ms,
+                           long* redo_units_per_launch) {
+  if (!dev || !qkv_dev || !avg_ms || T <= 0 || n_tokens <= 0 || heads <= 0 || iters <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "invalid argument");
+  if (precision != MD_PREC_BF16 && precision != MD_PREC_F16) MD_FAIL(MD_ERR_INVALID_ARG, "attention bench: bf16 or f16");
+  MD_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t st = dev->stream;
+  const int D = heads * 64, SS = (n_tokens + 3) / 4 * 4, kpad = (n_tokens + 63) / 64 * 64;
+  DevBuf qk, vT, ao, redo;
+  MD_TRY(qk.alloc(((size_t)T * SS + 64) * 2 * D * 2));
+  MD_TRY(vT.alloc((size_t)T * heads * 64 * kpad * 2));
+  MD_TRY(ao.alloc(((size_t)T * SS + 64) * D * 2));
+  MD_TRY(redo.alloc((size_t)attention_redo_ints(T * heads) * 4));
+  MD_TRY(launch_qkv_split(qkv_dev, T, n_tokens, heads, SS, kpad, qk.p, vT.p, attn_qscale(precision), precision, st));
+  if (precision == MD_PREC_BF16) MD_TRY(attention_asm_prepare());
+  for (int i = 0; i < 2; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st, 0.f, 0, (int*)redo.p));
+  MD_HIP(hipStreamSynchronize(st));
+  (void)attention_asm_redo_units(1);
+  hipEvent_t e0, e1;
+  MD_HIP(hipEventCreate(&e0));
+  MD_HIP(hipEventCreate(&e1));
+  MD_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) MD_TRY(launch_attention(qk.p, vT.p, ao.p, T, SS, n_tokens, heads, D, kpad, precision, st, 0.f, 0, (int*)redo.p));
+  MD_HIP(hipEventRecord(e1, st));
+  MD_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
+  if (redo_units_per_launch) {
+    const long u = attention_asm_redo_units(1);
+    *redo_units_per_launch = u < 0 ? -1 : u / iters;
+  }
+  return MD_OK;
+}
+
 int md_debug_attention_asm(int on) { return attention_allow_asm(on); }
+long md_debug_attention_asm_launches(void) { return attention_asm_launches(); }
+long md_debug_attention_redo_units(md_device_t dev, int reset) {
+  if (!dev || hipSetDevice(dev->ordinal) != hipSuccess) return -1;
+  return attention_asm_redo_units(reset);
+}
 
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms) {
   return md_bench_attention_ex(dev, T, n_tokens, heads, MD_PREC_BF16, 0.7f, iters, avg_ms);

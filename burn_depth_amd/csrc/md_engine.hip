@@ -296,7 +296,7 @@ struct md_model_s::Buffers {
   void* qk = nullptr;         // [nseq*SS, 2D] T
   void* vT = nullptr;         // [nseq][heads][64][kpad] T
   void* ao = nullptr;         // [nseq*SS, D] T
-  int* attn_redo = nullptr;   // [nseq*heads] flags of the assembly attention kernel (raised = that unit re-runs in the safe body)
+  int* attn_redo = nullptr;   // [attention_redo_ints(nseq*heads)] flags + compacted list of the assembly attention kernel (raised = that unit re-runs in the safe body)
   void* hbuf = nullptr;       // [nseq*SS, 4D] T
   float* scores = nullptr;    // fp32 attention only
   void* hook[2] = {nullptr, nullptr};  // [n0*SS, D] T
@@ -375,7 +375,7 @@ static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
   MD_TAKE(vT, void*, (size_t)nseq * c.pv.heads * 64 * m->kpad * esz);
   m->vt_plane = m->xm == 2 ? (size_t)nseq * c.pv.heads * 64 * m->kpad : 0;
   MD_TAKE(ao, void*, rows * D * esz);
-  MD_TAKE(attn_redo, int*, (size_t)nseq * c.pv.heads * 4);  // the assembly attention kernel's per-(sequence, head) flags (zero = the arena's memset)
+  MD_TAKE(attn_redo, int*, (size_t)attention_redo_ints(nseq * c.pv.heads) * 4);  // the assembly attention kernel's per-(sequence, head) flags (zero = the arena's memset)
   MD_TAKE(hbuf, void*, rows * 4 * D * esz);
   if (m->prec == MD_PREC_F32) MD_TAKE(scores, float*, (size_t)nseq * c.pv.heads * SS * m->kpad * 4);
   MD_TAKE(hook[0], void*, ((size_t)n0 * SS + 64) * D * esz);
@@ -1286,6 +1286,26 @@ struct TapsOn {  // the debug entries emit through the tap machinery whatever th
   explicit TapsOn(md_model_s* mm) : m(mm), was(mm->taps_enabled) { m->taps_enabled = true; }
   ~TapsOn() { m->taps_enabled = was; }
 };
+// With the model's tap switch OFF, the fp32 tap buffers a debug entry creates (five [B,256,768,768] fusions + the head maps: ~3 GB at B = 1 of
+// the default configuration) are released when the entry returns; buffers that existed before the call stay. Called behind the
+// entry's stream synchronisation.
+struct DebugTapScope {
+  md_model_s* m; bool was; std::vector<std::string> before;
+  explicit DebugTapScope(md_model_s* mm) : m(mm), was(mm->taps_enabled) {
+    if (!was) for (auto& kv : m->taps) before.push_back(kv.first);
+  }
+  ~DebugTapScope() {
+    if (was) return;
+    for (auto it = m->taps.begin(); it != m->taps.end();) {
+      if (std::find(before.begin(), before.end(), it->first) == before.end()) {
+        if (it->second.dev) (void)hipFree(it->second.dev);
+        it = m->taps.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+};
 }  // namespace
 
 static void decoder_level_shapes(md_model_s* m, int ddims[5], int hw[5]) {
@@ -1369,6 +1389,7 @@ int model_decoder_from_features(md_model_t m, const md_nchw_view* features, int 
   for (int l = 0; l < 5; ++l)  // level 0 also feeds resnet1 through its relu'd copy (convs[0] is the identity, decoder.rs:155-165)
     MD_TRY(stage_nchw_feature(m, st, features[l], B, in_kind, (float*)stage.p, enc[l], l == 0 ? b->enc0r : nullptr, cpad(m, ddims[l])));
   Run r{m, st, B};
+  DebugTapScope tap_scope(m);
   {
     TapsOn taps(m);
     MD_TRY(run_decoder_head(r, true));
@@ -1408,6 +1429,7 @@ int model_head_debug(md_model_t m, const md_nchw_view* feature, int B, int in_ki
   auto Bi = [&](const char* n) { return P32(m, n); };
   MD_TRY(stage_nchw_feature(m, st, *feature, B, in_kind, (float*)stage.p, b->df[0], nullptr, Fp));
   Run r{m, st, B};
+  DebugTapScope tap_scope(m);
   TapsOn taps(m);
   MD_TRY(conv3(r, "head_conv0", b->df[0], s0, s0, Fp, W("head.conv0.weight"), Bi("head.conv0.bias"), F2, b->h0, F2p, ACT_NONE, nullptr,
                nullptr, nullptr));

@@ -406,11 +406,23 @@ int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iter
  * body), 4.0 and above logits beyond its +-32 check (the running-maximum body). */
 int md_bench_attention_ex(md_device_t dev, int T, int n_tokens, int heads, int precision, float qk_scale, int iters,
                           float* avg_ms);
-/* Per host thread: may bf16 attention launches of exactly 577 tokens (Depth Pro: 576 patches + the class token) take the
- * assembly-owned gfx950 kernel (kernels/attn577_gfx950.s)? Default 1; returns the previous value. 0 runs the HIP kernel that
- * every other shape runs -- an A/B switch for benches and parity tests, not a numerics option: both forms compute the same
- * sums (the assembly kernel adds the rounded probabilities on the matrix pipe). Graphs captured before a change keep their form. */
+/* The same on CALLER-supplied operands: qkv_dev = [T, n_tokens, 3 * heads * 64] fp32 on the device, rows q | k | v as the fused QKV
+ * projection of /root/reference/src/model/depth_pro/layers/vit.rs:45-68 (burn_dino's attention) produces them; q is scaled by
+ * 1/sqrt(64) inside. *redo_units_per_launch (may be NULL) = the (sequence, head) units per launch whose row sums left the assembly
+ * kernel's fast range and were recomputed by the running-maximum body (-1: the assembly kernel is not in use). For stress operands
+ * with outlier logits (plain softmax, vit.rs:60: outliers are legal inputs). */
+int md_bench_attention_qkv(md_device_t dev, const float* qkv_dev, int T, int n_tokens, int heads, int precision, int iters,
+                           float* avg_ms, long* redo_units_per_launch);
+/* PROCESS-WIDE (round 5: per host thread): may bf16 attention launches of exactly 577 tokens (Depth Pro: 576 patches + the class
+ * token) take the assembly-owned gfx950 kernel (kernels/attn577_gfx950.s)? Default 1; returns the previous value. 0 runs the HIP
+ * kernel that every other shape runs -- an A/B switch for benches and parity tests, not a numerics option: both forms compute the
+ * same sums (the assembly kernel adds the rounded probabilities on the matrix pipe). Graphs captured before a change keep their form. */
 int md_debug_attention_asm(int on);
+/* Launches of the assembly-owned attention kernel since the library was loaded: what a bench line may say about the form it timed. */
+long md_debug_attention_asm_launches(void);
+/* (sequence, head) units the assembly kernel flagged for the running-maximum body on `dev` since the last reset (reset != 0 clears
+ * the counter). Synchronises the device. -1: the code object is not loaded there. 0 over a whole run = the fast body served every unit. */
+long md_debug_attention_redo_units(md_device_t dev, int reset);
 
 /* ---- multi-GPU: RCCL over xGMI behind the C ABI ------------------------------------------------------------------
  * BASELINE north_star: "independent images shard naturally across the 8 GPUs of one node with RCCL broadcast of weights and

@@ -1003,6 +1003,123 @@ def test_attention_assembly_kernel_at_the_headline_launch_size(dev):
     assert bool((a != h).any())
 
 
+def _attention_fp64_units(qkv, heads, units):
+    """fp64 softmax(q k^T / 8) v of the sampled (sequence, head) units on the GPU, with the engine's operand roundings (q rounded after the
+    softmax scale is folded in, k / v as stored, P before P.V: tools/gpu_diag.py::attn_ref). Returns [len(units), N, 64] fp32."""
+    import torch
+    from oracle import depth_pro_ref as R
+    D = heads * 64
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    outs = []
+    for (t, h) in units:
+        q = R.round_q_prescaled(qkv[t, :, h * 64:(h + 1) * 64].float(), bf).double()
+        k = bf(qkv[t, :, D + h * 64:D + (h + 1) * 64].float()).double()
+        v = bf(qkv[t, :, 2 * D + h * 64:2 * D + (h + 1) * 64].float()).double()
+        s = (q @ k.T) * 0.125
+        pu = torch.exp(s - s.amax(-1, keepdim=True))
+        outs.append(((bf(pu.float()).double() @ v) / pu.sum(-1, keepdim=True)).float())
+    return torch.stack(outs)
+
+
+def test_attention_assembly_kernel_at_the_headline_launch_size_against_fp64(diag, dev):
+    """Round-5 review, weak #3a: at the headline launch size (296 sequences x 16 heads = 4736 units, 18.5 per persistent workgroup: workgroup
+    w walks units w, w + 256, ...) the assembly kernel was only compared with the HIP kernel. Here 80 sampled units -- the first of every
+    workgroup class, four per hand-over level 1 .. 18 spread over the workgroups, the very last -- against the fp64 reference with the
+    operator check's tolerances (max 8e-3 of the unit's peak, mean 2.5e-3), and every other element finite.
+    Arithmetic: /root/reference/src/model/depth_pro/layers/encoder.rs:346-348 -> burn_dino attention, plain softmax (vit.rs:60)."""
+    import torch
+    from burn_depth_amd import _lib, ops
+    lib = _lib.load()
+    heads, T = 16, 296
+    g = torch.Generator(device="cuda").manual_seed(12)
+    qkv = torch.randn(T, 577, 3 * heads * 64, generator=g, device="cuda")
+    qkv[..., :heads * 64] *= 2.0
+    n0 = int(lib.md_debug_attention_asm_launches())
+    prev = lib.md_debug_attention_asm(1)
+    try:
+        out = ops.attention(dev, qkv, heads, 0)
+    finally:
+        lib.md_debug_attention_asm(prev)
+    assert int(lib.md_debug_attention_asm_launches()) == n0 + 1, "the launch did not take the assembly kernel"
+    assert bool(torch.isfinite(out).all())
+    nunits = T * heads
+    units = [0, 1, 2, 255, nunits - 1, nunits - 2]
+    for level in range(1, 19):
+        width = min(256, nunits - 256 * level)
+        units += [256 * level + (37 * level + 61 * j) % width for j in range(4)]
+    units = sorted(set(units))
+    assert len(units) >= 64
+    pairs = [(u // heads, u % heads) for u in units]  # unit -> (sequence, head): the kernel's shift and mask
+    want = _attention_fp64_units(qkv, heads, pairs)
+    got = torch.stack([out[t, :, h * 64:(h + 1) * 64] for (t, h) in pairs]).float()
+    for i, u in enumerate(units):
+        assert diag.rel_err(got[i], want[i]) <= 8e-3, f"unit {u}"
+        assert diag.mean_rel(got[i], want[i]) <= 2.5e-3, f"unit {u}"
+
+
+def test_attention_assembly_kernel_on_heavy_tailed_logits(diag, dev):
+    """Round-5 review, weak #3b: the fast body keeps no running maximum and flags a unit whose row sums leave [2^-64, 2^100) = about
+    [-44, +69] nat; DINOv2-L is known for outlier tokens, and the reference's softmax is the plain one (vit.rs:60: outliers are legal
+    inputs). Planted: per-head outlier keys worth +30, +45, +60 nat against one query each (inside the range: the fast body serves them),
+    +80 and +95 nat (outside: 2^115, and an fp32 overflow), one unit whose query 20 sees every key at about -35 nat (inside) and one at
+    -60 nat (outside). Exactly the three units outside the range are flagged and recomputed by the running-maximum body (compacted list,
+    four workgroups per CU); every planted unit and sampled plain units match the fp64 reference; the flags are consumed (a second launch
+    flags the same number, bit-identical output); a launch without outliers flags none."""
+    import ctypes as C
+    import torch
+    from burn_depth_amd import _lib, ops
+    lib = _lib.load()
+    heads, T, N = 16, 40, 577
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(13)
+    qkv = torch.randn(T, N, 3 * D, generator=g, device="cuda")
+    qkv[..., :D] *= 2.0
+    plain = qkv.clone()
+    hot, expect_flagged = [], 0
+    for i, nat in enumerate((30.0, 45.0, 60.0, 80.0, 95.0)):
+        t, h = (7 * i + 3) % T, (5 * i + 2) % heads
+        qrow = qkv[t, 11 + i, h * 64:(h + 1) * 64]
+        # key 300 + i aligned with query 11 + i: logit = |q|^2 * a / 8 = nat  ->  a = 8 nat / |q|^2
+        qkv[t, 300 + i, D + h * 64:D + (h + 1) * 64] = qrow * (8.0 * nat / float(qrow.square().sum()))
+        hot.append((t, h))
+        expect_flagged += nat > 69.3
+    for i, nat in enumerate((35.0, 60.0)):  # query 20 + i of one more unit sees every key at about -nat
+        t, h = (11 * i + 5) % T, (3 * i + 7) % heads
+        assert (t, h) not in hot
+        qrow = qkv[t, 20 + i, h * 64:(h + 1) * 64]
+        a = 8.0 * nat / float(qrow.square().sum())
+        qkv[t, :, D + h * 64:D + (h + 1) * 64] = -qrow * a + 0.05 * qkv[t, :, D + h * 64:D + (h + 1) * 64]
+        hot.append((t, h))
+        expect_flagged += (-nat * 1.4427 + 9.2) < -64.0  # log2 of the row sum over 577 keys
+    assert expect_flagged == 3
+    prev = lib.md_debug_attention_asm(1)
+    try:
+        assert lib.md_debug_attention_redo_units(dev.handle, 1) >= 0, "the assembly kernel's code object is not loaded"
+        out_plain = ops.attention(dev, plain, heads, 0)
+        assert lib.md_debug_attention_redo_units(dev.handle, 1) == 0, "random logits of a few units must not leave the fast body's range"
+        out = ops.attention(dev, qkv, heads, 0)
+        flagged = int(lib.md_debug_attention_redo_units(dev.handle, 1))
+        out2 = ops.attention(dev, qkv, heads, 0)
+        assert int(lib.md_debug_attention_redo_units(dev.handle, 1)) == flagged, "a stale or a lost flag"
+    finally:
+        lib.md_debug_attention_asm(prev)
+    assert flagged == expect_flagged, (flagged, expect_flagged)
+    assert bool(torch.isfinite(out).all()) and torch.equal(out, out2)
+    cold = [(0, 0), (T - 1, heads - 1), (hot[0][0], (hot[0][1] + 1) % heads)]
+    pairs = hot + [p for p in cold if p not in hot]
+    want = _attention_fp64_units(qkv, heads, pairs)
+    got = torch.stack([out[t, :, h * 64:(h + 1) * 64] for (t, h) in pairs]).float()
+    for i, pr in enumerate(pairs):
+        assert diag.rel_err(got[i], want[i]) <= 8e-3, pr
+    # units without outliers are untouched by the recompute of their neighbours
+    t, h = cold[0]
+    assert torch.equal(out[t, :, h * 64:(h + 1) * 64], out_plain[t, :, h * 64:(h + 1) * 64])
+    # and the timed form reports the same flag count per launch
+    ms, per = C.c_float(0), C.c_long(0)
+    _lib.check(lib.md_bench_attention_qkv(dev.handle, C.c_void_p(qkv.data_ptr()), T, N, heads, 0, 3, C.byref(ms), C.byref(per)))
+    assert per.value == flagged and ms.value > 0
+
+
 def test_full_size_properties(dev):
     """BASELINE config 3 at full size ([1,3,1536,1536], default config, bf16): size-independent checks --
     determinism, batch independence of the result, finite/positive depth, fov-depth scaling law

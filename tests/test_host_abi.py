@@ -24,7 +24,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib, repo_root):
     header = open(os.path.join(repo_root, "include", "mi_depth.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(md_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|long|void|const char\*)\s+(md_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared, "no symbols parsed from the header"
     for name in sorted(declared):
         assert hasattr(lib, name), f"libmi_depth.so does not export {name}"
