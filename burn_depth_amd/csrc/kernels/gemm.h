@@ -91,6 +91,20 @@ struct GemmParams {
   const void* res1 = nullptr;   // optional residual inputs, element type T
   const void* res2 = nullptr;
   long ldr = 0;
+  // ---- LayerNorm folded into the GEMMs on either side of it (round 6; the 256 x 256 kernel's EK 5 / 6 / 7, dense A, 16-bit operands) ----
+  // LN(x) W^T + b  =  rstd_m * (round(gamma . x) W^T  -  mu_m * c)  +  d,   c[n] = sum_k gamma[k] W[n][k],  d[n] = b[n] + sum_k beta[k] W[n][k]:
+  // the PRODUCER of x (EPI_RESID_LS: proj / fc2) also writes round_T(gamma_next . x_new) as the next GEMM's A operand and, per row and
+  // 256-column tile, (sum x, sum x^2) of x_new in fp32; the CONSUMER (qkv / fc1) finishes its accumulators with the row's mu / rstd. The
+  // stand-alone LayerNorm launch between them (read 4 B + write 2 B per element at HBM rate, 49 per ViT pass) is gone. The weights stay
+  // untouched (f16 checkpoint weights remain exact split-half operands); c, d are built at commit from the operand-rounded weights.
+  void* ln_out = nullptr;          // producer: [rows][ln_ldo] T (split-half: lo plane ln_plane elements behind the hi plane)
+  long ln_ldo = 0, ln_plane = 0;
+  const float* ln_gamma[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // producer: gamma of the NEXT LayerNorm [N]
+  float* ln_stats_out = nullptr;   // producer: [rows][N / 256][2] fp32 partial (sum, sum of squares)
+  const float* ln_stats = nullptr; // consumer: the same array; ln_parts partials per row
+  int ln_parts = 0;
+  float ln_inv_n = 0.f, ln_eps = 0.f;
+  const float* ln_c[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};      // consumer: c [N] (bias[] then carries d)
   int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)
   int res_mod = 0;              // > 0: res1's row = m % res_mod (a per-image table shared by the batch, or an input two weight groups share); res2 is never wrapped
   // EPI_PATCH_EMBED / EPI_QKV

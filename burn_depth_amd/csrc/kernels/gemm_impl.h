@@ -798,8 +798,22 @@ __global__ __launch_bounds__(WGM* WGN * 64 * KSPLIT) void gemm_kernel(const Gemm
 // and scratch spills): 0 generic (epilogue4 per vector), 1 read-modify-write residual (EPI_RESID_LS), 2 2-byte store
 // with optional residual inputs (EPI_STORE / q,k of EPI_QKV), 3 pixel shuffle (EPI_PIXSHUF), 4 = 2 with the GELU fused
 // at compile time (the fc1 GEMM: its own kernel symbol, so profilers report it separately).
+// LayerNorm folded into its neighbours (GemmParams::ln_*, round 6): 5 = 1 that also emits round_T(gamma_next . x_new) and the row
+// statistics of x_new (per 256-column tile: mean and centred sum of squares, combined without cancellation), 6 = 2 / 7 = 4 that finish
+// the accumulators with rstd_m * (acc - mu_m * c[n]) + d[n] before the store (q | k | V^T tiles of EPI_QKV; fc1's GELU).
 // DIAG = true is the diagnostic build used by md_bench_gemm only (in-kernel stamps and timing-only ablation flags); the
 // engine never launches it and the production instantiations contain none of that code.
+// sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), the total in every lane: rotations by 8, 4, 2, 1 add the same pairs
+// in every lane, so all sixteen hold bit-identical totals
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+constexpr int kLnXchg = 8 * 64 * 272;  // LDS offset of the LayerNorm-fold exchange area: behind the eight wave-private staging regions (8 KB used)
+
 template <typename T, int AMODE, int EK, bool DIAG>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
@@ -1117,6 +1131,33 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       stamp[7] = __builtin_amdgcn_s_memrealtime();
     }
   };
+  constexpr bool ln_cons = EK == 6 || EK == 7, ln_emit = EK == 5, gelu_k = EK == 4 || EK == 7;
+  float* const lnx = (float*)(smem + kLnXchg);
+  if constexpr (ln_cons) {
+    // the rows' (rstd, -mu * rstd) from the producer's per-tile partials (mean_t, M2_t over 256 columns each; Chan's combination: every
+    // term is non-negative), once per tile by threads 0 .. 255, handed to the lanes through LDS: [row][2] fp32 at kLnXchg. The loads are
+    // issued before the barrier that ends the ring's life, the LDS writes behind it.
+    float A_ = 0.f, B_ = 0.f;
+    if (tid < BM && m_base + tid < m_end) {
+      const float* sp = p.ln_stats + (long)(m_base + tid) * (2 * p.ln_parts);
+      float mu = 0.f, m2 = 0.f;
+      for (int j = 0; j < p.ln_parts; ++j) mu += sp[2 * j];
+      mu *= 1.0f / (float)p.ln_parts;
+      for (int j = 0; j < p.ln_parts; ++j) {
+        const float dl = sp[2 * j] - mu;
+        m2 += sp[2 * j + 1] + 256.0f * dl * dl;
+      }
+      const float rstd = 1.0f / sqrtf(m2 * p.ln_inv_n + p.ln_eps);
+      A_ = rstd;
+      B_ = -mu * rstd;
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+    asm volatile("" ::: "memory");
+    if (tid < BM) *(f32x2_t*)(lnx + 2 * tid) = (f32x2_t){A_, B_};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
     if constexpr (sizeof(TO) == 2) {
@@ -1138,7 +1179,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
           bia[it] = bp_[it * 4 + nl0];
-          wsc[it] = wsp_ ? wsp_[n0 + wn * WTN + it * 4 + nl0] * p.ascale : 1.f;
+          if constexpr (ln_cons) wsc[it] = MD_SEL_G(p.ln_c, g)[n0 + wn * WTN + it * 4 + nl0];  // c[n]; bia = d[n]
+          else wsc[it] = wsp_ ? wsp_[n0 + wn * WTN + it * 4 + nl0] * p.ascale : 1.f;
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -1154,6 +1196,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             }
           asm volatile("" ::: "memory");
           const int m = m_base + wm * WTM + half * 64 + (lane & 15) * 4;  // first of this lane's 4 tokens
+          f32x4_t lnA4 = {1.f, 1.f, 1.f, 1.f}, lnB4 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (ln_cons) {  // (rstd, -mu rstd) of the lane's 4 tokens
+            const float* ab = lnx + 2 * (wm * WTM + half * 64 + (lane & 15) * 4);
+            const f32x4_t t0 = *(const f32x4_t*)ab, t1 = *(const f32x4_t*)(ab + 4);
+            lnA4 = (f32x4_t){t0[0], t0[2], t1[0], t1[2]};
+            lnB4 = (f32x4_t){t0[1], t0[3], t1[1], t1[3]};
+          }
           const int seq = fdiv(m, p.fd_seq_stride);
           const int tok = m - seq * p.seq_stride;
           TO* vrow = (TO*)p.vT + (((long)seq * p.heads + hd) * 64) * p.kpad + tok;
@@ -1162,7 +1211,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           for (int it = 0; it < 16; ++it) {
             const int nl = it * 4 + nl0;
             f32x4_t v = *(const f32x4_t*)(stt + nl * SRT + (lane & 15) * 16);
-            v = v * wsc[it] + bia[it];
+            if constexpr (ln_cons) v = fma4(v, lnA4, fma4(lnB4, (f32x4_t){wsc[it], wsc[it], wsc[it], wsc[it]}, (f32x4_t){bia[it], bia[it], bia[it], bia[it]}));
+            else v = v * wsc[it] + bia[it];
             if (ok) store4p<TO>(vrow + (long)nl * p.kpad, p.v_plane, v);  // split-half: the lo plane v_plane elements behind
           }
           asm volatile("" ::: "memory");
@@ -1193,8 +1243,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int col = (lane & 15) * 4;
   const int n = n0 + wn * WTN + col;
   const bool nvalid = n < p.N;
-  constexpr bool rmw = EK == 1;
-  constexpr bool fast_store = (EK == 2 || EK == 4) && sizeof(TO) == 2;  // EK 4: GELU fused at compile time (fc1)
+  constexpr bool rmw = EK == 1 || EK == 5;
+  constexpr bool fast_store = (EK == 2 || EK == 4 || EK == 6 || EK == 7) && sizeof(TO) == 2;  // EK 4 / 7: GELU fused at compile time (fc1)
   constexpr bool pixshuf = EK == 3;
   const float* biasp = MD_SEL_G(p.bias, g);
   const int r16 = lane & 15;
@@ -1211,7 +1261,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const f32x4acc_t c = acc16[a][half * 4 + bb];
-        const f32x4_t v = xform(a, (f32x4_t){c[0], c[1], c[2], c[3]});
+        const f32x4_t v = xform(a, half * 4 + bb, (f32x4_t){c[0], c[1], c[2], c[3]});
         const int row = bb * 16 + r16;
         const int chunk = (a * 2 + (q16 >> 1)) ^ (row & 7);
         if constexpr (is_split<TO>::value) {
@@ -1258,7 +1308,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         asm volatile("" ::: "memory");
-        stage_half_2b(half, [&](int a, f32x4_t v) { return v + bq[a]; });
+        stage_half_2b(half, [&](int a, int, f32x4_t v) { return v + bq[a]; });
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1309,18 +1359,36 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int na = n0 + wn * WTN + a * 16 + 4 * q16;
         bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         wq[a] = (wsp && na < p.N) ? *(const f32x4_t*)(wsp + na) * p.ascale : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        if constexpr (ln_cons) wq[a] = na < p.N ? *(const f32x4_t*)(MD_SEL_G(p.ln_c, g) + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};  // c[n]; bq = d[n]
         if (p.epi == EPI_QKV && na < p.embed) {  // q columns: (acc * w + b) * qscale, folded into the two vectors
           bq[a] *= p.qscale;
           wq[a] *= p.qscale;
+        }
+      }
+      // LayerNorm fold: out = acc * rstd_m + (c[n] * (-mu_m rstd_m) + d[n]), (x qscale on q tiles: a tile lies inside one section);
+      // the lane's eight rows are r16 of the m-blocks 0 .. 7
+      float lnA[8], lnB[8];
+      if constexpr (ln_cons) {
+        const float qs_t = (p.epi == EPI_QKV && n0 < p.embed) ? p.qscale : 1.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const f32x2_t t = *(const f32x2_t*)(lnx + 2 * (wm * WTM + b * 16 + r16));
+          lnA[b] = t[0] * qs_t;
+          lnB[b] = t[1];
         }
       }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         asm volatile("" ::: "memory");
         if (!(DIAG && (p.debug_flags & 8)))  // timing-only ablation: skip the staging writes
-          stage_half_2b(half, [&](int a, f32x4_t v) {
-            v = fma4(v, wq[a], bq[a]);
-            if constexpr (EK == 4) {
+          stage_half_2b(half, [&](int a, int b, f32x4_t v) {
+            if constexpr (ln_cons) {
+              const f32x4_t Bv = {lnB[b], lnB[b], lnB[b], lnB[b]}, Av = {lnA[b], lnA[b], lnA[b], lnA[b]};
+              v = fma4(v, Av, fma4(wq[a], Bv, bq[a]));
+            } else {
+              v = fma4(v, wq[a], bq[a]);
+            }
+            if constexpr (gelu_k) {
               v = gelu4<TO>(v);
             } else if (relu) {
               v = relu4(v);
@@ -1404,7 +1472,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             lo += a0;
             hi += a1;
           }
-          if constexpr (EK == 4) {
+          if constexpr (gelu_k) {
             lo = gelu4<TO>(lo);
             hi = gelu4<TO>(hi);
           } else if (relu) {
@@ -1461,6 +1529,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
   }
   // wave-uniform tile base + 32-bit lane offsets (one VGPR per address instead of a 64-bit pair)
+  f32x4_t gam4 = {0.f, 0.f, 0.f, 0.f};
+  char* ln_b = nullptr;
+  if constexpr (ln_emit) {
+    if (nvalid) gam4 = *(const f32x4_t*)(MD_SEL_G(p.ln_gamma, g) + n);
+    ln_b = (char*)p.ln_out + ((long)m_base * p.ln_ldo + n0) * 2;
+  }
   char* out_b = (char*)p.out + (out_boff + (long)m_base * p.ldo + n0) * 4;
   const char* rsrc_b = p.resid_src ? (const char*)p.resid_src + ((long)m_base * p.ldo + n0) * 4 : out_b;  // EPI_RESID_LS: x is read here
   const unsigned lcol = (unsigned)(wn * WTN + col);
@@ -1498,8 +1572,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int m = m0 + it * 4;
         const unsigned lr = (unsigned)(lrow0 + it * 4);
         const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
-        if (interior || (m < m_end && nvalid))
-          *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = resid_ls4(pre2[half][it], scale4, v * ws4 + bias4);
+        const f32x4_t xnew = resid_ls4(pre2[half][it], scale4, v * ws4 + bias4);
+        if (interior || (m < m_end && nvalid)) {
+          *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = xnew;
+          if constexpr (ln_emit)  // the next GEMM's A operand: round_T(gamma_next . x_new) (split-half: both planes)
+            store4p<TO>((TO*)(ln_b + (lr * (unsigned)p.ln_ldo + lcol) * 2u), p.ln_plane, xnew * gam4);
+        }
+        if constexpr (ln_emit) {
+          // the row's statistics over this wave's 64 columns: mean, then the centred sum of squares (two 16-lane sums)
+          const float mean_w = row_sum16((xnew[0] + xnew[1]) + (xnew[2] + xnew[3])) * (1.0f / 64.0f);
+          const f32x4_t dl = xnew - mean_w;
+          const float m2_w = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
+          if ((lane & 15) == 0) *(f32x2_t*)(lnx + ((int)lr * 4 + wn) * 2) = (f32x2_t){mean_w, m2_w};
+        }
         if (half == 0 && it == 7) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) prefetch(1, j);
@@ -1540,6 +1625,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     if (half == 0) {
 #pragma unroll
       for (int it = 8; it < 16; ++it) prefetch(1, it);
+    }
+  }
+  if constexpr (ln_emit) {
+    // the four waves' (mean, M2) of a row -> the tile's: mean_t = their average (64 columns each), M2_t = sum M2_w + 64 sum (mean_w - mean_t)^2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < BM && m_base + tid < m_end) {
+      const f32x4_t a = *(const f32x4_t*)(lnx + tid * 8), b = *(const f32x4_t*)(lnx + tid * 8 + 4);
+      const float mean_t = ((a[0] + a[2]) + (b[0] + b[2])) * 0.25f;
+      const float d0 = a[0] - mean_t, d1 = a[2] - mean_t, d2 = b[0] - mean_t, d3 = b[2] - mean_t;
+      const float m2_t = ((a[1] + a[3]) + (b[1] + b[3])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      *(f32x2_t*)(p.ln_stats_out + ((long)(m_base + tid) * p.ln_parts + tile_n) * 2) = (f32x2_t){mean_t, m2_t};
     }
   }
   stamp_end();
@@ -1589,7 +1687,17 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
   };
   // epilogue specialisation (EK) from the runtime parameters
   int ek = 0;
-  if (p.epi == EPI_RESID_LS) ek = 1;
+  const bool ln_prod = p.ln_out != nullptr, ln_cons = p.ln_stats != nullptr;
+  if (ln_prod || ln_cons) {  // the LayerNorm fold exists for the dense 16-bit forms of the 256 x 256 kernel only: refuse anything else loudly
+    if (AMODE != A_DENSE || sizeof(typename OutT<T>::type) != 2 || std::is_same<T, fp8_t>::value || p.N % BN != 0 || p.batch > 1)
+      MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the LayerNorm fold needs dense 16-bit operands and N %% 256 == 0 (N=%d)", p.N);
+    if (ln_prod && (p.epi != EPI_RESID_LS || !p.ln_stats_out || p.ln_parts != p.N / BN || !p.ln_gamma[0] || p.ln_ldo % 4 != 0))
+      MD_FAIL(MD_ERR_INVALID_ARG, "gemm: LayerNorm-fold producer parameters");
+    if (ln_cons && (p.ln_parts <= 0 || !p.ln_c[0] || !p.bias[0] || p.wscale[0] || p.res1 || p.res2 || p.out2 || p.out_f32 || p.out_fp8 ||
+                    !((p.epi == EPI_QKV && p.embed % BN == 0) || (p.epi == EPI_STORE && p.act == ACT_GELU && p.res_mod == 0))))
+      MD_FAIL(MD_ERR_INVALID_ARG, "gemm: LayerNorm-fold consumer parameters");
+  }
+  if (p.epi == EPI_RESID_LS) ek = ln_prod ? 5 : 1;
   else if (p.epi == EPI_PIXSHUF) ek = 3;
   else if (sizeof(typename OutT<T>::type) == 2) {
     const long ldo_e = p.epi == EPI_QKV ? 2L * p.embed : p.ldo;
@@ -1599,11 +1707,17 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     const bool split_ok = !is_split<T>::value || (!p.res1 && !p.res2 && !p.out2 && !p.out_f32 && !p.out_fp8 && p.o_plane % 8 == 0 &&
                                                   (p.epi != EPI_QKV || p.embed % BN == 0));
     if (!split_ok) ek = 0;
-    else if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = 4;
-    else if (vec8 && ((p.epi == EPI_STORE && p.res_mod == 0 && p.act != ACT_GELU) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0))) ek = 2;
+    else if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = ln_cons ? 7 : 4;
+    else if (vec8 && ((p.epi == EPI_STORE && p.res_mod == 0 && p.act != ACT_GELU) || (p.epi == EPI_QKV && (2 * p.embed) % BN == 0))) ek = (ln_cons && p.epi == EPI_QKV) ? 6 : 2;
+    if (ln_cons && ek != 6 && ek != 7) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the LayerNorm-fold consumer needs the 16-byte store epilogue (N, ldo %% 8 == 0)");
   }
   const bool diag = p.stamps != nullptr || p.debug_flags != 0;
-  static std::atomic<unsigned long> set[5], dset[5];  // zero-initialised statics
+  static std::atomic<unsigned long> set[8], dset[5];  // zero-initialised statics
+  if constexpr (AMODE == A_DENSE && sizeof(typename OutT<T>::type) == 2 && !std::is_same<T, fp8_t>::value) {
+    if (ek == 5) return go(gemm256_kernel<T, AMODE, 5, false>, &set[5]);
+    if (ek == 6) return go(gemm256_kernel<T, AMODE, 6, false>, &set[6]);
+    if (ek == 7) return go(gemm256_kernel<T, AMODE, 7, false>, &set[7]);
+  }
   if (diag) {  // md_bench_gemm only: the stamped / ablation build exists for dense bf16 operands
     if constexpr (std::is_same<T, bf16_t>::value && AMODE == A_DENSE) {
       switch (ek) {

@@ -69,6 +69,11 @@ int launch_cls_init(float* x, int nseq_total, int S, int n_tokens, int D, const 
 int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int S, const SeqGroups& g, int prec,
                      int out_f32, hipStream_t s, float fp8_inv_scale = 1.f, const float* tok0 = nullptr, int tok0_stride = 0,
                      float* x_rw = nullptr);
+// The vectors of a LayerNorm folded into the linear layer behind it (gemm.h GemmParams::ln_*): c[n] = sum_k gamma[k] Wr[n][k],
+// d[n] = bias[n] + sum_k beta[k] Wr[n][k] with Wr = the weight as its MFMA operand holds it (rounded to bf16 / f16; split-half: hi + lo),
+// so that mu * c cancels the mean's share of the accumulators exactly as the operands produced it. W = fp32 master [N][K]; fp64 sums.
+int launch_ln_fold_vectors(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, int prec, float* c,
+                           float* d, hipStream_t s);
 // fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width = 0);
 

@@ -784,6 +784,45 @@ int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStre
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
+// ---- LayerNorm fold vectors (one wave per output row n) ----
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
+                                                              float* __restrict__ c, float* __restrict__ d) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float* w = W + (long)n * K;
+  double sc = 0.0, sd = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    float wr;
+    if constexpr (sizeof(T) == 4) {
+      wr = w[k];
+    } else {
+      const float hi = (float)cvt_elem<T>(w[k]);
+      wr = is_split<T>::value ? hi + (float)cvt_elem<T>(w[k] - hi) : hi;
+    }
+    sc += (double)gamma[k] * (double)wr;
+    sd += (double)beta[k] * (double)wr;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sc += __shfl_xor(sc, o);
+    sd += __shfl_xor(sd, o);
+  }
+  if (lane == 0) {
+    c[n] = (float)sc;
+    d[n] = (float)(sd + (bias ? (double)bias[n] : 0.0));
+  }
+}
+
+int launch_ln_fold_vectors(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, int prec, float* c,
+                           float* d, hipStream_t s) {
+  if (!W || !gamma || !beta || !c || !d || N <= 0 || K <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "ln_fold_vectors: invalid argument");
+  MD_BY_PREC(prec, hipLaunchKernelGGL(ln_fold_vectors_kernel<T>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, W, gamma, beta, bias, N, K, c, d));
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width) {
   return launch_f32_to_rows(x, count, out, prec, s, width);
 }

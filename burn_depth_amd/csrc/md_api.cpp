@@ -294,6 +294,8 @@ int md_model_query(md_model_t m, const char* key, int64_t* out) {
   else if (k == "allocs") *out = m->alloc_count;
   else if (k == "da3_shape_builds") *out = da3_shape_builds(m);
   else if (k == "batch_invariant") *out = m->batch_invariant ? 1 : 0;
+  else if (k == "ln_fold") *out = m->ln_fold_opt;
+  else if (k == "ln_fold_active") *out = m->ln_fold_on() ? 1 : 0;
   else if (model_decoder_query(m, k, out)) {}
   else MD_FAIL(MD_ERR_INVALID_ARG, "unknown query key `%s`", key);
   return MD_OK;
@@ -309,6 +311,19 @@ int md_model_set_option(md_model_t m, const char* key, int64_t value) {
       MD_HIP(hipSetDevice(m->dev->ordinal));
       MD_HIP(hipDeviceSynchronize());
       for (auto& kv : m->graphs)  // captured graphs hold the kernel forms of the old setting
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      m->graphs.clear();
+    }
+    return MD_OK;
+  }
+  if (k == "ln_fold") {
+    if (value < 0 || value > 2) MD_FAIL(MD_ERR_INVALID_ARG, "ln_fold takes 0 (off), 1 (automatic) or 2 (on whenever the model can)");
+    if (value == 2 && !m->ln_fold_can) MD_FAIL(MD_ERR_UNSUPPORTED, "ln_fold: this model cannot fold its LayerNorms (16-bit Depth Pro models of width %% 256 == 0 can)");
+    if (m->ln_fold_opt != (int)value) {
+      m->ln_fold_opt = (int)value;
+      MD_HIP(hipSetDevice(m->dev->ordinal));
+      MD_HIP(hipDeviceSynchronize());
+      for (auto& kv : m->graphs)  // captured graphs hold the launches of the old setting
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
       m->graphs.clear();
     }

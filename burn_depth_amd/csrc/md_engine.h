@@ -62,6 +62,8 @@ struct PackEntry {
 struct VitBlockW {
   const float *n1g, *n1b, *n2g, *n2b, *qkv_b, *proj_b, *ls1, *fc1_b, *fc2_b, *ls2;
   const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+  // LayerNorm fold (gemm.h GemmParams::ln_*; null when the model cannot fold): c / d of norm1 -> qkv [3D] and of norm2 -> fc1 [4D]
+  const float *qkv_c = nullptr, *qkv_d = nullptr, *fc1_c = nullptr, *fc1_d = nullptr;
 };
 struct VitW {
   const void* pe_w;
@@ -134,6 +136,14 @@ struct md_model_s {
   // md_model_set_option("batch_invariant"): no launch-size-dependent kernel form (k-split GEMM, small-launch attention): an image's result
   // has the same bits alone and inside a batch, like the reference's `infer` (a pure batch map, encoder.rs:216-225)
   bool batch_invariant = false;
+  // md_model_set_option("ln_fold"): the LayerNorms between the ViT's GEMMs folded into those GEMMs (run_vit; gemm.h GemmParams::ln_*).
+  // 1 = automatic (on for 16-bit Depth Pro models of width % 256 == 0 whose sequences have >= 256 tokens: the launches that run the
+  // 256 x 256 tiles anyway), 0 = off, 2 = on whenever the model can (small presets too: the four GEMMs of a block then keep to the
+  // 256 x 256 kernel). A MODEL-level choice, never a per-launch one: a window of a call computes the same bits as the whole call.
+  int ln_fold_opt = 1;
+  bool ln_fold_can = false;    // 16-bit Depth Pro, D % 256 == 0: the workspace and the fold vectors exist
+  float* lnfold_base = nullptr;  // root: the c / d vectors of every block (VitBlockW points into it)
+  bool ln_fold_on() const { return ln_fold_can && (ln_fold_opt == 2 || (ln_fold_opt == 1 && NT >= 256)); }
   struct GraphEntry {
     int seen = 0;
     hipGraphExec_t exec = nullptr;

@@ -293,6 +293,7 @@ struct md_model_s::Buffers {
   void* patches = nullptr;    // [nseq_p*P, Kpe] T
   float* xres = nullptr;      // [nseq*SS, D] fp32 residual stream
   void* xn = nullptr;         // [nseq*SS, D] T
+  float* ln_stats = nullptr;  // [nseq*SS, D/256, 2] fp32: per row and 256-column tile (mean, centred sum of squares) of the residual stream (LayerNorm fold)
   void* qk = nullptr;         // [nseq*SS, 2D] T
   void* vT = nullptr;         // [nseq][heads][64][kpad] T
   void* ao = nullptr;         // [nseq*SS, D] T
@@ -371,6 +372,7 @@ static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
   const size_t rows = (size_t)nseq * SS + 64;
   MD_TAKE(xres, float*, rows * D * 4);
   MD_TAKE(xn, void*, rows * D * esz);
+  if (m->ln_fold_can) MD_TAKE(ln_stats, float*, rows * (D / 256) * 8);
   MD_TAKE(qk, void*, rows * 2 * D * esz);
   MD_TAKE(vT, void*, (size_t)nseq * c.pv.heads * 64 * m->kpad * esz);
   m->vt_plane = m->xm == 2 ? (size_t)nseq * c.pv.heads * 64 * m->kpad : 0;
@@ -459,6 +461,7 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   m->xm = cfg.precision == MD_PREC_F16X2 ? 2 : 1;
   m->wterms = m->xm == 2 ? 3 : 1;
   m->ngroups = 2 + ((cfg.use_fov_head && cfg.has_fov_vit) ? 1 : 0);
+  m->ln_fold_can = (m->prec == MD_PREC_BF16 || m->prec == MD_PREC_F16 || m->prec == MD_PREC_F16X2) && cfg.pv.D % 256 == 0;
   m->S = cfg.img_size();
   m->win = cfg.pv.img;
   m->g = cfg.pv.grid();
@@ -608,6 +611,19 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
       w.blk.push_back(k);
     }
   }
+  if (m->ln_fold_can) {  // c / d of every block's two folded LayerNorms: [group][block][qkv_c 3D | qkv_d 3D | fc1_c 4D | fc1_d 4D]
+    const size_t per_blk = (size_t)14 * D;
+    if (hipMalloc((void**)&m->lnfold_base, (size_t)m->ngroups * cfg.pv.depth * per_blk * 4) != hipSuccess) {
+      set_error("hipMalloc of the LayerNorm-fold vectors failed");
+      return fail(MD_ERR_OOM);
+    }
+    for (int gi = 0; gi < m->ngroups; ++gi)
+      for (int i = 0; i < cfg.pv.depth; ++i) {
+        float* q = m->lnfold_base + ((size_t)gi * cfg.pv.depth + i) * per_blk;
+        VitBlockW& k = m->vit[gi].blk[i];
+        k.qkv_c = q; k.qkv_d = q + 3 * D; k.fc1_c = q + 6 * D; k.fc1_d = q + 10 * D;
+      }
+  }
 
   // ---- workspace ----
   m->buf = new md_model_s::Buffers();
@@ -645,6 +661,7 @@ int model_destroy(md_model_t m) {
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->w32_base) (void)hipFree(m->w32_base);
   if (m->wpk_base) (void)hipFree(m->wpk_base);
+  if (m->lnfold_base && !m->parent) (void)hipFree(m->lnfold_base);
   if (m->ws.base) (void)hipFree(m->ws.base);
   if (m->zero_page) (void)hipFree(m->zero_page);
   for (auto& kv : m->index_tables) (void)hipFree(kv.second);
@@ -689,6 +706,7 @@ int model_fork(md_model_t src, md_model_t* out) {
   m->wpk_base = root->wpk_base; m->wpk_bytes = root->wpk_bytes;
   m->committed = true;
   m->ngroups = root->ngroups;
+  m->ln_fold_can = root->ln_fold_can; m->ln_fold_opt = root->ln_fold_opt; m->lnfold_base = root->lnfold_base;
   for (int g = 0; g < 3; ++g) m->vit[g] = root->vit[g];
   m->head_b_host = root->head_b_host;
   m->S = root->S; m->win = root->win; m->g = root->g; m->P = root->P; m->NT = root->NT; m->SS = root->SS; m->kpad = root->kpad;
@@ -850,6 +868,17 @@ int model_commit(md_model_t m) {
       MD_TRY(pack_weight(composed, e, m->prec, s));
     }
   }
+  if (m->kind == 0 && m->ln_fold_can && m->lnfold_base) {
+    const int D = m->cfg.pv.D;
+    const char* vnames[3] = {"encoder.patch_encoder", "encoder.image_encoder", "fov.encoder"};
+    for (int gi = 0; gi < m->ngroups; ++gi)
+      for (int i = 0; i < m->cfg.pv.depth; ++i) {
+        const std::string b = std::string(vnames[gi]) + ".blocks." + std::to_string(i);
+        const VitBlockW& k = m->vit[gi].blk[i];
+        MD_TRY(launch_ln_fold_vectors(P32(m, b + ".attn.qkv.weight"), k.n1g, k.n1b, k.qkv_b, 3 * D, D, m->prec, (float*)k.qkv_c, (float*)k.qkv_d, s));
+        MD_TRY(launch_ln_fold_vectors(P32(m, b + ".mlp.fc1.weight"), k.n2g, k.n2b, k.fc1_b, 4 * D, D, m->prec, (float*)k.fc1_c, (float*)k.fc1_d, s));
+      }
+  }
   auto it = m->pindex.find(m->kind == 1 ? "head_mono.scratch.output_conv2.conv2.bias" : "head.conv_out.bias");
   if (it != m->pindex.end()) MD_HIP(hipMemcpyAsync(&m->head_b_host, m->w32[it->second], 4, hipMemcpyDeviceToHost, s));
   MD_HIP(hipStreamSynchronize(s));
@@ -1003,21 +1032,44 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
     }
   };
   const size_t vt_seq = (size_t)heads * 64 * m->kpad * m->esz;  // bytes of one sequence in a V^T plane
+  // LayerNorm fold (gemm.h GemmParams::ln_*): norm2 of every block and norm1 of blocks 1.. never run as launches -- the GEMM that
+  // produces the residual stream (proj / fc2) also writes round_T(gamma . x) and the rows' statistics, the GEMM behind the norm
+  // (fc1 / qkv) finishes its accumulators with them. Block 0's norm1 (behind the patch embedding) and the final norm stay launches.
+  // The four GEMMs of a block then always run the 256 x 256 kernel: the fold is a model-level choice, so that any window of a call
+  // (tile-parallel mode) computes the same bits as the whole call.
+  const bool fold = m->ln_fold_on();
+  const int fold_tile = fold ? TILE_256x256 : TILE_AUTO;
+  auto fold_producer = [&](GemmParams& p, int blk, bool norm2) {
+    p.ln_out = b->xn; p.ln_ldo = (long)D * m->xm; p.ln_plane = m->xm == 2 ? D : 0;
+    p.ln_stats_out = b->ln_stats; p.ln_parts = D / 256;
+    for (int g = 0; g < G; ++g) p.ln_gamma[g] = norm2 ? m->vit[gi[g]].blk[blk].n2g : m->vit[gi[g]].blk[blk].n1g;
+  };
+  auto fold_consumer = [&](GemmParams& p) {
+    p.ln_stats = b->ln_stats; p.ln_parts = D / 256; p.ln_inv_n = 1.0f / (float)D; p.ln_eps = c.ln_eps;
+  };
   for (int i = 0; i < c.pv.depth; ++i) {
-    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n1g; sg.b[g] = m->vit[gi[g]].blk[i].n1b; }
-    r.begin("layernorm");
-    MD_TRY(launch_layernorm(xres_w, trow(b->xn, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
-    r.end();
+    const bool fold1 = fold && i > 0;  // this block's norm1 was folded by the previous block's fc2
+    if (!fold1) {
+      for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n1g; sg.b[g] = m->vit[gi[g]].blk[i].n1b; }
+      r.begin("layernorm");
+      MD_TRY(launch_layernorm(xres_w, trow(b->xn, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+      r.end();
+    }
     {
       GemmParams p;
       p.N = 3 * D; group_rows(p);
-      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[gi[g]].blk[i].qkv_w; p.bias[g] = m->vit[gi[g]].blk[i].qkv_b; }
+      for (int g = 0; g < G; ++g) {
+        p.W[g] = m->vit[gi[g]].blk[i].qkv_w;
+        p.bias[g] = fold1 ? m->vit[gi[g]].blk[i].qkv_d : m->vit[gi[g]].blk[i].qkv_b;
+        if (fold1) p.ln_c[g] = m->vit[gi[g]].blk[i].qkv_c;
+      }
+      if (fold1) fold_consumer(p);
       p.A = b->xn;
       split_dense_a(m, p, D, D, 0);
       p.v_plane = (long)m->vt_plane;
       p.epi = EPI_QKV; p.out = b->qk; p.vT = b->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = m->kpad; p.qscale = attn_qscale(m->prec);
       r.begin("qkv_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold1 ? TILE_256x256 : TILE_AUTO, r.st));
       r.end();
     }
     void* vT_w = (char*)b->vT + (size_t)s_lo * vt_seq;
@@ -1061,24 +1113,32 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
       p.A = b->ao;
       split_dense_a(m, p, D, D, 0);
       p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
+      if (fold) fold_producer(p, i, true);
       r.begin("proj_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold_tile, r.st));
       r.end();
     }
-    for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n2g; sg.b[g] = m->vit[gi[g]].blk[i].n2b; }
-    r.begin("layernorm");
-    MD_TRY(launch_layernorm(xres_w, trow(b->xn, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
-    r.end();
+    if (!fold) {
+      for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n2g; sg.b[g] = m->vit[gi[g]].blk[i].n2b; }
+      r.begin("layernorm");
+      MD_TRY(launch_layernorm(xres_w, trow(b->xn, D), rows, D, c.ln_eps, SS, sg, m->prec, 0, r.st));
+      r.end();
+    }
     {
       GemmParams p;
       p.N = 4 * D; group_rows(p);
-      for (int g = 0; g < G; ++g) { p.W[g] = m->vit[gi[g]].blk[i].fc1_w; p.bias[g] = m->vit[gi[g]].blk[i].fc1_b; }
+      for (int g = 0; g < G; ++g) {
+        p.W[g] = m->vit[gi[g]].blk[i].fc1_w;
+        p.bias[g] = fold ? m->vit[gi[g]].blk[i].fc1_d : m->vit[gi[g]].blk[i].fc1_b;
+        if (fold) p.ln_c[g] = m->vit[gi[g]].blk[i].fc1_c;
+      }
+      if (fold) fold_consumer(p);
       p.A = b->xn;
       split_dense_a(m, p, D, D, 0);
       p.epi = EPI_STORE; p.act = ACT_GELU; p.out = b->hbuf;
       split_out(m, p, 4 * D, true);
       r.begin("fc1_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold_tile, r.st));
       r.end();
     }
     {
@@ -1090,8 +1150,9 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
       p.A = b->hbuf;
       split_dense_a(m, p, 4 * D, 4 * D, 0);
       p.epi = EPI_RESID_LS; p.out = b->xres; p.ldo = D;
+      if (fold && i + 1 < c.pv.depth) fold_producer(p, i + 1, false);
       r.begin("fc2_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, TILE_AUTO, r.st));
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold_tile, r.st));
       r.end();
     }
     // hooks: un-normalised tokens incl. cls after blocks hook_ids[0], hook_ids[1] (vit.rs:30,63): the first n0 sequences

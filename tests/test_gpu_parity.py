@@ -1497,6 +1497,35 @@ def test_native_rccl_entry_points_one_rank(dev):
         comm.destroy()
 
 
+def test_two_gpus_native_rccl_scatter_infer_gather_and_tile_exchange(dev):
+    """SURVEY 8(e) on real links, whenever the box has a second GPU (round-5 review, next #8; the 1-GPU pool skips it -- the
+    driver's multi-GPU tier is where it runs): two FRESH child processes, one per GPU (tools/two_gpu_check.py; started with
+    subprocess, i.e. before any GPU call of their own -- never an exec of this process), rendezvous id drawn here. Each asserts
+    ncclCommCount == 2, rank 1 starts from other weights and must hold rank 0's after md_comm_broadcast_weights, scatter -> infer ->
+    gather equals the one-GPU batch bit for bit, and md_comm_depth_pro_infer_tiles (tile_exchange's ncclSend / ncclRecv between two
+    devices, md_comm.cpp) equals `infer` for both roots."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: RCCL between two devices cannot run here")
+    from burn_depth_amd.parallel import NativeComm
+    uid = NativeComm.unique_id().hex()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "two_gpu_check.py"), str(r), "2", uid], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()  # exactly the two processes started here
+            pytest.fail("a rank of the two-GPU check did not finish in 420 s")
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} OK ranks_seen=2" in o, o[-3000:]
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16x2"])
 def test_tile_parallel_windows_are_bit_identical(dev, precision):
     """SURVEY 8(e), second mode: the ViT stage of one call split over sequence windows (the sliding-window tiles of
