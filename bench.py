@@ -139,6 +139,8 @@ def parse_args(argv=None):
                          "(no `kernels` / `roofline` in the line: latency mode for the single-image configurations)")
     ap.add_argument("--attention-form", choices=["asm", "hip"], default="asm",
                     help="bf16 Depth Pro attention (577 tokens): the assembly-owned gfx950 kernel (the product) or the HIP kernel every other shape runs -- an A/B switch (md_debug_attention_asm), recorded in config.attention_form when it is not the default")
+    ap.add_argument("--ln-fold", choices=["auto", "off"], default="auto",
+                    help="the LayerNorms between the ViT's GEMMs folded into those GEMMs (md_model_set_option(\"ln_fold\"): automatic = on for 16-bit models with 577-token sequences) or as stand-alone launches -- an A/B switch, recorded in config.layernorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-launch HIP events in the timed region (the `kernels` / `roofline` objects are then empty): measures what the events themselves cost")
     ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the whole-frame CPU baseline may take (predicted from a 2-tile probe); beyond it the sampled estimate is reported")
@@ -235,6 +237,8 @@ def main(argv=None) -> int:
     # weights: random init (DepthPro::new, bench/inference.rs:25). Rank 0 generates, the others receive
     # the fp32 weight arena over RCCL (one-time, outside the timed region).
     model = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
+    if args.ln_fold == "off":
+        model.set_option("ln_fold", 0)
     t_bcast = 0.0
     ncomm = None
     if args.native_comm:
@@ -473,6 +477,8 @@ def main(argv=None) -> int:
                        "streams_per_gpu": args.streams, "global_batch": B * world * args.streams,
                        "parallelism": f"dp{world}",
                        "attention_form": attention_form,
+                       "layernorm": ("folded into proj / fc2 (round(gamma x) + row statistics) and qkv / fc1 (rstd (acc - mu c) + d); block 0's norm1 and the final norm are launches"
+                                     if model.query("ln_fold_active") else "stand-alone launches"),
                        "scatter_inputs_from_rank0": do_scatter, "gather_depth_to_rank0": do_gather,
                        "comm": "native md_comm_* (RCCL point-to-point groups on a side stream)" if ncomm is not None else ("torch.distributed (RCCL)" if world > 1 else None),
                        # what the communicator itself reports (ncclCommCount / the process group's size), beside WORLD_SIZE
@@ -1166,7 +1172,7 @@ def pmc_traffic(kernel: str, B: int, args):
     WRITE_SIZE are collected in separate runs of this same command; tools/pmc_traffic.py applies the
     gfx950 corrections of MI355X_MICROARCH.md and writes profiles/rNN_traffic.json). None if the
     passes were made for another batch/precision."""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)

@@ -970,6 +970,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int q16 = lane >> 4;
   const int lane_off16 = (lane & 15) * 128 + (((((lane & 15) >> 1) & 7) ^ q16) << 4);
 
+  constexpr bool ln_cons = EK == 6 || EK == 7, ln_emit = EK == 5, gelu_k = EK == 4 || EK == 7;
   // half-tile order: A0 W0 A1 W1 A2 | W2 A3 | W3 A4 | ...   (slot = order index mod 5)
   if (DIAG && stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
   int issued = 2, slot_i = 2;
@@ -1023,6 +1024,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
   };
 
+  // LayerNorm-fold consumer (EK 6 / 7): the tile's 256 (rstd, -mu rstd) pairs (2 KB of p.ln_stats) arrive by LDS-DMA -- no VGPR rides
+  // through the main loop, no compiler-placed wait: waves 0 and 1 request them in the load segment of the LAST k-tile into the exchange
+  // area at kLnXchg (inside ring slot 4, behind every wave's staging region), when that slot is idle then (its last reader was k-tile
+  // KT - 2 or earlier: true for KT = 16 and 32); otherwise behind the loop's last barrier. Three earlier forms -- the partials combined
+  // behind the main loop; in the prologue with two VGPRs through the loop (hipcc spilled an address register whose reload in k-tile 0
+  // waits vmcnt(0): the LDS-DMA pipeline drained once per tile); eight 8-byte loads per lane in the epilogue -- each cost 2.3 - 3.8 us
+  // of a 32-us fc1 tile: the epilogue's first microsecond is latency-bound.
+  const bool ln_in_loop = ln_cons && KT >= 2 && (2 * KT - 2) % NSLOT != 4 && (2 * KT - 1) % NSLOT != 4;
+  auto issue_ln_ab = [&]() __attribute__((always_inline)) {
+    if (wave < 2) {
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));  // keeps the address arithmetic (and its two VGPRs) out of the main loop's live ranges
+      int r2 = m_base + 2 * (wave * 64 + l2);
+      r2 = r2 < m_end - 2 ? r2 : m_end - 2;  // rows past the group are never used; keep the request inside the array
+      glds16((const char*)p.ln_stats + (long)r2 * 8, smem + kLnXchg + wave * 1024);
+    }
+  };
   // ---- the staggered two-group schedule on 16x16x32 MFMAs, with 512-cycle MFMA clusters ----
   // Two phases per k-tile (one per 32-deep k-step): R = 4 W + 8 A fragment reads (+ the LDS-DMA issue of the next
   // half-tiles), M = 32 MFMAs = 512 cycles, so the ~100-cycle s_barrier round trip is paid 4 times per k-tile. Every R
@@ -1101,6 +1119,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         if (ks == 0) issue_next_W(t);
         if (ks == 1) issue_next_A(t);
       }
+      if constexpr (ln_cons) {
+        if (ks == 0 && t == KT - 1 && ln_in_loop) issue_ln_ab();
+      }
       if (g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -1131,32 +1152,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       stamp[7] = __builtin_amdgcn_s_memrealtime();
     }
   };
-  constexpr bool ln_cons = EK == 6 || EK == 7, ln_emit = EK == 5, gelu_k = EK == 4 || EK == 7;
   float* const lnx = (float*)(smem + kLnXchg);
+  // LayerNorm-fold consumer (EK 6 / 7): p.ln_stats = [rows][2] fp32 (rstd, -mu rstd) per row, finished from the producer's partials by
+  // ln_finish_kernel between the two GEMMs. (Two earlier forms: the partials combined here behind the main loop -- dependent loads, a
+  // division and a square root in front of the epilogue: +2.4 us per 32-us fc1 tile; combined in the prologue and carried through the
+  // main loop in two VGPRs -- the kernel sits at the 256-register edge, hipcc spilled an address register and its reload in k-tile 0
+  // waits vmcnt(0), draining the LDS-DMA pipeline once per tile: the same +2.3 us.)
   if constexpr (ln_cons) {
-    // the rows' (rstd, -mu * rstd) from the producer's per-tile partials (mean_t, M2_t over 256 columns each; Chan's combination: every
-    // term is non-negative), once per tile by threads 0 .. 255, handed to the lanes through LDS: [row][2] fp32 at kLnXchg. The loads are
-    // issued before the barrier that ends the ring's life, the LDS writes behind it.
-    float A_ = 0.f, B_ = 0.f;
-    if (tid < BM && m_base + tid < m_end) {
-      const float* sp = p.ln_stats + (long)(m_base + tid) * (2 * p.ln_parts);
-      float mu = 0.f, m2 = 0.f;
-      for (int j = 0; j < p.ln_parts; ++j) mu += sp[2 * j];
-      mu *= 1.0f / (float)p.ln_parts;
-      for (int j = 0; j < p.ln_parts; ++j) {
-        const float dl = sp[2 * j] - mu;
-        m2 += sp[2 * j + 1] + 256.0f * dl * dl;
-      }
-      const float rstd = 1.0f / sqrtf(m2 * p.ln_inv_n + p.ln_eps);
-      A_ = rstd;
-      B_ = -mu * rstd;
+    if (!ln_in_loop) {  // slot 4 was the last k-tile's: request the pairs once every wave has left the ring
+      __builtin_amdgcn_s_barrier();
+      issue_ln_ab();
     }
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring
-    asm volatile("" ::: "memory");
-    if (tid < BM) *(f32x2_t*)(lnx + 2 * tid) = (f32x2_t){A_, B_};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requesting waves' pairs have landed; each path's first barrier publishes them
   }
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {
@@ -1197,7 +1204,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           asm volatile("" ::: "memory");
           const int m = m_base + wm * WTM + half * 64 + (lane & 15) * 4;  // first of this lane's 4 tokens
           f32x4_t lnA4 = {1.f, 1.f, 1.f, 1.f}, lnB4 = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (ln_cons) {  // (rstd, -mu rstd) of the lane's 4 tokens
+          if constexpr (ln_cons) {  // (rstd, -mu rstd) of the lane's 4 tokens (rows m .. m + 3: all inside or all outside the group)
             const float* ab = lnx + 2 * (wm * WTM + half * 64 + (lane & 15) * 4);
             const f32x4_t t0 = *(const f32x4_t*)ab, t1 = *(const f32x4_t*)(ab + 4);
             lnA4 = (f32x4_t){t0[0], t0[2], t1[0], t1[2]};
@@ -1418,8 +1425,85 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
     // residual inputs / fp32, fp8 or second output: fp32 staging, the raw residual vectors of a half prefetched before
     // its staging pass (the dependent load -> store chain, not bandwidth, set the cost of the residual-conv epilogue)
-    // (one-plane outputs only: launch_256 sends split-half launches with residuals / second outputs to the generic kind)
-    if constexpr (is_split<TO>::value) return;
+    // Split-half outputs (round 6; they took the generic per-vector epilogue before: dec_conv3x3 2.24x its bf16 time): the same
+    // fp32 staging, both planes of the residual inputs through a rolling window of four row groups (a value is its hi + lo), both
+    // planes of the result (and of the relu'd second output) by 16-byte stores.
+    if constexpr (is_split<TO>::value) {
+      f32x4_t bl = {0.f, 0.f, 0.f, 0.f}, bh = bl;
+      if (biasp && nv8) {
+        bl = *(const f32x4_t*)(biasp + n8);
+        bh = *(const f32x4_t*)(biasp + n8 + 4);
+      }
+      const long trb = (long)m_base * p.ldr + n0;
+      const char* q1b = (const char*)p.res1 + trb * 2;
+      const char* q2b = (const char*)p.res2 + trb * 2;
+      const unsigned rlo = (unsigned)p.r_plane * 2u, olo = (unsigned)lo_off * 2u;
+      i32x4_t w1h[4], w1l[4], w2h[4], w2l[4];
+      auto issue_res = [&](int half, int it) __attribute__((always_inline)) {
+        if (!any_res) return;
+        const int lrow_t = wm * WTM + half * 64 + it * 8 + rsub;
+        const bool ok = interior || (m_base + lrow_t < m_end && nv8);
+        const unsigned ro = ((unsigned)lrow_t * (unsigned)p.ldr + lc8) * 2u;
+        const i32x4_t z = {0, 0, 0, 0};
+        w1h[it & 3] = (r1 && ok) ? *(const i32x4_t*)(q1b + ro) : z;
+        w1l[it & 3] = (r1 && ok) ? *(const i32x4_t*)(q1b + ro + rlo) : z;
+        w2h[it & 3] = (r2 && ok) ? *(const i32x4_t*)(q2b + ro) : z;
+        w2l[it & 3] = (r2 && ok) ? *(const i32x4_t*)(q2b + ro + rlo) : z;
+      };
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        asm volatile("" ::: "memory");
+        stage_half_f32(half);
+        asm volatile("" ::: "memory");
+        if (half == 0) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) issue_res(0, it);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + rsub;
+          const int lrow_t = wm * WTM + half * 64 + row;
+          f32x4_t lo = *(const f32x4_t*)(st + row * SROW + c8 * 4);
+          f32x4_t hi = *(const f32x4_t*)(st + row * SROW + c8 * 4 + 16);
+          if (interior || (m_base + lrow_t < m_end && nv8)) {
+            lo += bl;
+            hi += bh;
+            if (any_res) {
+              // the generic epilogue's order, so that a layer computes the same bits on every tile size: (acc + bias) + (r1_hi + r1_lo) + (r2_hi + r2_lo)
+              f32x4_t a0, a1, b0, b1;
+              widen8<TO>(w1h[it & 3], a0, a1);
+              widen8<TO>(w1l[it & 3], b0, b1);
+              if (r1) { lo += a0 + b0; hi += a1 + b1; }
+              widen8<TO>(w2h[it & 3], a0, a1);
+              widen8<TO>(w2l[it & 3], b0, b1);
+              if (r2) { lo += a0 + b0; hi += a1 + b1; }
+            }
+            if constexpr (gelu_k) {
+              lo = gelu4<TO>(lo);
+              hi = gelu4<TO>(hi);
+            } else if (relu) {
+              lo = relu4(lo);
+              hi = relu4(hi);
+            }
+            const unsigned eo = ((unsigned)lrow_t * (unsigned)ldo8 + lc8) * 2u;
+            i32x4_t ph, pl;
+            split8<TO>(lo, hi, ph, pl);
+            *(i32x4_t*)(ob + eo) = ph;
+            *(i32x4_t*)(ob + eo + olo) = pl;
+            if (has_o2) {
+              split8<TO>(relu4(lo), relu4(hi), ph, pl);
+              *(i32x4_t*)(o2b + eo) = ph;
+              *(i32x4_t*)(o2b + eo + olo) = pl;
+            }
+          }
+          if (it + 4 < 8) issue_res(half, it + 4);
+          else if (half == 0) issue_res(1, it - 4);
+        }
+        asm volatile("" ::: "memory");
+      }
+      stamp_end();
+      return;
+    }
     f32x4_t bl = {0.f, 0.f, 0.f, 0.f}, bh = bl;
     if (biasp && nv8) {
       bl = *(const f32x4_t*)(biasp + n8);
@@ -1693,7 +1777,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
       MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the LayerNorm fold needs dense 16-bit operands and N %% 256 == 0 (N=%d)", p.N);
     if (ln_prod && (p.epi != EPI_RESID_LS || !p.ln_stats_out || p.ln_parts != p.N / BN || !p.ln_gamma[0] || p.ln_ldo % 4 != 0))
       MD_FAIL(MD_ERR_INVALID_ARG, "gemm: LayerNorm-fold producer parameters");
-    if (ln_cons && (p.ln_parts <= 0 || !p.ln_c[0] || !p.bias[0] || p.wscale[0] || p.res1 || p.res2 || p.out2 || p.out_f32 || p.out_fp8 ||
+    if (ln_cons && (!p.ln_c[0] || !p.bias[0] || p.wscale[0] || p.res1 || p.res2 || p.out2 || p.out_f32 || p.out_fp8 ||
                     !((p.epi == EPI_QKV && p.embed % BN == 0) || (p.epi == EPI_STORE && p.act == ACT_GELU && p.res_mod == 0))))
       MD_FAIL(MD_ERR_INVALID_ARG, "gemm: LayerNorm-fold consumer parameters");
   }
@@ -1704,7 +1788,8 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     const bool vec8 = p.N % 8 == 0 && ldo_e % 8 == 0 && (!(p.res1 || p.res2) || p.ldr % 8 == 0);
     // split-half outputs take the store kinds only for their lean sub-path (no residual inputs, no second / fp32 output) and,
     // for q | k tiles, when a tile cannot straddle the q | k sections of the [q_hi | q_lo | k_hi | k_lo] rows
-    const bool split_ok = !is_split<T>::value || (!p.res1 && !p.res2 && !p.out2 && !p.out_f32 && !p.out_fp8 && p.o_plane % 8 == 0 &&
+    // (round 6: residual inputs and the relu'd second output included)
+    const bool split_ok = !is_split<T>::value || (!p.out_f32 && !p.out_fp8 && p.o_plane % 8 == 0 && (!(p.res1 || p.res2) || p.r_plane % 8 == 0) &&
                                                   (p.epi != EPI_QKV || p.embed % BN == 0));
     if (!split_ok) ek = 0;
     else if (vec8 && p.epi == EPI_STORE && p.res_mod == 0 && p.act == ACT_GELU) ek = ln_cons ? 7 : 4;

@@ -74,6 +74,9 @@ int launch_layernorm(const float* x, void* out, long rows, int D, float eps, int
 // so that mu * c cancels the mean's share of the accumulators exactly as the operands produced it. W = fp32 master [N][K]; fp64 sums.
 int launch_ln_fold_vectors(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K, int prec, float* c,
                            float* d, hipStream_t s);
+// LayerNorm fold: the per-row partials the producer GEMM wrote ([rows][4][2]: mean and centred sum of squares of each 256-column tile)
+// combined (Chan: every term non-negative) into ab[row] = (rstd, -mu * rstd) for the consumer GEMM's epilogue. D = 1024.
+int launch_ln_finish(const float* parts, float* ab, long rows, float inv_n, float eps, hipStream_t s);
 // fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width = 0);
 

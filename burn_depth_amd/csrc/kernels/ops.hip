@@ -784,6 +784,26 @@ int launch_f32_to_rows(const float* in, long count, void* out, int prec, hipStre
   MD_HIP(hipGetLastError());
   return MD_OK;
 }
+// ---- LayerNorm fold: (mean_t, M2_t) x 4 -> (rstd, -mu rstd) per row ----
+__global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict__ parts, float* __restrict__ ab, long rows, float inv_n, float eps) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const f32x4_t p0 = *(const f32x4_t*)(parts + r * 8), p1 = *(const f32x4_t*)(parts + r * 8 + 4);
+  const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+  const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
+  const float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + 256.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+  const float rstd = 1.0f / sqrtf(m2 * inv_n + eps);
+  ab[r * 2] = rstd;
+  ab[r * 2 + 1] = -mu * rstd;
+}
+
+int launch_ln_finish(const float* parts, float* ab, long rows, float inv_n, float eps, hipStream_t s) {
+  if (!parts || !ab || rows <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "ln_finish: invalid argument");
+  hipLaunchKernelGGL(ln_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, parts, ab, rows, inv_n, eps);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 // ---- LayerNorm fold vectors (one wave per output row n) ----
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const float* __restrict__ W, const float* __restrict__ gamma,

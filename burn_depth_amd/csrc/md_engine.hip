@@ -294,6 +294,7 @@ struct md_model_s::Buffers {
   float* xres = nullptr;      // [nseq*SS, D] fp32 residual stream
   void* xn = nullptr;         // [nseq*SS, D] T
   float* ln_stats = nullptr;  // [nseq*SS, D/256, 2] fp32: per row and 256-column tile (mean, centred sum of squares) of the residual stream (LayerNorm fold)
+  float* ln_ab = nullptr;     // [nseq*SS, 2] fp32: (rstd, -mu rstd) per row, finished from ln_stats between the producer and the consumer GEMM
   void* qk = nullptr;         // [nseq*SS, 2D] T
   void* vT = nullptr;         // [nseq][heads][64][kpad] T
   void* ao = nullptr;         // [nseq*SS, D] T
@@ -373,6 +374,7 @@ static int plan_workspace(md_model_s* m, bool dry, size_t* total_out) {
   MD_TAKE(xres, float*, rows * D * 4);
   MD_TAKE(xn, void*, rows * D * esz);
   if (m->ln_fold_can) MD_TAKE(ln_stats, float*, rows * (D / 256) * 8);
+  if (m->ln_fold_can) MD_TAKE(ln_ab, float*, rows * 8);
   MD_TAKE(qk, void*, rows * 2 * D * esz);
   MD_TAKE(vT, void*, (size_t)nseq * c.pv.heads * 64 * m->kpad * esz);
   m->vt_plane = m->xm == 2 ? (size_t)nseq * c.pv.heads * 64 * m->kpad : 0;
@@ -461,7 +463,7 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   m->xm = cfg.precision == MD_PREC_F16X2 ? 2 : 1;
   m->wterms = m->xm == 2 ? 3 : 1;
   m->ngroups = 2 + ((cfg.use_fov_head && cfg.has_fov_vit) ? 1 : 0);
-  m->ln_fold_can = (m->prec == MD_PREC_BF16 || m->prec == MD_PREC_F16 || m->prec == MD_PREC_F16X2) && cfg.pv.D % 256 == 0;
+  m->ln_fold_can = (m->prec == MD_PREC_BF16 || m->prec == MD_PREC_F16 || m->prec == MD_PREC_F16X2) && cfg.pv.D == 1024;  // four 256-column tiles per row: the consumer reads exactly four partials
   m->S = cfg.img_size();
   m->win = cfg.pv.img;
   m->g = cfg.pv.grid();
@@ -1045,7 +1047,13 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
     for (int g = 0; g < G; ++g) p.ln_gamma[g] = norm2 ? m->vit[gi[g]].blk[blk].n2g : m->vit[gi[g]].blk[blk].n1g;
   };
   auto fold_consumer = [&](GemmParams& p) {
-    p.ln_stats = b->ln_stats; p.ln_parts = D / 256; p.ln_inv_n = 1.0f / (float)D; p.ln_eps = c.ln_eps;
+    p.ln_stats = b->ln_ab; p.ln_parts = D / 256; p.ln_inv_n = 1.0f / (float)D; p.ln_eps = c.ln_eps;
+  };
+  auto fold_finish = [&]() -> int {  // the window's rows: (mean, M2) x 4 -> (rstd, -mu rstd)
+    r.begin("ln_finish");
+    const int st_ = launch_ln_finish(b->ln_stats + (size_t)s_lo * SS * (D / 256) * 2, b->ln_ab + (size_t)s_lo * SS * 2, rows, 1.0f / (float)D, c.ln_eps, r.st);
+    r.end();
+    return st_;
   };
   for (int i = 0; i < c.pv.depth; ++i) {
     const bool fold1 = fold && i > 0;  // this block's norm1 was folded by the previous block's fc2
@@ -1117,6 +1125,7 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
       r.begin("proj_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold_tile, r.st));
       r.end();
+      if (fold) MD_TRY(fold_finish());
     }
     if (!fold) {
       for (int g = 0; g < G; ++g) { sg.a[g] = m->vit[gi[g]].blk[i].n2g; sg.b[g] = m->vit[gi[g]].blk[i].n2b; }
@@ -1154,6 +1163,7 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
       r.begin("fc2_gemm");
       MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold_tile, r.st));
       r.end();
+      if (fold && i + 1 < c.pv.depth) MD_TRY(fold_finish());
     }
     // hooks: un-normalised tokens incl. cls after blocks hook_ids[0], hook_ids[1] (vit.rs:30,63): the first n0 sequences
     // (the 5 x 5 high-resolution tiles, encoder.rs:379-390)

@@ -304,6 +304,11 @@ def interpolate_pos_encoding(pos: Tensor, gh: int, gw: int, offset: float = 0.1)
     return torch.cat([pos[:, :1], patch.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], 1)
 
 
+# Operand-rounding emulation only (q is not identity): restate the engine's LayerNorm fold (every norm2, norm1 of blocks 1..) so that a
+# test can hold a 16-bit mode to an oracle that rounds WHERE the engine rounds. False = the reference's order of operations with the
+# operand roundings of the unfolded schedule. The fp32 oracle (q = identity) never looks at it.
+LN_FOLD_EMULATION = False
+
 ATTN_QSCALE = float(np.float32(0.125) * np.float32(1.4426950408889634))  # head_dim^-0.5 * log2(e), head_dim = 64
 
 
@@ -328,10 +333,22 @@ def _vit_forward_chunk(x, W, prefix, v, hook_ids, q, fp8=False):
     N = xs.shape[1]
     scale = hd ** -0.5
     hooks: List[Tensor] = []
+
+    def norm_linear(xs_, g_, b_, w_, bias_, folded):
+        """LN(x) W^T + bias. `folded` (operand-rounding emulation only): the engine's LayerNorm fold -- the MFMA operand is
+        round(gamma . x), not round(LN x), and the row statistics finish the product: rstd (acc - mu c) + d with c = Wq gamma,
+        d = Wq beta + bias (csrc/kernels/gemm.h GemmParams::ln_*). Same value in exact arithmetic; the rounding falls elsewhere."""
+        if not folded:
+            return F.linear(qn(F.layer_norm(xs_, (D,), g_, b_, v.ln_eps)), qw(w_), bias_)
+        wq_ = qw(w_)
+        mu = xs_.mean(-1, keepdim=True)
+        rstd = (xs_.var(-1, unbiased=False, keepdim=True) + v.ln_eps).rsqrt()
+        return rstd * (F.linear(qn(xs_ * g_), wq_) - mu * (wq_ @ g_)) + (wq_ @ b_ + bias_)
+
+    fold = LN_FOLD_EMULATION and q is not identity and not fp8
     for i in range(v.depth):
         b = f"blocks.{i}"
-        xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), v.ln_eps))
-        qkv = F.linear(xn, qw(p(f"{b}.attn.qkv.weight")), p(f"{b}.attn.qkv.bias"))
+        qkv = norm_linear(xs, p(f"{b}.norm1.gamma"), p(f"{b}.norm1.beta"), p(f"{b}.attn.qkv.weight"), p(f"{b}.attn.qkv.bias"), fold and i > 0)
         qkv = qkv.reshape(B, N, 3, Hn, hd).permute(2, 0, 3, 1, 4)
         qq, kk, vv = round_q_prescaled(qkv[0], q), q(qkv[1]), q(qkv[2])
         s = (qq @ kk.transpose(-2, -1)) * scale
@@ -339,8 +356,7 @@ def _vit_forward_chunk(x, W, prefix, v, hook_ids, q, fp8=False):
         o = (q(pu) @ vv) / pu.sum(-1, keepdim=True)
         o = qo(o.transpose(1, 2).reshape(B, N, D))
         xs = xs + p(f"{b}.ls1.gamma") * F.linear(o, qw(p(f"{b}.attn.proj.weight")), p(f"{b}.attn.proj.bias"))
-        xn = qn(F.layer_norm(xs, (D,), p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), v.ln_eps))
-        h = qh(F.gelu(F.linear(xn, qw(p(f"{b}.mlp.fc1.weight")), p(f"{b}.mlp.fc1.bias"))))
+        h = qh(F.gelu(norm_linear(xs, p(f"{b}.norm2.gamma"), p(f"{b}.norm2.beta"), p(f"{b}.mlp.fc1.weight"), p(f"{b}.mlp.fc1.bias"), fold)))
         xs = xs + p(f"{b}.ls2.gamma") * F.linear(h, qw(p(f"{b}.mlp.fc2.weight")), p(f"{b}.mlp.fc2.bias"))
         for hid in hook_ids:
             if hid == i:

@@ -116,6 +116,65 @@ def test_depth_pro_small_preset_end_to_end(diag, dev, precision):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("precision", [0, 3, 4])
+def test_layernorm_fold_small_preset_against_the_oracle(diag, dev, precision):
+    """Round 6: the LayerNorms between a ViT block's GEMMs folded into those GEMMs (gemm.h GemmParams::ln_*: proj / fc2 also write
+    round_T(gamma . x) and the rows' (mean, M2) partials, qkv / fc1 finish their accumulators with rstd (acc - mu c) + d). Automatic
+    only for 577-token models; forced on here (`ln_fold` = 2) for the reference's CI preset (ViT-L, 65 tokens: src/lib.rs:102-112) and
+    held to the fp32 oracle with the SAME tolerances as the unfolded path, taps included (bf16, f16, split-half on f16 weights).
+    Arithmetic restated: burn_dino block order at oracle/depth_pro_ref.py:331-347 (x += ls1 attn(LN1 x); x += ls2 mlp(LN2 x))."""
+    from burn_depth_amd.config import DepthProConfig
+    start = len(diag.RESULTS)
+    diag.guarded("small-fold")(diag.run_e2e)(dev, DepthProConfig.small_test(), f"small/fold/p{precision}", 1, (512, 512), precision,
+                                             f16_weights=precision == 4, ln_fold=2)
+    _assert_new_results_ok(diag, start)
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 6e-2), (3, 8e-3), (4, 1e-4)])
+def test_layernorm_fold_against_the_unfolded_path_and_over_windows(dev, precision, tol):
+    """The folded and the unfolded schedule of ONE model on the same frames: depth within `tol` (relative, maximum over the frame; the
+    two differ in where the operand rounding falls -- round(gamma x) against round(LN x) -- bf16 6e-2, f16 8e-3, split-half 1e-4) and
+    fov within the modes' bounds; 46 of the 49 stand-alone LayerNorm launches per ViT pass are gone (block 0's norm1 and the final norm
+    stay; three encoders share the launches); the folded result is bit-identical over sequence windows (a model-level choice: the
+    tile-parallel mode of SURVEY 8(e) computes the bits of the whole call) and across batch sizes."""
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    cfg = DepthProConfig.small_test()
+    cfg.precision = precision
+    cfg.max_batch = 2
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    if precision == 4:
+        m.round_weights_to_f16()
+    assert m.query("ln_fold") == 1 and m.query("ln_fold_active") == 0  # automatic: off for 65-token sequences
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 512, 512, device="cuda")
+    want = m.infer(x)
+    m.enable_timing(True)
+    m.infer(x)
+    plain_ln = m.read_timing()["layernorm"][1]
+    m.set_option("ln_fold", 2)
+    assert m.query("ln_fold_active") == 1
+    m.infer(x)
+    fold_ln = m.read_timing()["layernorm"][1]
+    m.enable_timing(False)
+    assert plain_ln == 49 and fold_ln == 2, (plain_ln, fold_ln)
+    got = m.infer(x)
+    rel = ((got.depth - want.depth).abs() / want.depth.abs()).max().item()
+    assert rel <= tol, rel
+    assert (got.fovx_deg - want.fovx_deg).abs().max().item() <= {0: 0.05, 3: 8e-3, 4: 1e-3}[precision]
+    one = m.infer(x[:1])
+    assert torch.equal(one.depth, got.depth[:1])  # batch-independent bits
+    for parts in (2, 5, 37):
+        assert torch.equal(m.infer_windows(x, parts).depth, got.depth), parts
+    g = m.fork()
+    assert g.query("ln_fold_active") == 1 and torch.equal(g.infer(x).depth, got.depth)
+    g.destroy()
+    m.set_option("ln_fold", 0)
+    assert torch.equal(m.infer(x).depth, want.depth)
+    m.destroy()
+
+
 @pytest.mark.parametrize("precision,B,host,preset", [(1, 1, False, "tiny"), (4, 2, True, "tiny"), (0, 1, False, "tiny"), (3, 1, False, "tiny"),
                                                      (1, 1, True, "small"), (4, 1, False, "small")])
 def test_decoder_from_features_and_head_debug(diag, dev, precision, B, host, preset):

@@ -571,11 +571,14 @@ def pctl(t: torch.Tensor, q: float) -> float:
     return float(flat.kthvalue(k).values)
 
 
-def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY, tols=None, emulated=True, timing=True, f16_weights=False):
+def run_e2e(dev, cfg, label, B, hw, precision, taps=True, scheme=Wt.INIT_PARITY, tols=None, emulated=True, timing=True, f16_weights=False, ln_fold=None):
     cfg.precision = precision
     cfg.max_batch = max(B, 1)
     t0 = time.time()
     model = DepthPro.new(dev, cfg, seed=0, init_scheme=scheme)
+    if ln_fold is not None:  # md_model_set_option("ln_fold"): 0 off, 1 automatic, 2 on whenever the model can
+        model.set_option("ln_fold", ln_fold)
+        record(f"{label} ln_fold_active", float(model.query("ln_fold_active")), 1.0 if ln_fold == 2 else 0.0)
     print(f"      model created in {time.time() - t0:.1f}s  workspace={model.query('workspace_bytes') / 1e9:.2f} GB weights={model.query('weight_bytes') / 1e9:.2f} GB", flush=True)
     W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, scheme))
     if f16_weights:  # an f16 checkpoint of the seeded weights (mod.rs:206) on both sides
@@ -728,7 +731,11 @@ def run_full_size(dev, precisions=(Precision.F32, Precision.F16, Precision.BF16)
             record(f"{label} fovx_deg abs", (out.fovx_deg.cpu() - ref['fovx_deg']).abs().max().item(), ftol[0], f"fov={ref['fovx_deg'].tolist()}")
         else:
             record(f"{label} fovy_rad abs", (out.fovy_rad.cpu() - ref['fovy_rad']).abs().max().item(), ftol[1])
-        record(f"{label} focallength rel", rel_err(out.focallength_px, ref["focallength_px"]), tol[1])
+        # f_px = 0.5 W / tan(0.5 fovx): its relative error is fovx's relative error, so the bound cannot be tighter than the fov bound
+        # over the fov itself (config 1 -- zeros, reference initialisation -- has fovx = 0.057 deg: 3.9e-4 deg of bf16 error, inside the
+        # 5e-2 deg fov bound, is 6.9e-3 of the focal length)
+        fov_ref = float(ref["fovx_deg"].abs().min())
+        record(f"{label} focallength rel", rel_err(out.focallength_px, ref["focallength_px"]), max(tol[1], ftol[0] / max(fov_ref, 1e-6) if rgb is None else tol[1]))
         model.destroy()
 
 
