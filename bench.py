@@ -139,7 +139,7 @@ def parse_args(argv=None):
                          "(no `kernels` / `roofline` in the line: latency mode for the single-image configurations)")
     ap.add_argument("--attention-form", choices=["asm", "hip"], default="asm",
                     help="bf16 Depth Pro attention (577 tokens): the assembly-owned gfx950 kernel (the product) or the HIP kernel every other shape runs -- an A/B switch (md_debug_attention_asm), recorded in config.attention_form when it is not the default")
-    ap.add_argument("--ln-fold", choices=["auto", "off"], default="auto",
+    ap.add_argument("--ln-fold", choices=["auto", "off", "neutral"], default="auto",
                     help="the LayerNorms between the ViT's GEMMs folded into those GEMMs (md_model_set_option(\"ln_fold\"): automatic = on for 16-bit models with 577-token sequences) or as stand-alone launches -- an A/B switch, recorded in config.layernorm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-launch HIP events in the timed region (the `kernels` / `roofline` objects are then empty): measures what the events themselves cost")
@@ -237,8 +237,8 @@ def main(argv=None) -> int:
     # weights: random init (DepthPro::new, bench/inference.rs:25). Rank 0 generates, the others receive
     # the fp32 weight arena over RCCL (one-time, outside the timed region).
     model = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
-    if args.ln_fold == "off":
-        model.set_option("ln_fold", 0)
+    if args.ln_fold != "auto":  # "neutral": a diagnostic -- the unfolded schedule through the fold-form consumer kernels on neutral statistics
+        model.set_option("ln_fold", 0 if args.ln_fold == "off" else 3)
     t_bcast = 0.0
     ncomm = None
     if args.native_comm:

@@ -1659,9 +1659,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const f32x4_t xnew = resid_ls4(pre2[half][it], scale4, v * ws4 + bias4);
         if (interior || (m < m_end && nvalid)) {
           *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = xnew;
+#ifndef MD_LNFOLD_NOCOPY
           if constexpr (ln_emit)  // the next GEMM's A operand: round_T(gamma_next . x_new) (split-half: both planes)
+#else
+          if constexpr (false)
+#endif
             store4p<TO>((TO*)(ln_b + (lr * (unsigned)p.ln_ldo + lcol) * 2u), p.ln_plane, xnew * gam4);
         }
+#ifndef MD_LNFOLD_NOSTATS  // (timing-only experiment: EXTRA=-DMD_LNFOLD_NOSTATS leaves the statistics out; results are wrong)
         if constexpr (ln_emit) {
           // the row's statistics over this wave's 64 columns: mean, then the centred sum of squares (two 16-lane sums)
           const float mean_w = row_sum16((xnew[0] + xnew[1]) + (xnew[2] + xnew[3])) * (1.0f / 64.0f);
@@ -1669,6 +1674,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           const float m2_w = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
           if ((lane & 15) == 0) *(f32x2_t*)(lnx + ((int)lr * 4 + wn) * 2) = (f32x2_t){mean_w, m2_w};
         }
+#endif
         if (half == 0 && it == 7) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) prefetch(1, j);

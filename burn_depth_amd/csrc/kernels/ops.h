@@ -76,6 +76,8 @@ int launch_ln_fold_vectors(const float* W, const float* gamma, const float* beta
                            float* d, hipStream_t s);
 // LayerNorm fold: the per-row partials the producer GEMM wrote ([rows][4][2]: mean and centred sum of squares of each 256-column tile)
 // combined (Chan: every term non-negative) into ab[row] = (rstd, -mu * rstd) for the consumer GEMM's epilogue. D = 1024.
+// ab[row] = (a, b) for `rows` rows (the diagnostic form of the fold: neutral statistics)
+int launch_fill_pairs(float* ab, long rows, float a, float b, hipStream_t s);
 int launch_ln_finish(const float* parts, float* ab, long rows, float inv_n, float eps, hipStream_t s);
 // fp32 rows -> T rows (hooks: un-normalised tokens), same row layout.
 int launch_convert_rows(const float* x, void* out, long count, int prec, hipStream_t s, int width = 0);

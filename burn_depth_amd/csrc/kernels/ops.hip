@@ -797,6 +797,17 @@ __global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict_
   ab[r * 2 + 1] = -mu * rstd;
 }
 
+__global__ __launch_bounds__(256) void fill_pairs_kernel(float* __restrict__ ab, long rows, float a, float b) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) { ab[2 * r] = a; ab[2 * r + 1] = b; }
+}
+int launch_fill_pairs(float* ab, long rows, float a, float b, hipStream_t s) {
+  if (!ab || rows <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "fill_pairs: invalid argument");
+  hipLaunchKernelGGL(fill_pairs_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, ab, rows, a, b);
+  MD_HIP(hipGetLastError());
+  return MD_OK;
+}
+
 int launch_ln_finish(const float* parts, float* ab, long rows, float inv_n, float eps, hipStream_t s) {
   if (!parts || !ab || rows <= 0) MD_FAIL(MD_ERR_INVALID_ARG, "ln_finish: invalid argument");
   hipLaunchKernelGGL(ln_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, parts, ab, rows, inv_n, eps);

@@ -615,7 +615,8 @@ int model_create(md_device_t dev, const ModelCfg& cfg, md_model_t* out) {
   }
   if (m->ln_fold_can) {  // c / d of every block's two folded LayerNorms: [group][block][qkv_c 3D | qkv_d 3D | fc1_c 4D | fc1_d 4D]
     const size_t per_blk = (size_t)14 * D;
-    if (hipMalloc((void**)&m->lnfold_base, (size_t)m->ngroups * cfg.pv.depth * per_blk * 4) != hipSuccess) {
+    if (hipMalloc((void**)&m->lnfold_base, ((size_t)m->ngroups * cfg.pv.depth * per_blk + 4 * D) * 4) != hipSuccess ||
+        hipMemset(m->lnfold_base + (size_t)m->ngroups * cfg.pv.depth * per_blk, 0, (size_t)4 * D * 4) != hipSuccess) {  // (+ 4D zeros: the diagnostic form's c)
       set_error("hipMalloc of the LayerNorm-fold vectors failed");
       return fail(MD_ERR_OOM);
     }
@@ -1041,6 +1042,11 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
   // (tile-parallel mode) computes the same bits as the whole call.
   const bool fold = m->ln_fold_on();
   const int fold_tile = fold ? TILE_256x256 : TILE_AUTO;
+  // ln_fold = 3 (diagnostic, benches only): the UNFOLDED schedule through the fold-form consumer kernels (EK 6 / 7) on neutral statistics
+  // (rstd = 1, mu = 0, c = 0, d = bias): isolates what those epilogues cost from what the colder A operand of the folded schedule costs
+  const bool neutral = !fold && m->ln_fold_can && m->ln_fold_opt == 3;
+  const float* zero_c = m->lnfold_base ? m->lnfold_base + (size_t)m->ngroups * c.pv.depth * 14 * D : nullptr;
+  if (neutral) MD_TRY(launch_fill_pairs(b->ln_ab + (size_t)s_lo * SS * 2, rows, 1.0f, 0.0f, r.st));
   auto fold_producer = [&](GemmParams& p, int blk, bool norm2) {
     p.ln_out = b->xn; p.ln_ldo = (long)D * m->xm; p.ln_plane = m->xm == 2 ? D : 0;
     p.ln_stats_out = b->ln_stats; p.ln_parts = D / 256;
@@ -1072,12 +1078,13 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
         if (fold1) p.ln_c[g] = m->vit[gi[g]].blk[i].qkv_c;
       }
       if (fold1) fold_consumer(p);
+      if (neutral) { fold_consumer(p); for (int g = 0; g < G; ++g) p.ln_c[g] = zero_c; }
       p.A = b->xn;
       split_dense_a(m, p, D, D, 0);
       p.v_plane = (long)m->vt_plane;
       p.epi = EPI_QKV; p.out = b->qk; p.vT = b->vT; p.seq_stride = SS; p.embed = D; p.heads = heads; p.kpad = m->kpad; p.qscale = attn_qscale(m->prec);
       r.begin("qkv_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold1 ? TILE_256x256 : TILE_AUTO, r.st));
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, (fold1 || neutral) ? TILE_256x256 : TILE_AUTO, r.st));
       r.end();
     }
     void* vT_w = (char*)b->vT + (size_t)s_lo * vt_seq;
@@ -1142,12 +1149,13 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
         if (fold) p.ln_c[g] = m->vit[gi[g]].blk[i].fc1_c;
       }
       if (fold) fold_consumer(p);
+      if (neutral) { fold_consumer(p); for (int g = 0; g < G; ++g) p.ln_c[g] = zero_c; }
       p.A = b->xn;
       split_dense_a(m, p, D, D, 0);
       p.epi = EPI_STORE; p.act = ACT_GELU; p.out = b->hbuf;
       split_out(m, p, 4 * D, true);
       r.begin("fc1_gemm");
-      MD_TRY(launch_gemm(p, A_DENSE, m->prec, fold_tile, r.st));
+      MD_TRY(launch_gemm(p, A_DENSE, m->prec, (fold || neutral) ? TILE_256x256 : TILE_AUTO, r.st));
       r.end();
     }
     {

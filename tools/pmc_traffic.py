@@ -33,7 +33,7 @@ def main():
         # one dispatch per launch of a family: the assembly attention kernel (`md_attn577_bf16`) stands for its launch, the flag-consuming
         # `attention_redo_kernel` behind it (4 us, no traffic on trained weights) is left out
         rows = [r for r in load(dirname, counter) if r["Kernel_Name"].startswith(("void md::", "md::", "md_attn577"))
-                and "attention_redo_kernel" not in r["Kernel_Name"]]
+                and "attention_redo" not in r["Kernel_Name"]]  # (the scan and the recompute kernel)
         # keep only the launches of whole infers at the END of the run (the timed steps)
         n = len(fam) * order["infers"]
         rows = rows[-n:]
