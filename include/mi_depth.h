@@ -306,7 +306,15 @@ int md_model_query(md_model_t m, const char* key, int64_t* out);
  * always do (bit for bit, tested). Depth-Anything-v3 models in the 16-bit modes pick two kernel forms by LAUNCH SIZE (the k-split
  * GEMM of small long-K launches and the two-key-group attention of few-workgroup launches, DESIGN.md sections 5.1 / 5.2): deterministic,
  * but another summation order -- the last bits of an image's result can then differ between B = 1 and B = 8. With the option set
- * neither form is used (config 2: ~8 % slower at B = 1) and the batch map is exact. Also a md_model_query key. */
+ * neither form is used (config 2: ~8 % slower at B = 1) and the batch map is exact. Also a md_model_query key.
+ * "ln_fold" (0 | 1 | 2 | 3, default 1; Depth Pro): the LayerNorms between the GEMMs of a ViT block (burn_dino block order, called from
+ * /root/reference/src/model/depth_pro/layers/encoder.rs:346-348) run inside those GEMMs instead of as launches (DESIGN.md section
+ * 5.1.1): LN(x) W^T + b = rstd (round(gamma x) W^T - mu c) + d. Same values in exact arithmetic; the operand rounding falls on
+ * gamma x instead of LN(x). 1 = automatic: on for the 16-bit modes when the ViT is 1024 wide and its sequences have >= 256 tokens
+ * (the default configuration); 0 = off (stand-alone LayerNorm launches); 2 = on whenever the model can (MD_ERR_UNSUPPORTED when it
+ * cannot: fp32 / fp8 modes, other widths); 3 = a bench diagnostic (the unfolded schedule through the fold-form kernels on neutral
+ * statistics). A MODEL-level choice: batch sizes, sequence windows and forks compute the same bits. Query keys: "ln_fold",
+ * "ln_fold_active". */
 int md_model_set_option(md_model_t m, const char* key, int64_t value);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs

@@ -151,3 +151,46 @@ def test_infer_shapes_zeros_input():
     assert tuple(out["depth"].shape) == (1, S, S)
     assert tuple(out["focallength_px"].shape) == (1,)
     assert torch.isfinite(out["depth"]).all()
+
+
+def test_layernorm_fold_restatement_is_the_same_function():
+    """oracle/depth_pro_ref.py::LN_FOLD_EMULATION restates the engine's LayerNorm fold (csrc/kernels/gemm.h GemmParams::ln_*:
+    LN(x) W^T + b = rstd (round(gamma x) W^T - mu c) + d) for the operand-rounding oracle only. It must be the SAME function of x:
+    ignored by the fp32 oracle (q = identity), equal to the unfolded form when no operand is rounded (fp64 here, to 1e-12), and within
+    the rounding of the operand type when operands are rounded (bf16: both forms sit at the same distance from the fp32 oracle).
+    Block order: burn_dino (called from /root/reference/src/model/depth_pro/layers/encoder.rs:346-348)."""
+    import torch
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from oracle import depth_pro_ref as R
+    cfg = DepthProConfig.tiny_test()
+    v = cfg.patch_vit()
+    W = R.weights_to_torch(Wt.generate_depth_pro_weights(cfg, 0, Wt.INIT_PARITY))
+    g = torch.Generator().manual_seed(1)
+    for k in list(W):  # non-trivial gamma / beta so that c, d matter
+        if k.endswith((".norm1.gamma", ".norm2.gamma")):
+            W[k] = W[k] * (0.5 + torch.rand(W[k].shape, generator=g))
+        if k.endswith((".norm1.beta", ".norm2.beta")):
+            W[k] = W[k] + 0.3 * torch.randn(W[k].shape, generator=g)
+    x = torch.randn(2, 3, v.img_size, v.img_size, generator=g)
+    with torch.no_grad():
+        ref, ref_h = R.vit_forward(x, W, "encoder.patch_encoder", v, (1, 2))
+        prev = R.LN_FOLD_EMULATION
+        try:
+            R.LN_FOLD_EMULATION = True
+            same, _ = R.vit_forward(x, W, "encoder.patch_encoder", v, (1, 2))              # identity quantiser: the flag is ignored
+            noround = lambda t: t                                                          # noqa: E731  (a quantiser that rounds nothing)
+            Wd = {k: t.double() for k, t in W.items()}
+            fold64, _ = R.vit_forward(x.double(), Wd, "encoder.patch_encoder", v, (1, 2), q=noround)
+            fold_bf, _ = R.vit_forward(x, W, "encoder.patch_encoder", v, (1, 2), q=R.bf16_round)
+            R.LN_FOLD_EMULATION = False
+            plain64, _ = R.vit_forward(x.double(), Wd, "encoder.patch_encoder", v, (1, 2), q=noround)
+            plain_bf, _ = R.vit_forward(x, W, "encoder.patch_encoder", v, (1, 2), q=R.bf16_round)
+        finally:
+            R.LN_FOLD_EMULATION = prev
+    assert torch.equal(same, ref)
+    assert (fold64 - plain64).abs().max().item() <= 1e-11 * plain64.abs().max().item()
+    scale = ref.abs().max().item()
+    e_fold, e_plain = (fold_bf - ref).abs().max().item() / scale, (plain_bf - ref).abs().max().item() / scale
+    assert 0 < e_fold <= 3 * e_plain + 1e-3 and e_plain <= 3 * e_fold + 1e-3, (e_fold, e_plain)
+    assert not torch.equal(fold_bf, plain_bf)
