@@ -141,6 +141,8 @@ def parse_args(argv=None):
                     help="bf16 Depth Pro attention (577 tokens): the assembly-owned gfx950 kernel (the product) or the HIP kernel every other shape runs -- an A/B switch (md_debug_attention_asm), recorded in config.attention_form when it is not the default")
     ap.add_argument("--ln-fold", choices=["auto", "off", "neutral"], default="auto",
                     help="the LayerNorms between the ViT's GEMMs folded into those GEMMs (md_model_set_option(\"ln_fold\"): automatic = on for 16-bit models with 577-token sequences) or as stand-alone launches -- an A/B switch, recorded in config.layernorm")
+    ap.add_argument("--direct-store", choices=["on", "off"], default="on",
+                    help="lean 2-byte store epilogues of the 256 x 256 GEMM kernel straight from the accumulator layout (the product) or staged through LDS (md_debug_gemm_direct_store): an A/B switch, same bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-launch HIP events in the timed region (the `kernels` / `roofline` objects are then empty): measures what the events themselves cost")
     ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the whole-frame CPU baseline may take (predicted from a 2-tile probe); beyond it the sampled estimate is reported")
@@ -219,6 +221,9 @@ def main(argv=None) -> int:
 
     dev = Device(local_rank)
     tdev = torch.device("cuda", local_rank)
+    if args.direct_store == "off":
+        from burn_depth_amd import _lib as _lds
+        _lds.load().md_debug_gemm_direct_store(0)
     if args.attention_form == "hip":  # before the model exists: its graphs capture whichever form the first infer launches
         from burn_depth_amd import _lib as _l
         _l.load().md_debug_attention_asm(0)

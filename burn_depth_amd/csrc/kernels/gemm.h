@@ -105,6 +105,12 @@ struct GemmParams {
   int ln_parts = 0;
   float ln_inv_n = 0.f, ln_eps = 0.f;
   const float* ln_c[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};      // consumer: c [N] (bias[] then carries d)
+  // 256 x 256 kernel, lean 2-byte store kinds (EK 2 / 4 / 6 / 7, no residual inputs / second output): stores straight from the accumulator
+  // layout, no LDS staging. The W tile's LDS image is filled in a PERMUTED row order (the LDS-DMA source rows; LDS addressing, bank
+  // pattern and register use unchanged) such that a lane's accumulators of the n-blocks 2h, 2h + 1 are 8 CONSECUTIVE output columns: one
+  // 16-byte store per (m-block, h), 16 rows x 64 bytes per wave-instruction, the two h of a row completing its 128-byte line back to
+  // back. Same values, same bits as the staged form. Set by launch_gemm for eligible launches (gemm_direct_store()).
+  int direct_store = 0;
   int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)
   int res_mod = 0;              // > 0: res1's row = m % res_mod (a per-image table shared by the batch, or an input two weight groups share); res2 is never wrapped
   // EPI_PATCH_EMBED / EPI_QKV
@@ -163,6 +169,8 @@ struct GemmParams {
 // The contraction split inside the workgroup (gemm_kernel's KSPLIT) changes the summation order of a launch that is small enough to
 // take it, so a result may differ in its last bits between batch sizes. Depth Pro promises (and tests) bit-identical images across batch
 // sizes: the split is off unless the calling thread turned it on -- the Depth-Anything-v3 engine does, around each of its calls.
+// process-wide A/B switch of GemmParams::direct_store (default 1); returns the previous value
+int gemm_direct_store(int on);
 int gemm_allow_ksplit(int on);  // per host thread; returns the previous value
 void gemm_count_ksplit_launch();   // diagnostics: md_gemm_ksplit_launches()
 long long gemm_ksplit_launches();

@@ -816,6 +816,11 @@ constexpr int kLnXchg = 8 * 64 * 272;  // LDS offset of the LayerNorm-fold excha
 
 template <typename T, int AMODE, int EK, bool DIAG>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  // EK 8 / 9 / 10 / 11 = the lean 2-byte store kinds 2 / 4 / 6 / 7 in their DIRECT-store form (GemmParams::direct_store): its own
+  // instantiation, so that the staged form's code and live ranges are not part of it (as a runtime branch of one kernel the pair sat
+  // at 256 VGPRs and hipcc spilled LDS-DMA source addresses into the main loop's first k-tile)
+  constexpr bool DS = EK >= 8;
+  constexpr int EKB = EK == 8 ? 2 : (EK == 9 ? 4 : (EK == 10 ? 6 : (EK == 11 ? 7 : EK)));
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4;
   constexpr int WTM = 128, WTN = 64;
   constexpr int HALF_BYTES = 256 * 128;  // one half-tile slot
@@ -911,14 +916,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     }
   }
   const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
-  const char* srcW[LPH];
+  // direct-store tiles (GemmParams::direct_store): LDS row r = 64 wn + 16 a + i of the W tile holds weight row
+  // 64 wn + 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1) + (i & 3): a lane's (a = 2h, 2h + 1) accumulators are then 8 consecutive columns
+  // (launch_256 picks the direct form only for launches whose every non-V^T tile qualifies: no residual inputs, no second / fp32 / fp8
+  // output, N % 256 == 0; the V^T tiles of a QKV launch keep the plain image and their transposed staging)
+  const bool dstore = DS && !(p.epi == EPI_QKV && n0 >= 2 * p.embed);
+  // W pieces as 32-bit byte offsets from the (wave-uniform) group base: a weight matrix is far below 4 GB, the LDS-DMA takes the base
+  // from SGPRs (global_load_lds ... v_off, s[base]) and four VGPRs ride through the main loop instead of eight (round 6: the direct-store
+  // kinds sat 4 registers over the budget and hipcc spilled source addresses into k-tile 0)
+  unsigned offW[LPH];
 #pragma unroll
   for (int i = 0; i < LPH; ++i) {
     const int r = (i * NW + wave) * 8 + lrow;
     const int lc = pc ^ ((r >> 1) & 7);
-    int n = n0 + r;
+    const int rp = (r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);
+    int n = n0 + (dstore ? rp : r);
     n = n < p.N ? n : p.N - 1;
-    srcW[i] = Wg + (long)n * (long)(int)(ldw * ESZ) + lc * 16;
+    offW[i] = (unsigned)n * (unsigned)(ldw * ESZ) + (unsigned)(lc * 16);
   }
   const char* zsrc = (const char*)p.zero_page + pc * 16;
   const int KT = p.K / KE;
@@ -933,8 +947,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   auto issue_W = [&](int kt, int slot) __attribute__((always_inline)) {
     char* sbase = smem + slot * HALF_BYTES;
     if (DIAG && freeze_k) kt = 0;
+    const char* wk = Wg + (long)kt * 128;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < LPH; ++i) glds16(srcW[i] + (long)kt * 128, sbase + (i * NW + wave) * 1024);
+    for (int i = 0; i < LPH; ++i) glds16(wk + offW[i], sbase + (i * NW + wave) * 1024);
   };
   auto issue_A = [&](int kt, int slot) __attribute__((always_inline)) {
     char* sbase = smem + slot * HALF_BYTES;
@@ -970,7 +985,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int q16 = lane >> 4;
   const int lane_off16 = (lane & 15) * 128 + (((((lane & 15) >> 1) & 7) ^ q16) << 4);
 
-  constexpr bool ln_cons = EK == 6 || EK == 7, ln_emit = EK == 5, gelu_k = EK == 4 || EK == 7;
+  constexpr bool ln_cons = EKB == 6 || EKB == 7, ln_emit = EKB == 5, gelu_k = EKB == 4 || EKB == 7;
   // half-tile order: A0 W0 A1 W1 A2 | W2 A3 | W3 A4 | ...   (slot = order index mod 5)
   if (DIAG && stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
   int issued = 2, slot_i = 2;
@@ -1250,9 +1265,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int col = (lane & 15) * 4;
   const int n = n0 + wn * WTN + col;
   const bool nvalid = n < p.N;
-  constexpr bool rmw = EK == 1 || EK == 5;
-  constexpr bool fast_store = (EK == 2 || EK == 4 || EK == 6 || EK == 7) && sizeof(TO) == 2;  // EK 4 / 7: GELU fused at compile time (fc1)
-  constexpr bool pixshuf = EK == 3;
+  constexpr bool rmw = EKB == 1 || EKB == 5;
+  constexpr bool fast_store = (EKB == 2 || EKB == 4 || EKB == 6 || EKB == 7) && sizeof(TO) == 2;  // EK 4 / 7: GELU fused at compile time (fc1)
+  constexpr bool pixshuf = EKB == 3;
   const float* biasp = MD_SEL_G(p.bias, g);
   const int r16 = lane & 15;
   const int c8 = (lane & 7) * 8, rsub = lane >> 3;
@@ -1363,7 +1378,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       f32x4_t bq[4], wq[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int na = n0 + wn * WTN + a * 16 + 4 * q16;
+        // the 4 columns of the lane's accumulators of n-block a: consecutive from here (direct-store tiles: the permuted image)
+        const int na = dstore ? n0 + wn * WTN + (a >> 1) * 32 + q16 * 8 + (a & 1) * 4 : n0 + wn * WTN + a * 16 + 4 * q16;
         bq[a] = (biasp && na < p.N) ? *(const f32x4_t*)(biasp + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         wq[a] = (wsp && na < p.N) ? *(const f32x4_t*)(wsp + na) * p.ascale : (f32x4_t){1.f, 1.f, 1.f, 1.f};
         if constexpr (ln_cons) wq[a] = na < p.N ? *(const f32x4_t*)(MD_SEL_G(p.ln_c, g) + na) : (f32x4_t){0.f, 0.f, 0.f, 0.f};  // c[n]; bq = d[n]
@@ -1384,24 +1400,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
           lnB[b] = t[1];
         }
       }
+      auto finish = [&](int a, int b, f32x4_t v) __attribute__((always_inline)) {
+        if constexpr (ln_cons) {
+          const f32x4_t Bv = {lnB[b], lnB[b], lnB[b], lnB[b]}, Av = {lnA[b], lnA[b], lnA[b], lnA[b]};
+          v = fma4(v, Av, fma4(wq[a], Bv, bq[a]));
+        } else {
+          v = fma4(v, wq[a], bq[a]);
+        }
+        if constexpr (gelu_k) {
+          v = gelu4<TO>(v);
+        } else if (relu) {
+          v = relu4(v);
+        }
+        return v;
+      };
+      if constexpr (DS) {
+        // straight from the accumulator layout: lane (r16, q16) owns row b * 16 + r16 of m-block b and, for h = 0, 1, the 8 columns
+        // 64 wn + 32 h + 8 q16 .. + 7 (n-blocks 2h and 2h + 1 of the permuted image)
+        // (lane indices made opaque here: hipcc otherwise hoists the sixteen store offsets above the main loop and carries them through it)
+        int r16e = r16, q16e = q16;
+        asm volatile("" : "+v"(r16e), "+v"(q16e));
+        const unsigned lcd = (unsigned)(wn * WTN + q16e * 8);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const int lrow_t = wm * WTM + b * 16 + r16e;
+          const bool ok = interior || m_base + lrow_t < m_end;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4acc_t c0 = acc16[2 * h][b], c1 = acc16[2 * h + 1][b];
+            const f32x4_t v0 = finish(2 * h, b, (f32x4_t){c0[0], c0[1], c0[2], c0[3]});
+            const f32x4_t v1 = finish(2 * h + 1, b, (f32x4_t){c1[0], c1[1], c1[2], c1[3]});
+            const unsigned eo = ((unsigned)lrow_t * (unsigned)ldo8 + lcd + (unsigned)(h * 32)) * 2u;
+            if constexpr (PLN == 2) {
+              i32x4_t ph, pl;
+              split8<TO>(v0, v1, ph, pl);
+              if (ok) {
+                *(i32x4_t*)(ob + eo) = ph;
+                *(i32x4_t*)(ob + eo + (unsigned)lo_off * 2u) = pl;
+              }
+            } else {
+              const i32x4_t raw = pack8<TO>(v0, v1);
+              if (ok) *(i32x4_t*)(ob + eo) = raw;
+            }
+          }
+          // one m-block at a time: left free, the scheduler interleaves all sixteen (b, h) groups, the epilogue's pressure passes 256
+          // registers and the allocator answers by spilling LDS-DMA source addresses whose reloads land in the main loop's first k-tile
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp_end();
+        return;
+      } else {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         asm volatile("" ::: "memory");
         if (!(DIAG && (p.debug_flags & 8)))  // timing-only ablation: skip the staging writes
-          stage_half_2b(half, [&](int a, int b, f32x4_t v) {
-            if constexpr (ln_cons) {
-              const f32x4_t Bv = {lnB[b], lnB[b], lnB[b], lnB[b]}, Av = {lnA[b], lnA[b], lnA[b], lnA[b]};
-              v = fma4(v, Av, fma4(wq[a], Bv, bq[a]));
-            } else {
-              v = fma4(v, wq[a], bq[a]);
-            }
-            if constexpr (gelu_k) {
-              v = gelu4<TO>(v);
-            } else if (relu) {
-              v = relu4(v);
-            }
-            return v;
-          });
+          stage_half_2b(half, finish);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1422,7 +1475,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       }
       stamp_end();
       return;
+      }
     }
+    if constexpr (DS) return;  // (the direct kinds are launched for lean launches only)
     // residual inputs / fp32, fp8 or second output: fp32 staging, the raw residual vectors of a half prefetched before
     // its staging pass (the dependent load -> store chain, not bandwidth, set the cost of the residual-conv epilogue)
     // Split-half outputs (round 6; they took the generic per-vector epilogue before: dec_conv3x3 2.24x its bf16 time): the same
@@ -1803,7 +1858,31 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     if (ln_cons && ek != 6 && ek != 7) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: the LayerNorm-fold consumer needs the 16-byte store epilogue (N, ldo %% 8 == 0)");
   }
   const bool diag = p.stamps != nullptr || p.debug_flags != 0;
-  static std::atomic<unsigned long> set[8], dset[5];  // zero-initialised statics
+  static std::atomic<unsigned long> set[12], dset[5];  // zero-initialised statics
+  // the direct-store form of a lean store launch (GemmParams::direct_store)
+  const bool lean = !p.res1 && !p.res2 && !p.out2 && !p.out_f32 && !p.out_fp8 && p.N % BN == 0 && p.batch <= 1;
+  if constexpr (sizeof(typename OutT<T>::type) == 2) {
+    // Measured in the model (bench.py --direct-store off | on, one box, twice each; profiles/r06_direct_store_ab.txt): the GELU kinds gain
+    // (fc1 36.18 -> 35.46 ms per step: their stores leave spread out between the polynomial's arithmetic), the plain kinds LOSE (qkv 23.61 ->
+    // 24.52: sixteen half-line stores per wave in one burst cost more than the LDS transpose they replace) -- so only EK 4 / 7 take the
+    // direct form; EK 8 / 10 stay instantiable for A/B builds (MD_DIRECT_STORE_ALL).
+    if (!diag && p.direct_store && lean) {
+#ifdef MD_DIRECT_STORE_ALL
+      if constexpr (AMODE != A_CONV3) {
+        if (ek == 2) return go(gemm256_kernel<T, AMODE, 8, false>, &set[8]);
+      }
+#endif
+      if constexpr (AMODE == A_DENSE) {
+        if (ek == 4) return go(gemm256_kernel<T, AMODE, 9, false>, &set[9]);
+        if constexpr (!std::is_same<T, fp8_t>::value) {
+#ifdef MD_DIRECT_STORE_ALL
+          if (ek == 6) return go(gemm256_kernel<T, AMODE, 10, false>, &set[10]);
+#endif
+          if (ek == 7) return go(gemm256_kernel<T, AMODE, 11, false>, &set[11]);
+        }
+      }
+    }
+  }
   if constexpr (AMODE == A_DENSE && sizeof(typename OutT<T>::type) == 2 && !std::is_same<T, fp8_t>::value) {
     if (ek == 5) return go(gemm256_kernel<T, AMODE, 5, false>, &set[5]);
     if (ek == 6) return go(gemm256_kernel<T, AMODE, 6, false>, &set[6]);

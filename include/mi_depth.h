@@ -407,6 +407,12 @@ int md_gemm_pick_tile(int M, int N, int K, int precision);
  * (gemm_kernel's KSPLIT) since the library was loaded (modulo 2^31) -- lets a test check that the form it
  * means to exercise actually ran. */
 int md_gemm_ksplit_launches(void);
+/* PROCESS-WIDE A/B switch (default 1; returns the previous value): may the lean 2-byte store epilogues of the 256 x 256 GEMM kernel
+ * (fc1, the q | k tiles of qkv, convolutions without residual inputs) store straight from the accumulator layout -- the W tile's
+ * LDS image in a permuted row order, one 16-byte store per lane and (m-block, column half) -- instead of staging the tile through
+ * LDS? Same values, same bits; for benches and the bit-identity test. Graphs captured before a change keep
+ * their form. */
+int md_debug_gemm_direct_store(int on);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
 /* The same with the operand type (MD_PREC_BF16 | MD_PREC_F16) and the range of the random q / k values, uniform in

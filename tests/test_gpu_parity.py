@@ -89,6 +89,37 @@ def test_storage_epilogues_f16x2(diag, dev):
     _assert_new_results_ok(diag, start)
 
 
+@pytest.mark.parametrize("precision", [0, 3, 4])
+def test_direct_store_epilogue_is_bit_identical_to_the_staged_one(dev, precision):
+    """Round 6: the GELU store kinds of the 256 x 256 kernel (fc1: EK 4 -> 9, with the LayerNorm fold EK 7 -> 11) store straight from the
+    accumulator layout -- the W tile's LDS image in a permuted row order, one 16-byte store per lane and (m-block, column half) --
+    instead of staging the tile through LDS. `md_debug_gemm_direct_store(0 | 1)` switches between the two forms of ONE launch (partial
+    last m-tile, two n-tiles, the 256 x 256 tile forced): the same bits in bf16, f16 and split-half storage, against fp64 to the
+    storage type's rounding. (GELU: exact erf, burn_dino's MLP -- /root/reference/src/model/depth_pro/layers/vit.rs:45-68.)"""
+    import torch.nn.functional as F
+    from burn_depth_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 600, 512, 1024
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    b = torch.randn(N, generator=g) * 0.1
+    if precision == 4:  # operands exact in two half planes / one half: the GEMM itself is then exact to fp32 accumulation
+        x, w = x.half().float(), w.half().float()
+    rnd = {0: lambda t: t.bfloat16().float(), 3: lambda t: t.half().float(), 4: lambda t: t}[precision]
+    want = F.gelu(F.linear(rnd(x).double(), rnd(w).double(), b.double())).float()
+    prev = lib.md_debug_gemm_direct_store(1)
+    try:
+        direct = ops.linear(dev, x.cuda(), w.cuda(), b.cuda(), act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
+        lib.md_debug_gemm_direct_store(0)
+        staged = ops.linear(dev, x.cuda(), w.cuda(), b.cuda(), act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
+    finally:
+        lib.md_debug_gemm_direct_store(prev)
+    assert torch.equal(direct, staged)
+    err = ((direct.cpu() - want).abs().max() / want.abs().max()).item()
+    assert err <= {0: 8e-3, 3: 1.5e-3, 4: 2e-5}[precision], err
+
+
 @pytest.mark.parametrize("precision", [1, 0, 3])
 def test_depth_pro_tiny_end_to_end(diag, dev, precision):
     from burn_depth_amd.config import DepthProConfig
