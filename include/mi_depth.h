@@ -313,8 +313,9 @@ int md_model_query(md_model_t m, const char* key, int64_t* out);
  * gamma x instead of LN(x). 1 = automatic: on for the 16-bit modes when the ViT is 1024 wide and its sequences have >= 256 tokens
  * (the default configuration); 0 = off (stand-alone LayerNorm launches); 2 = on whenever the model can (MD_ERR_UNSUPPORTED when it
  * cannot: fp32 / fp8 modes, other widths); 3 = a bench diagnostic (the unfolded schedule through the fold-form kernels on neutral
- * statistics). A MODEL-level choice: batch sizes, sequence windows and forks compute the same bits. Query keys: "ln_fold",
- * "ln_fold_active". */
+ * statistics). A MODEL-level choice: batch sizes, sequence windows and forks compute the same bits. Set it before md_model_fork (a fork
+ * copies its root's setting when it is made) and to the same value on every rank of md_comm_depth_pro_infer_tiles (latency mode at >= 4
+ * ranks: 0 is faster there, the windows are too small for the 256 x 256 tiles the fold keeps to). Query keys: "ln_fold", "ln_fold_active". */
 int md_model_set_option(md_model_t m, const char* key, int64_t value);
 
 /* Debug taps (EncoderDebug encoder.rs:106-123, HeadDebug mod.rs:135-142, fusion outputs

@@ -1596,24 +1596,29 @@ def test_two_gpus_native_rccl_scatter_infer_gather_and_tile_exchange(dev):
     devices, md_comm.cpp) equals `infer` for both roots."""
     import subprocess
     import sys
-    if torch.cuda.device_count() < 2:
-        pytest.skip("one GPU on this box: RCCL between two devices cannot run here")
     from burn_depth_amd.parallel import NativeComm
-    uid = NativeComm.unique_id().hex()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "two_gpu_check.py"), str(r), "2", uid], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=420)[0])
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()  # exactly the two processes started here
-            pytest.fail("a rank of the two-GPU check did not finish in 420 s")
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"rank {r} OK ranks_seen=2" in o, o[-3000:]
+
+    def run_world(world):
+        uid = NativeComm.unique_id().hex()
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "two_gpu_check.py"), str(r), str(world), uid], env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=420)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()  # exactly the processes started here
+                pytest.fail(f"a rank of the {world}-rank check did not finish in 420 s")
+        for r, (p, o) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0 and f"rank {r} OK ranks_seen={world}" in o, o[-3000:]
+
+    run_world(1)  # the same script as ONE rank, on every box: its own logic (seeds, shapes, assertions) is exercised wherever the suite runs
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the one-rank form of the check passed; RCCL between two devices cannot run here")
+    run_world(2)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16", "f16x2"])
