@@ -139,7 +139,7 @@ def parse_args(argv=None):
                          "(no `kernels` / `roofline` in the line: latency mode for the single-image configurations)")
     ap.add_argument("--attention-form", choices=["asm", "hip"], default="asm",
                     help="bf16 Depth Pro attention (577 tokens): the assembly-owned gfx950 kernel (the product) or the HIP kernel every other shape runs -- an A/B switch (md_debug_attention_asm), recorded in config.attention_form when it is not the default")
-    ap.add_argument("--ln-fold", choices=["auto", "off", "neutral"], default="auto",
+    ap.add_argument("--ln-fold", choices=["auto", "off", "neutral", "finish-launch"], default="auto",
                     help="the LayerNorms between the ViT's GEMMs folded into those GEMMs (md_model_set_option(\"ln_fold\"): automatic = on for 16-bit models with 577-token sequences) or as stand-alone launches -- an A/B switch, recorded in config.layernorm")
     ap.add_argument("--direct-store", choices=["on", "off"], default="on",
                     help="lean 2-byte store epilogues of the 256 x 256 GEMM kernel straight from the accumulator layout (the product) or staged through LDS (md_debug_gemm_direct_store): an A/B switch, same bits")
@@ -243,7 +243,7 @@ def main(argv=None) -> int:
     # the fp32 weight arena over RCCL (one-time, outside the timed region).
     model = DepthPro.new(dev, cfg, seed=0 if rank == 0 else 1 + rank, init_scheme=Wt.INIT_PARITY)
     if args.ln_fold != "auto":  # "neutral": a diagnostic -- the unfolded schedule through the fold-form consumer kernels on neutral statistics
-        model.set_option("ln_fold", 0 if args.ln_fold == "off" else 3)
+        model.set_option("ln_fold", {"off": 0, "neutral": 3, "finish-launch": 4}[args.ln_fold])
     t_bcast = 0.0
     ncomm = None
     if args.native_comm:

@@ -101,7 +101,8 @@ struct GemmParams {
   long ln_ldo = 0, ln_plane = 0;
   const float* ln_gamma[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // producer: gamma of the NEXT LayerNorm [N]
   float* ln_stats_out = nullptr;   // producer: [rows][N / 256][2] fp32 partial (sum, sum of squares)
-  const float* ln_stats = nullptr; // consumer: the same array; ln_parts partials per row
+  const float* ln_stats = nullptr; // consumer: ln_raw = 1: the producer's array (4 partials per row, combined in the epilogue); 0: [rows][2] (rstd, -mu rstd) from ln_finish
+  int ln_raw = 0;
   int ln_parts = 0;
   float ln_inv_n = 0.f, ln_eps = 0.f;
   const float* ln_c[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};      // consumer: c [N] (bias[] then carries d)

@@ -1047,12 +1047,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // waits vmcnt(0): the LDS-DMA pipeline drained once per tile); eight 8-byte loads per lane in the epilogue -- each cost 2.3 - 3.8 us
   // of a 32-us fc1 tile: the epilogue's first microsecond is latency-bound.
   const bool ln_in_loop = ln_cons && KT >= 2 && (2 * KT - 2) % NSLOT != 4 && (2 * KT - 1) % NSLOT != 4;
+  // ln_raw (round 6, last form): p.ln_stats holds the producer's PARTIALS ([rows][4][2]: mean and centred sum of squares per 256-column
+  // tile); every wave requests the 32 rows x 32 bytes of its share (8 KB per tile, behind the 2 KB of pairs in the exchange area) and the
+  // epilogue's threads 0 .. 255 combine them into the pairs -- the ln_finish launch between the two GEMMs (47 per ViT pass, 6.5 us each
+  // whatever the batch: 1.3 % of a B = 1 frame) is gone.
+  const bool ln_raw = ln_cons && p.ln_raw != 0;
   auto issue_ln_ab = [&]() __attribute__((always_inline)) {
-    if (wave < 2) {
+    if (ln_raw) {
       int l2 = lane;
       asm volatile("" : "+v"(l2));  // keeps the address arithmetic (and its two VGPRs) out of the main loop's live ranges
+      int r2 = m_base + wave * 32 + (l2 >> 1);
+      r2 = r2 < m_end - 1 ? r2 : m_end - 1;  // rows past the group are never used; keep the request inside the array
+      glds16((const char*)p.ln_stats + (long)r2 * 32 + (l2 & 1) * 16, smem + kLnXchg + 2048 + wave * 1024);
+    } else if (wave < 2) {
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));
       int r2 = m_base + 2 * (wave * 64 + l2);
-      r2 = r2 < m_end - 2 ? r2 : m_end - 2;  // rows past the group are never used; keep the request inside the array
+      r2 = r2 < m_end - 2 ? r2 : m_end - 2;
       glds16((const char*)p.ln_stats + (long)r2 * 8, smem + kLnXchg + wave * 1024);
     }
   };
@@ -1179,6 +1190,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       issue_ln_ab();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requesting waves' pairs have landed; each path's first barrier publishes them
+    if (ln_raw) {  // partials -> pairs (Chan's combination: every term of the variance is non-negative), one row per thread
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tid < BM) {
+        const f32x4_t p0 = *(const f32x4_t*)(lnx + 512 + tid * 8), p1 = *(const f32x4_t*)(lnx + 512 + tid * 8 + 4);
+        const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+        const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
+        const float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + 256.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = 1.0f / sqrtf(m2 * p.ln_inv_n + p.ln_eps);
+        *(f32x2_t*)(lnx + 2 * tid) = (f32x2_t){rstd, -mu * rstd};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
   const bool direct = (p.epi == EPI_QKV && n0 >= 2 * p.embed);  // V^T wants lanes along tokens
   if (direct) {

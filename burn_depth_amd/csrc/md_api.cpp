@@ -317,7 +317,7 @@ int md_model_set_option(md_model_t m, const char* key, int64_t value) {
     return MD_OK;
   }
   if (k == "ln_fold") {
-    if (value < 0 || value > 3) MD_FAIL(MD_ERR_INVALID_ARG, "ln_fold takes 0 (off), 1 (automatic), 2 (on whenever the model can) or 3 (bench diagnostic: unfolded schedule, fold-form consumer kernels on neutral statistics)");
+    if (value < 0 || value > 4) MD_FAIL(MD_ERR_INVALID_ARG, "ln_fold takes 0 (off), 1 (automatic), 2 (on whenever the model can), 3 / 4 (bench diagnostics: unfolded schedule through the fold-form consumer kernels on neutral statistics / the fold with the ln_finish launch)");
     if (value >= 2 && !m->ln_fold_can) MD_FAIL(MD_ERR_UNSUPPORTED, "ln_fold: this model cannot fold its LayerNorms (16-bit Depth Pro models of width %% 256 == 0 can)");
     if (m->ln_fold_opt != (int)value) {
       m->ln_fold_opt = (int)value;

@@ -143,7 +143,7 @@ struct md_model_s {
   int ln_fold_opt = 1;
   bool ln_fold_can = false;    // 16-bit Depth Pro, D % 256 == 0: the workspace and the fold vectors exist
   float* lnfold_base = nullptr;  // root: the c / d vectors of every block (VitBlockW points into it)
-  bool ln_fold_on() const { return ln_fold_can && (ln_fold_opt == 2 || (ln_fold_opt == 1 && NT >= 256)); }  // (3: a bench diagnostic, run_vit)
+  bool ln_fold_on() const { return ln_fold_can && (ln_fold_opt == 2 || ln_fold_opt == 4 || (ln_fold_opt == 1 && NT >= 256)); }  // (3: a bench diagnostic, run_vit)
   struct GraphEntry {
     int seen = 0;
     hipGraphExec_t exec = nullptr;

@@ -1052,10 +1052,14 @@ static int run_vit(Run& r, int nseq_p, int nseq, int s_lo, int s_hi) {
     p.ln_stats_out = b->ln_stats; p.ln_parts = D / 256;
     for (int g = 0; g < G; ++g) p.ln_gamma[g] = norm2 ? m->vit[gi[g]].blk[blk].n2g : m->vit[gi[g]].blk[blk].n1g;
   };
+  // (ln_fold = 4: the pairs come from the ln_finish launch -- the A/B form; default: the consumer combines the partials itself)
+  const bool finish_launch = neutral || m->ln_fold_opt == 4;
   auto fold_consumer = [&](GemmParams& p) {
-    p.ln_stats = b->ln_ab; p.ln_parts = D / 256; p.ln_inv_n = 1.0f / (float)D; p.ln_eps = c.ln_eps;
+    p.ln_stats = finish_launch ? b->ln_ab : b->ln_stats; p.ln_raw = finish_launch ? 0 : 1;
+    p.ln_parts = D / 256; p.ln_inv_n = 1.0f / (float)D; p.ln_eps = c.ln_eps;
   };
   auto fold_finish = [&]() -> int {  // the window's rows: (mean, M2) x 4 -> (rstd, -mu rstd)
+    if (!finish_launch) return MD_OK;
     r.begin("ln_finish");
     const int st_ = launch_ln_finish(b->ln_stats + (size_t)s_lo * SS * (D / 256) * 2, b->ln_ab + (size_t)s_lo * SS * 2, rows, 1.0f / (float)D, c.ln_eps, r.st);
     r.end();
