@@ -61,6 +61,8 @@ int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
 
 static std::atomic<int> g_direct_store{1};
 int gemm_direct_store(int on) { return g_direct_store.exchange(on ? 1 : 0); }
+static std::atomic<int> g_persist{1};
+int gemm_persistent(int on) { return g_persist.exchange(on ? 1 : 0); }
 static thread_local int g_ksplit_ok = 0;
 int gemm_allow_ksplit(int on) {  // returns the previous value (KsplitScope restores it)
   const int prev = g_ksplit_ok;
@@ -75,6 +77,7 @@ int launch_gemm(GemmParams p, int amode, int prec, int tile, hipStream_t stream)
   const int ke = prec == MD_PREC_F32 ? 32 : (prec == MD_PREC_FP8 ? 128 : 64);
   p.ksplit_ok = g_ksplit_ok;
   p.direct_store = g_direct_store.load(std::memory_order_relaxed);
+  p.persist = g_persist.load(std::memory_order_relaxed);
   if (p.ngroups < 1 || p.ngroups > kMaxGroups) MD_FAIL(MD_ERR_INVALID_ARG, "gemm: ngroups %d", p.ngroups);
   if (p.N <= 0 || p.N % 4 != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: N=%d must be a positive multiple of 4", p.N);
   if (p.K <= 0 || p.K % ke != 0) MD_FAIL(MD_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", p.K, ke);

@@ -1812,6 +1812,269 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   stamp_end();
 }
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the fc1 GEMM (round 6): dense A, bias (+ LayerNorm fold) + GELU, 2-byte direct stores -- EK 9 / 11 of gemm256_kernel as a
+// tile LOOP: one workgroup per CU walks its XCD's share of the raster, and the first k-tile of the NEXT tile is requested before the
+// epilogue of the current one, so the 2.5 - 3 us of a tile's prologue (setup, issue, first k-tile landing) pass under the 4 - 5 us of
+// the GELU epilogue. What makes that possible here and did not in rounds 1 - 2 (whose tile loop around the staged epilogues spilled
+// and lost 5 - 14 %): the direct-store epilogue uses no LDS (the ring is free for the next tile), holds no prefetch arrays, and takes
+// bias / c / d and the LayerNorm partials from LDS (requested by LDS-DMA in the last k-tile's load segment), so no compiler-placed
+// vmcnt(0) drains the next tile's requests. Stores are younger than those requests: the wait for the next tile's k-tile 0 is
+// vmcnt(stores of this epilogue). Same main loop, same arithmetic, same bits as the one-tile kernel.
+// LDS exchange area (inside ring slot 4, idle in the last k-tile for KT = 16 / 32): [pairs 2 KB][partials 8 KB][c or bias 1 KB][d 1 KB].
+template <typename T, bool FOLD>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, NW = 8, WGN = 4, WTM = 128, WTN = 64, HALF_BYTES = 256 * 128, NSLOT = 5, LPH = 4, KE = 64, PLN = kPlanes<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lrow = lane >> 3, pc = lane & 7, q16 = lane >> 4, r16 = lane & 15;
+  const int lane_off16 = r16 * 128 + ((((r16 >> 1) & 7) ^ q16) << 4);
+  const int KT = p.K / KE;
+  const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
+  float* const lnx = (float*)(smem + kLnXchg);
+  // this workgroup's tiles: XCD x (blocks b, b + 8, .. share one) owns the contiguous id range [xs, xs + xc) of the raster; block j of the
+  // XCD takes ids xs + j, xs + j + G / 8, ...
+  const int ntiles = p.ptiles, G = gridDim.x;
+  int it, xs, xc;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
+    xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xc = q + (xcd < r ? 1 : 0);
+    it = blockIdx.x >> 3;
+  }
+  const int istep = G >> 3;
+  if (it >= xc) return;
+
+  int m_base, m_end, n0, g;
+  const char* Wg;
+  const char* srcA[LPH];
+  unsigned offW[LPH];
+  auto locate = [&](int id) __attribute__((always_inline)) {
+    int tile_n, tile_mg;
+    if (id < p.map_full_gsz) {
+      const int ng = fdiv(id, p.fd_map_gsz), r = id - ng * p.map_gsz;
+      tile_mg = fdiv(r, p.fd_map_gn);
+      tile_n = ng * p.map_gn + (r - tile_mg * p.map_gn);
+    } else {
+      const int r = id - p.map_full_gsz;
+      tile_mg = fdiv(r, p.fd_map_rn);
+      tile_n = p.map_full * p.map_gn + (r - tile_mg * p.map_rn);
+    }
+    g = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroups; ++i)
+      if (i < p.ngroups && tile_mg >= p.g_tile0[i]) g = i;
+    const int g_row0 = MD_SEL_G(p.g_row0, g), g_arow0 = MD_SEL_G(p.g_arow0, g);
+    m_base = g_row0 + (tile_mg - MD_SEL_G(p.g_tile0, g)) * BM;
+    m_end = g_row0 + MD_SEL_G(p.g_rows, g);
+    n0 = tile_n * BN;
+    Wg = (const char*)MD_SEL_G(p.W, g);
+    // (the lane's row / chunk indices are re-derived per tile from an opaque copy of the lane id: as loop invariants hipcc keeps a dozen of
+    // them alive through the whole tile loop and spills them)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int lrow_o = lane_o >> 3, pc_o = lane_o & 7;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) {
+      const int r = (i * NW + wave) * 8 + lrow_o;
+      const int lc = pc_o ^ ((r >> 1) & 7);
+      int m = m_base + r;
+      m = m < m_end ? m : m_end - 1;
+      const long am = (long)g_arow0 + (m - g_row0);
+      srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
+      const int rp = (r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);  // the direct-store image
+      offW[i] = (unsigned)(n0 + rp) * (unsigned)(ldw * 2) + (unsigned)(lc * 16);
+    }
+  };
+  auto issue_W = [&](int kt, int slot) __attribute__((always_inline)) {
+    char* sbase = smem + slot * HALF_BYTES;
+    const char* wk = Wg + (long)kt * 128;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) glds16(wk + offW[i], sbase + (i * NW + wave) * 1024);
+  };
+  auto issue_A = [&](int kt, int slot) __attribute__((always_inline)) {
+    char* sbase = smem + slot * HALF_BYTES;
+    const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
+  };
+  locate(xs + it);
+  issue_A(0, 0);
+  issue_W(0, 1);
+  bool first = true, prev_interior = true;
+  const bool g1 = wm == 1;
+  for (;;) {
+    f32x4acc_t acc16[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc16[a][b] = (f32x4acc_t){0.f, 0.f, 0.f, 0.f};
+    int issued = 2, slot_i = 2, slot_c = 0;
+    auto wait_tile = [&](int t) __attribute__((always_inline)) {
+      const int younger = issued - (2 * t + 2);
+      if (younger >= 3) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else if (younger == 2) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (younger == 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    // k-tile 0 of this tile: requested before the previous tile's epilogue, whose 16 (x 2 planes) stores are younger -- when that tile was an
+    // interior one (every store instruction was issued by every wave); behind a group's last, partial tile a wave may have skipped
+    // stores, so everything is waited for
+    if (first || !prev_interior) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (PLN == 2) {
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < KT; ++t) {
+      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = lane_off16 ^ (ks << 6);
+        i32x4_t wf[4], af[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 2048 + off);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) af[b] = *(const i32x4_t*)(As + b * 2048 + off);
+        if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
+          if (ks == 0 && KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
+          if (ks == 1 && KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
+        } else {
+          if (ks == 0 && t + 1 < KT) { issue_W(t + 1, slot_i); ++issued; slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1; }
+          if (ks == 1 && t + 2 < KT) { issue_A(t + 2, slot_i); ++issued; slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1; }
+        }
+        if (ks == 0 && t == KT - 1) {  // the epilogue's operands into the exchange area (slot 4 is idle in the last k-tile: launch_256 checks KT)
+          int l2 = lane;
+          asm volatile("" : "+v"(l2));
+          if constexpr (FOLD) {
+            int r2 = m_base + wave * 32 + (l2 >> 1);
+            r2 = r2 < m_end - 1 ? r2 : m_end - 1;
+            glds16((const char*)p.ln_stats + (long)r2 * 32 + (l2 & 1) * 16, smem + kLnXchg + 2048 + wave * 1024);
+            if (wave == 0) glds16((const char*)(MD_SEL_G(p.ln_c, g) + n0) + l2 * 16, smem + kLnXchg + 10240);
+          }
+          if (wave == 1) glds16((const char*)(MD_SEL_G(p.bias, g) + n0) + l2 * 16, smem + kLnXchg + 11264);
+        }
+        if (g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) Atom16<T>::mma(wf[a], af[b], acc16[a][b]);
+        if (!g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
+    // ---- hand-over: everything of this tile has landed; the next tile's k-tile 0 goes out before the epilogue ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int e_m_base = m_base, e_m_end = m_end, e_n0 = n0;
+    it += istep;
+    const bool has_next = it < xc;
+    __builtin_amdgcn_s_barrier();  // the exchange area is complete and visible; every wave has left the ring
+    asm volatile("" ::: "memory");
+    if (has_next) {
+      locate(xs + it);
+      issue_A(0, 0);
+      issue_W(0, 1);
+    }
+    if constexpr (FOLD) {  // partials -> (rstd, -mu rstd), one row per thread
+      if (tid < BM) {
+        const f32x4_t p0 = *(const f32x4_t*)(lnx + 512 + tid * 8), p1 = *(const f32x4_t*)(lnx + 512 + tid * 8 + 4);
+        const float mu = ((p0[0] + p0[2]) + (p1[0] + p1[2])) * 0.25f;
+        const float d0 = p0[0] - mu, d1 = p0[2] - mu, d2 = p1[0] - mu, d3 = p1[2] - mu;
+        const float m2 = ((p0[1] + p0[3]) + (p1[1] + p1[3])) + 256.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float rstd = 1.0f / sqrtf(m2 * p.ln_inv_n + p.ln_eps);
+        *(f32x2_t*)(lnx + 2 * tid) = (f32x2_t){rstd, -mu * rstd};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // ---- epilogue: direct stores from the accumulator layout (the permuted W image: gemm256_kernel's EK 9 / 11) ----
+    {
+      const bool interior = e_m_base + BM <= e_m_end;
+      // (lane indices made opaque per tile: hipcc otherwise hoists the epilogue's LDS and store offsets out of the TILE loop, spills them and
+      // reloads each behind a vmcnt(0) -- which would wait for the next tile's requests)
+      int r16e = r16, q16e = q16;
+      asm volatile("" : "+v"(r16e), "+v"(q16e));
+      f32x4_t bq[4], wq[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int cl = wn * WTN + (a >> 1) * 32 + q16e * 8 + (a & 1) * 4;  // tile-local column of the lane's 4 accumulators of n-block a
+        bq[a] = *(const f32x4_t*)(lnx + 2816 + cl);
+        wq[a] = FOLD ? *(const f32x4_t*)(lnx + 2560 + cl) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+      }
+      float lnA[8], lnB[8];
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const f32x2_t t2 = *(const f32x2_t*)(lnx + 2 * (wm * WTM + b * 16 + r16e));
+          lnA[b] = t2[0];
+          lnB[b] = t2[1];
+        }
+      }
+      char* ob = (char*)p.out + ((long)e_m_base * p.ldo + e_n0) * 2;
+      const unsigned lcd = (unsigned)(wn * WTN + q16e * 8), lo_off = (unsigned)p.o_plane * 2u;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int lrow_t = wm * WTM + b * 16 + r16e;
+        const bool ok = interior || e_m_base + lrow_t < e_m_end;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4_t v[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int a = 2 * h + j;
+            const f32x4acc_t c = acc16[a][b];
+            f32x4_t x = {c[0], c[1], c[2], c[3]};
+            if constexpr (FOLD) {
+              const f32x4_t Bv = {lnB[b], lnB[b], lnB[b], lnB[b]}, Av = {lnA[b], lnA[b], lnA[b], lnA[b]};
+              x = fma4(x, Av, fma4(wq[a], Bv, bq[a]));
+            } else {
+              x = fma4(x, wq[a], bq[a]);
+            }
+            v[j] = gelu4<T>(x);
+          }
+          const unsigned eo = ((unsigned)lrow_t * (unsigned)p.ldo + lcd + (unsigned)(h * 32)) * 2u;
+          if constexpr (PLN == 2) {
+            i32x4_t ph, pl;
+            split8<T>(v[0], v[1], ph, pl);
+            if (ok) {
+              *(i32x4_t*)(ob + eo) = ph;
+              *(i32x4_t*)(ob + eo + lo_off) = pl;
+            }
+          } else {
+            const i32x4_t raw = pack8<T>(v[0], v[1]);
+            if (ok) *(i32x4_t*)(ob + eo) = raw;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!has_next) break;
+    first = false;
+    prev_interior = e_m_base + BM <= e_m_end;
+  }
+}
+
 // host side of map_tile: n-tiles are walked in groups of gn (L2-aware raster), the last group may be narrower
 static inline void prep_tile_map(GemmParams& p, int tiles_m, int tiles_n) {
   const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
@@ -1890,6 +2153,32 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     // (fc1 36.18 -> 35.46 ms per step: their stores leave spread out between the polynomial's arithmetic), the plain kinds LOSE (qkv 23.61 ->
     // 24.52: sixteen half-line stores per wave in one burst cost more than the LDS transpose they replace) -- so only EK 4 / 7 take the
     // direct form; EK 8 / 10 stay instantiable for A/B builds (MD_DIRECT_STORE_ALL).
+    if constexpr (AMODE == A_DENSE && !std::is_same<T, fp8_t>::value) {
+      // the persistent tile loop of the fc1 form (gemm256p_kernel): GemmParams::persist, enough tiles to give every CU several, a k-tile
+      // count that leaves ring slot 4 idle in the last k-tile (16, 32: K' = 1024, 2048)
+      const int KTp = p.K / 64;
+      if (!diag && p.persist && p.direct_store && lean && (ek == 4 || ek == 7) && !p.wscale[0] && p.bias[0] && blocks >= 1024 && KTp >= 3 &&
+          (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4 && (ek == 4 || p.ln_raw)) {
+        int ordinal = 0, cus = 0;
+        MD_HIP(hipGetDevice(&ordinal));
+        MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
+        const int G = (cus > 0 ? cus : 256) & ~7;
+        p.ptiles = (int)blocks;
+        auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
+          const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
+          if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {
+            MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set->fetch_or(bit, std::memory_order_release);
+          }
+          hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(512), smem, stream, p);
+          MD_HIP(hipGetLastError());
+          return MD_OK;
+        };
+        static std::atomic<unsigned long> pset[2];
+        if (ek == 7) return gop(gemm256p_kernel<T, true>, &pset[1]);
+        return gop(gemm256p_kernel<T, false>, &pset[0]);
+      }
+    }
     if (!diag && p.direct_store && lean) {
 #ifdef MD_DIRECT_STORE_ALL
       if constexpr (AMODE != A_CONV3) {

@@ -720,6 +720,7 @@ __attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, 
 }  // namespace
 
 int md_debug_gemm_direct_store(int on) { return md::gemm_direct_store(on); }
+int md_debug_gemm_persistent(int on) { return md::gemm_persistent(on); }
 
 int md_gemm_ksplit_launches(void) { return (int)(md::gemm_ksplit_launches() & 0x7fffffff); }
 

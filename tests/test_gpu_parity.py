@@ -120,6 +120,64 @@ def test_direct_store_epilogue_is_bit_identical_to_the_staged_one(dev, precision
     assert err <= {0: 8e-3, 3: 1.5e-3, 4: 2e-5}[precision], err
 
 
+@pytest.mark.parametrize("precision", [0, 3, 4])
+def test_persistent_fc1_kernel_is_bit_identical_to_the_one_tile_kernel(dev, precision):
+    """Round 6: launches of the fc1 form with >= 1024 tiles run `gemm256p_kernel` -- one workgroup per CU walks its XCD's share of the raster
+    and requests the NEXT tile's first k-tile before the current tile's (direct-store, LDS-free) epilogue; bias / c / d and the LayerNorm
+    partials reach the epilogue through LDS-DMA. Same main loop, same arithmetic: the same bits as the one-tile kernel
+    (`md_debug_gemm_persistent(0 | 1)`) on a GELU linear layer of 65 x 16 tiles whose last m-tile is partial, twice (the tile walk is
+    deterministic), in bf16, f16 and split-half storage. (The folded form is held to the one-tile kernel on whole DepthPro::infer calls
+    below; fc1 = burn_dino's MLP, /root/reference/src/model/depth_pro/layers/vit.rs:45-68.)"""
+    from burn_depth_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256 * 64 + 100, 4096, 1024
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    if precision == 4:
+        x, w = x.half().float(), w.half().float()
+    prev = lib.md_debug_gemm_persistent(0)
+    try:
+        ref = ops.linear(dev, x, w, b, act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
+        lib.md_debug_gemm_persistent(1)
+        got = ops.linear(dev, x, w, b, act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
+        got2 = ops.linear(dev, x, w, b, act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
+    finally:
+        lib.md_debug_gemm_persistent(prev)
+    assert torch.equal(ref, got) and torch.equal(got, got2)
+    assert bool(torch.isfinite(got).all()) and float(got.abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("precision", [0, 4])
+def test_persistent_fc1_kernel_inside_the_model(dev, precision):
+    """DepthPro::infer on [2,3,1536,1536] (default configuration: fc1 = 2688 tiles per launch, the LayerNorm fold on) with the persistent
+    fc1 kernel and with the one-tile kernel: bit-identical depth, fov and focal length, bf16 and split-half."""
+    from burn_depth_amd import _lib
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    lib = _lib.load()
+    cfg = DepthProConfig()
+    cfg.precision = precision
+    cfg.max_batch = 2
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    if precision == 4:
+        m.round_weights_to_f16()
+    assert m.query("ln_fold_active") == 1
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 1536, 1536, device="cuda")
+    prev = lib.md_debug_gemm_persistent(0)
+    try:
+        a = m.infer(x)
+        lib.md_debug_gemm_persistent(1)
+        b = m.infer(x)
+    finally:
+        lib.md_debug_gemm_persistent(prev)
+    assert torch.equal(a.depth, b.depth) and torch.equal(a.fovx_deg, b.fovx_deg) and torch.equal(a.focallength_px, b.focallength_px)
+    m.destroy()
+
+
 @pytest.mark.parametrize("precision", [1, 0, 3])
 def test_depth_pro_tiny_end_to_end(diag, dev, precision):
     from burn_depth_amd.config import DepthProConfig

@@ -1,0 +1,58 @@
+"""Persistent fc1 kernel (gemm256p_kernel; md_debug_gemm_persistent): bit-identity against the one-tile kernel on a stand-alone GELU linear
+layer with >= 1024 tiles (a partial last m-tile included) and on whole DepthPro::infer calls (LayerNorm fold on), bf16 / f16 / f16x2."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from burn_depth_amd import _lib, ops  # noqa: E402
+from burn_depth_amd import weights as Wt  # noqa: E402
+from burn_depth_amd.config import DepthProConfig  # noqa: E402
+from burn_depth_amd.depth_pro import DepthPro, Device  # noqa: E402
+
+
+def main():
+    dev = Device(0)
+    lib = _lib.load()
+    ok = True
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256 * 64 + 100, 4096, 1024
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    for prec in (0, 3, 4):
+        xx, ww = (x.half().float(), w.half().float()) if prec == 4 else (x, w)
+        lib.md_debug_gemm_persistent(0)
+        ref = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
+        lib.md_debug_gemm_persistent(1)
+        got = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
+        got2 = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
+        lib.md_debug_gemm_persistent(0)
+        same = torch.equal(ref, got) and torch.equal(got, got2)
+        print(f"linear prec {prec}: persistent == one-tile: {same}  (max |diff| {(ref - got).abs().max().item():.3e})", flush=True)
+        ok = ok and same
+    for prec in (0, 4):
+        cfg = DepthProConfig()
+        cfg.precision = prec
+        cfg.max_batch = 2
+        m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+        if prec == 4:
+            m.round_weights_to_f16()
+        torch.manual_seed(1)
+        xi = torch.randn(2, 3, 1536, 1536, device="cuda")
+        lib.md_debug_gemm_persistent(0)
+        a = m.infer(xi).depth.clone()
+        lib.md_debug_gemm_persistent(1)
+        bb = m.infer(xi).depth.clone()
+        cc = m.infer(xi).depth.clone()
+        lib.md_debug_gemm_persistent(0)
+        same = torch.equal(a, bb) and torch.equal(bb, cc)
+        print(f"DepthPro::infer [2,3,1536,1536] prec {prec} (fold {m.query('ln_fold_active')}): persistent == one-tile: {same}", flush=True)
+        ok = ok and same
+        m.destroy()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
