@@ -1822,7 +1822,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 // vmcnt(0) drains the next tile's requests. Stores are younger than those requests: the wait for the next tile's k-tile 0 is
 // vmcnt(stores of this epilogue). Same main loop, same arithmetic, same bits as the one-tile kernel.
 // LDS exchange area (inside ring slot 4, idle in the last k-tile for KT = 16 / 32): [pairs 2 KB][partials 8 KB][c or bias 1 KB][d 1 KB].
-template <typename T, bool FOLD>
+// QKV = true: the fused QKV projection (EPI_QKV, one-plane types): q | k tiles through the lean staged store epilogue, its staging moved to
+// ring slots 2 - 3 so that slots 0 - 1 can take the next tile's first k-tile meanwhile; V^T tiles (a third of the launch) through their
+// transposed staging, which covers slots 0 - 1 -- behind a V^T tile the next request goes out AFTER the epilogue (no overlap there).
+template <typename T, bool FOLD, bool QKV = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4, WTM = 128, WTN = 64, HALF_BYTES = 256 * 128, NSLOT = 5, LPH = 4, KE = 64, PLN = kPlanes<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1884,7 +1887,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       m = m < m_end ? m : m_end - 1;
       const long am = (long)g_arow0 + (m - g_row0);
       srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
-      const int rp = (r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3);  // the direct-store image
+      const int rp = QKV ? r : ((r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3));  // fc1: the direct-store image
       offW[i] = (unsigned)(n0 + rp) * (unsigned)(ldw * 2) + (unsigned)(lc * 16);
     }
   };
@@ -1903,7 +1906,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   locate(xs + it);
   issue_A(0, 0);
   issue_W(0, 1);
-  bool first = true, prev_interior = true;
+  bool first = true, prev_counted = true;  // prev_counted: the previous tile's epilogue issued exactly kStores stores BEHIND this tile's first requests
+  constexpr int kStores = 16 * PLN;
   const bool g1 = wm == 1;
   for (;;) {
     f32x4acc_t acc16[4][8];
@@ -1927,9 +1931,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     // k-tile 0 of this tile: requested before the previous tile's epilogue, whose 16 (x 2 planes) stores are younger -- when that tile was an
     // interior one (every store instruction was issued by every wave); behind a group's last, partial tile a wave may have skipped
     // stores, so everything is waited for
-    if (first || !prev_interior) {
+    if (first || !prev_counted) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if (PLN == 2) {
+    } else if (kStores == 32) {
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -1990,7 +1994,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const bool has_next = it < xc;
     __builtin_amdgcn_s_barrier();  // the exchange area is complete and visible; every wave has left the ring
     asm volatile("" ::: "memory");
-    if (has_next) {
+    const bool e_vt = QKV && e_n0 >= 2 * p.embed;  // a V^T tile: its transposed staging covers ring slots 0 - 1
+    const bool early = has_next && !e_vt;
+    if (early) {
       locate(xs + it);
       issue_A(0, 0);
       issue_W(0, 1);
@@ -2008,8 +2014,120 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+    if constexpr (QKV) {
+      const bool interior = e_m_base + BM <= e_m_end;
+      int r16e = r16, q16e = q16, lane_e = lane;
+      asm volatile("" : "+v"(r16e), "+v"(q16e), "+v"(lane_e));
+      if (e_vt) {
+        // ---- V^T tile: staged transposed (gemm256_kernel's `direct` path), c / d / bias from the exchange area ----
+        constexpr int SRT = 272;
+        char* stt = smem + wave * (64 * SRT);
+        const int nl0 = q16e;
+        const int hd = (e_n0 - 2 * p.embed + wn * WTN) >> 6;
+        float bia[16], wsc[16];
+#pragma unroll
+        for (int i2 = 0; i2 < 16; ++i2) {
+          bia[i2] = lnx[2816 + wn * WTN + i2 * 4 + nl0];
+          wsc[i2] = FOLD ? lnx[2560 + wn * WTN + i2 * 4 + nl0] : 1.f;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const f32x4acc_t c = acc16[a][half * 4 + bb];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) *(float*)(stt + (a * 16 + 4 * q16e + j) * SRT + (bb * 16 + r16e) * 4) = c[j];
+            }
+          asm volatile("" ::: "memory");
+          const int m = e_m_base + wm * WTM + half * 64 + r16e * 4;
+          f32x4_t lnA4 = {1.f, 1.f, 1.f, 1.f}, lnB4 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (FOLD) {
+            const float* ab = lnx + 2 * (wm * WTM + half * 64 + r16e * 4);
+            const f32x4_t t0 = *(const f32x4_t*)ab, t1 = *(const f32x4_t*)(ab + 4);
+            lnA4 = (f32x4_t){t0[0], t0[2], t1[0], t1[2]};
+            lnB4 = (f32x4_t){t0[1], t0[3], t1[1], t1[3]};
+          }
+          const int seq = fdiv(m, p.fd_seq_stride);
+          const int tok = m - seq * p.seq_stride;
+          T* vrow = (T*)p.vT + (((long)seq * p.heads + hd) * 64) * p.kpad + tok;
+          const bool ok = m < e_m_end;
+#pragma unroll
+          for (int i2 = 0; i2 < 16; ++i2) {
+            const int nl = i2 * 4 + nl0;
+            f32x4_t v = *(const f32x4_t*)(stt + nl * SRT + r16e * 16);
+            if constexpr (FOLD) v = fma4(v, lnA4, fma4(lnB4, (f32x4_t){wsc[i2], wsc[i2], wsc[i2], wsc[i2]}, (f32x4_t){bia[i2], bia[i2], bia[i2], bia[i2]}));
+            else v = v * wsc[i2] + bia[i2];
+            if (ok) store4<T>(vrow + (long)nl * p.kpad, v);
+          }
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        // ---- q | k tile: the lean staged store epilogue, staging in ring slots 2 - 3 (8 KB per wave) ----
+        const float qs = e_n0 < p.embed ? p.qscale : 1.f;
+        f32x4_t bq[4], wq[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int cl = wn * WTN + a * 16 + 4 * q16e;
+          bq[a] = *(const f32x4_t*)(lnx + 2816 + cl) * qs;
+          wq[a] = (FOLD ? *(const f32x4_t*)(lnx + 2560 + cl) : (f32x4_t){1.f, 1.f, 1.f, 1.f}) * qs;
+        }
+        float lnA[8], lnB[8];
+        if constexpr (FOLD) {
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const f32x2_t t2 = *(const f32x2_t*)(lnx + 2 * (wm * WTM + b * 16 + r16e));
+            lnA[b] = t2[0] * qs;
+            lnB[b] = t2[1];
+          }
+        }
+        char* st = smem + 2 * HALF_BYTES + wave * 8192;
+        const long ldo8 = 2L * p.embed;
+        char* ob = (char*)p.out + ((long)e_m_base * ldo8 + e_n0) * 2;
+        const int rsub = lane_e >> 3;
+        const unsigned lc8 = (unsigned)(wn * WTN + (lane_e & 7) * 8);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const int b = half * 4 + bb;
+              const f32x4acc_t c = acc16[a][b];
+              f32x4_t x = {c[0], c[1], c[2], c[3]};
+              if constexpr (FOLD) {
+                const f32x4_t Bv = {lnB[b], lnB[b], lnB[b], lnB[b]}, Av = {lnA[b], lnA[b], lnA[b], lnA[b]};
+                x = fma4(x, Av, fma4(wq[a], Bv, bq[a]));
+              } else {
+                x = fma4(x, wq[a], bq[a]);
+              }
+              const int row = bb * 16 + r16e;
+              const int chunk = (a * 2 + (q16e >> 1)) ^ (row & 7);
+              *(i32x2_t*)(st + row * 128 + chunk * 16 + (q16e & 1) * 8) = pack4<T>(x);
+            }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int i2 = 0; i2 < 8; ++i2) {
+            const int row = i2 * 8 + rsub;
+            const int lrow_t = wm * WTM + half * 64 + row;
+            const i32x4_t raw = *(const i32x4_t*)(st + row * 128 + (((lane_e & 7) ^ (row & 7)) << 4));
+            if (interior || e_m_base + lrow_t < e_m_end) *(i32x4_t*)(ob + ((unsigned)lrow_t * (unsigned)ldo8 + lc8) * 2u) = raw;
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+      if (has_next && e_vt) {  // behind a V^T tile: every wave is done with its staging (slots 0 - 1) before the next requests go out
+        __builtin_amdgcn_s_barrier();
+        locate(xs + it);
+        issue_A(0, 0);
+        issue_W(0, 1);
+      }
+    }
     // ---- epilogue: direct stores from the accumulator layout (the permuted W image: gemm256_kernel's EK 9 / 11) ----
-    {
+    if constexpr (!QKV) {
       const bool interior = e_m_base + BM <= e_m_end;
       // (lane indices made opaque per tile: hipcc otherwise hoists the epilogue's LDS and store offsets out of the TILE loop, spills them and
       // reloads each behind a vmcnt(0) -- which would wait for the next tile's requests)
@@ -2071,7 +2189,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     }
     if (!has_next) break;
     first = false;
-    prev_interior = e_m_base + BM <= e_m_end;
+    prev_counted = early && e_m_base + BM <= e_m_end;  // (an interior tile: every wave issued every store instruction)
   }
 }
 
@@ -2177,6 +2295,31 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         static std::atomic<unsigned long> pset[2];
         if (ek == 7) return gop(gemm256p_kernel<T, true>, &pset[1]);
         return gop(gemm256p_kernel<T, false>, &pset[0]);
+      }
+      // the fused QKV projection as the same tile loop (one-plane types): q | k tiles overlap the next tile's first requests, V^T tiles do not
+      if constexpr (!is_split<T>::value) {
+        if (!diag && p.persist && lean && p.epi == EPI_QKV && (ek == 2 || ek == 6) && !p.wscale[0] && p.bias[0] && !p.qkn_g[0] && blocks >= 1024 &&
+            KTp >= 3 && (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4 && (ek == 2 || p.ln_raw) && p.embed % BN == 0 && (p.seq_stride & 3) == 0 &&
+            p.N == 3 * p.embed) {
+          int ordinal = 0, cus = 0;
+          MD_HIP(hipGetDevice(&ordinal));
+          MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
+          const int G = (cus > 0 ? cus : 256) & ~7;
+          p.ptiles = (int)blocks;
+          auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
+            const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
+            if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {
+              MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+              attr_set->fetch_or(bit, std::memory_order_release);
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(512), smem, stream, p);
+            MD_HIP(hipGetLastError());
+            return MD_OK;
+          };
+          static std::atomic<unsigned long> qset[2];
+          if (ek == 6) return gop(gemm256p_kernel<T, true, true>, &qset[1]);
+          return gop(gemm256p_kernel<T, false, true>, &qset[0]);
+        }
       }
     }
     if (!diag && p.direct_store && lean) {

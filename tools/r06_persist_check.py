@@ -32,11 +32,12 @@ def main():
         same = torch.equal(ref, got) and torch.equal(got, got2)
         print(f"linear prec {prec}: persistent == one-tile: {same}  (max |diff| {(ref - got).abs().max().item():.3e})", flush=True)
         ok = ok and same
-    for prec in (0, 4):
+    for prec, fold in ((0, 1), (0, 0), (3, 1), (4, 1)):   # (the QKV projection runs the tile loop in the one-plane types, folded and unfolded)
         cfg = DepthProConfig()
         cfg.precision = prec
         cfg.max_batch = 2
         m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+        m.set_option("ln_fold", fold)
         if prec == 4:
             m.round_weights_to_f16()
         torch.manual_seed(1)
@@ -48,7 +49,7 @@ def main():
         cc = m.infer(xi).depth.clone()
         lib.md_debug_gemm_persistent(0)
         same = torch.equal(a, bb) and torch.equal(bb, cc)
-        print(f"DepthPro::infer [2,3,1536,1536] prec {prec} (fold {m.query('ln_fold_active')}): persistent == one-tile: {same}", flush=True)
+        print(f"DepthPro::infer [2,3,1536,1536] prec {prec} (fold {m.query('ln_fold_active')}): persistent == one-tile: {same}  max |diff| {(a - bb).abs().max().item():.3e}", flush=True)
         ok = ok and same
         m.destroy()
     sys.exit(0 if ok else 1)
