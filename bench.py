@@ -143,8 +143,8 @@ def parse_args(argv=None):
                     help="the LayerNorms between the ViT's GEMMs folded into those GEMMs (md_model_set_option(\"ln_fold\"): automatic = on for 16-bit models with 577-token sequences) or as stand-alone launches -- an A/B switch, recorded in config.layernorm")
     ap.add_argument("--direct-store", choices=["on", "off"], default="on",
                     help="lean 2-byte store epilogues of the 256 x 256 GEMM kernel straight from the accumulator layout (the product) or staged through LDS (md_debug_gemm_direct_store): an A/B switch, same bits")
-    ap.add_argument("--persistent-fc1", choices=["on", "off"], default="on",
-                    help="the fc1 GEMM as a persistent tile loop (md_debug_gemm_persistent): an A/B switch, same bits")
+    ap.add_argument("--persistent-fc1", choices=["on", "off", "fc1", "fc1qkv"], default="on",
+                    help="the ViT GEMMs as persistent tile loops (md_debug_gemm_persistent; on = fc1 + QKV + proj / fc2): an A/B switch, same bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-launch HIP events in the timed region (the `kernels` / `roofline` objects are then empty): measures what the events themselves cost")
     ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the whole-frame CPU baseline may take (predicted from a 2-tile probe); beyond it the sampled estimate is reported")
@@ -223,9 +223,9 @@ def main(argv=None) -> int:
 
     dev = Device(local_rank)
     tdev = torch.device("cuda", local_rank)
-    if args.persistent_fc1 == "off":
+    if args.persistent_fc1 != "on":
         from burn_depth_amd import _lib as _lps
-        _lps.load().md_debug_gemm_persistent(0)
+        _lps.load().md_debug_gemm_persistent({"off": 0, "fc1": 1, "fc1qkv": 3}[args.persistent_fc1])
     if args.direct_store == "off":
         from burn_depth_amd import _lib as _lds
         _lds.load().md_debug_gemm_direct_store(0)
@@ -449,7 +449,7 @@ def main(argv=None) -> int:
             launches = calls // args.steps
             tfl = fl[dom] / (per_step * 1e-3) / 1e12
             # the rocprofv3 row of the same command: EK 11 = the GELU store kind with the LayerNorm fold, direct stores (EK 9 without the fold)
-            pf = args.persistent_fc1 == "on"
+            pf = args.persistent_fc1 != "off"
             symbols = {"fc1_gemm": ((("md::gemm256p_kernel<md::bf16_t, true> (persistent tile loop, " if pf else "md::gemm256_kernel<md::bf16_t, 0, 11, false> (")
                                      + "dense A, 16x16x32 two-group schedule, LayerNorm fold + bias + GELU, direct store)")
                                     if model.query("ln_fold_active") else

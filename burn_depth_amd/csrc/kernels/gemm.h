@@ -112,7 +112,7 @@ struct GemmParams {
   // 16-byte store per (m-block, h), 16 rows x 64 bytes per wave-instruction, the two h of a row completing its 128-byte line back to
   // back. Same values, same bits as the staged form. Set by launch_gemm for eligible launches (gemm_direct_store()).
   int direct_store = 0;
-  int persist = 0;   // set by launch_gemm (gemm_persistent()): the fc1 form may run as the persistent tile loop gemm256p_kernel
+  int persist = 0;   // set by launch_gemm (gemm_persistent()): which forms may run as persistent tile loops (1 fc1, 2 QKV: gemm256p_kernel; 4 read-modify-write: gemm256r_kernel)
   int ptiles = 0;    // persistent form: tiles of the launch (set by launch_256)
   int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)
   int res_mod = 0;              // > 0: res1's row = m % res_mod (a per-image table shared by the batch, or an input two weight groups share); res2 is never wrapped
@@ -174,8 +174,8 @@ struct GemmParams {
 // sizes: the split is off unless the calling thread turned it on -- the Depth-Anything-v3 engine does, around each of its calls.
 // process-wide A/B switch of GemmParams::direct_store (default 1); returns the previous value
 int gemm_direct_store(int on);
-// process-wide A/B switch of GemmParams::persist (default 1); returns the previous value
-int gemm_persistent(int on);
+// process-wide A/B switch of GemmParams::persist (a mask: 1 the fc1 form, 2 the QKV projection, 4 the read-modify-write GEMMs; default 7); returns the previous value
+int gemm_persistent(int mask);
 int gemm_allow_ksplit(int on);  // per host thread; returns the previous value
 void gemm_count_ksplit_launch();   // diagnostics: md_gemm_ksplit_launches()
 long long gemm_ksplit_launches();

@@ -61,8 +61,8 @@ int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
 
 static std::atomic<int> g_direct_store{1};
 int gemm_direct_store(int on) { return g_direct_store.exchange(on ? 1 : 0); }
-static std::atomic<int> g_persist{1};
-int gemm_persistent(int on) { return g_persist.exchange(on ? 1 : 0); }
+static std::atomic<int> g_persist{7};
+int gemm_persistent(int mask) { return g_persist.exchange(mask & 7); }
 static thread_local int g_ksplit_ok = 0;
 int gemm_allow_ksplit(int on) {  // returns the previous value (KsplitScope restores it)
   const int prev = g_ksplit_ok;

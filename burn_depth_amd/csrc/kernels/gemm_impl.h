@@ -2193,6 +2193,258 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   }
 }
 
+// The read-modify-write GEMMs (proj, fc2: EPI_RESID_LS, with or without the LayerNorm fold's producer part) as the same tile loop. The one-tile
+// kernel's fp32 staging (17 KB per wave) covers the whole ring; here a wave stages 32 rows at a time (8.5 KB per wave in ring slots 2 - 4), so
+// that slots 0 - 1 can take the next tile's first k-tile under the 12 - 16 us of this epilogue. Same arithmetic, same bits.
+template <typename T, bool EMIT>
+__global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
+  constexpr bool FOLD = false, QKV = true;  // (QKV = true below only selects the plain W image)
+  constexpr int BM = 256, BN = 256, NW = 8, WGN = 4, WTM = 128, WTN = 64, HALF_BYTES = 256 * 128, NSLOT = 5, LPH = 4, KE = 64, PLN = kPlanes<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lrow = lane >> 3, pc = lane & 7, q16 = lane >> 4, r16 = lane & 15;
+  const int lane_off16 = r16 * 128 + ((((r16 >> 1) & 7) ^ q16) << 4);
+  const int KT = p.K / KE;
+  const long ldw = p.ldw > 0 ? p.ldw : (long)p.K;
+  float* const lnx = (float*)(smem + kLnXchg);
+  // this workgroup's tiles: XCD x (blocks b, b + 8, .. share one) owns the contiguous id range [xs, xs + xc) of the raster; block j of the
+  // XCD takes ids xs + j, xs + j + G / 8, ...
+  const int ntiles = p.ptiles, G = gridDim.x;
+  int it, xs, xc;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
+    xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    xc = q + (xcd < r ? 1 : 0);
+    it = blockIdx.x >> 3;
+  }
+  const int istep = G >> 3;
+  if (it >= xc) return;
+
+  int m_base, m_end, n0, g;
+  const char* Wg;
+  const char* srcA[LPH];
+  unsigned offW[LPH];
+  auto locate = [&](int id) __attribute__((always_inline)) {
+    int tile_n, tile_mg;
+    if (id < p.map_full_gsz) {
+      const int ng = fdiv(id, p.fd_map_gsz), r = id - ng * p.map_gsz;
+      tile_mg = fdiv(r, p.fd_map_gn);
+      tile_n = ng * p.map_gn + (r - tile_mg * p.map_gn);
+    } else {
+      const int r = id - p.map_full_gsz;
+      tile_mg = fdiv(r, p.fd_map_rn);
+      tile_n = p.map_full * p.map_gn + (r - tile_mg * p.map_rn);
+    }
+    g = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroups; ++i)
+      if (i < p.ngroups && tile_mg >= p.g_tile0[i]) g = i;
+    const int g_row0 = MD_SEL_G(p.g_row0, g), g_arow0 = MD_SEL_G(p.g_arow0, g);
+    m_base = g_row0 + (tile_mg - MD_SEL_G(p.g_tile0, g)) * BM;
+    m_end = g_row0 + MD_SEL_G(p.g_rows, g);
+    n0 = tile_n * BN;
+    Wg = (const char*)MD_SEL_G(p.W, g);
+    // (the lane's row / chunk indices are re-derived per tile from an opaque copy of the lane id: as loop invariants hipcc keeps a dozen of
+    // them alive through the whole tile loop and spills them)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int lrow_o = lane_o >> 3, pc_o = lane_o & 7;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) {
+      const int r = (i * NW + wave) * 8 + lrow_o;
+      const int lc = pc_o ^ ((r >> 1) & 7);
+      int m = m_base + r;
+      m = m < m_end ? m : m_end - 1;
+      const long am = (long)g_arow0 + (m - g_row0);
+      srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
+      const int rp = QKV ? r : ((r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3));  // fc1: the direct-store image
+      offW[i] = (unsigned)(n0 + rp) * (unsigned)(ldw * 2) + (unsigned)(lc * 16);
+    }
+  };
+  auto issue_W = [&](int kt, int slot) __attribute__((always_inline)) {
+    char* sbase = smem + slot * HALF_BYTES;
+    const char* wk = Wg + (long)kt * 128;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) glds16(wk + offW[i], sbase + (i * NW + wave) * 1024);
+  };
+  auto issue_A = [&](int kt, int slot) __attribute__((always_inline)) {
+    char* sbase = smem + slot * HALF_BYTES;
+    const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+#pragma unroll
+    for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
+  };
+  locate(xs + it);
+  issue_A(0, 0);
+  issue_W(0, 1);
+  bool first = true, prev_counted = true;  // prev_counted: the previous tile's epilogue issued exactly kStores stores BEHIND this tile's first requests
+  const bool g1 = wm == 1;
+  for (;;) {
+    f32x4acc_t acc16[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc16[a][b] = (f32x4acc_t){0.f, 0.f, 0.f, 0.f};
+    int issued = 2, slot_i = 2, slot_c = 0;
+    auto wait_tile = [&](int t) __attribute__((always_inline)) {
+      const int younger = issued - (2 * t + 2);
+      if (younger >= 3) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else if (younger == 2) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (younger == 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    // k-tile 0 of this tile: requested before the previous tile's epilogue, whose 16 (x 2 planes) stores are younger -- when that tile was an
+    // interior one (every store instruction was issued by every wave); behind a group's last, partial tile a wave may have skipped
+    // stores, so everything is waited for
+    if (first || !prev_counted) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // (32: the x stores alone; a safe lower bound of what follows the requests in either form)
+    }
+    __builtin_amdgcn_s_barrier();
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < KT; ++t) {
+      const int slot_w = slot_c == NSLOT - 1 ? 0 : slot_c + 1;
+      const char* As = smem + slot_c * HALF_BYTES + wm * WTM * 128;
+      const char* Ws = smem + slot_w * HALF_BYTES + wn * WTN * 128;
+      slot_c = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = lane_off16 ^ (ks << 6);
+        i32x4_t wf[4], af[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wf[a] = *(const i32x4_t*)(Ws + a * 2048 + off);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) af[b] = *(const i32x4_t*)(As + b * 2048 + off);
+        if (t == 0) {  // rest of the pipeline fill, in half-tile order A1 W1 A2 (slots 2, 3, 4)
+          if (ks == 0 && KT > 1) { issue_A(1, 2); issue_W(1, 3); issued = 4; slot_i = 4; }
+          if (ks == 1 && KT > 2) { issue_A(2, 4); issued = 5; slot_i = 0; }
+        } else {
+          if (ks == 0 && t + 1 < KT) { issue_W(t + 1, slot_i); ++issued; slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1; }
+          if (ks == 1 && t + 2 < KT) { issue_A(t + 2, slot_i); ++issued; slot_i = slot_i == NSLOT - 1 ? 0 : slot_i + 1; }
+        }
+        if (ks == 0 && t == KT - 1) {  // the epilogue's column vectors into the exchange area (slot 4 is idle in the last k-tile: launch_256 checks KT)
+          int l2 = lane;
+          asm volatile("" : "+v"(l2));
+          if (wave == 0) glds16((const char*)(MD_SEL_G(p.bias, g) + n0) + l2 * 16, smem + kLnXchg + 8192);
+          if (wave == 1) glds16((const char*)(MD_SEL_G(p.scale, g) + n0) + l2 * 16, smem + kLnXchg + 9216);
+          if constexpr (EMIT) {
+            if (wave == 2) glds16((const char*)(MD_SEL_G(p.ln_gamma, g) + n0) + l2 * 16, smem + kLnXchg + 10240);
+          }
+        }
+        if (g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) Atom16<T>::mma(wf[a], af[b], acc16[a][b]);
+        if (!g1 && ks == 1 && t + 1 < KT) wait_tile(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
+    // ---- hand-over: everything of this tile has landed; the next tile's k-tile 0 goes out before the epilogue ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int e_m_base = m_base, e_m_end = m_end, e_n0 = n0;
+    it += istep;
+    const bool has_next = it < xc;
+    __builtin_amdgcn_s_barrier();  // the exchange area is complete and visible; every wave has left the ring
+    asm volatile("" ::: "memory");
+    if (has_next) {
+      locate(xs + it);
+      issue_A(0, 0);
+      issue_W(0, 1);
+    }
+    // ---- epilogue: x(f32) += scale * (acc + bias), in four passes of 32 rows per wave through fp32 staging in ring slots 2 - 4 (8.5 KB per wave:
+    //      slots 0 - 1 belong to the next tile's first k-tile); EMIT: + round_T(gamma_next . x_new) and the rows' (mean, M2) (gemm256_kernel's EK 5) ----
+    const bool interior = e_m_base + BM <= e_m_end;
+    {
+      int r16e = r16, q16e = q16, lane_e = lane;
+      asm volatile("" : "+v"(r16e), "+v"(q16e), "+v"(lane_e));
+      constexpr int SROW = 272;
+      char* st = smem + 2 * HALF_BYTES + wave * (32 * SROW);
+      const int col = (lane_e & 15) * 4, rq = lane_e >> 4;
+      const f32x4_t bias4 = *(const f32x4_t*)(lnx + 2048 + wn * WTN + col);
+      const f32x4_t scale4 = *(const f32x4_t*)(lnx + 2304 + wn * WTN + col);
+      f32x4_t gam4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (EMIT) gam4 = *(const f32x4_t*)(lnx + 2560 + wn * WTN + col);
+      char* out_b = (char*)p.out + ((long)e_m_base * p.ldo + e_n0) * 4;
+      char* ln_b = EMIT ? (char*)p.ln_out + ((long)e_m_base * p.ln_ldo + e_n0) * 2 : nullptr;
+      const unsigned lcol = (unsigned)(wn * WTN + col);
+      f32x4_t pre[4][8];
+      auto prefetch = [&](int q, int i2) __attribute__((always_inline)) {
+        const int lrow_t = wm * WTM + q * 32 + i2 * 4 + rq;
+        const bool ok = interior || e_m_base + lrow_t < e_m_end;
+        pre[q][i2] = ok ? *(const f32x4_t*)(out_b + ((unsigned)lrow_t * (unsigned)p.ldo + lcol) * 4u) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      };
+#pragma unroll
+      for (int i2 = 0; i2 < 8; ++i2) prefetch(0, i2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const f32x4acc_t c = acc16[a][q * 2 + bb];
+            *(f32x4_t*)(st + (bb * 16 + r16e) * SROW + (a * 16 + 4 * q16e) * 4) = (f32x4_t){c[0], c[1], c[2], c[3]};
+          }
+        asm volatile("" ::: "memory");
+        if (q < 3) {
+#pragma unroll
+          for (int i2 = 0; i2 < 8; ++i2) prefetch(q + 1, i2);
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 8; ++i2) {
+          const int row = i2 * 4 + rq;
+          const unsigned lr = (unsigned)(wm * WTM + q * 32 + row);
+          const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
+          const f32x4_t xnew = resid_ls4(pre[q][i2], scale4, v + bias4);
+          if (interior || e_m_base + (int)lr < e_m_end) {
+            *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = xnew;
+            if constexpr (EMIT) store4p<T>((T*)(ln_b + (lr * (unsigned)p.ln_ldo + lcol) * 2u), p.ln_plane, xnew * gam4);
+          }
+          if constexpr (EMIT) {
+            const float mean_w = row_sum16((xnew[0] + xnew[1]) + (xnew[2] + xnew[3])) * (1.0f / 64.0f);
+            const f32x4_t dl = xnew - mean_w;
+            const float m2_w = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
+            if ((lane_e & 15) == 0) *(f32x2_t*)(lnx + ((int)lr * 4 + wn) * 2) = (f32x2_t){mean_w, m2_w};
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (EMIT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < BM && e_m_base + tid < e_m_end) {
+          const f32x4_t a4 = *(const f32x4_t*)(lnx + tid * 8), b4 = *(const f32x4_t*)(lnx + tid * 8 + 4);
+          const float mean_t = ((a4[0] + a4[2]) + (b4[0] + b4[2])) * 0.25f;
+          const float d0 = a4[0] - mean_t, d1 = a4[2] - mean_t, d2 = b4[0] - mean_t, d3 = b4[2] - mean_t;
+          const float m2_t = ((a4[1] + a4[3]) + (b4[1] + b4[3])) + 64.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          *(f32x2_t*)(p.ln_stats_out + ((long)(e_m_base + tid) * p.ln_parts + (e_n0 >> 8)) * 2) = (f32x2_t){mean_t, m2_t};
+        }
+      }
+    }
+    const bool early = has_next;
+    if (!has_next) break;
+    first = false;
+    prev_counted = early && interior;  // (an interior tile: every wave issued every store instruction)
+  }
+}
+
+
 // host side of map_tile: n-tiles are walked in groups of gn (L2-aware raster), the last group may be narrower
 static inline void prep_tile_map(GemmParams& p, int tiles_m, int tiles_n) {
   const int gn = p.raster_gn > 0 ? p.raster_gn : tiles_n;
@@ -2275,7 +2527,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
       // the persistent tile loop of the fc1 form (gemm256p_kernel): GemmParams::persist, enough tiles to give every CU several, a k-tile
       // count that leaves ring slot 4 idle in the last k-tile (16, 32: K' = 1024, 2048)
       const int KTp = p.K / 64;
-      if (!diag && p.persist && p.direct_store && lean && (ek == 4 || ek == 7) && !p.wscale[0] && p.bias[0] && blocks >= 1024 && KTp >= 3 &&
+      if (!diag && (p.persist & 1) && p.direct_store && lean && (ek == 4 || ek == 7) && !p.wscale[0] && p.bias[0] && blocks >= 1024 && KTp >= 3 &&
           (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4 && (ek == 4 || p.ln_raw)) {
         int ordinal = 0, cus = 0;
         MD_HIP(hipGetDevice(&ordinal));
@@ -2296,9 +2548,31 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         if (ek == 7) return gop(gemm256p_kernel<T, true>, &pset[1]);
         return gop(gemm256p_kernel<T, false>, &pset[0]);
       }
+      // the read-modify-write GEMMs (proj, fc2; with the LayerNorm fold's producer part: EK 5) as the tile loop gemm256r_kernel
+      if (!diag && (p.persist & 4) && (ek == 1 || ek == 5) && !p.wscale[0] && p.bias[0] && p.scale[0] && !p.resid_src && p.N % BN == 0 && p.batch <= 1 &&
+          blocks >= 1024 && KTp >= 3 && (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4) {
+        int ordinal = 0, cus = 0;
+        MD_HIP(hipGetDevice(&ordinal));
+        MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
+        const int G = (cus > 0 ? cus : 256) & ~7;
+        p.ptiles = (int)blocks;
+        auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
+          const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
+          if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {
+            MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set->fetch_or(bit, std::memory_order_release);
+          }
+          hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(512), smem, stream, p);
+          MD_HIP(hipGetLastError());
+          return MD_OK;
+        };
+        static std::atomic<unsigned long> rset[2];
+        if (ek == 5) return gop(gemm256r_kernel<T, true>, &rset[1]);
+        return gop(gemm256r_kernel<T, false>, &rset[0]);
+      }
       // the fused QKV projection as the same tile loop (one-plane types): q | k tiles overlap the next tile's first requests, V^T tiles do not
       if constexpr (!is_split<T>::value) {
-        if (!diag && p.persist && lean && p.epi == EPI_QKV && (ek == 2 || ek == 6) && !p.wscale[0] && p.bias[0] && !p.qkn_g[0] && blocks >= 1024 &&
+        if (!diag && (p.persist & 2) && lean && p.epi == EPI_QKV && (ek == 2 || ek == 6) && !p.wscale[0] && p.bias[0] && !p.qkn_g[0] && blocks >= 1024 &&
             KTp >= 3 && (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4 && (ek == 2 || p.ln_raw) && p.embed % BN == 0 && (p.seq_stride & 3) == 0 &&
             p.N == 3 * p.embed) {
           int ordinal = 0, cus = 0;

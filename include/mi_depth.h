@@ -414,10 +414,11 @@ int md_gemm_ksplit_launches(void);
  * LDS? Same values, same bits; for benches and the bit-identity test. Graphs captured before a change keep
  * their form. */
 int md_debug_gemm_direct_store(int on);
-/* PROCESS-WIDE A/B switch (default 1; returns the previous value): may the fc1 form of the 256 x 256 GEMM kernel (dense A, bias (+ LayerNorm
- * fold) + GELU, direct stores, >= 1024 tiles) run as a persistent tile loop -- one workgroup per CU, the next tile's first k-tile
- * requested before the current tile's epilogue (gemm256p_kernel)? Same arithmetic, same bits. */
-int md_debug_gemm_persistent(int on);
+/* PROCESS-WIDE A/B switch (a mask, default 7; returns the previous value): which launches of the 256 x 256 GEMM kernel with >= 1024 tiles
+ * may run as a persistent tile loop -- one workgroup per CU, the next tile's first k-tile requested before the current tile's epilogue
+ * (DESIGN.md section 5.1.2): 1 = the fc1 form (dense A, bias (+ LayerNorm fold) + GELU, direct stores: gemm256p_kernel), 2 = the fused
+ * QKV projection (one-plane types), 4 = the read-modify-write GEMMs proj / fc2 (gemm256r_kernel). Same arithmetic, same bits. */
+int md_debug_gemm_persistent(int mask);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
 /* The same with the operand type (MD_PREC_BF16 | MD_PREC_F16) and the range of the random q / k values, uniform in

@@ -140,7 +140,7 @@ def test_persistent_fc1_kernel_is_bit_identical_to_the_one_tile_kernel(dev, prec
     prev = lib.md_debug_gemm_persistent(0)
     try:
         ref = ops.linear(dev, x, w, b, act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
-        lib.md_debug_gemm_persistent(1)
+        lib.md_debug_gemm_persistent(7)
         got = ops.linear(dev, x, w, b, act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
         got2 = ops.linear(dev, x, w, b, act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True)
     finally:
@@ -170,7 +170,7 @@ def test_persistent_fc1_kernel_inside_the_model(dev, precision):
     prev = lib.md_debug_gemm_persistent(0)
     try:
         a = m.infer(x)
-        lib.md_debug_gemm_persistent(1)
+        lib.md_debug_gemm_persistent(7)
         b = m.infer(x)
     finally:
         lib.md_debug_gemm_persistent(prev)

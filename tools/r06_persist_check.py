@@ -25,7 +25,7 @@ def main():
         xx, ww = (x.half().float(), w.half().float()) if prec == 4 else (x, w)
         lib.md_debug_gemm_persistent(0)
         ref = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
-        lib.md_debug_gemm_persistent(1)
+        lib.md_debug_gemm_persistent(7)
         got = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
         got2 = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
         lib.md_debug_gemm_persistent(0)
@@ -44,7 +44,7 @@ def main():
         xi = torch.randn(2, 3, 1536, 1536, device="cuda")
         lib.md_debug_gemm_persistent(0)
         a = m.infer(xi).depth.clone()
-        lib.md_debug_gemm_persistent(1)
+        lib.md_debug_gemm_persistent(7)
         bb = m.infer(xi).depth.clone()
         cc = m.infer(xi).depth.clone()
         lib.md_debug_gemm_persistent(0)

@@ -5,7 +5,7 @@ timeout -k 10 600 python tools/r06_persist_check.py > gpurun_out/r06_persist_che
 rc=$?
 grep -v amdgpu.ids gpurun_out/r06_persist_check.log | tail -8
 [ $rc -eq 0 ] || exit $rc
-for m in off on off on; do
+for m in fc1qkv on fc1qkv on; do
   timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --persistent-fc1 $m > gpurun_out/r06_pf_$m.json 2> gpurun_out/r06_pf_$m.err || exit 1
   python - $m <<'PY'
 import json,sys
