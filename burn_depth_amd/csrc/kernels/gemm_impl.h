@@ -121,24 +121,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-__device__ __forceinline__ f32x2_t gelu2_poly(f32x2_t x) {
-  const float lim = 4.4f;
-  f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -lim, lim), __builtin_amdgcn_fmed3f(x[1], -lim, lim)};
-  const f32x2_t t = xc * xc;
-  f32x2_t p = {8.829475345306648e-11f, 8.829475345306648e-11f};
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-8.98145824379526e-09f, -8.98145824379526e-09f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){4.0165326709029614e-07f, 4.0165326709029614e-07f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-1.0493913578102365e-05f, -1.0493913578102365e-05f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.00018038309644907713f, 0.00018038309644907713f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.002187085337936878f, -0.002187085337936878f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.01956046372652054f, 0.01956046372652054f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.13261185586452484f, -0.13261185586452484f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.7977733016014099f, 0.7977733016014099f});
-  f32x2_t e = xc * p;
-  e[0] = __builtin_amdgcn_fmed3f(e[0], -1.0f, 1.0f);
-  e[1] = __builtin_amdgcn_fmed3f(e[1], -1.0f, 1.0f);
-  const f32x2_t hx = x * 0.5f;
-  return __builtin_elementwise_fma(hx, e, hx);
+// (round 6) GELU(x) = x Phi(x), Phi = 1/2 + 1/2 erf(x / sqrt 2) = clamp01(1/2 + x P'(x^2)) with P' = P / 2 (the halved coefficients are exact):
+// the [0, 1] clamp is the output modifier of the packed FMA that forms Phi (VOP3P `clamp`; hipcc does not fold a clamp into a packed fp32
+// instruction by itself, hence the asm), and it also stands in for the range clamp of x: beyond the fitted |x| <= 4.4 the polynomial x P(x^2) is
+// monotone and >= 1.00005 in magnitude (it runs off to +-inf with the sign of x: leading coefficient > 0), so Phi saturates to exactly 0 / 1 as the
+// former med3(x, +-4.4) -> med3(e, +-1) pair made it. 11 packed instructions per element PAIR instead of 12 + 4 scalar med3; four elements are
+// evaluated together so that no packed result is read by the very next instruction (gfx950's one-wait-state forwarding hazard behind VOP3P: hipcc
+// fills it with s_nop otherwise, one per Horner step).
+__device__ __forceinline__ f32x4_t gelu4_poly(f32x4_t x) {
+  const f32x4_t t = x * x;
+  f32x4_t p = __builtin_elementwise_fma((f32x4_t){4.414737672653324e-11f, 4.414737672653324e-11f, 4.414737672653324e-11f, 4.414737672653324e-11f}, t,
+                   (f32x4_t){-4.49072912189763e-09f, -4.49072912189763e-09f, -4.49072912189763e-09f, -4.49072912189763e-09f});
+#define MD_G8(c) p = __builtin_elementwise_fma(p, t, (f32x4_t){c, c, c, c})
+  MD_G8(2.0082663354514807e-07f); MD_G8(-5.2469567890511825e-06f); MD_G8(9.019154822453856e-05f); MD_G8(-0.001093542668968439f);
+  MD_G8(0.00978023186326027f); MD_G8(-0.06630592793226242f); MD_G8(0.39888665080070496f);
+#undef MD_G8
+  f32x2_t ph0, ph1;
+  const f32x2_t x0 = {x[0], x[1]}, x1 = {x[2], x[3]}, p0 = {p[0], p[1]}, p1 = {p[2], p[3]};
+  asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(ph0) : "v"(x0), "v"(p0));
+  asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(ph1) : "v"(x1), "v"(p1));
+  const f32x2_t o0 = x0 * ph0, o1 = x1 * ph1;
+  return (f32x4_t){o0[0], o0[1], o1[0], o1[1]};
 }
 
 // f16 mode: erf by Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and ten plain VALU
@@ -198,9 +201,7 @@ __device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
     return r;
 #endif
   } else {
-    const f32x2_t a = gelu2_poly((f32x2_t){v[0], v[1]}), b = gelu2_poly((f32x2_t){v[2], v[3]});
-    f32x4_t r = {a[0], a[1], b[0], b[1]};
-    return r;
+    return gelu4_poly(v);
   }
 }
 
