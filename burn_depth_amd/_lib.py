@@ -104,6 +104,7 @@ SYMBOLS = {
     "md_gemm_ksplit_launches": (_I, []),
     "md_debug_gemm_direct_store": (_I, [_I]),
     "md_debug_gemm_persistent": (_I, [_I]),
+    "md_debug_gemm_stagger": (_I, [_I, _I]),
     "md_da3_infer_raw": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "md_da3_infer_from_tokens": (_I, [_P, C.POINTER(C.c_void_p), _I, _I, _I, _I, _I, _P, _I, _P]),
     "md_da3_param_inventory": (_I, [C.POINTER(MdDa3Cfg), _I, _I, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), _F, _F]),

@@ -114,6 +114,7 @@ struct GemmParams {
   int direct_store = 0;
   int persist = 0;   // set by launch_gemm (gemm_persistent()): which forms may run as persistent tile loops (1 fc1, 2 QKV: gemm256p_kernel; 4 read-modify-write: gemm256r_kernel)
   int ptiles = 0;    // persistent form: tiles of the launch (set by launch_256)
+  int stagger = 0;   // read-modify-write tile loop: the odd workgroups of every XCD start this many 10-ns ticks late (gemm_stagger(); set by launch_256 per k-tile count)
   int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)
   int res_mod = 0;              // > 0: res1's row = m % res_mod (a per-image table shared by the batch, or an input two weight groups share); res2 is never wrapped
   // EPI_PATCH_EMBED / EPI_QKV
@@ -176,6 +177,10 @@ struct GemmParams {
 int gemm_direct_store(int on);
 // process-wide A/B switch of GemmParams::persist (a mask: 1 the fc1 form, 2 the QKV projection, 4 the read-modify-write GEMMs; default 7); returns the previous value
 int gemm_persistent(int mask);
+// start offset (10-ns ticks of the constant 100 MHz counter) between the two halves of a tile loop's workgroups. which: 0 the read-modify-write loop at
+// <= 16 k-tiles per tile (proj), 1 the same at more (fc2), 2 the fc1 loop, 3 the QKV loop
+void gemm_stagger(int which, int ticks);
+int gemm_stagger_ticks(int which);
 int gemm_allow_ksplit(int on);  // per host thread; returns the previous value
 void gemm_count_ksplit_launch();   // diagnostics: md_gemm_ksplit_launches()
 long long gemm_ksplit_launches();

@@ -144,7 +144,7 @@ __device__ __forceinline__ f32x4_t gelu4_poly(f32x4_t x) {
   return (f32x4_t){o0[0], o0[1], o1[0], o1[1]};
 }
 
-// f16 mode: erf by Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and ten plain VALU
+// split-half f16 mode (f16x2; the one-plane f16 mode until round 6): erf by Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7): one v_rcp_f32, one v_exp_f32 and ten plain VALU
 // operations per element, about a third of libm's erff. GELU(x) = h + |h| - |h| * poly(t) * exp(-x^2/2), h = x/2,
 // t = 1 / (1 + p |x| / sqrt 2): |abs error| <= 3.4e-7 and <= 1.7e-4 relative wherever |GELU| >= 1e-3, inside half an f16
 // ulp (2.4e-4); the bf16 polynomial's 8.5e-5 absolute is not.
@@ -161,45 +161,41 @@ __device__ __forceinline__ float gelu_as(float x) {
   return fmaf(-ha, p * e, h + ha);
 }
 
-#ifdef MD_GELU_POLY16
-// A/B builds only (tools/probes/gelu_ab.sh, profiles/r05_gelu_ab.txt; not the shipped form): erf(x / sqrt 2) ~ x * Q(w), w = x^2 / 3.92^2 - 1 in
-// [-1, 1] for |x| <= 5.54, Q of degree 16 in the SHIFTED variable (a monomial Horner form in x^2 itself loses 1e-3 in fp32 near |x| = 5), two
-// elements per packed fp32 instruction, no transcendental, |GELU abs error| <= 4.6e-7 on |x| <= 12; the leading coefficient is positive, so
-// beyond the fitted range x * Q runs off to +-inf with the sign of x and the clamp to +-1 finishes it.
-__device__ __forceinline__ f32x2_t gelu2_poly16(f32x2_t x) {
-  const f32x2_t u = x * x;
-  const f32x2_t w = __builtin_elementwise_fma(u, (f32x2_t){0.0650770515203476f, 0.0650770515203476f}, (f32x2_t){-1.0f, -1.0f});
-  f32x2_t p = {2.229404490e-04f, 2.229404490e-04f};
-#define MD_G16(c) p = __builtin_elementwise_fma(p, w, (f32x2_t){c, c})
-  MD_G16(-6.364517612e-04f); MD_G16(5.990146310e-04f); MD_G16(-8.361310465e-04f); MD_G16(2.781286370e-03f);
-  MD_G16(-5.642272066e-03f); MD_G16(8.859087713e-03f); MD_G16(-1.396695524e-02f); MD_G16(2.154735103e-02f);
-  MD_G16(-3.078402951e-02f); MD_G16(4.115563259e-02f); MD_G16(-5.232557654e-02f); MD_G16(6.407836080e-02f);
-  MD_G16(-7.720266283e-02f); MD_G16(9.481133521e-02f); MD_G16(-1.273559928e-01f); MD_G16(2.550794482e-01f);
+// f16 mode, one plane (round 6; the split-half mode keeps gelu_as: 65.6 -> 65.3 ms there, and its documented error budget): Phi(x) = clamp01(1/2 + x Q'(w)), w = x^2 / 3.92^2 - 1 in [-1, 1] for |x| <= 5.54, Q' = Q / 2 of degree 16 in the
+// SHIFTED variable (a monomial Horner form in x^2 itself loses 1e-3 in fp32 near |x| = 5), four elements per step on the packed fp32 pipe, no
+// transcendental, the clamp as the packed FMA's output modifier (as gelu4_poly); |GELU abs error| <= 6.6e-7, <= 1.9e-4 relative where |GELU| >= 1e-3; the
+// leading coefficient is positive, so beyond the fitted range x Q runs off to +-inf with the sign of x and the clamp finishes it.
+__device__ __forceinline__ f32x4_t gelu4_poly16(f32x4_t x) {
+  const f32x4_t u = x * x;
+  const f32x4_t w = __builtin_elementwise_fma(u, (f32x4_t){0.0650770515203476f, 0.0650770515203476f, 0.0650770515203476f, 0.0650770515203476f},
+                                              (f32x4_t){-1.0f, -1.0f, -1.0f, -1.0f});
+  f32x4_t p = {1.114702245e-04f, 1.114702245e-04f, 1.114702245e-04f, 1.114702245e-04f};
+#define MD_G16(c) p = __builtin_elementwise_fma(p, w, (f32x4_t){c, c, c, c})
+  MD_G16(-3.182258806e-04f); MD_G16(2.995073155e-04f); MD_G16(-4.180655232e-04f); MD_G16(1.390643185e-03f);
+  MD_G16(-2.821136033e-03f); MD_G16(4.429543856e-03f); MD_G16(-6.983477620e-03f); MD_G16(1.077367551e-02f);
+  MD_G16(-1.539201476e-02f); MD_G16(2.057781629e-02f); MD_G16(-2.616278827e-02f); MD_G16(3.203918040e-02f);
+  MD_G16(-3.860133142e-02f); MD_G16(4.740566761e-02f); MD_G16(-6.367799640e-02f); MD_G16(1.275397241e-01f);
 #undef MD_G16
-  f32x2_t e = x * p;
-  e[0] = __builtin_amdgcn_fmed3f(e[0], -1.0f, 1.0f);
-  e[1] = __builtin_amdgcn_fmed3f(e[1], -1.0f, 1.0f);
-  const f32x2_t hx = x * 0.5f;
-  return __builtin_elementwise_fma(hx, e, hx);
+  f32x2_t ph0, ph1;
+  const f32x2_t x0 = {x[0], x[1]}, x1 = {x[2], x[3]}, p0 = {p[0], p[1]}, p1 = {p[2], p[3]};
+  asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(ph0) : "v"(x0), "v"(p0));
+  asm("v_pk_fma_f32 %0, %1, %2, 0.5 op_sel_hi:[1,1,0] clamp" : "=v"(ph1) : "v"(x1), "v"(p1));
+  const f32x2_t o0 = x0 * ph0, o1 = x1 * ph1;
+  return (f32x4_t){o0[0], o0[1], o1[0], o1[1]};
 }
-#endif
 
 template <typename T>
 __device__ __forceinline__ f32x4_t gelu4(f32x4_t v) {
   if constexpr (std::is_same<T, float>::value) {  // fp32 parity mode: libm erff
     f32x4_t r = {gelu_erf<T>(v[0]), gelu_erf<T>(v[1]), gelu_erf<T>(v[2]), gelu_erf<T>(v[3])};
     return r;
+  } else if constexpr (std::is_same<T, f16_t>::value) {
+    // (the packed degree-16 polynomial against gelu_as, profiles/r06_gelu16_ab.txt: fc1 39.3 -> 36.9 ms per step in the f16 mode; round 5's form of it --
+    // two med3 per pair, a hazard nop per Horner step -- had reached 39.3 from 40.3)
+    return gelu4_poly16(v);
   } else if constexpr (is_half<T>::value) {
-    // (round 5: a packed degree-16 polynomial in the shifted variable w = x^2 / 3.92^2 - 1 -- no transcendental, 4.6e-7 -- measured against this
-    // form: fc1 40.3 -> 39.3 ms per step in the f16 mode, 66.7 -> 67.6 in the split-half mode, profiles/r05_gelu_ab.txt; not kept)
-#ifdef MD_GELU_POLY16
-    const f32x2_t a = gelu2_poly16((f32x2_t){v[0], v[1]}), b = gelu2_poly16((f32x2_t){v[2], v[3]});
-    f32x4_t r = {a[0], a[1], b[0], b[1]};
-    return r;
-#else
     f32x4_t r = {gelu_as(v[0]), gelu_as(v[1]), gelu_as(v[2]), gelu_as(v[3])};
     return r;
-#endif
   } else {
     return gelu4_poly(v);
   }
@@ -1904,6 +1900,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
   };
+  if (p.stagger > 0 && ((blockIdx.x >> 5) & 1)) {  // (gemm256r_kernel's start offset between the halves of an XCD's workgroups: a measurement switch here)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+  }
   locate(xs + it);
   issue_A(0, 0);
   issue_W(0, 1);
@@ -2276,6 +2276,13 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
   };
+  // start offset between the two halves of every XCD's workgroups (blocks 4 - 7, 12 - 15, .. of the XCD: the four n-tiles of an m-panel stay
+  // together): all workgroups run the same tile sequence at the same speed, so without it every epilogue of the launch -- the fp32 residual
+  // stream's read + write, HBM-bound -- meets every other one, and the main loops leave HBM idle in between
+  if (p.stagger > 0 && ((blockIdx.x >> 5) & 1)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+  }
   locate(xs + it);
   issue_A(0, 0);
   issue_W(0, 1);
@@ -2535,6 +2542,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
         const int G = (cus > 0 ? cus : 256) & ~7;
         p.ptiles = (int)blocks;
+        p.stagger = blocks >= 2048 ? gemm_stagger_ticks(2) : 0;
         auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
           const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
           if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {
@@ -2557,6 +2565,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
         const int G = (cus > 0 ? cus : 256) & ~7;
         p.ptiles = (int)blocks;
+        p.stagger = blocks >= 2048 ? gemm_stagger_ticks(KTp <= 16 ? 0 : 1) : 0;  // (the offset is idle time at either end of the launch: 8 rounds of tiles and more)
         auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
           const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
           if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {
@@ -2581,6 +2590,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
           MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
           const int G = (cus > 0 ? cus : 256) & ~7;
           p.ptiles = (int)blocks;
+          p.stagger = blocks >= 2048 ? gemm_stagger_ticks(3) : 0;
           auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
             const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
             if (!bit || !(attr_set->load(std::memory_order_acquire) & bit)) {

@@ -721,6 +721,11 @@ __attribute__((unused)) int fill_random(void* dst, size_t elems, int precision, 
 
 int md_debug_gemm_direct_store(int on) { return md::gemm_direct_store(on); }
 int md_debug_gemm_persistent(int on) { return md::gemm_persistent(on); }
+int md_debug_gemm_stagger(int which, int ticks) {
+  if (which < 0 || which > 3 || ticks < 0) return MD_ERR_INVALID_ARG;
+  md::gemm_stagger(which, ticks);
+  return MD_OK;
+}
 
 int md_gemm_ksplit_launches(void) { return (int)(md::gemm_ksplit_launches() & 0x7fffffff); }
 

@@ -419,6 +419,11 @@ int md_debug_gemm_direct_store(int on);
  * (DESIGN.md section 5.1.2): 1 = the fc1 form (dense A, bias (+ LayerNorm fold) + GELU, direct stores: gemm256p_kernel), 2 = the fused
  * QKV projection (one-plane types), 4 = the read-modify-write GEMMs proj / fc2 (gemm256r_kernel). Same arithmetic, same bits. */
 int md_debug_gemm_persistent(int mask);
+/* Timing switch of the tile loops: half of every XCD's workgroups start `ticks` (10 ns each) after the other half, so that one half's
+ * epilogues (proj / fc2: the fp32 residual stream's read + write, HBM-bound) meet the other half's main loops instead of each other.
+ * which: 0 the read-modify-write loop at <= 16 k-tiles per tile (proj; default 2000), 1 the same at more (fc2; 0), 2 the fc1 loop (0),
+ * 3 the QKV loop (0). Same bits. MD_ERR_INVALID_ARG for another `which` or negative ticks. */
+int md_debug_gemm_stagger(int which, int ticks);
 /* Same for the fused bf16 attention kernel: T sequences of n_tokens, `heads` heads of 64. */
 int md_bench_attention(md_device_t dev, int T, int n_tokens, int heads, int iters, float* avg_ms);
 /* The same with the operand type (MD_PREC_BF16 | MD_PREC_F16) and the range of the random q / k values, uniform in
