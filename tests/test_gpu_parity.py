@@ -178,6 +178,76 @@ def test_persistent_fc1_kernel_inside_the_model(dev, precision):
     m.destroy()
 
 
+@pytest.mark.parametrize("precision", [0, 4])
+def test_read_modify_write_tile_loop_inside_the_model(dev, precision):
+    """proj / fc2 (x += ls (A W^T + b), with the LayerNorm fold's producer part) reach 1024 tiles per launch -- `gemm256r_kernel`, the tile
+    loop with 32-row staging passes -- from B = 4, and 2048 -- its start offset between the two halves of an XCD's workgroups
+    (`md_debug_gemm_stagger`) -- from B = 7: DepthPro::infer on [8,3,1536,1536] with the loop on (offset on / off) and off, and with every tile
+    loop off: the same bits, bf16 and split-half. (The residual branches: burn_dino's block, /root/reference/src/model/depth_pro/layers/vit.rs:45-68.)"""
+    from burn_depth_amd import _lib
+    from burn_depth_amd import weights as Wt
+    from burn_depth_amd.config import DepthProConfig
+    from burn_depth_amd.depth_pro import DepthPro
+    lib = _lib.load()
+    cfg = DepthProConfig()
+    cfg.precision = precision
+    cfg.max_batch = 8
+    m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+    if precision == 4:
+        m.round_weights_to_f16()
+    torch.manual_seed(2)
+    x = torch.randn(8, 3, 1536, 1536, device="cuda")
+    prev = lib.md_debug_gemm_persistent(3)
+    try:
+        a = m.infer(x).depth.clone()
+        lib.md_debug_gemm_persistent(7)
+        b = m.infer(x).depth.clone()
+        assert lib.md_debug_gemm_stagger(0, 0) == 0
+        c = m.infer(x).depth.clone()
+        lib.md_debug_gemm_persistent(0)
+        d = m.infer(x).depth.clone()
+    finally:
+        lib.md_debug_gemm_stagger(0, 2000)
+        lib.md_debug_gemm_persistent(prev)
+    assert lib.md_debug_gemm_stagger(4, 0) < 0 and lib.md_debug_gemm_stagger(0, -1) < 0
+    assert torch.equal(a, b) and torch.equal(b, c) and torch.equal(c, d)
+    assert bool(torch.isfinite(a).all())
+    m.destroy()
+
+
+@pytest.mark.parametrize("precision", [0, 3, 4])
+def test_gelu_epilogue_pointwise_error_and_saturation(dev, precision):
+    """The GELU of the store epilogues, value by value (fc1 of burn_dino's MLP: exact-erf `Gelu`, /root/reference/src/model/depth_pro/layers/vit.rs:45-68):
+    a linear layer whose weight rows select input column 0, so that every output is GELU of one planted value -- a grid over [-12, 12]
+    (exact in the storage type) plus values far outside every fitted range. bf16: x clamp01(1/2 + x P'(x^2)), degree 8, |error| <= 8.5e-5;
+    f16: the degree-16 polynomial of the same form, <= 6.6e-7; split-half: Abramowitz & Stegun 7.1.26, <= 3.4e-7 -- each plus the storage
+    type's rounding; beyond the fitted ranges Phi saturates to exactly 0 / 1 (the clamp is the packed FMA's output modifier)."""
+    from burn_depth_amd import _lib, ops
+    M, N, K = 512, 256, 64
+    grid = torch.linspace(-12.0, 12.0, M - 12)
+    far = torch.tensor([-3.0e4, -1000.0, -100.0, -30.0, -13.0, 13.0, 30.0, 100.0, 1000.0, 3.0e4, 0.0, -0.0])
+    v = torch.cat([grid, far])
+    v = v.bfloat16().float() if precision == 0 else v.half().float()
+    x = torch.zeros(M, K)
+    x[:, 0] = v
+    w = torch.zeros(N, K)
+    w[:, 0] = 1.0
+    b = torch.zeros(N)
+    got = ops.linear(dev, x.cuda(), w.cuda(), b.cuda(), act=2, precision=precision, tile=_lib.TILE_256x256, storage_out=True).cpu().double()
+    assert got.shape == (M, N) and bool((got == got[:, :1]).all())  # every column carries the same value
+    y = got[:, 0]
+    vd = v.double()
+    want = 0.5 * vd * (1.0 + torch.erf(vd / 2.0 ** 0.5))
+    abs_tol, rel_tol = {0: (8.5e-5, 2.0 ** -8), 3: (6.6e-7, 2.0 ** -11), 4: (3.4e-7, 2.0 ** -21)}[precision]
+    err = (y - want).abs()
+    bound = abs_tol * 1.05 + rel_tol * want.abs() + 1e-12
+    assert bool((err <= bound).all()), (precision, float((err / bound).max()), float(vd[(err / bound).argmax()]))
+    big = vd >= 13.0
+    assert bool((y[big] == vd[big]).all())  # Phi == 1: the value itself
+    small = vd <= -13.0
+    assert bool((y[small].abs() <= (1e-6 if precision == 4 else 0.0)).all()), y[small]  # Phi == 0 (A&S: h + |h| - |h| p e with e = 0)
+
+
 @pytest.mark.parametrize("precision", [1, 0, 3])
 def test_depth_pro_tiny_end_to_end(diag, dev, precision):
     from burn_depth_amd.config import DepthProConfig

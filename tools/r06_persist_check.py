@@ -52,6 +52,31 @@ def main():
         print(f"DepthPro::infer [2,3,1536,1536] prec {prec} (fold {m.query('ln_fold_active')}): persistent == one-tile: {same}  max |diff| {(a - bb).abs().max().item():.3e}", flush=True)
         ok = ok and same
         m.destroy()
+    # proj / fc2 reach 1024 tiles (gemm256r_kernel) from B = 4 and 2048 (its start offset between the halves of an XCD's workgroups) from B = 7
+    for prec in (0, 3, 4):
+        cfg = DepthProConfig()
+        cfg.precision = prec
+        cfg.max_batch = 8
+        m = DepthPro.new(dev, cfg, seed=0, init_scheme=Wt.INIT_PARITY)
+        if prec == 4:
+            m.round_weights_to_f16()
+        torch.manual_seed(2)
+        xi = torch.randn(8, 3, 1536, 1536, device="cuda")
+        lib.md_debug_gemm_persistent(3)
+        a = m.infer(xi).depth.clone()
+        lib.md_debug_gemm_persistent(7)
+        bb = m.infer(xi).depth.clone()
+        lib.md_debug_gemm_stagger(0, 0)
+        cc = m.infer(xi).depth.clone()
+        lib.md_debug_gemm_stagger(0, 2000)
+        lib.md_debug_gemm_persistent(0)
+        dd = m.infer(xi).depth.clone()
+        lib.md_debug_gemm_persistent(7)
+        same = torch.equal(a, bb) and torch.equal(bb, cc) and torch.equal(cc, dd)
+        print(f"DepthPro::infer [8,3,1536,1536] prec {prec}: read-modify-write tile loop (with / without its start offset) == one-tile kernels: {same}  "
+              f"max |diff| {(a - bb).abs().max().item():.3e} {(a - cc).abs().max().item():.3e} {(a - dd).abs().max().item():.3e}", flush=True)
+        ok = ok and same
+        m.destroy()
     sys.exit(0 if ok else 1)
 
 
