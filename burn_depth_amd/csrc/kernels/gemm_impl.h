@@ -2325,7 +2325,11 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
     // k-tile 0 of this tile: requested before the previous tile's epilogue, whose 16 (x 2 planes) stores are younger -- when that tile was an
     // interior one (every store instruction was issued by every wave); behind a group's last, partial tile a wave may have skipped
     // stores, so everything is waited for
+#ifdef MD_RABL
+    if (true) {
+#else
     if (first || !prev_counted) {
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // (32: the x stores alone; a safe lower bound of what follows the requests in either form)
@@ -2409,7 +2413,13 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
       auto prefetch = [&](int q, int i2) __attribute__((always_inline)) {
         const int lrow_t = wm * WTM + q * 32 + i2 * 4 + rq;
         const bool ok = interior || e_m_base + lrow_t < e_m_end;
-        pre[q][i2] = ok ? *(const f32x4_t*)(out_b + ((unsigned)lrow_t * (unsigned)p.ldo + lcol) * 4u) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#if defined(MD_RABL) && (MD_RABL & 1)  // timing-only builds (tools/probes/rmw_loop_ablation.sh): no x loads
+        pre[q][i2] = (f32x4_t){(float)lrow_t, 0.f, 0.f, 0.f};
+#else
+        // (non-temporal: the residual stream is read once per GEMM and 0.66 GB at B = 8 -- kept out of the L2's way, proj 12.47 -> 12.03 and fc2
+        // 29.48 -> 29.22 ms per step; the same hint on the x stores -0.2 / +0.07, on fc1's stores +1.1 ms: profiles/r06_nt_ab.txt)
+        pre[q][i2] = ok ? __builtin_nontemporal_load((const f32x4_t*)(out_b + ((unsigned)lrow_t * (unsigned)p.ldo + lcol) * 4u)) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#endif
       };
 #pragma unroll
       for (int i2 = 0; i2 < 8; ++i2) prefetch(0, i2);
@@ -2434,11 +2444,22 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
           const unsigned lr = (unsigned)(wm * WTM + q * 32 + row);
           const f32x4_t v = *(const f32x4_t*)(st + row * SROW + col * 4);
           const f32x4_t xnew = resid_ls4(pre[q][i2], scale4, v + bias4);
+#ifdef MD_RABL
+          const bool never = xnew[0] == 1.2345678e30f && xnew[3] == -7.7e-30f;  // (keeps the values alive)
+          if (interior || e_m_base + (int)lr < e_m_end) {
+            if (!(MD_RABL & 2) || never) *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = xnew;
+            if constexpr (EMIT) {
+              if (!(MD_RABL & 4) || never) store4p<T>((T*)(ln_b + (lr * (unsigned)p.ln_ldo + lcol) * 2u), p.ln_plane, xnew * gam4);
+            }
+          }
+          if constexpr (EMIT && !(MD_RABL & 8)) {
+#else
           if (interior || e_m_base + (int)lr < e_m_end) {
             *(f32x4_t*)(out_b + (lr * (unsigned)p.ldo + lcol) * 4u) = xnew;
             if constexpr (EMIT) store4p<T>((T*)(ln_b + (lr * (unsigned)p.ln_ldo + lcol) * 2u), p.ln_plane, xnew * gam4);
           }
           if constexpr (EMIT) {
+#endif
             const float mean_w = row_sum16((xnew[0] + xnew[1]) + (xnew[2] + xnew[3])) * (1.0f / 64.0f);
             const f32x4_t dl = xnew - mean_w;
             const float m2_w = row_sum16((dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]));
