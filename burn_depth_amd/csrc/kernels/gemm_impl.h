@@ -2002,8 +2002,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const bool has_next = it < xc;
     __builtin_amdgcn_s_barrier();  // the exchange area is complete and visible; every wave has left the ring
     asm volatile("" ::: "memory");
-    const bool e_vt = QKV && e_n0 >= 2 * p.embed;  // a V^T tile: its transposed staging covers ring slots 0 - 1
-    const bool early = has_next && !e_vt;
+    const bool e_vt = QKV && e_n0 >= 2 * p.embed;  // a V^T tile
+    const bool early = has_next;
     if (early) {
       locate(xs + it);
       issue_A(0, 0);
@@ -2027,16 +2027,28 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       int r16e = r16, q16e = q16, lane_e = lane;
       asm volatile("" : "+v"(r16e), "+v"(q16e), "+v"(lane_e));
       if (e_vt) {
-        // ---- V^T tile: staged transposed (gemm256_kernel's `direct` path), c / d / bias from the exchange area ----
-        constexpr int SRT = 272;
-        char* stt = smem + wave * (64 * SRT);
-        const int nl0 = q16e;
+        // ---- V^T tile: fold / bias in the ACCUMULATOR layout (the q | k path's form of the same fused multiply-adds), then staged TRANSPOSED in the
+        //      output type: 64 n-rows x (64 tokens x 2 B + 8) per wave and half = 8.5 KB per wave in ring slots 2 - 4, below the exchange area -- the
+        //      one-tile kernel stages fp32 (17 KB per wave: the whole ring). Slots 0 - 1 take the next tile's first k-tile meanwhile; same values, same
+        //      bits, the same 128-byte store segments. ----
+        constexpr int SRT = 136;
+        char* stt = smem + 2 * HALF_BYTES + wave * (64 * SRT);
         const int hd = (e_n0 - 2 * p.embed + wn * WTN) >> 6;
-        float bia[16], wsc[16];
+        f32x4_t bq[4], wq[4];
 #pragma unroll
-        for (int i2 = 0; i2 < 16; ++i2) {
-          bia[i2] = lnx[2816 + wn * WTN + i2 * 4 + nl0];
-          wsc[i2] = FOLD ? lnx[2560 + wn * WTN + i2 * 4 + nl0] : 1.f;
+        for (int a = 0; a < 4; ++a) {
+          const int cl = wn * WTN + a * 16 + 4 * q16e;
+          bq[a] = *(const f32x4_t*)(lnx + 2816 + cl);
+          wq[a] = FOLD ? *(const f32x4_t*)(lnx + 2560 + cl) : (f32x4_t){1.f, 1.f, 1.f, 1.f};
+        }
+        float lnA[8], lnB[8];
+        if constexpr (FOLD) {
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const f32x2_t t2 = *(const f32x2_t*)(lnx + 2 * (wm * WTM + b * 16 + r16e));
+            lnA[b] = t2[0];
+            lnB[b] = t2[1];
+          }
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -2045,30 +2057,33 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-              const f32x4acc_t c = acc16[a][half * 4 + bb];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) *(float*)(stt + (a * 16 + 4 * q16e + j) * SRT + (bb * 16 + r16e) * 4) = c[j];
+              const int b = half * 4 + bb;
+              const f32x4acc_t c = acc16[a][b];
+              f32x4_t x = {c[0], c[1], c[2], c[3]};
+              if constexpr (FOLD) {
+                const f32x4_t Bv = {lnB[b], lnB[b], lnB[b], lnB[b]}, Av = {lnA[b], lnA[b], lnA[b], lnA[b]};
+                x = fma4(x, Av, fma4(Bv, wq[a], bq[a]));
+              } else {
+                x = x * wq[a] + bq[a];
+              }
+              const i32x2_t pk = pack4<T>(x);
+              char* wp = stt + (a * 16 + 4 * q16e) * SRT + (bb * 16 + r16e) * 2;
+              *(unsigned short*)(wp) = (unsigned short)(pk[0] & 0xffff);
+              *(unsigned short*)(wp + SRT) = (unsigned short)((unsigned)pk[0] >> 16);
+              *(unsigned short*)(wp + 2 * SRT) = (unsigned short)(pk[1] & 0xffff);
+              *(unsigned short*)(wp + 3 * SRT) = (unsigned short)((unsigned)pk[1] >> 16);
             }
           asm volatile("" ::: "memory");
           const int m = e_m_base + wm * WTM + half * 64 + r16e * 4;
-          f32x4_t lnA4 = {1.f, 1.f, 1.f, 1.f}, lnB4 = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (FOLD) {
-            const float* ab = lnx + 2 * (wm * WTM + half * 64 + r16e * 4);
-            const f32x4_t t0 = *(const f32x4_t*)ab, t1 = *(const f32x4_t*)(ab + 4);
-            lnA4 = (f32x4_t){t0[0], t0[2], t1[0], t1[2]};
-            lnB4 = (f32x4_t){t0[1], t0[3], t1[1], t1[3]};
-          }
           const int seq = fdiv(m, p.fd_seq_stride);
           const int tok = m - seq * p.seq_stride;
           T* vrow = (T*)p.vT + (((long)seq * p.heads + hd) * 64) * p.kpad + tok;
           const bool ok = m < e_m_end;
 #pragma unroll
           for (int i2 = 0; i2 < 16; ++i2) {
-            const int nl = i2 * 4 + nl0;
-            f32x4_t v = *(const f32x4_t*)(stt + nl * SRT + r16e * 16);
-            if constexpr (FOLD) v = fma4(v, lnA4, fma4(lnB4, (f32x4_t){wsc[i2], wsc[i2], wsc[i2], wsc[i2]}, (f32x4_t){bia[i2], bia[i2], bia[i2], bia[i2]}));
-            else v = v * wsc[i2] + bia[i2];
-            if (ok) store4<T>(vrow + (long)nl * p.kpad, v);
+            const int nl = i2 * 4 + q16e;
+            const i32x2_t raw = *(const i32x2_t*)(stt + nl * SRT + r16e * 8);
+            if (ok) *(i32x2_t*)(vrow + (long)nl * p.kpad) = raw;
           }
           asm volatile("" ::: "memory");
         }
@@ -2126,12 +2141,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           }
           asm volatile("" ::: "memory");
         }
-      }
-      if (has_next && e_vt) {  // behind a V^T tile: every wave is done with its staging (slots 0 - 1) before the next requests go out
-        __builtin_amdgcn_s_barrier();
-        locate(xs + it);
-        issue_A(0, 0);
-        issue_W(0, 1);
       }
     }
     // ---- epilogue: direct stores from the accumulator layout (the permuted W image: gemm256_kernel's EK 9 / 11) ----
