@@ -2627,7 +2627,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
       }
       // the fused QKV projection as the same tile loop (one-plane types): q | k tiles overlap the next tile's first requests, V^T tiles do not
       if constexpr (!is_split<T>::value) {
-        if (!diag && (p.persist & 2) && lean && p.epi == EPI_QKV && (ek == 2 || ek == 6) && !p.wscale[0] && p.bias[0] && !p.qkn_g[0] && blocks >= 1024 &&
+        if (!diag && (p.persist & 2) && lean && p.epi == EPI_QKV && (ek == 2 || ek == 6) && !p.wscale[0] && p.bias[0] && !p.qkn_g[0] && blocks >= 768 &&
             KTp >= 3 && (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4 && (ek == 2 || p.ln_raw) && p.embed % BN == 0 && (p.seq_stride & 3) == 0 &&
             p.N == 3 * p.embed) {
           int ordinal = 0, cus = 0;

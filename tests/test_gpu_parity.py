@@ -170,11 +170,14 @@ def test_persistent_fc1_kernel_inside_the_model(dev, precision):
     prev = lib.md_debug_gemm_persistent(0)
     try:
         a = m.infer(x)
+        a1 = m.infer(x[:1]).depth.clone()
         lib.md_debug_gemm_persistent(7)
         b = m.infer(x)
+        b1 = m.infer(x[:1]).depth.clone()  # one image: fc1 1344 tiles, the QKV projection 1008 (its loop starts at 768), proj / fc2 on the one-tile kernel
     finally:
         lib.md_debug_gemm_persistent(prev)
     assert torch.equal(a.depth, b.depth) and torch.equal(a.fovx_deg, b.fovx_deg) and torch.equal(a.focallength_px, b.focallength_px)
+    assert torch.equal(a1, b1) and torch.equal(a1, a.depth[:1])
     m.destroy()
 
 
