@@ -2585,7 +2585,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         int ordinal = 0, cus = 0;
         MD_HIP(hipGetDevice(&ordinal));
         MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
-        const int G = (cus > 0 ? cus : 256) & ~7;
+        const int G = cus >= 8 ? (cus & ~7) : 8;  // (a multiple of 8: XCD x = blocks x, x + 8, ..; more workgroups than CUs only costs residency)
         p.ptiles = (int)blocks;
         p.stagger = blocks >= 2048 ? gemm_stagger_ticks(2) : 0;
         auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
@@ -2608,7 +2608,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         int ordinal = 0, cus = 0;
         MD_HIP(hipGetDevice(&ordinal));
         MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
-        const int G = (cus > 0 ? cus : 256) & ~7;
+        const int G = cus >= 8 ? (cus & ~7) : 8;  // (a multiple of 8: XCD x = blocks x, x + 8, ..; more workgroups than CUs only costs residency)
         p.ptiles = (int)blocks;
         p.stagger = blocks >= 2048 ? gemm_stagger_ticks(KTp <= 16 ? 0 : 1) : 0;  // (the offset is idle time at either end of the launch: 8 rounds of tiles and more)
         auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
@@ -2633,7 +2633,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
           int ordinal = 0, cus = 0;
           MD_HIP(hipGetDevice(&ordinal));
           MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
-          const int G = (cus > 0 ? cus : 256) & ~7;
+          const int G = cus >= 8 ? (cus & ~7) : 8;  // (a multiple of 8: XCD x = blocks x, x + 8, ..; more workgroups than CUs only costs residency)
           p.ptiles = (int)blocks;
           p.stagger = blocks >= 2048 ? gemm_stagger_ticks(3) : 0;
           auto gop = [&](auto kern, std::atomic<unsigned long>* attr_set) -> int {
