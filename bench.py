@@ -144,8 +144,8 @@ def parse_args(argv=None):
     ap.add_argument("--direct-store", choices=["on", "off"], default="on",
                     help="lean 2-byte store epilogues of the 256 x 256 GEMM kernel straight from the accumulator layout (the product) or staged through LDS (md_debug_gemm_direct_store): an A/B switch, same bits")
     ap.add_argument("--stagger", default="", help="md_debug_gemm_stagger: 'proj,fc2,fc1,qkv' ticks (10 ns each; -1 = the default): a timing switch, same bits")
-    ap.add_argument("--persistent-fc1", choices=["on", "off", "fc1", "fc1qkv", "noqkv"], default="on",
-                    help="the ViT GEMMs as persistent tile loops (md_debug_gemm_persistent; on = fc1 + QKV + proj / fc2): an A/B switch, same bits")
+    ap.add_argument("--persistent-fc1", choices=["on", "off", "fc1", "fc1qkv", "noqkv", "noconv"], default="on",
+                    help="the GEMMs that run as persistent tile loops (md_debug_gemm_persistent; on = fc1 + QKV + proj / fc2 + the lean 3x3 convolutions): an A/B switch, same bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no per-launch HIP events in the timed region (the `kernels` / `roofline` objects are then empty): measures what the events themselves cost")
     ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the whole-frame CPU baseline may take (predicted from a 2-tile probe); beyond it the sampled estimate is reported")
@@ -226,7 +226,7 @@ def main(argv=None) -> int:
     tdev = torch.device("cuda", local_rank)
     if args.persistent_fc1 != "on":
         from burn_depth_amd import _lib as _lps
-        _lps.load().md_debug_gemm_persistent({"off": 0, "fc1": 1, "fc1qkv": 3, "noqkv": 5}[args.persistent_fc1])
+        _lps.load().md_debug_gemm_persistent({"off": 0, "fc1": 1, "fc1qkv": 3, "noqkv": 5, "noconv": 7}[args.persistent_fc1])
     if args.stagger:
         from burn_depth_amd import _lib as _lst
         for which, ticks in enumerate(int(v) for v in args.stagger.split(",")):

@@ -112,7 +112,7 @@ struct GemmParams {
   // 16-byte store per (m-block, h), 16 rows x 64 bytes per wave-instruction, the two h of a row completing its 128-byte line back to
   // back. Same values, same bits as the staged form. Set by launch_gemm for eligible launches (gemm_direct_store()).
   int direct_store = 0;
-  int persist = 0;   // set by launch_gemm (gemm_persistent()): which forms may run as persistent tile loops (1 fc1, 2 QKV: gemm256p_kernel; 4 read-modify-write: gemm256r_kernel)
+  int persist = 0;   // set by launch_gemm (gemm_persistent()): which forms may run as persistent tile loops (1 fc1, 2 QKV, 8 lean 3 x 3 convolutions: gemm256p_kernel; 4 read-modify-write: gemm256r_kernel)
   int ptiles = 0;    // persistent form: tiles of the launch (set by launch_256)
   int stagger = 0;   // read-modify-write tile loop: the odd workgroups of every XCD start this many 10-ns ticks late (gemm_stagger(); set by launch_256 per k-tile count)
   int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)
@@ -175,7 +175,7 @@ struct GemmParams {
 // sizes: the split is off unless the calling thread turned it on -- the Depth-Anything-v3 engine does, around each of its calls.
 // process-wide A/B switch of GemmParams::direct_store (default 1); returns the previous value
 int gemm_direct_store(int on);
-// process-wide A/B switch of GemmParams::persist (a mask: 1 the fc1 form, 2 the QKV projection, 4 the read-modify-write GEMMs; default 7); returns the previous value
+// process-wide A/B switch of GemmParams::persist (a mask: 1 the fc1 form, 2 the QKV projection, 4 the read-modify-write GEMMs, 8 the lean 3 x 3 convolutions; default 15); returns the previous value
 int gemm_persistent(int mask);
 // start offset (10-ns ticks of the constant 100 MHz counter) between the two halves of a tile loop's workgroups. which: 0 the read-modify-write loop at
 // <= 16 k-tiles per tile (proj), 1 the same at more (fc2), 2 the fc1 loop, 3 the QKV loop

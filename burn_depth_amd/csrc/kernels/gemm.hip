@@ -61,8 +61,8 @@ int gemm_pick_tile(const GemmParams& p, int prec) { return pick_tile(p, prec); }
 
 static std::atomic<int> g_direct_store{1};
 int gemm_direct_store(int on) { return g_direct_store.exchange(on ? 1 : 0); }
-static std::atomic<int> g_persist{7};
-int gemm_persistent(int mask) { return g_persist.exchange(mask & 7); }
+static std::atomic<int> g_persist{15};
+int gemm_persistent(int mask) { return g_persist.exchange(mask & 15); }
 // (proj at B = 8, 2528 tiles of 16 k-tiles: 13.43 -> 12.72 ms per step with 20 us, 12.92 with 10, 13.03 with 30; fc2, 64 k-tiles: no effect at 15 / 30 us --
 // profiles/r06_stagger_ab.txt)
 static std::atomic<int> g_stagger[4] = {{2000}, {0}, {0}, {0}};

@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 // QKV = true: the fused QKV projection (EPI_QKV, one-plane types): q | k tiles through the lean staged store epilogue, its staging moved to
 // ring slots 2 - 3 so that slots 0 - 1 can take the next tile's first k-tile meanwhile; V^T tiles (a third of the launch) through their
 // transposed staging, which covers slots 0 - 1 -- behind a V^T tile the next request goes out AFTER the epilogue (no overlap there).
-template <typename T, bool FOLD, bool QKV = false>
+template <typename T, bool FOLD, bool QKV = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4, WTM = 128, WTN = 64, HALF_BYTES = 256 * 128, NSLOT = 5, LPH = 4, KE = 64, PLN = kPlanes<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1851,6 +1851,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   const char* Wg;
   const char* srcA[LPH];
   unsigned offW[LPH];
+  unsigned maskA[LPH];  // CONV: the nine taps' validity per staged row (3 row bits x 3 column bits)
   auto locate = [&](int id) __attribute__((always_inline)) {
     int tile_n, tile_mg;
     if (id < p.map_full_gsz) {
@@ -1883,7 +1884,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
       int m = m_base + r;
       m = m < m_end ? m : m_end - 1;
       const long am = (long)g_arow0 + (m - g_row0);
-      srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
+      if constexpr (CONV) {  // implicit 3 x 3 GEMM (gemm256_kernel's A_CONV3 setup): the centre tap's pixel, the taps' border mask
+        const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
+        const int t2 = fdiv((int)am, p.fd_ow);
+        const int ox = (int)am - t2 * ow;
+        const int bimg = fdiv(t2, p.fd_oh);
+        const int oy = t2 - bimg * oh;
+        const int x = ox * p.cstride, y = oy * p.cstride;
+        unsigned c3 = 0, mk = 0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) c3 |= ((unsigned)(x + kx - 1) < (unsigned)p.cW ? 1u : 0u) << kx;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) mk |= ((unsigned)(y + ky - 1) < (unsigned)p.cH ? c3 : 0u) << (3 * ky);
+        maskA[i] = mk;
+        const int pix = (bimg * p.cH + y) * p.cW + x;
+        srcA[i] = (const char*)p.A + (long)pix * (long)(p.cC * 2) + lc * 16;
+      } else {
+        maskA[i] = 0;
+        srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
+      }
       const int rp = QKV ? r : ((r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3));  // fc1: the direct-store image
       offW[i] = (unsigned)(n0 + rp) * (unsigned)(ldw * 2) + (unsigned)(lc * 16);
     }
@@ -1894,11 +1913,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < LPH; ++i) glds16(wk + offW[i], sbase + (i * NW + wave) * 1024);
   };
+  const int cblocks = CONV ? (p.cCk > 0 ? p.cCk : p.cC) / KE : 1;
   auto issue_A = [&](int kt, int slot) __attribute__((always_inline)) {
     char* sbase = smem + slot * HALF_BYTES;
-    const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+    if constexpr (CONV) {
+      const int tap = fdiv(kt, p.fd_cblocks);
+      const int cb = kt - tap * cblocks;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 9
+      const long a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * 2 + (long)cb * 128;
+      int pc_o = lane;
+      asm volatile("" : "+v"(pc_o));
+      const char* zsrc = (const char*)p.zero_page + (pc_o & 7) * 16;
 #pragma unroll
-    for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
+      for (int i = 0; i < LPH; ++i) glds16(((maskA[i] >> tap) & 1u) ? srcA[i] + a_delta : zsrc, sbase + (i * NW + wave) * 1024);
+    } else {
+      const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+#pragma unroll
+      for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
+    }
   };
   if (p.stagger > 0 && ((blockIdx.x >> 5) & 1)) {  // (gemm256r_kernel's start offset between the halves of an XCD's workgroups: a measurement switch here)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -2002,7 +2034,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
     const bool has_next = it < xc;
     __builtin_amdgcn_s_barrier();  // the exchange area is complete and visible; every wave has left the ring
     asm volatile("" ::: "memory");
-    const bool e_vt = QKV && e_n0 >= 2 * p.embed;  // a V^T tile
+    const bool e_vt = QKV && !CONV && e_n0 >= 2 * p.embed;  // a V^T tile
     const bool early = has_next;
     if (early) {
       locate(xs + it);
@@ -2089,7 +2121,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
         }
       } else {
         // ---- q | k tile: the lean staged store epilogue, staging in ring slots 2 - 3 (8 KB per wave) ----
-        const float qs = e_n0 < p.embed ? p.qscale : 1.f;
+        const float qs = (!CONV && e_n0 < p.embed) ? p.qscale : 1.f;
+        const bool relu_o = CONV && p.act == ACT_RELU;
         f32x4_t bq[4], wq[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -2107,7 +2140,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
           }
         }
         char* st = smem + 2 * HALF_BYTES + wave * 8192;
-        const long ldo8 = 2L * p.embed;
+        const long ldo8 = CONV ? (long)p.ldo : 2L * p.embed;
         char* ob = (char*)p.out + ((long)e_m_base * ldo8 + e_n0) * 2;
         const int rsub = lane_e >> 3;
         const unsigned lc8 = (unsigned)(wn * WTN + (lane_e & 7) * 8);
@@ -2127,6 +2160,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
               } else {
                 x = fma4(x, wq[a], bq[a]);
               }
+              if (relu_o) x = relu4(x);
               const int row = bb * 16 + r16e;
               const int chunk = (a * 2 + (q16e >> 1)) ^ (row & 7);
               *(i32x2_t*)(st + row * 128 + chunk * 16 + (q16e & 1) * 8) = pack4<T>(x);
@@ -2576,6 +2610,30 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
     // (fc1 36.18 -> 35.46 ms per step: their stores leave spread out between the polynomial's arithmetic), the plain kinds LOSE (qkv 23.61 ->
     // 24.52: sixteen half-line stores per wave in one burst cost more than the LDS transpose they replace) -- so only EK 4 / 7 take the
     // direct form; EK 8 / 10 stay instantiable for A/B builds (MD_DIRECT_STORE_ALL).
+    if constexpr (AMODE == A_CONV3 && !is_split<T>::value && !std::is_same<T, fp8_t>::value) {
+      // the implicit 3 x 3 GEMM with a lean store epilogue (bias, optional ReLU, one 2-byte output: the first convolution of the decoder's residual
+      // units) as the tile loop of the q | k form (persist bit 8)
+      const int KTc = p.K / 64;
+      if (!diag && (p.persist & 8) && lean && ek == 2 && p.epi == EPI_STORE && !p.wscale[0] && p.bias[0] && p.ngroups <= 1 && p.a_wrap == 0 && blocks >= 1024 &&
+          KTc >= 3 && (2 * KTc - 2) % 5 != 4 && (2 * KTc - 1) % 5 != 4 && p.N == BN && (p.act == ACT_NONE || p.act == ACT_RELU)) {
+        int ordinal = 0, cus = 0;
+        MD_HIP(hipGetDevice(&ordinal));
+        MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
+        const int G = cus >= 8 ? (cus & ~7) : 8;
+        p.ptiles = (int)blocks;
+        p.stagger = 0;
+        static std::atomic<unsigned long> cset;
+        const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
+        auto kern = gemm256p_kernel<T, false, true, true>;
+        if (!bit || !(cset.load(std::memory_order_acquire) & bit)) {
+          MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+          cset.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(512), smem, stream, p);
+        MD_HIP(hipGetLastError());
+        return MD_OK;
+      }
+    }
     if constexpr (AMODE == A_DENSE && !std::is_same<T, fp8_t>::value) {
       // the persistent tile loop of the fc1 form (gemm256p_kernel): GemmParams::persist, enough tiles to give every CU several, a k-tile
       // count that leaves ring slot 4 idle in the last k-tile (16, 32: K' = 1024, 2048)

@@ -25,7 +25,7 @@ def main():
         xx, ww = (x.half().float(), w.half().float()) if prec == 4 else (x, w)
         lib.md_debug_gemm_persistent(0)
         ref = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
-        lib.md_debug_gemm_persistent(7)
+        lib.md_debug_gemm_persistent(15)
         got = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
         got2 = ops.linear(dev, xx, ww, b, act=2, precision=prec, tile=_lib.TILE_256x256, storage_out=True)
         lib.md_debug_gemm_persistent(0)
@@ -44,7 +44,7 @@ def main():
         xi = torch.randn(2, 3, 1536, 1536, device="cuda")
         lib.md_debug_gemm_persistent(0)
         a = m.infer(xi).depth.clone()
-        lib.md_debug_gemm_persistent(7)
+        lib.md_debug_gemm_persistent(15)
         bb = m.infer(xi).depth.clone()
         cc = m.infer(xi).depth.clone()
         lib.md_debug_gemm_persistent(0)
@@ -65,14 +65,16 @@ def main():
         lib.md_debug_gemm_persistent(3)
         a = m.infer(xi).depth.clone()
         lib.md_debug_gemm_persistent(7)
+        a7 = m.infer(xi).depth.clone()  # (15 adds the decoder's lean 3 x 3 convolutions)
+        lib.md_debug_gemm_persistent(15)
         bb = m.infer(xi).depth.clone()
         lib.md_debug_gemm_stagger(0, 0)
         cc = m.infer(xi).depth.clone()
         lib.md_debug_gemm_stagger(0, 2000)
         lib.md_debug_gemm_persistent(0)
         dd = m.infer(xi).depth.clone()
-        lib.md_debug_gemm_persistent(7)
-        same = torch.equal(a, bb) and torch.equal(bb, cc) and torch.equal(cc, dd)
+        lib.md_debug_gemm_persistent(15)
+        same = torch.equal(a, bb) and torch.equal(bb, cc) and torch.equal(cc, dd) and torch.equal(a, a7)
         print(f"DepthPro::infer [8,3,1536,1536] prec {prec}: read-modify-write tile loop (with / without its start offset) == one-tile kernels: {same}  "
               f"max |diff| {(a - bb).abs().max().item():.3e} {(a - cc).abs().max().item():.3e} {(a - dd).abs().max().item():.3e}", flush=True)
         ok = ok and same
