@@ -112,7 +112,7 @@ struct GemmParams {
   // 16-byte store per (m-block, h), 16 rows x 64 bytes per wave-instruction, the two h of a row completing its 128-byte line back to
   // back. Same values, same bits as the staged form. Set by launch_gemm for eligible launches (gemm_direct_store()).
   int direct_store = 0;
-  int persist = 0;   // set by launch_gemm (gemm_persistent()): which forms may run as persistent tile loops (1 fc1, 2 QKV, 8 lean 3 x 3 convolutions: gemm256p_kernel; 4 read-modify-write: gemm256r_kernel)
+  int persist = 0;   // set by launch_gemm (gemm_persistent()): which forms may run as persistent tile loops (1 fc1, 2 QKV, 8 3 x 3 convolutions -- lean: gemm256p_kernel, with residual inputs / second output: gemm256r_kernel; 4 read-modify-write: gemm256r_kernel)
   int ptiles = 0;    // persistent form: tiles of the launch (set by launch_256)
   int stagger = 0;   // read-modify-write tile loop: the odd workgroups of every XCD start this many 10-ns ticks late (gemm_stagger(); set by launch_256 per k-tile count)
   int ksplit_ok = 0;            // set by launch_gemm from gemm_allow_ksplit(): the 64 x 64 kernel may split K over wave groups (KSPLIT)

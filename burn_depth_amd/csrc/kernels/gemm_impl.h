@@ -2255,7 +2255,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 // The read-modify-write GEMMs (proj, fc2: EPI_RESID_LS, with or without the LayerNorm fold's producer part) as the same tile loop. The one-tile
 // kernel's fp32 staging (17 KB per wave) covers the whole ring; here a wave stages 32 rows at a time (8.5 KB per wave in ring slots 2 - 4), so
 // that slots 0 - 1 can take the next tile's first k-tile under the 12 - 16 us of this epilogue. Same arithmetic, same bits.
-template <typename T, bool EMIT>
+template <typename T, bool EMIT, bool CONVR = false>
 __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
   constexpr bool FOLD = false, QKV = true;  // (QKV = true below only selects the plain W image)
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4, WTM = 128, WTN = 64, HALF_BYTES = 256 * 128, NSLOT = 5, LPH = 4, KE = 64, PLN = kPlanes<T>;
@@ -2285,6 +2285,7 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
   const char* Wg;
   const char* srcA[LPH];
   unsigned offW[LPH];
+  unsigned maskA[LPH];  // CONVR: the nine taps' validity per staged row
   auto locate = [&](int id) __attribute__((always_inline)) {
     int tile_n, tile_mg;
     if (id < p.map_full_gsz) {
@@ -2317,7 +2318,25 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
       int m = m_base + r;
       m = m < m_end ? m : m_end - 1;
       const long am = (long)g_arow0 + (m - g_row0);
-      srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
+      if constexpr (CONVR) {  // implicit 3 x 3 GEMM (gemm256_kernel's A_CONV3 setup): the centre tap's pixel, the taps' border mask
+        const int ow = p.cOW > 0 ? p.cOW : p.cW, oh = p.cOH > 0 ? p.cOH : p.cH;
+        const int t2 = fdiv((int)am, p.fd_ow);
+        const int ox = (int)am - t2 * ow;
+        const int bimg = fdiv(t2, p.fd_oh);
+        const int oy = t2 - bimg * oh;
+        const int x = ox * p.cstride, y = oy * p.cstride;
+        unsigned c3 = 0, mk = 0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) c3 |= ((unsigned)(x + kx - 1) < (unsigned)p.cW ? 1u : 0u) << kx;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) mk |= ((unsigned)(y + ky - 1) < (unsigned)p.cH ? c3 : 0u) << (3 * ky);
+        maskA[i] = mk;
+        const int pix = (bimg * p.cH + y) * p.cW + x;
+        srcA[i] = (const char*)p.A + (long)pix * (long)(p.cC * 2) + lc * 16;
+      } else {
+        maskA[i] = 0;
+        srcA[i] = (const char*)p.A + (long)(int)am * (long)(int)(p.lda * 2) + lc * 16;
+      }
       const int rp = QKV ? r : ((r & ~63) | (((r >> 5) & 1) << 5) | (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3));  // fc1: the direct-store image
       offW[i] = (unsigned)(n0 + rp) * (unsigned)(ldw * 2) + (unsigned)(lc * 16);
     }
@@ -2328,11 +2347,24 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < LPH; ++i) glds16(wk + offW[i], sbase + (i * NW + wave) * 1024);
   };
+  const int cblocks = CONVR ? (p.cCk > 0 ? p.cCk : p.cC) / KE : 1;
   auto issue_A = [&](int kt, int slot) __attribute__((always_inline)) {
     char* sbase = smem + slot * HALF_BYTES;
-    const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+    if constexpr (CONVR) {
+      const int tap = fdiv(kt, p.fd_cblocks);
+      const int cb = kt - tap * cblocks;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;  // tap / 3 for tap < 9
+      const long a_delta = ((long)(ky - 1) * p.cW + (kx - 1)) * p.cC * 2 + (long)cb * 128;
+      int pc_z = lane;
+      asm volatile("" : "+v"(pc_z));
+      const char* zsrc = (const char*)p.zero_page + (pc_z & 7) * 16;
 #pragma unroll
-    for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
+      for (int i = 0; i < LPH; ++i) glds16(((maskA[i] >> tap) & 1u) ? srcA[i] + a_delta : zsrc, sbase + (i * NW + wave) * 1024);
+    } else {
+      const int kta = (p.a_wrap > 0 && kt >= p.a_wrap) ? kt - p.a_wrap : kt;
+#pragma unroll
+      for (int i = 0; i < LPH; ++i) glds16(srcA[i] + (long)kta * 128, sbase + (i * NW + wave) * 1024);
+    }
   };
   // start offset between the two halves of every XCD's workgroups (blocks 4 - 7, 12 - 15, .. of the XCD: the four n-tiles of an m-panel stay
   // together): all workgroups run the same tile sequence at the same speed, so without it every epilogue of the launch -- the fp32 residual
@@ -2374,6 +2406,8 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
     if (first || !prev_counted) {
 #endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (CONVR) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (the 16 output stores: a lower bound of what follows the requests, whatever the residual inputs)
     } else {
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // (32: the x stores alone; a safe lower bound of what follows the requests in either form)
     }
@@ -2403,7 +2437,9 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
           int l2 = lane;
           asm volatile("" : "+v"(l2));
           if (wave == 0) glds16((const char*)(MD_SEL_G(p.bias, g) + n0) + l2 * 16, smem + kLnXchg + 8192);
-          if (wave == 1) glds16((const char*)(MD_SEL_G(p.scale, g) + n0) + l2 * 16, smem + kLnXchg + 9216);
+          if constexpr (!CONVR) {
+            if (wave == 1) glds16((const char*)(MD_SEL_G(p.scale, g) + n0) + l2 * 16, smem + kLnXchg + 9216);
+          }
           if constexpr (EMIT) {
             if (wave == 2) glds16((const char*)(MD_SEL_G(p.ln_gamma, g) + n0) + l2 * 16, smem + kLnXchg + 10240);
           }
@@ -2439,7 +2475,79 @@ __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
     // ---- epilogue: x(f32) += scale * (acc + bias), in four passes of 32 rows per wave through fp32 staging in ring slots 2 - 4 (8.5 KB per wave:
     //      slots 0 - 1 belong to the next tile's first k-tile); EMIT: + round_T(gamma_next . x_new) and the rows' (mean, M2) (gemm256_kernel's EK 5) ----
     const bool interior = e_m_base + BM <= e_m_end;
-    {
+    if constexpr (CONVR) {
+      // ---- the 2-byte store epilogue with residual inputs and / or a relu'd second output (gemm256_kernel's one-plane form of it: out = act(acc + bias
+      //      + res1 + res2), out2 = relu(out)), in four passes of 32 rows per wave through the same fp32 staging; a lane owns 8 columns of 4 rows per
+      //      pass, the raw residual vectors of a pass are requested one pass ahead ----
+      int r16e = r16, q16e = q16, lane_e = lane;
+      asm volatile("" : "+v"(r16e), "+v"(q16e), "+v"(lane_e));
+      constexpr int SROW = 272;
+      char* st = smem + 2 * HALF_BYTES + wave * (32 * SROW);
+      const int c8 = (lane_e & 7) * 8, rsub = lane_e >> 3;
+      const f32x4_t bl = *(const f32x4_t*)(lnx + 2048 + wn * WTN + c8), bh = *(const f32x4_t*)(lnx + 2048 + wn * WTN + c8 + 4);
+      const bool r1 = p.res1 != nullptr, r2 = p.res2 != nullptr, relu = p.act == ACT_RELU, has_o2 = p.out2 != nullptr;
+      const long tb = (long)e_m_base * p.ldo + e_n0, trb = (long)e_m_base * p.ldr + e_n0;
+      char* ob = (char*)p.out + tb * 2;
+      char* o2b = (char*)p.out2 + tb * 2;
+      const char* q1b = (const char*)p.res1 + trb * 2;
+      const char* q2b = (const char*)p.res2 + trb * 2;
+      const unsigned lc8 = (unsigned)(wn * WTN + c8);
+      i32x4_t pr1[4][4], pr2[4][4];
+      auto pf8 = [&](int q, int i2) __attribute__((always_inline)) {
+        const int lrow_t = wm * WTM + q * 32 + i2 * 8 + rsub;
+        const bool ok = interior || e_m_base + lrow_t < e_m_end;
+        const unsigned ro = ((unsigned)lrow_t * (unsigned)p.ldr + lc8) * 2u;
+        const i32x4_t z = {0, 0, 0, 0};
+        pr1[q][i2] = (r1 && ok) ? *(const i32x4_t*)(q1b + ro) : z;
+        pr2[q][i2] = (r2 && ok) ? *(const i32x4_t*)(q2b + ro) : z;
+      };
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2) pf8(0, i2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const f32x4acc_t c = acc16[a][q * 2 + bb];
+            *(f32x4_t*)(st + (bb * 16 + r16e) * SROW + (a * 16 + 4 * q16e) * 4) = (f32x4_t){c[0], c[1], c[2], c[3]};
+          }
+        asm volatile("" ::: "memory");
+        if (q < 3) {
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) pf8(q + 1, i2);
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const int row = i2 * 8 + rsub;
+          const unsigned lr = (unsigned)(wm * WTM + q * 32 + row);
+          f32x4_t lo = *(const f32x4_t*)(st + row * SROW + c8 * 4);
+          f32x4_t hi = *(const f32x4_t*)(st + row * SROW + c8 * 4 + 16);
+          if (interior || e_m_base + (int)lr < e_m_end) {
+            lo = lo * (f32x4_t){1.f, 1.f, 1.f, 1.f} + bl;
+            hi = hi * (f32x4_t){1.f, 1.f, 1.f, 1.f} + bh;
+            if (r1 || r2) {
+              f32x4_t a0, a1;
+              widen8<T>(pr1[q][i2], a0, a1);
+              lo += a0;
+              hi += a1;
+              widen8<T>(pr2[q][i2], a0, a1);
+              lo += a0;
+              hi += a1;
+            }
+            if (relu) {
+              lo = relu4(lo);
+              hi = relu4(hi);
+            }
+            const unsigned eo = (lr * (unsigned)p.ldo + lc8) * 2u;
+            *(i32x4_t*)(ob + eo) = pack8<T>(lo, hi);
+            if (has_o2) *(i32x4_t*)(o2b + eo) = pack8<T>(relu4(lo), relu4(hi));
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
+    } else {
       int r16e = r16, q16e = q16, lane_e = lane;
       asm volatile("" : "+v"(r16e), "+v"(q16e), "+v"(lane_e));
       constexpr int SROW = 272;
@@ -2628,6 +2736,28 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         if (!bit || !(cset.load(std::memory_order_acquire) & bit)) {
           MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
           cset.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(512), smem, stream, p);
+        MD_HIP(hipGetLastError());
+        return MD_OK;
+      }
+      // the same with residual inputs and / or a relu'd second output (the second convolution of a residual unit: x + conv2(..) [+ skip], and
+      // its relu'd copy for the next unit): the read-modify-write loop's skeleton, 32-row staging passes
+      if (!diag && (p.persist & 8) && !lean && ek == 2 && p.epi == EPI_STORE && (p.res1 || p.res2 || p.out2) && !p.out_f32 && !p.out_fp8 && !p.wscale[0] &&
+          p.bias[0] && p.ngroups <= 1 && p.a_wrap == 0 && p.batch <= 1 && blocks >= 1024 && KTc >= 3 && (2 * KTc - 2) % 5 != 4 && (2 * KTc - 1) % 5 != 4 &&
+          p.N == BN && (p.act == ACT_NONE || p.act == ACT_RELU)) {
+        int ordinal = 0, cus = 0;
+        MD_HIP(hipGetDevice(&ordinal));
+        MD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ordinal));
+        const int G = cus >= 8 ? (cus & ~7) : 8;
+        p.ptiles = (int)blocks;
+        p.stagger = 0;
+        static std::atomic<unsigned long> c2set;
+        const unsigned long bit = (ordinal >= 0 && ordinal < 64) ? 1ul << ordinal : 0ul;
+        auto kern = gemm256r_kernel<T, false, true>;
+        if (!bit || !(c2set.load(std::memory_order_acquire) & bit)) {
+          MD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+          c2set.fetch_or(bit, std::memory_order_release);
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(512), smem, stream, p);
         MD_HIP(hipGetLastError());

@@ -417,8 +417,8 @@ int md_debug_gemm_direct_store(int on);
 /* PROCESS-WIDE A/B switch (a mask, default 15; returns the previous value): which launches of the 256 x 256 GEMM kernel with >= 1024 tiles (the QKV projection: 768)
  * may run as a persistent tile loop -- one workgroup per CU, the next tile's first k-tile requested before the current tile's epilogue
  * (DESIGN.md section 5.1.2): 1 = the fc1 form (dense A, bias (+ LayerNorm fold) + GELU, direct stores: gemm256p_kernel), 2 = the fused
- * QKV projection (one-plane types), 4 = the read-modify-write GEMMs proj / fc2 (gemm256r_kernel), 8 = the implicit 3 x 3 GEMMs with a lean store epilogue (the first convolution
- * of the decoder's residual units). Same arithmetic, same bits. */
+ * QKV projection (one-plane types), 4 = the read-modify-write GEMMs proj / fc2 (gemm256r_kernel), 8 = the implicit 3 x 3 GEMMs of the decoder's residual units (bias; with or without residual
+ * inputs / a relu'd second output). Same arithmetic, same bits. */
 int md_debug_gemm_persistent(int mask);
 /* Timing switch of the tile loops: half of every XCD's workgroups start `ticks` (10 ns each) after the other half, so that one half's
  * epilogues (proj / fc2: the fp32 residual stream's read + write, HBM-bound) meet the other half's main loops instead of each other.
