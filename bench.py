@@ -456,10 +456,10 @@ def main(argv=None) -> int:
             tfl = fl[dom] / (per_step * 1e-3) / 1e12
             # the rocprofv3 row of the same command: EK 11 = the GELU store kind with the LayerNorm fold, direct stores (EK 9 without the fold)
             pf = args.persistent_fc1 != "off"
-            symbols = {"fc1_gemm": ((("md::gemm256p_kernel<md::bf16_t, true, false> (persistent tile loop, " if pf else "md::gemm256_kernel<md::bf16_t, 0, 11, false> (")
+            symbols = {"fc1_gemm": ((("md::gemm256p_kernel<md::bf16_t, true, false, false> (persistent tile loop, " if pf else "md::gemm256_kernel<md::bf16_t, 0, 11, false> (")
                                      + "dense A, 16x16x32 two-group schedule, LayerNorm fold + bias + GELU, direct store)")
                                     if model.query("ln_fold_active") else
-                                    (("md::gemm256p_kernel<md::bf16_t, false, false> (persistent tile loop, " if pf else "md::gemm256_kernel<md::bf16_t, 0, 9, false> (")
+                                    (("md::gemm256p_kernel<md::bf16_t, false, false, false> (persistent tile loop, " if pf else "md::gemm256_kernel<md::bf16_t, 0, 9, false> (")
                                      + "dense A, 16x16x32 two-group schedule, fused bias + GELU, direct store)"))}
             roofline = {"kernel": dom, "kernel_symbol": symbols.get(dom) if args.precision == "bf16" else None,
                         "bound": "mfma", "achieved": round(tfl, 2), "peak": peak, "unit": "TFLOP/s",
