@@ -1820,8 +1820,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 // vmcnt(stores of this epilogue). Same main loop, same arithmetic, same bits as the one-tile kernel.
 // LDS exchange area (inside ring slot 4, idle in the last k-tile for KT = 16 / 32): [pairs 2 KB][partials 8 KB][c or bias 1 KB][d 1 KB].
 // QKV = true: the fused QKV projection (EPI_QKV, one-plane types): q | k tiles through the lean staged store epilogue, its staging moved to
-// ring slots 2 - 3 so that slots 0 - 1 can take the next tile's first k-tile meanwhile; V^T tiles (a third of the launch) through their
-// transposed staging, which covers slots 0 - 1 -- behind a V^T tile the next request goes out AFTER the epilogue (no overlap there).
+// ring slots 2 - 3 so that slots 0 - 1 can take the next tile's first k-tile meanwhile; V^T tiles (a third of the launch) staged transposed in
+// the OUTPUT type (8.5 KB per wave in slots 2 - 4; the one-tile kernel's fp32 staging covers the whole ring), so they overlap the same way.
+// CONV = true (with QKV = true: the plain W image and the lean staged store): the implicit 3 x 3 GEMM with bias (+ ReLU) and one 2-byte
+// output -- the first convolution of the decoder's residual units; the tile setup adds the pixel decomposition and the nine taps' border masks.
 template <typename T, bool FOLD, bool QKV = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NW = 8, WGN = 4, WTM = 128, WTN = 64, HALF_BYTES = 256 * 128, NSLOT = 5, LPH = 4, KE = 64, PLN = kPlanes<T>;
@@ -2255,6 +2257,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const GemmParams p) {
 // The read-modify-write GEMMs (proj, fc2: EPI_RESID_LS, with or without the LayerNorm fold's producer part) as the same tile loop. The one-tile
 // kernel's fp32 staging (17 KB per wave) covers the whole ring; here a wave stages 32 rows at a time (8.5 KB per wave in ring slots 2 - 4), so
 // that slots 0 - 1 can take the next tile's first k-tile under the 12 - 16 us of this epilogue. Same arithmetic, same bits.
+// CONVR = true: the implicit 3 x 3 GEMM whose 2-byte store epilogue has residual inputs and / or a relu'd second output (the second convolution of
+// the decoder's residual units) on the same skeleton: gemm256_kernel's arithmetic of that form in the 32-row passes.
 template <typename T, bool EMIT, bool CONVR = false>
 __global__ __launch_bounds__(512) void gemm256r_kernel(const GemmParams p) {
   constexpr bool FOLD = false, QKV = true;  // (QKV = true below only selects the plain W image)
@@ -2813,7 +2817,7 @@ static int launch_256(GemmParams& p, hipStream_t stream) {
         if (ek == 5) return gop(gemm256r_kernel<T, true>, &rset[1]);
         return gop(gemm256r_kernel<T, false>, &rset[0]);
       }
-      // the fused QKV projection as the same tile loop (one-plane types): q | k tiles overlap the next tile's first requests, V^T tiles do not
+      // the fused QKV projection as the same tile loop (one-plane types)
       if constexpr (!is_split<T>::value) {
         if (!diag && (p.persist & 2) && lean && p.epi == EPI_QKV && (ek == 2 || ek == 6) && !p.wscale[0] && p.bias[0] && !p.qkn_g[0] && blocks >= 768 &&
             KTp >= 3 && (2 * KTp - 2) % 5 != 4 && (2 * KTp - 1) % 5 != 4 && (ek == 2 || p.ln_raw) && p.embed % BN == 0 && (p.seq_stride & 3) == 0 &&
